@@ -1,0 +1,283 @@
+/*
+ * pll_amd.h - public C interface of the MI355X (gfx950) build of the libpll-2 partial-likelihood
+ * hot path.
+ *
+ * This header is written from the ABI record in SURVEY.md section 8b, not transcribed from the
+ * reference header. It declares ONLY what the hot path needs, with struct layouts that are
+ * byte-identical to the reference (x86-64 LP64) so that a caller compiled against the
+ * reference's own pll.h can link against libpll_amd.so unchanged. Every declaration cites the
+ * reference declaration it replaces (paths relative to the reference checkout).
+ *
+ * The library computes on the GPU only. There is no CPU kernel behind these entry points: if no
+ * gfx950 device (or the HIP code object) is available, pll_partition_create() fails with
+ * pll_errno = PLL_ERROR_GPU_UNAVAILABLE instead of silently falling back.
+ */
+#ifndef PLL_AMD_H_
+#define PLL_AMD_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status / limits (src/pll.h:82-110) --------------------------------------------------- */
+#define PLL_FAILURE 0
+#define PLL_SUCCESS 1
+#define PLL_FALSE 0
+#define PLL_TRUE 1
+
+#define PLL_ALIGNMENT_CPU 8
+#define PLL_ALIGNMENT_SSE 16
+#define PLL_ALIGNMENT_AVX 32
+#define PLL_ASCII_SIZE 256
+
+/* 2^256 and its inverse, exact in binary64 (src/pll.h:96-97) */
+#define PLL_SCALE_FACTOR 0x1p256
+#define PLL_SCALE_THRESHOLD 0x1p-256
+#define PLL_SCALE_BUFFER_NONE (-1)
+#define PLL_SCALE_RATE_MAXDIFF 4 /* src/pll.h:104 */
+
+/* ---- attribute word (src/pll.h:112-137) --------------------------------------------------- */
+/* The ARCH bits only select the *host-visible layout* (states_padded, alignment) so existing
+ * callers that pass ARCH_AVX2 keep seeing the padding they expect; arithmetic always runs on
+ * the MI355X. */
+#define PLL_ATTRIB_ARCH_CPU 0u
+#define PLL_ATTRIB_ARCH_SSE (1u << 0)
+#define PLL_ATTRIB_ARCH_AVX (1u << 1)
+#define PLL_ATTRIB_ARCH_AVX2 (1u << 2)
+#define PLL_ATTRIB_ARCH_AVX512 (1u << 3)
+#define PLL_ATTRIB_ARCH_MASK 0xFu
+#define PLL_ATTRIB_PATTERN_TIP (1u << 4)
+#define PLL_ATTRIB_AB_LEWIS (1u << 5)
+#define PLL_ATTRIB_AB_FELSENSTEIN (2u << 5)
+#define PLL_ATTRIB_AB_STAMATAKIS (3u << 5)
+#define PLL_ATTRIB_AB_MASK (7u << 5)
+#define PLL_ATTRIB_AB_FLAG (1u << 8)
+#define PLL_ATTRIB_RATE_SCALERS (1u << 9)
+#define PLL_ATTRIB_SITE_REPEATS (1u << 10)
+#define PLL_REPEATS_LOOKUP_SIZE 2000000u
+#define PLL_ATTRIB_MASK ((1u << 11) - 1)
+
+/* ---- error codes (subset of src/pll.h:154-190 that this path can raise) -------------------- */
+#define PLL_ERROR_MEM_ALLOC 112
+#define PLL_ERROR_PARAM_INVALID 113
+#define PLL_ERROR_TIPDATA_ILLEGALSTATE 114
+#define PLL_ERROR_TIPDATA_ILLEGALFUNCTION 115
+#define PLL_ERROR_INVAR_INCOMPAT 117
+#define PLL_ERROR_INVAR_PROPORTION 118
+#define PLL_ERROR_INVAR_PARAMINDEX 119
+#define PLL_ERROR_INVAR_NONEFOUND 120
+#define PLL_ERROR_AB_INVALIDMETHOD 121
+#define PLL_ERROR_AB_NOSUPPORT 122
+/* new, outside the reference's range: device problems are reported through the same
+ * pll_errno / pll_errmsg convention */
+#define PLL_ERROR_GPU_UNAVAILABLE 900
+#define PLL_ERROR_GPU_RUNTIME 901
+#define PLL_ERROR_GPU_UNSUPPORTED 902
+
+#define PLL_GAMMA_RATES_MEAN 0
+#define PLL_GAMMA_RATES_MEDIAN 1
+
+/* ---- types ------------------------------------------------------------------------------- */
+typedef unsigned long long pll_state_t; /* src/pll.h:217: one bit per state, <= 64 states */
+
+struct pll_repeats;
+
+/* src/pll.h:241-288; sizeof == 232, offsets asserted in csrc/host/abi_check.c */
+typedef struct pll_partition
+{
+  unsigned int tips;
+  unsigned int clv_buffers;
+  unsigned int nodes;
+  unsigned int states;
+  unsigned int sites;
+  unsigned int pattern_weight_sum;
+  unsigned int rate_matrices;
+  unsigned int prob_matrices;
+  unsigned int rate_cats;
+  unsigned int scale_buffers;
+  unsigned int attributes;
+  size_t alignment;
+  unsigned int states_padded;
+  double **clv;                  /* host mirror of the device CLVs, see pll_gpu_sync_* below */
+  double **pmatrix;
+  double *rates;
+  double *rate_weights;
+  double **subst_params;
+  unsigned int **scale_buffer;   /* host mirror of the device scalers */
+  double **frequencies;
+  double *prop_invar;
+  int *invariant;
+  unsigned int *pattern_weights;
+  int *eigen_decomp_valid;
+  double **eigenvecs;
+  double **inv_eigenvecs;
+  double **eigenvals;
+  unsigned int maxstates;
+  unsigned char **tipchars;
+  unsigned char *charmap;
+  double *ttlookup;              /* kept NULL: the device kernels need no tip-tip table */
+  pll_state_t *tipmap;
+  int asc_bias_alloc;
+  int asc_additional_sites;
+  struct pll_repeats *repeats;
+} pll_partition_t;
+
+/* src/pll.h:290-321; sizeof == 104 */
+typedef struct pll_repeats
+{
+  unsigned int **pernode_site_id;
+  unsigned int **pernode_id_site;
+  unsigned int *pernode_ids;
+  unsigned int *perscale_ids;
+  unsigned int *pernode_allocated_clvs;
+  unsigned int (*enable_repeats)(struct pll_partition *partition, unsigned int left_clv,
+                                 unsigned int right_clv);
+  void (*reallocate_repeats)(struct pll_partition *partition, unsigned int parent,
+                             int scaler_index, unsigned int sites_to_alloc);
+  unsigned int *lookup_buffer;
+  unsigned int *toclean_buffer;
+  unsigned int *id_site_buffer;
+  double *bclv_buffer;
+  unsigned int lookup_buffer_size;
+  char *charmap;
+} pll_repeats_t;
+
+/* src/pll.h:325-335; eight 4-byte fields, sizeof == 32 */
+typedef struct pll_operation
+{
+  unsigned int parent_clv_index;
+  int parent_scaler_index;
+  unsigned int child1_clv_index;
+  unsigned int child1_matrix_index;
+  int child1_scaler_index;
+  unsigned int child2_clv_index;
+  unsigned int child2_matrix_index;
+  int child2_scaler_index;
+} pll_operation_t;
+
+/* ---- thread-local error state (src/pll.h:553-555, src/pll.c:24-25) ------------------------- */
+extern __thread int pll_errno;
+extern __thread char pll_errmsg[200];
+
+/* ---- character maps callers hand to pll_set_tip_states (src/pll.h:557-560, src/maps.c) ----- */
+extern const pll_state_t pll_map_bin[256];
+extern const pll_state_t pll_map_nt[256];
+extern const pll_state_t pll_map_aa[256];
+
+/* ---- lifecycle (src/pll.h:638-648, src/pll.c:424-873) -------------------------------------- */
+pll_partition_t *pll_partition_create(unsigned int tips, unsigned int clv_buffers,
+                                      unsigned int states, unsigned int sites,
+                                      unsigned int rate_matrices, unsigned int prob_matrices,
+                                      unsigned int rate_cats, unsigned int scale_buffers,
+                                      unsigned int attributes);
+void pll_partition_destroy(pll_partition_t *partition);
+void *pll_aligned_alloc(size_t size, size_t alignment); /* src/pll.h:778 */
+void pll_aligned_free(void *ptr);                       /* src/pll.h:780 */
+
+/* ---- inputs (src/pll.h:650-661,746-758; src/pll.c:1026-1143; src/models.c:445-493) --------- */
+int pll_set_tip_states(pll_partition_t *partition, unsigned int tip_index,
+                       const pll_state_t *map, const char *sequence);
+int pll_set_tip_clv(pll_partition_t *partition, unsigned int tip_index, const double *clv,
+                    int padding);
+void pll_set_pattern_weights(pll_partition_t *partition, const unsigned int *pattern_weights);
+void pll_set_frequencies(pll_partition_t *partition, unsigned int params_index,
+                         const double *frequencies);
+void pll_set_subst_params(pll_partition_t *partition, unsigned int params_index,
+                          const double *params);
+void pll_set_category_rates(pll_partition_t *partition, const double *rates);
+void pll_set_category_weights(pll_partition_t *partition, const double *rate_weights);
+int pll_update_invariant_sites_proportion(pll_partition_t *partition, unsigned int params_index,
+                                          double prop_invar); /* src/models.c:495-540 */
+int pll_update_invariant_sites(pll_partition_t *partition);  /* src/models.c:628-752 */
+unsigned int pll_count_invariant_sites(pll_partition_t *partition,
+                                       unsigned int *state_inv_count); /* src/models.c:542-626 */
+
+/* model side ("next" rows f2 of SURVEY section 8; host code, feeds the path) */
+int pll_update_eigen(pll_partition_t *partition, unsigned int params_index); /* models.c:293 */
+int pll_update_prob_matrices(pll_partition_t *partition, const unsigned int *params_indices,
+                             const unsigned int *matrix_indices, const double *branch_lengths,
+                             unsigned int count); /* src/models.c:412-443 */
+int pll_compute_gamma_cats(double alpha, unsigned int categories, double *output_rates,
+                           int rates_mode); /* src/gamma.c:220-292 */
+
+/* ---- THE HOT PATH (src/pll.h:790-797,823-830) ---------------------------------------------- */
+/* src/partials.c:237-291. Asynchronous: kernels are enqueued on the partition's HIP stream and
+ * the call returns; results stay resident in HBM. */
+void pll_update_partials(pll_partition_t *partition, const pll_operation_t *operations,
+                         unsigned int count);
+void pll_update_partials_rep(pll_partition_t *partition, const pll_operation_t *operations,
+                             unsigned int count, unsigned int update_repeats);
+/* src/likelihood.c:586-636. Synchronises the stream; returns -INFINITY (and sets pll_errno) on
+ * a device error. persite_lnl may be NULL. */
+double pll_compute_edge_loglikelihood(pll_partition_t *partition, unsigned int parent_clv_index,
+                                      int parent_scaler_index, unsigned int child_clv_index,
+                                      int child_scaler_index, unsigned int matrix_index,
+                                      const unsigned int *freqs_indices, double *persite_lnl);
+/* src/likelihood.c:122-189 ("next" row f3) */
+double pll_compute_root_loglikelihood(pll_partition_t *partition, unsigned int clv_index,
+                                      int scaler_index, const unsigned int *freqs_indices,
+                                      double *persite_lnl);
+
+/* ---- site repeats bookkeeping (src/pll.h:682-742, src/repeats.c) --------------------------- */
+#define PLL_GET_ID(site_id, site) ((site_id) ? ((site_id)[(site)]) : (site))
+#define PLL_GET_SITE(id_site, site) ((id_site) ? ((id_site)[(site)]) : (site))
+int pll_repeats_enabled(const pll_partition_t *partition);
+void pll_resize_repeats_lookup(pll_partition_t *partition, unsigned int size);
+unsigned int pll_get_sites_number(const pll_partition_t *partition, unsigned int clv_index);
+unsigned int *pll_get_site_id(const pll_partition_t *partition, unsigned int clv_index);
+unsigned int *pll_get_id_site(const pll_partition_t *partition, unsigned int clv_index);
+unsigned int pll_get_clv_size(const pll_partition_t *partition, unsigned int clv_index);
+unsigned int pll_default_enable_repeats(pll_partition_t *partition, unsigned int left_clv,
+                                        unsigned int right_clv);
+unsigned int pll_no_enable_repeats(pll_partition_t *partition, unsigned int left_clv,
+                                   unsigned int right_clv);
+void pll_default_reallocate_repeats(pll_partition_t *partition, unsigned int parent,
+                                    int scaler_index, unsigned int sites_to_alloc);
+int pll_repeats_initialize(pll_partition_t *partition);
+int pll_update_repeats_tips(pll_partition_t *partition, unsigned int tip_index,
+                            const pll_state_t *map, const char *sequence);
+void pll_update_repeats(pll_partition_t *partition, const pll_operation_t *op);
+void pll_disable_bclv(pll_partition_t *partition);
+void pll_fill_parent_scaler(unsigned int scaler_size, unsigned int *parent_scaler,
+                            const unsigned int *left_scaler, const unsigned int *right_scaler);
+
+/* ---- device-residency contract (new; SURVEY section 7 "hard parts" 1 and 2) ---------------- */
+/* CLVs and scalers live in HBM; partition->clv[i] / scale_buffer[i] are a lazily refreshed host
+ * mirror. Callers that read those arrays directly call one of these first. */
+int pll_gpu_sync_clv(pll_partition_t *partition, unsigned int clv_index);     /* D2H one CLV */
+int pll_gpu_sync_scaler(pll_partition_t *partition, unsigned int scaler_index);
+int pll_gpu_sync_all(pll_partition_t *partition);
+/* Callers that WRITE partition arrays directly (instead of through the setters above) tell the
+ * library which device copies are stale. what = bitwise OR of PLL_GPU_DIRTY_*; index = array
+ * slot or -1 for "all". */
+#define PLL_GPU_DIRTY_PMATRIX 1u
+#define PLL_GPU_DIRTY_FREQS 2u
+#define PLL_GPU_DIRTY_RATE_WEIGHTS 4u
+#define PLL_GPU_DIRTY_PATTERN_WEIGHTS 8u
+#define PLL_GPU_DIRTY_INVARIANT 16u
+#define PLL_GPU_DIRTY_CLV 32u    /* host copy of clv[index] is newer than the device copy */
+#define PLL_GPU_DIRTY_SCALER 64u
+#define PLL_GPU_DIRTY_TIPCHARS 128u
+#define PLL_GPU_DIRTY_REPEATS 256u
+void pll_gpu_invalidate(pll_partition_t *partition, unsigned int what, int index);
+/* stream plumbing: by default each partition owns a stream; a harness may substitute its own
+ * (a hipStream_t passed as void*) so that its events see the kernels. */
+int pll_gpu_set_stream(pll_partition_t *partition, void *hip_stream);
+void *pll_gpu_get_stream(const pll_partition_t *partition);
+int pll_gpu_synchronize(pll_partition_t *partition);
+/* HIP-event stopwatch on the partition's stream (bench.py's roofline leg): start .. stop
+ * brackets whatever was enqueued in between; returns elapsed milliseconds from stop(). */
+int pll_gpu_timer_start(pll_partition_t *partition);
+double pll_gpu_timer_stop(pll_partition_t *partition);
+/* number of kernel launches issued by the last pll_update_partials call (bench bookkeeping) */
+unsigned int pll_gpu_last_launch_count(const pll_partition_t *partition);
+int pll_gpu_device_count(void);
+/* 1 if a usable gfx950 device is present, 0 otherwise (the analogue of src/hardware.c's probe) */
+int pll_gpu_available(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLL_AMD_H_ */

@@ -1,0 +1,84 @@
+/*
+ * pll_oracle.h - CPU restatement of the libpll-2 partial-likelihood hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY. Nothing under libpll-2_amd/ (the product) may include, link, dlopen
+ * or execute this code; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do,
+ * and there only as the checker. Parity status: PINNED - the restatement is checked against
+ * (a) the reference itself (oracle/_ref/libpll_ref.so, built from /root/reference/src by
+ * oracle/Makefile) on randomised inputs in tests/test_oracle_vs_reference.py (authoring
+ * container only) and (b) the committed golden vectors under tests/golden/, which were produced
+ * by the reference (oracle/gen_golden.py) and include the values pinned by the reference's own
+ * test outputs (the .out files under test/out).
+ *
+ * Plain scalar C, flat arrays, no partition object. Layouts are the reference's:
+ *   clv     [entry][rate][states_padded]            (src/pll.c:565-567)
+ *   pmatrix [rate][row = parent state][states_padded] (src/pll.c:598-611, src/core_pmatrix.c:230-234)
+ *   scaler  [entry] or [entry][rate] with per-rate scaling (src/pll.c:838-857)
+ */
+#ifndef PLL_ORACLE_H_
+#define PLL_ORACLE_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef unsigned long long orc_state_t;
+
+/* One child of a CLV update or one end of an edge. Exactly one of clv / tipchars is non-NULL. */
+typedef struct orc_child
+{
+  const double *clv;             /* dense CLV, or NULL */
+  const unsigned char *tipchars; /* PATTERN_TIP codes, or NULL (src/pll.c:875-957) */
+  const orc_state_t *tipmap;     /* code -> state bitmask; NULL means code IS the mask (4-state) */
+  const unsigned int *scaler;    /* or NULL */
+  const unsigned int *site_id;   /* site -> entry (site repeats), or NULL for identity */
+} orc_child_t;
+
+/* scale_mode: 0 = parent has no scaler, 1 = per-site, 2 = per-rate (PLL_ATTRIB_RATE_SCALERS).
+ * parent_id_site: entry -> representative site (site repeats), or NULL for identity.
+ * Follows src/core_partials.c:691-764 (ii), :273-351 + :462-507 (ti), :48-80 + :1013-1071 (tt,
+ * evaluated directly instead of through the lookup table), :797-879 (repeats). Per-rate scaling
+ * is honoured for every child kind, as the reference's AVX/AVX2 kernels do
+ * (src/core_partials_avx2.c:109-125,281); only states < `states` take part in the scaling test. */
+void orc_update_partial(unsigned int states, unsigned int states_padded, unsigned int rate_cats,
+                        unsigned int parent_entries, double *parent_clv,
+                        unsigned int *parent_scaler, const unsigned int *parent_id_site,
+                        const orc_child_t *left, const double *left_matrix,
+                        const orc_child_t *right, const double *right_matrix, int scale_mode);
+
+/* Edge log-likelihood, src/core_likelihood.c:1361-1495 (ii), :785-920 (ti), :1049-1188
+ * (repeats). `sites` = alignment sites; both ends are addressed through their site_id maps.
+ * frequencies: array of pointers [rate_matrices] -> [states_padded]. invariant may be NULL,
+ * prop_invar may be NULL. persite_lnl may be NULL. Sequential summation in site order. */
+double orc_edge_loglikelihood(unsigned int states, unsigned int states_padded,
+                              unsigned int rate_cats, unsigned int sites,
+                              const orc_child_t *parent, const orc_child_t *child,
+                              const double *pmatrix, const double *const *frequencies,
+                              const double *rate_weights, const unsigned int *pattern_weights,
+                              const double *prop_invar, const int *invariant,
+                              const unsigned int *freqs_indices, double *persite_lnl,
+                              int per_rate_scaling);
+
+/* Root log-likelihood, src/core_likelihood.c:25-209 / src/core_likelihood_avx.c:25-111. The
+ * reference indexes the scaler per site even when PLL_ATTRIB_RATE_SCALERS lays it out [site][rate]
+ * (src/core_likelihood.c:197-198); here per-rate scalers are combined the way the edge routine
+ * does (min over rates + capped excess). Without per-rate scaling the two coincide. */
+double orc_root_loglikelihood(unsigned int states, unsigned int states_padded,
+                              unsigned int rate_cats, unsigned int sites, const orc_child_t *node,
+                              const double *const *frequencies, const double *rate_weights,
+                              const unsigned int *pattern_weights, const double *prop_invar,
+                              const int *invariant, const unsigned int *freqs_indices,
+                              double *persite_lnl, int per_rate_scaling);
+
+/* Site-repeats class ids for a parent, src/repeats.c:334-347: first-occurrence numbering of the
+ * pairs (left id, right id). Returns the number of classes; site_id_parent[sites],
+ * id_site_parent[<= sites] are filled. Own O(n log n)-free restatement with a direct table. */
+unsigned int orc_repeat_classes(unsigned int sites, const unsigned int *site_id_left,
+                                unsigned int ids_left, const unsigned int *site_id_right,
+                                unsigned int ids_right, unsigned int *site_id_parent,
+                                unsigned int *id_site_parent);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
