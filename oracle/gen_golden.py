@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (oracle/_ref/libpll_ref.so).
+
+TEST INFRASTRUCTURE ONLY; runs in the authoring container (needs /root/reference for the
+pinned values in test/out/*.out and oracle/_ref built by oracle/Makefile). Every fixture holds
+the inputs of one case and the outputs the reference's AVX2 path produced for them. The three
+"kat_*" fixtures replay the reference's own self-contained tests (test/src/00010_NMDU_lkcalc.c,
+00011_NMAU_lkcalc.c, 00012_NMOU_lkcalc.c, 00020_NMDR_lkcalc.c) through the reference's model API
+and additionally store the log-likelihoods pinned in test/out/*.out; generation asserts that
+the library reproduces those pinned numbers to their printed precision.
+
+usage: python oracle/gen_golden.py [outdir]
+"""
+import os
+import re
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "libpll-2_amd"))
+sys.path.insert(0, ROOT)
+
+from pllamd import api, driver, fixtures, workload as W  # noqa: E402
+
+REF_ROOT = os.environ.get("PLL_REFERENCE", "/root/reference")
+REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libpll_ref.so")
+
+
+def ref_pmatrices(ref, states, exch, freqs, alpha, cats, brlens, arch=api.ARCH_AVX2):
+    """P-matrices through the reference's own model code (src/models.c:293-443,
+    src/gamma.c:220-292)."""
+    p = ref.pll_partition_create(2, 1, states, 4, 1, len(brlens), cats, 0, arch)
+    assert p
+    part = p.contents
+    sp = part.states_padded
+    f = np.ascontiguousarray(freqs, dtype=np.float64)
+    e = np.ascontiguousarray(exch, dtype=np.float64)
+    rates = np.zeros(cats)
+    assert ref.pll_compute_gamma_cats(alpha, cats, api.dptr(rates), 0)
+    ref.pll_set_frequencies(p, 0, api.dptr(f))
+    ref.pll_set_subst_params(p, 0, api.dptr(e))
+    ref.pll_set_category_rates(p, api.dptr(rates))
+    pi = np.zeros(cats, dtype=np.uint32)
+    mi = np.arange(len(brlens), dtype=np.uint32)
+    bl = np.ascontiguousarray(brlens, dtype=np.float64)
+    assert ref.pll_update_prob_matrices(p, api.uptr(pi), api.uptr(mi), api.dptr(bl), len(brlens))
+    out = np.empty((len(brlens), cats, states, states))
+    for i in range(len(brlens)):
+        out[i] = api.as_np(part.pmatrix[i], cats * states * sp, np.float64).reshape(cats, states, sp)[:, :, :states]
+    ref.pll_partition_destroy(p)
+    return out, rates
+
+
+def parse_out(name):
+    """pinned 'inner-inner logL' / 'tip-inner logL' / 'persite logL' lines of test/out/NAME.out"""
+    txt = open(os.path.join(REF_ROOT, "test", "out", name + ".out")).read()
+    lnl = [float(x) for x in re.findall(r"(?:inner-inner|tip-inner) logL:\s+(-?[0-9.]+)", txt)]
+    per = [[float(v) for v in m.split()] for m in re.findall(r"persite logL:\s+([-0-9. ]+)\n", txt)]
+    return lnl, per
+
+
+KAT_OPS = [(5, -1, 0, 1, -1, 1, 1, -1), (6, -1, 5, 0, -1, 2, 1, -1), (7, -1, 3, 1, -1, 4, 1, -1)]
+KAT_OPS2 = [(7, -1, 6, 0, -1, 3, 1, -1)]  # "move to tip inner" second call in the reference tests
+
+
+def odd_map():
+    """7-state map of test/src/00012_NMOU_lkcalc.c:32-44 (A..G; E is the ambiguity C|D)."""
+    m = np.zeros(256, dtype=np.uint64)
+    for i, v in enumerate([0x01, 0x02, 0x04, 0x08, 0x0C, 0x10, 0x20]):
+        m[ord("A") + i] = m[ord("a") + i] = v
+    for ch in "*-?":
+        m[ord(ch)] = 0x3F
+    return m
+
+
+def kat_cases(ref):
+    dayhoff_r = ref.const_doubles("pll_aa_rates_dayhoff", 190)
+    dayhoff_f = ref.const_doubles("pll_aa_freqs_dayhoff", 20)
+    specs = [
+        ("00010_NMDU_lkcalc", 4, [1, 2.5, 1, 1, 2.5, 1], [0.3, 0.4, 0.1, 0.2], W.map_nt(),
+         [b"WAC-CTA-ATCT", b"CCC-TTA-ATGT", b"A-C-TAG-CTCT", b"CTCTTAA-A-CG", b"CAC-TCA-A-TG"]),
+        ("00011_NMAU_lkcalc", 20, dayhoff_r, dayhoff_f, W.map_aa(),
+         [b"PIGLRVTLRRDRMWI", b"IQGMDITIVT-----", b"--AFALLQKIGMPFE", b"MDISIVT------TA", b"GLSEQTVFHEIDQDK"]),
+        ("00012_NMOU_lkcalc", 7,
+         [0.5, 2.0, 3.0, 4.0, 5.0, 1.1, 1.2, 1.3, 1.4, 1.5, 2.1, 2.2, 2.3, 2.4, 2.5, 3.1, 3.2, 3.3, 3.4, 3.5, 1.0],
+         [0.12, 0.14, 0.13, 0.11, 0.15, 0.13, 0.12], odd_map(),
+         [b"AAB-CCD-EFAA", b"ACC-FBA-ABGG", b"A-C-GAG-GCCF", b"ADCFCAA-A-CG", b"ABC-BCA-A-BG"]),
+    ]
+    for test, states, exch, freqs, cmap, seqs in specs:
+        pm, _ = ref_pmatrices(ref, states, exch, freqs, 0.5, 4, [0.1, 0.2, 1.0, 1.0])
+        pm_all = np.zeros((7,) + pm.shape[1:])
+        pm_all[:4] = pm
+        pinned_lnl, pinned_ps = parse_out(test)
+        for attr, tag in ((0, "plain"), (api.PATTERN_TIP, "tip")):
+            # first evaluation: three ops, edge (6,7) over matrix 0
+            case = driver.Case(name=f"kat_{test[:5]}_{tag}", states=states, rate_cats=4, tips=5, sites=len(seqs[0]),
+                               pmatrix=pm_all, freqs=np.asarray(freqs)[None, :], op_batches=[KAT_OPS],
+                               edges=[(6, -1, 7, -1, 0)], charmap=cmap, sequences=seqs, attributes=attr,
+                               clv_buffers=4, scale_buffers=0)
+            yield case, dict(kat_lnl=pinned_lnl[0], kat_persite=pinned_ps[0], source=f"test/out/{test}.out")
+            # second evaluation: re-rooted at the tip edge (7,4) over matrix 1
+            case2 = driver.Case(name=f"kat_{test[:5]}_{tag}_tipedge", states=states, rate_cats=4, tips=5,
+                                sites=len(seqs[0]), pmatrix=pm_all, freqs=np.asarray(freqs)[None, :],
+                                op_batches=[KAT_OPS, KAT_OPS2], edges=[(7, -1, 4, -1, 1)], charmap=cmap,
+                                sequences=seqs, attributes=attr, clv_buffers=4, scale_buffers=0)
+            yield case2, dict(kat_lnl=pinned_lnl[1], kat_persite=pinned_ps[1], source=f"test/out/{test}.out")
+    # rooted variant: pll_compute_root_loglikelihood (test/src/00020_NMDR_lkcalc.c)
+    pm, _ = ref_pmatrices(ref, 4, [1, 2.5, 1, 1, 2.5, 1], [0.3, 0.4, 0.1, 0.2], 0.5, 4, [0.5, 0.5, 0.3, 0.2])
+    pm_all = np.zeros((8,) + pm.shape[1:])
+    pm_all[:4] = pm
+    pinned_lnl, pinned_ps = parse_out("00020_NMDR_lkcalc")
+    seqs = [b"WAC-CTA-ATCT", b"CCC-TTA-ATGT", b"A-C-TAG-CTCT", b"CTCTTAA-A-CG", b"CAC-TCA-A-TG"]
+    for attr, tag in ((0, "plain"), (api.PATTERN_TIP, "tip")):
+        case = driver.Case(name=f"kat_00020_{tag}", states=4, rate_cats=4, tips=5, sites=12, pmatrix=pm_all,
+                           freqs=np.array([[0.3, 0.4, 0.1, 0.2]]),
+                           op_batches=[KAT_OPS + [(8, -1, 7, 2, -1, 6, 3, -1)]], edges=[], roots=[(8, -1)],
+                           charmap=W.map_nt(), sequences=seqs, attributes=attr, clv_buffers=5, scale_buffers=0)
+        yield case, dict(kat_root_lnl=pinned_lnl[0], kat_root_persite=pinned_ps[0],
+                         source="test/out/00020_NMDR_lkcalc.out")
+
+
+def synthetic_cases():
+    A = api
+    yield W.make_case("dna_plain", 4, 8, 160, ambiguity_pct=5)
+    yield W.make_case("dna_tip", 4, 8, 160, attributes=A.PATTERN_TIP, ambiguity_pct=5)
+    yield W.make_case("dna_repeats", 4, 16, 256, attributes=A.SITE_REPEATS, mutate_pct=10)
+    yield W.make_case("dna_rates8", 4, 8, 96, rate_cats=8)
+    yield W.make_case("dna_rates1", 4, 8, 96, rate_cats=1, attributes=A.PATTERN_TIP)
+    yield W.make_case("dna_rates2_rs", 4, 8, 96, rate_cats=2, attributes=A.RATE_SCALERS)
+    yield W.make_case("dna_pinv", 4, 16, 200, pinv=0.3, mutate_pct=5)
+    yield W.make_case("dna_pinv_tip", 4, 16, 200, pinv=0.3, mutate_pct=5, attributes=A.PATTERN_TIP)
+    rng = np.random.Generator(np.random.PCG64(5))
+    yield W.make_case("dna_weights", 4, 8, 128, pattern_weights=rng.integers(1, 50, 128).astype(np.uint32))
+    # deep trees that actually rescale (SURVEY section 8a note on scaling coverage)
+    yield W.make_case("dna_deep_site", 4, 300, 48, tree="caterpillar", brlen_scale=3)
+    yield W.make_case("dna_deep_rate", 4, 300, 48, tree="caterpillar", brlen_scale=3, attributes=A.RATE_SCALERS)
+    yield W.make_case("dna_deep_tip", 4, 300, 48, tree="caterpillar", brlen_scale=3, attributes=A.PATTERN_TIP)
+    yield W.make_case("dna_deep_tip_rate", 4, 300, 48, tree="caterpillar", brlen_scale=3,
+                      attributes=A.PATTERN_TIP | A.RATE_SCALERS)
+    yield W.make_case("dna_deep_repeats", 4, 300, 48, tree="caterpillar", brlen_scale=3, attributes=A.SITE_REPEATS,
+                      mutate_pct=3)
+    yield W.make_case("dna_deep_pinv", 4, 300, 48, tree="caterpillar", brlen_scale=3, pinv=0.2, mutate_pct=2)
+    yield W.make_case("dna_deep_pinv_rate", 4, 300, 48, tree="caterpillar", brlen_scale=3, pinv=0.2, mutate_pct=2,
+                      attributes=A.RATE_SCALERS)
+    yield W.make_case("aa_plain", 20, 8, 64, ambiguity_pct=5)
+    yield W.make_case("aa_tip", 20, 8, 64, attributes=A.PATTERN_TIP, ambiguity_pct=5)
+    yield W.make_case("aa_repeats", 20, 8, 96, attributes=A.SITE_REPEATS, mutate_pct=5)
+    yield W.make_case("aa_deep_rate_repeats", 20, 200, 32, tree="caterpillar", brlen_scale=3,
+                      attributes=A.RATE_SCALERS | A.SITE_REPEATS, mutate_pct=5)
+    yield W.make_case("aa_deep_tip", 20, 200, 32, tree="caterpillar", brlen_scale=3, attributes=A.PATTERN_TIP)
+    yield W.make_case("s5_plain", 5, 8, 64)
+    yield W.make_case("s5_tip_rs", 5, 8, 64, attributes=A.PATTERN_TIP | A.RATE_SCALERS)
+    yield W.make_case("s7_plain", 7, 8, 64, ambiguity_pct=5)
+    yield W.make_case("s61_plain", 61, 8, 24)
+    yield W.make_case("s61_tip", 61, 8, 24, attributes=A.PATTERN_TIP)
+    yield W.make_case("s61_clvtips", 61, 8, 24, tips_as="clv")
+    yield W.make_case("s64_plain", 64, 4, 16)
+
+
+def main():
+    outdir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    ref = api.PllLib(REF_LIB)
+    n = 0
+    for case, extra in kat_cases(ref):
+        exp = driver.run_case(ref, case, api.ARCH_AVX2)
+        if "kat_lnl" in extra:
+            assert abs(exp["lnl"][0] - extra["kat_lnl"]) < 5.1e-7, (case.name, exp["lnl"], extra["kat_lnl"])
+            assert np.allclose(exp["persite"][0], extra["kat_persite"], atol=5.1e-8, rtol=0), case.name
+        else:
+            assert abs(exp["root_lnl"][0] - extra["kat_root_lnl"]) < 5.1e-7, (case.name, exp["root_lnl"])
+            assert np.allclose(exp["root_persite"][0], extra["kat_root_persite"], atol=5.1e-8, rtol=0)
+        fixtures.save(os.path.join(outdir, case.name + ".npz"), case, exp, extra)
+        n += 1
+    for case in synthetic_cases():
+        exp = driver.run_case(ref, case, api.ARCH_AVX2)
+        # the reference's generic C path must agree with its AVX2 path (sanity of the fixture)
+        exp_cpu = driver.run_case(ref, case, api.ARCH_CPU)
+        assert abs(exp["lnl"][0] - exp_cpu["lnl"][0]) <= 1e-11 * abs(exp["lnl"][0]), case.name
+        nscal = int(sum(int(v.sum()) for v in exp["scaler"].values()))
+        # keep fixtures small: only the last few parents' CLVs
+        keep = sorted(exp["clv"])[-4:]
+        exp["clv"] = {k: exp["clv"][k] for k in keep}
+        exp["scaler"] = {k: v for k, v in exp["scaler"].items() if k in keep}
+        case.dump_clvs = keep
+        fixtures.save(os.path.join(outdir, case.name + ".npz"), case, exp, dict(scalings=nscal, source="oracle/_ref AVX2"))
+        n += 1
+    # model constants the synthetic protein workload uses (data exported by the reference library)
+    np.savez_compressed(os.path.join(outdir, "model_lg.npz"), rates=ref.const_doubles("pll_aa_rates_lg", 190),
+                        freqs=ref.const_doubles("pll_aa_freqs_lg", 20))
+    size = sum(os.path.getsize(os.path.join(outdir, f)) for f in os.listdir(outdir))
+    print(f"wrote {n} fixtures (+model_lg.npz) to {outdir}: {size / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
