@@ -190,9 +190,7 @@ void pll_set_category_rates(pll_partition_t *partition, const double *rates);
 void pll_set_category_weights(pll_partition_t *partition, const double *rate_weights);
 int pll_update_invariant_sites_proportion(pll_partition_t *partition, unsigned int params_index,
                                           double prop_invar); /* src/models.c:495-540 */
-int pll_update_invariant_sites(pll_partition_t *partition);  /* src/models.c:628-752 */
-unsigned int pll_count_invariant_sites(pll_partition_t *partition,
-                                       unsigned int *state_inv_count); /* src/models.c:542-626 */
+int pll_update_invariant_sites(pll_partition_t *partition);  /* src/models.c:651-752 */
 
 /* model side ("next" rows f2 of SURVEY section 8; host code, feeds the path) */
 int pll_update_eigen(pll_partition_t *partition, unsigned int params_index); /* models.c:293 */

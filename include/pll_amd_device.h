@@ -1,0 +1,134 @@
+/*
+ * pll_amd_device.h - the thin C ABI between the C host code (libpll-2_amd/csrc/host) and the
+ * HIP translation unit (libpll-2_amd/csrc/hip/pllgpu.hip) that owns the gfx950 kernels.
+ *
+ * Plain C: opaque context handle, indices, pointers and sizes only. The host side keeps every
+ * libpll-2 semantic (pll_partition_t bookkeeping, op classification, dependency levels, site
+ * repeats, error convention); this layer only moves bytes and launches kernels. Each entry point
+ * names the reference routine whose arithmetic it replaces.
+ *
+ * All functions return 0 on success or a negative pllgpu_status; pllgpu_last_error() gives text.
+ */
+#ifndef PLL_AMD_DEVICE_H_
+#define PLL_AMD_DEVICE_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pllgpu_ctx pllgpu_ctx_t;
+
+enum pllgpu_status
+{
+  PLLGPU_OK = 0,
+  PLLGPU_ENODEVICE = -1, /* no gfx950 device / HIP runtime unusable */
+  PLLGPU_ENOMEM = -2,
+  PLLGPU_ERUNTIME = -3,  /* a HIP call failed */
+  PLLGPU_EINVAL = -4,
+  PLLGPU_EUNSUPPORTED = -5
+};
+
+/* shape of one partition (immutable for the life of the context) */
+typedef struct pllgpu_geometry
+{
+  unsigned int tips;
+  unsigned int nodes;          /* tips + clv_buffers */
+  unsigned int states;
+  unsigned int states_padded;  /* host stride, kept on the device: mirror copies are memcpy */
+  unsigned int rate_cats;
+  unsigned int sites;          /* alignment sites */
+  unsigned int sites_alloc;    /* sites + asc-bias extra sites */
+  unsigned int prob_matrices;
+  unsigned int rate_matrices;
+  unsigned int scale_buffers;
+  unsigned int per_rate_scalers; /* PLL_ATTRIB_RATE_SCALERS */
+  unsigned int pattern_tip;      /* PLL_ATTRIB_PATTERN_TIP */
+} pllgpu_geometry_t;
+
+/* one CLV update after host-side classification (src/partials.c:24-235) */
+#define PLLGPU_OP_LEFT_TIP 1u   /* left child is given by tip codes, not a CLV */
+#define PLLGPU_OP_RIGHT_TIP 2u
+#define PLLGPU_OP_GATHER 4u     /* at least one of the three nodes is class-compressed */
+typedef struct pllgpu_op
+{
+  unsigned int parent_clv, left_clv, right_clv;       /* node indices */
+  int parent_scaler, left_scaler, right_scaler;       /* scale buffer indices or -1 */
+  unsigned int left_matrix, right_matrix;
+  unsigned int parent_entries;                        /* sites, or class count under repeats */
+  unsigned int flags;
+  unsigned int level;                                 /* dependency level, 0-based */
+} pllgpu_op_t;
+
+typedef struct pllgpu_edge
+{
+  unsigned int parent_clv, child_clv; /* parent is always a CLV node; child may be a tip */
+  int parent_scaler, child_scaler;
+  unsigned int matrix;
+  unsigned int child_is_tip;
+  unsigned int gather;                /* either end class-compressed */
+  const unsigned int *freqs_indices;  /* host, [rate_cats] */
+  int want_persite;
+} pllgpu_edge_t;
+
+int pllgpu_device_count(void);
+const char *pllgpu_last_error(void);
+
+pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device);
+void pllgpu_destroy(pllgpu_ctx_t *ctx);
+
+/* ---- data movement ------------------------------------------------------------------------ */
+/* entries = number of site entries (each entry is rate_cats*states_padded doubles) */
+int pllgpu_clv_reserve(pllgpu_ctx_t *ctx, unsigned int node, unsigned int entries);
+int pllgpu_clv_upload(pllgpu_ctx_t *ctx, unsigned int node, const double *host, unsigned int entries);
+int pllgpu_clv_download(pllgpu_ctx_t *ctx, unsigned int node, double *host, unsigned int entries);
+int pllgpu_scaler_reserve(pllgpu_ctx_t *ctx, unsigned int index, unsigned int entries);
+int pllgpu_scaler_upload(pllgpu_ctx_t *ctx, unsigned int index, const unsigned int *host,
+                         unsigned int entries);
+int pllgpu_scaler_download(pllgpu_ctx_t *ctx, unsigned int index, unsigned int *host,
+                           unsigned int entries);
+int pllgpu_tipchars_upload(pllgpu_ctx_t *ctx, unsigned int tip, const unsigned char *host,
+                           unsigned int count);
+/* code -> state mask table; NULL selects "code is the mask" (4-state, src/pll.c:875-910) */
+int pllgpu_tipmap_upload(pllgpu_ctx_t *ctx, const unsigned long long *host, unsigned int count);
+/* host_block: count matrices in the reference layout [rate][row][states_padded], contiguous
+ * (src/pll.c:593-611); re-laid-out for the kernels during the upload */
+int pllgpu_pmatrix_upload(pllgpu_ctx_t *ctx, unsigned int first, unsigned int count,
+                          const double *host_block);
+int pllgpu_frequencies_upload(pllgpu_ctx_t *ctx, unsigned int index, const double *host);
+int pllgpu_rate_weights_upload(pllgpu_ctx_t *ctx, const double *host);
+int pllgpu_prop_invar_upload(pllgpu_ctx_t *ctx, const double *host);
+int pllgpu_pattern_weights_upload(pllgpu_ctx_t *ctx, const unsigned int *host, unsigned int count);
+int pllgpu_invariant_upload(pllgpu_ctx_t *ctx, const int *host /* or NULL */, unsigned int count);
+/* site repeats maps of one node (src/pll.h:292-297): site_id[sites_alloc] site -> class,
+ * id_site[ids] class -> representative site; ids == 0 clears (node not compressed) */
+int pllgpu_repeats_upload(pllgpu_ctx_t *ctx, unsigned int node, const unsigned int *site_id,
+                          const unsigned int *id_site, unsigned int ids);
+
+/* ---- compute ------------------------------------------------------------------------------ */
+/* replaces pll_core_update_partial_{ii,ti,tt,repeats} + pll_core_create_lookup
+ * (src/core_partials.c:48-1210). Asynchronous on the context's stream. ops must be sorted by
+ * level; ops of one level are independent. */
+int pllgpu_update_partials(pllgpu_ctx_t *ctx, const pllgpu_op_t *ops, unsigned int count);
+/* replaces pll_core_edge_loglikelihood_{ii,ti,ti_4x4,repeats} (src/core_likelihood.c:351-1496).
+ * Synchronises. persite_host may be NULL. */
+int pllgpu_edge_loglikelihood(pllgpu_ctx_t *ctx, const pllgpu_edge_t *edge, double *persite_host,
+                              double *lnl_out);
+/* replaces pll_core_root_loglikelihood[_repeats] (src/core_likelihood.c:25-349) */
+int pllgpu_root_loglikelihood(pllgpu_ctx_t *ctx, unsigned int clv, int scaler, unsigned int gather,
+                              const unsigned int *freqs_indices, double *persite_host,
+                              double *lnl_out);
+
+/* ---- stream / timing ---------------------------------------------------------------------- */
+int pllgpu_set_stream(pllgpu_ctx_t *ctx, void *hip_stream);
+void *pllgpu_get_stream(const pllgpu_ctx_t *ctx);
+int pllgpu_synchronize(pllgpu_ctx_t *ctx);
+int pllgpu_timer_start(pllgpu_ctx_t *ctx);
+double pllgpu_timer_stop(pllgpu_ctx_t *ctx); /* ms, < 0 on error */
+unsigned int pllgpu_last_launch_count(const pllgpu_ctx_t *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

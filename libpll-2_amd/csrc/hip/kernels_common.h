@@ -1,0 +1,137 @@
+// kernels_common.h - device-side structures shared by the gfx950 kernels.
+//
+// Data layout in HBM (DESIGN.md "Data layout"):
+//   CLV      [entry][rate][states_padded] doubles - the reference's own site-major layout
+//            (src/pll.c:565-567), so one wavefront reads 64 consecutive 8/16/32-byte pieces.
+//   scaler   [entry] or [entry][rate] unsigned (src/pll.c:838-857)
+//   P matrix per branch, TRANSPOSED relative to the reference: PT[rate][col j][row i padded to
+//            SPT]; a kernel walking the contraction index j then finds the ICH parent-state
+//            coefficients it needs contiguous at a wave-uniform address (scalar loads).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PLLGPU_SCALE_FACTOR 0x1p256
+#define PLLGPU_SCALE_THRESHOLD 0x1p-256
+#define PLLGPU_LOG_THRESHOLD (-177.445678223345993274)  /* log(2^-256) = -256 ln 2 */
+#define PLLGPU_RATE_MAXDIFF 4u
+
+constexpr int kMaxOpsPerLaunch = 32;
+constexpr int kMaxRates = 64;
+
+// one CLV update, device pointers resolved on the host side of the HIP TU
+struct DevOp
+{
+  double *parent;
+  const double *left;          // null when the child is a tip given by codes
+  const double *right;
+  const unsigned char *ltip;   // tip codes or null
+  const unsigned char *rtip;
+  unsigned *pscaler;           // null = no scaling for this op
+  const unsigned *lscaler;
+  const unsigned *rscaler;
+  const double *lmat;          // PT layout
+  const double *rmat;
+  const unsigned *id_site;     // parent entry -> representative site, or null
+  const unsigned *lsid;        // site -> left entry, or null
+  const unsigned *rsid;
+  unsigned entries;
+  unsigned pad_;
+};
+
+// passed BY VALUE as a kernel argument: descriptors arrive through the kernarg segment (scalar
+// loads, no staging copy, graph-capturable). 32 * 112 B = 3584 B < 4 KiB kernarg limit.
+struct OpPack
+{
+  DevOp ops[kMaxOpsPerLaunch];
+};
+
+struct GenGeo
+{
+  unsigned S, SP, R;
+  unsigned SPT;      // padded row count of PT = nchunks * ICH
+  unsigned nchunks;  // parent-state chunks of ICH
+  unsigned RG;       // rate categories staged per LDS tile pass
+  unsigned ngroups;  // ceil(R / RG)
+  unsigned LSTR;     // LDS row stride in doubles (odd -> conflict-free ds_read_b64 by row)
+  int scale_mode;    // 0 none, 1 per site, 2 per rate
+};
+
+// one edge / root evaluation
+struct DevEdge
+{
+  const double *parent;        // CLV end (always present)
+  const double *child;         // CLV, or null (tip codes / root)
+  const unsigned char *ctip;
+  const unsigned *pscaler;
+  const unsigned *cscaler;
+  const double *mat;           // PT layout; unused for root
+  const unsigned *psid;        // site -> entry maps or null
+  const unsigned *csid;
+  const double *freqs;         // [rate_matrices][SP]
+  const double *rate_weights;  // [R]
+  const double *prop_invar;    // [rate_matrices]
+  const unsigned *pattern_weights;
+  const int *invariant;        // or null
+  double *persite;             // or null
+  double *block_sums;          // [gridDim.x]
+  unsigned sites;
+  int per_rate;
+  int is_root;
+  unsigned char fidx[kMaxRates]; // freqs_indices
+};
+
+// force a scalar (s_load) fetch for a wave-uniform read-only address: constant address space
+typedef const double __attribute__((address_space(4))) *cdouble_p;
+__device__ __forceinline__ cdouble_p as_const(const double *p)
+{
+  return (cdouble_p)(uintptr_t)p;
+}
+
+// quad (4 adjacent lanes) exchanges through DPP: no LDS traffic
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v)
+{
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ double dpp_f64_xor1(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(dpp_i32<0xB1>(hi), dpp_i32<0xB1>(lo)); // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ double dpp_f64_xor2(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(dpp_i32<0x4E>(hi), dpp_i32<0x4E>(lo)); // quad_perm [2,3,0,1]
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// log of the site likelihood with the scaling undone (src/core_likelihood.c:1462-1481 for an
+// edge, :193-198 for a root)
+__device__ __forceinline__ double finish_site(double terma, double terminv, unsigned scalings,
+                                              int is_root)
+{
+  if (is_root) return log(terma + terminv) + (scalings ? scalings * PLLGPU_LOG_THRESHOLD : 0.0);
+  if (scalings)
+  {
+    if (terminv > 0.)
+    {
+      unsigned c = scalings < PLLGPU_RATE_MAXDIFF ? scalings : PLLGPU_RATE_MAXDIFF;
+      return log(ldexp(terma, -256 * (int)c) + terminv);
+    }
+    return log(terma) + scalings * PLLGPU_LOG_THRESHOLD;
+  }
+  return log(terma + terminv);
+}
+
+// 2^(-256 d) for d = 1..4 (src/core_likelihood.c:1366-1375)
+__device__ __forceinline__ double minlh(unsigned d)
+{
+  return ldexp(1.0, -256 * (int)d);
+}

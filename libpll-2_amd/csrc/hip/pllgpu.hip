@@ -1,0 +1,735 @@
+// pllgpu.hip - device context, data movement and kernel launches behind include/pll_amd_device.h.
+// gfx950 (MI355X) only. No CPU path lives here: every compute entry point launches HIP kernels
+// or fails with an error.
+#include "../../../include/pll_amd_device.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "kernels_common.h"
+#include "kernels_dna.h"
+#include "kernels_generic.h"
+
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[256] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(call)                                                                            \
+  do                                                                                             \
+  {                                                                                              \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return fail(e_ == hipErrorOutOfMemory ? PLLGPU_ENOMEM : PLLGPU_ERUNTIME, "%s failed: %s",   \
+                  #call, hipGetErrorString(e_));                                                 \
+  } while (0)
+
+template <typename T>
+struct DevBuf
+{
+  T *p = nullptr;
+  size_t cap = 0; // elements
+  int ensure(size_t n)
+  {
+    if (n <= cap) return 0;
+    if (p)
+    {
+      HIP_TRY(hipFree(p)); // hipFree synchronises: no kernel still uses the old block
+      p = nullptr;
+      cap = 0;
+    }
+    HIP_TRY(hipMalloc(&p, n * sizeof(T)));
+    cap = n;
+    return 0;
+  }
+  void release()
+  {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct pllgpu_ctx
+{
+  pllgpu_geometry_t geo;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  // derived kernel geometry
+  GenGeo gg;
+  int ich = 0;
+  bool dna_fast = false;
+  size_t pm_stride = 0; // doubles per matrix in PT layout
+  unsigned span = 0;
+
+  std::vector<DevBuf<double>> clv;
+  std::vector<DevBuf<unsigned>> scaler;
+  std::vector<DevBuf<unsigned char>> tipchars;
+  std::vector<DevBuf<unsigned>> site_id, id_site;
+  std::vector<unsigned> ids;
+  DevBuf<unsigned long long> tipmap;
+  bool tipmap_set = false;
+  DevBuf<double> pmat, freqs, rate_weights, prop_invar, persite, block_sums, result;
+  DevBuf<unsigned> pattern_weights;
+  DevBuf<int> invariant;
+  bool invariant_set = false;
+  double *result_host = nullptr; // pinned
+  std::vector<double> stage;     // host staging for the P-matrix re-layout
+  unsigned last_launches = 0;
+};
+
+static inline int use(pllgpu_ctx *c)
+{
+  HIP_TRY(hipSetDevice(c->device));
+  return 0;
+}
+
+extern "C" const char *pllgpu_last_error(void) { return g_err; }
+
+extern "C" int pllgpu_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static void derive_geometry(pllgpu_ctx *c)
+{
+  const pllgpu_geometry_t &g = c->geo;
+  int ich = g.states <= 4 ? 4 : g.states <= 8 ? 8 : g.states <= 16 ? 16 : g.states <= 20 ? 20 : 16;
+  GenGeo &gg = c->gg;
+  gg.S = g.states;
+  gg.SP = g.states_padded;
+  gg.R = g.rate_cats;
+  gg.nchunks = (g.states + ich - 1) / ich;
+  gg.SPT = gg.nchunks * ich;
+  gg.RG = gg.nchunks == 1 ? std::min(g.rate_cats, 4u) : gg.nchunks == 2 ? std::min(g.rate_cats, 2u) : 1u;
+  gg.ngroups = (g.rate_cats + gg.RG - 1) / gg.RG;
+  gg.LSTR = (gg.RG * gg.SP) | 1u;
+  gg.scale_mode = g.per_rate_scalers ? 2 : 1;
+  c->ich = ich;
+  c->dna_fast = (g.states == 4 && g.states_padded == 4 && g.rate_cats == 4);
+  c->pm_stride = (size_t)g.rate_cats * g.states * gg.SPT;
+  c->span = g.rate_cats * g.states_padded;
+}
+
+extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
+{
+  int n = pllgpu_device_count();
+  if (n <= 0)
+  {
+    fail(PLLGPU_ENODEVICE, "no HIP device visible (hipGetDeviceCount = %d)", n);
+    return nullptr;
+  }
+  if (device < 0)
+  {
+    const char *env = getenv("PLL_AMD_DEVICE");
+    if (env)
+      device = atoi(env);
+    else if (hipGetDevice(&device) != hipSuccess)
+      device = 0;
+  }
+  if (device >= n)
+  {
+    fail(PLLGPU_EINVAL, "device %d out of range (%d visible)", device, n);
+    return nullptr;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+  {
+    fail(PLLGPU_ENODEVICE, "hipGetDeviceProperties(%d) failed", device);
+    return nullptr;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+  {
+    fail(PLLGPU_ENODEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only", device,
+         prop.gcnArchName);
+    return nullptr;
+  }
+  if (geo->states < 2 || geo->states > 64 || geo->rate_cats < 1 || geo->rate_cats > (unsigned)kMaxRates)
+  {
+    fail(PLLGPU_EUNSUPPORTED, "unsupported shape: states=%u (2..64) rate_cats=%u (1..%d)", geo->states,
+         geo->rate_cats, kMaxRates);
+    return nullptr;
+  }
+  pllgpu_ctx *c = new pllgpu_ctx();
+  c->geo = *geo;
+  c->device = device;
+  derive_geometry(c);
+  bool ok = hipSetDevice(device) == hipSuccess &&
+            hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
+            hipHostMalloc((void **)&c->result_host, 64, hipHostMallocDefault) == hipSuccess;
+  if (!ok)
+  {
+    fail(PLLGPU_ERUNTIME, "stream/event creation failed: %s", hipGetErrorString(hipGetLastError()));
+    pllgpu_destroy(c);
+    return nullptr;
+  }
+  c->own_stream = true;
+  c->clv.resize(geo->nodes);
+  c->scaler.resize(geo->scale_buffers);
+  c->tipchars.resize(geo->tips);
+  c->site_id.resize(geo->nodes);
+  c->id_site.resize(geo->nodes);
+  c->ids.assign(geo->nodes, 0);
+  if (c->pmat.ensure(c->pm_stride * geo->prob_matrices) || c->freqs.ensure((size_t)geo->rate_matrices * geo->states_padded) ||
+      c->rate_weights.ensure(geo->rate_cats) || c->prop_invar.ensure(geo->rate_matrices) ||
+      c->pattern_weights.ensure(geo->sites_alloc) || c->persite.ensure(geo->sites_alloc) ||
+      c->block_sums.ensure(4096) || c->result.ensure(8))
+  {
+    pllgpu_destroy(c);
+    return nullptr;
+  }
+  (void)hipMemsetAsync(c->pmat.p, 0, c->pmat.cap * sizeof(double), c->stream);
+  (void)hipMemsetAsync(c->prop_invar.p, 0, c->prop_invar.cap * sizeof(double), c->stream);
+  return c;
+}
+
+extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
+{
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto &b : c->clv) b.release();
+  for (auto &b : c->scaler) b.release();
+  for (auto &b : c->tipchars) b.release();
+  for (auto &b : c->site_id) b.release();
+  for (auto &b : c->id_site) b.release();
+  c->tipmap.release();
+  c->pmat.release();
+  c->freqs.release();
+  c->rate_weights.release();
+  c->prop_invar.release();
+  c->persite.release();
+  c->block_sums.release();
+  c->result.release();
+  c->pattern_weights.release();
+  c->invariant.release();
+  if (c->result_host) (void)hipHostFree(c->result_host);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+// ---- data movement ---------------------------------------------------------------------------
+// H2D copies from pageable caller memory: hipMemcpyAsync stages pageable sources before it
+// returns, so the caller may reuse its buffer; ordering with kernels is by the stream.
+#define CHECK_CTX(c)                         \
+  if (!(c)) return fail(PLLGPU_EINVAL, "null context"); \
+  if (int rc_ = use(c)) return rc_
+
+extern "C" int pllgpu_clv_reserve(pllgpu_ctx_t *c, unsigned node, unsigned entries)
+{
+  CHECK_CTX(c);
+  if (node >= c->geo.nodes) return fail(PLLGPU_EINVAL, "clv index %u out of range", node);
+  return c->clv[node].ensure((size_t)entries * c->span);
+}
+
+extern "C" int pllgpu_clv_upload(pllgpu_ctx_t *c, unsigned node, const double *host, unsigned entries)
+{
+  if (int rc = pllgpu_clv_reserve(c, node, entries)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->clv[node].p, host, (size_t)entries * c->span * sizeof(double),
+                         hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+extern "C" int pllgpu_clv_download(pllgpu_ctx_t *c, unsigned node, double *host, unsigned entries)
+{
+  CHECK_CTX(c);
+  if (node >= c->geo.nodes || (size_t)entries * c->span > c->clv[node].cap)
+    return fail(PLLGPU_EINVAL, "clv %u: download of %u entries exceeds the device buffer", node, entries);
+  HIP_TRY(hipMemcpyAsync(host, c->clv[node].p, (size_t)entries * c->span * sizeof(double),
+                         hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static inline size_t scaler_elems(const pllgpu_ctx *c, unsigned entries)
+{
+  return (size_t)entries * (c->geo.per_rate_scalers ? c->geo.rate_cats : 1u);
+}
+
+extern "C" int pllgpu_scaler_reserve(pllgpu_ctx_t *c, unsigned index, unsigned entries)
+{
+  CHECK_CTX(c);
+  if (index >= c->geo.scale_buffers) return fail(PLLGPU_EINVAL, "scale buffer %u out of range", index);
+  return c->scaler[index].ensure(scaler_elems(c, entries));
+}
+
+extern "C" int pllgpu_scaler_upload(pllgpu_ctx_t *c, unsigned index, const unsigned *host, unsigned entries)
+{
+  if (int rc = pllgpu_scaler_reserve(c, index, entries)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->scaler[index].p, host, scaler_elems(c, entries) * sizeof(unsigned),
+                         hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+extern "C" int pllgpu_scaler_download(pllgpu_ctx_t *c, unsigned index, unsigned *host, unsigned entries)
+{
+  CHECK_CTX(c);
+  if (index >= c->geo.scale_buffers || scaler_elems(c, entries) > c->scaler[index].cap)
+    return fail(PLLGPU_EINVAL, "scale buffer %u: download exceeds the device buffer", index);
+  HIP_TRY(hipMemcpyAsync(host, c->scaler[index].p, scaler_elems(c, entries) * sizeof(unsigned),
+                         hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int pllgpu_tipchars_upload(pllgpu_ctx_t *c, unsigned tip, const unsigned char *host, unsigned count)
+{
+  CHECK_CTX(c);
+  if (tip >= c->geo.tips) return fail(PLLGPU_EINVAL, "tip %u out of range", tip);
+  if (int rc = c->tipchars[tip].ensure(count)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->tipchars[tip].p, host, count, hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+extern "C" int pllgpu_tipmap_upload(pllgpu_ctx_t *c, const unsigned long long *host, unsigned count)
+{
+  CHECK_CTX(c);
+  if (!host)
+  {
+    c->tipmap_set = false;
+    return 0;
+  }
+  if (int rc = c->tipmap.ensure(256)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->tipmap.p, host, std::min(count, 256u) * sizeof(unsigned long long),
+                         hipMemcpyHostToDevice, c->stream));
+  c->tipmap_set = true;
+  return 0;
+}
+
+extern "C" int pllgpu_pmatrix_upload(pllgpu_ctx_t *c, unsigned first, unsigned count, const double *host)
+{
+  CHECK_CTX(c);
+  const pllgpu_geometry_t &g = c->geo;
+  if (first + count > g.prob_matrices) return fail(PLLGPU_EINVAL, "p-matrix range [%u,%u) out of range", first, first + count);
+  const unsigned S = g.states, SP = g.states_padded, R = g.rate_cats, SPT = c->gg.SPT;
+  const size_t host_stride = (size_t)R * S * SP;
+  // the previous async copy may still be reading the staging vector
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->stage.assign(c->pm_stride * count, 0.0);
+  for (unsigned m = 0; m < count; ++m)
+    for (unsigned k = 0; k < R; ++k)
+      for (unsigned i = 0; i < S; ++i)
+      {
+        const double *row = host + m * host_stride + ((size_t)k * S + i) * SP;
+        double *dst = c->stage.data() + m * c->pm_stride + (size_t)k * S * SPT + i;
+        for (unsigned j = 0; j < S; ++j) dst[(size_t)j * SPT] = row[j];
+      }
+  HIP_TRY(hipMemcpyAsync(c->pmat.p + (size_t)first * c->pm_stride, c->stage.data(),
+                         c->stage.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+extern "C" int pllgpu_frequencies_upload(pllgpu_ctx_t *c, unsigned index, const double *host)
+{
+  CHECK_CTX(c);
+  if (index >= c->geo.rate_matrices) return fail(PLLGPU_EINVAL, "frequency set %u out of range", index);
+  HIP_TRY(hipMemcpyAsync(c->freqs.p + (size_t)index * c->geo.states_padded, host,
+                         c->geo.states_padded * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+extern "C" int pllgpu_rate_weights_upload(pllgpu_ctx_t *c, const double *host)
+{
+  CHECK_CTX(c);
+  HIP_TRY(hipMemcpyAsync(c->rate_weights.p, host, c->geo.rate_cats * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+extern "C" int pllgpu_prop_invar_upload(pllgpu_ctx_t *c, const double *host)
+{
+  CHECK_CTX(c);
+  HIP_TRY(hipMemcpyAsync(c->prop_invar.p, host, c->geo.rate_matrices * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+extern "C" int pllgpu_pattern_weights_upload(pllgpu_ctx_t *c, const unsigned *host, unsigned count)
+{
+  CHECK_CTX(c);
+  if (count > c->geo.sites_alloc) return fail(PLLGPU_EINVAL, "pattern weight count %u > %u", count, c->geo.sites_alloc);
+  HIP_TRY(hipMemcpyAsync(c->pattern_weights.p, host, count * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+extern "C" int pllgpu_invariant_upload(pllgpu_ctx_t *c, const int *host, unsigned count)
+{
+  CHECK_CTX(c);
+  if (!host)
+  {
+    c->invariant_set = false;
+    return 0;
+  }
+  if (int rc = c->invariant.ensure(count)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->invariant.p, host, count * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  c->invariant_set = true;
+  return 0;
+}
+
+extern "C" int pllgpu_repeats_upload(pllgpu_ctx_t *c, unsigned node, const unsigned *site_id,
+                                     const unsigned *id_site, unsigned ids)
+{
+  CHECK_CTX(c);
+  if (node >= c->geo.nodes) return fail(PLLGPU_EINVAL, "node %u out of range", node);
+  c->ids[node] = ids;
+  if (!ids) return 0;
+  if (int rc = c->site_id[node].ensure(c->geo.sites_alloc)) return rc;
+  if (int rc = c->id_site[node].ensure(c->geo.sites_alloc)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->site_id[node].p, site_id, c->geo.sites_alloc * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+  if (id_site)
+    HIP_TRY(hipMemcpyAsync(c->id_site[node].p, id_site, ids * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+// ---- launches --------------------------------------------------------------------------------
+static int resolve_op(pllgpu_ctx *c, const pllgpu_op_t &o, DevOp &d)
+{
+  const pllgpu_geometry_t &g = c->geo;
+  if (o.parent_clv >= g.nodes || o.left_clv >= g.nodes || o.right_clv >= g.nodes)
+    return fail(PLLGPU_EINVAL, "operation references a CLV out of range");
+  if (o.left_matrix >= g.prob_matrices || o.right_matrix >= g.prob_matrices)
+    return fail(PLLGPU_EINVAL, "operation references a p-matrix out of range");
+  memset(&d, 0, sizeof d);
+  if (int rc = c->clv[o.parent_clv].ensure((size_t)o.parent_entries * c->span)) return rc;
+  d.parent = c->clv[o.parent_clv].p;
+  d.entries = o.parent_entries;
+  if (o.flags & PLLGPU_OP_LEFT_TIP)
+  {
+    if (o.left_clv >= g.tips || !c->tipchars[o.left_clv].p) return fail(PLLGPU_EINVAL, "tip %u has no codes on the device", o.left_clv);
+    d.ltip = c->tipchars[o.left_clv].p;
+  }
+  else
+  {
+    if (!c->clv[o.left_clv].p) return fail(PLLGPU_EINVAL, "CLV %u was never computed or uploaded", o.left_clv);
+    d.left = c->clv[o.left_clv].p;
+  }
+  if (o.flags & PLLGPU_OP_RIGHT_TIP)
+  {
+    if (o.right_clv >= g.tips || !c->tipchars[o.right_clv].p) return fail(PLLGPU_EINVAL, "tip %u has no codes on the device", o.right_clv);
+    d.rtip = c->tipchars[o.right_clv].p;
+  }
+  else
+  {
+    if (!c->clv[o.right_clv].p) return fail(PLLGPU_EINVAL, "CLV %u was never computed or uploaded", o.right_clv);
+    d.right = c->clv[o.right_clv].p;
+  }
+  auto scal = [&](int idx, const unsigned *&out, unsigned need) -> int {
+    out = nullptr;
+    if (idx < 0) return 0;
+    if ((unsigned)idx >= g.scale_buffers) return fail(PLLGPU_EINVAL, "scale buffer %d out of range", idx);
+    if (need)
+    {
+      if (int rc = c->scaler[idx].ensure(scaler_elems(c, need))) return rc;
+    }
+    else if (!c->scaler[idx].p)
+      return fail(PLLGPU_EINVAL, "scale buffer %d read before it was written", idx);
+    out = c->scaler[idx].p;
+    return 0;
+  };
+  const unsigned *ps = nullptr;
+  if (int rc = scal(o.parent_scaler, ps, o.parent_entries)) return rc;
+  d.pscaler = const_cast<unsigned *>(ps);
+  if (int rc = scal(o.left_scaler, d.lscaler, 0)) return rc;
+  if (int rc = scal(o.right_scaler, d.rscaler, 0)) return rc;
+  d.lmat = c->pmat.p + (size_t)o.left_matrix * c->pm_stride;
+  d.rmat = c->pmat.p + (size_t)o.right_matrix * c->pm_stride;
+  if (o.flags & PLLGPU_OP_GATHER)
+  {
+    d.id_site = c->ids[o.parent_clv] ? c->id_site[o.parent_clv].p : nullptr;
+    d.lsid = c->ids[o.left_clv] ? c->site_id[o.left_clv].p : nullptr;
+    d.rsid = c->ids[o.right_clv] ? c->site_id[o.right_clv].p : nullptr;
+  }
+  return 0;
+}
+
+template <int ICH>
+static void launch_generic(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
+{
+  const unsigned tiles = (maxent + 63) / 64;
+  unsigned tpb = std::max(1u, (tiles * nops) / 2048u);
+  dim3 grid((tiles + tpb - 1) / tpb, nops), block(256);
+  const size_t lds = (size_t)64 * c->gg.LSTR * sizeof(double) + 4 * 64;
+  const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
+#define GEN_LAUNCH(LT, RT, GA) \
+  hipLaunchKernelGGL((k_partials_generic<ICH, LT, RT, GA>), grid, block, lds, c->stream, pack, c->gg, tm, tpb)
+  if (kind == 0)
+  {
+    if (gather) GEN_LAUNCH(false, false, true); else GEN_LAUNCH(false, false, false);
+  }
+  else if (kind == 1)
+  {
+    if (gather) GEN_LAUNCH(true, false, true); else GEN_LAUNCH(true, false, false);
+  }
+  else
+  {
+    if (gather) GEN_LAUNCH(true, true, true); else GEN_LAUNCH(true, true, false);
+  }
+#undef GEN_LAUNCH
+}
+
+static void launch_dna(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
+{
+  // entries per block: enough blocks to fill 256 CUs several times over, at least 64 entries
+  const unsigned want_blocks = 2048;
+  unsigned epb = (unsigned)(((size_t)maxent * nops + want_blocks - 1) / want_blocks);
+  epb = std::max(64u, (epb + 63u) & ~63u);
+  dim3 grid((maxent + epb - 1) / epb, nops), block(256);
+  const int mode = c->gg.scale_mode;
+#define DNA_LAUNCH(LT, RT, GA) hipLaunchKernelGGL((k_partials_dna<LT, RT, GA>), grid, block, 0, c->stream, pack, mode, epb)
+  if (kind == 0)
+  {
+    if (gather) DNA_LAUNCH(false, false, true); else DNA_LAUNCH(false, false, false);
+  }
+  else if (kind == 1)
+  {
+    if (gather) DNA_LAUNCH(true, false, true); else DNA_LAUNCH(true, false, false);
+  }
+  else
+  {
+    if (gather) DNA_LAUNCH(true, true, true); else DNA_LAUNCH(true, true, false);
+  }
+#undef DNA_LAUNCH
+}
+
+extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, unsigned count)
+{
+  CHECK_CTX(c);
+  c->last_launches = 0;
+  unsigned i = 0;
+  while (i < count)
+  {
+    // [i, j) = one dependency level
+    unsigned j = i;
+    while (j < count && ops[j].level == ops[i].level) ++j;
+    // within the level: one launch group per (child kinds, gather) in packs of kMaxOpsPerLaunch
+    for (unsigned kind = 0; kind < 3; ++kind)
+      for (unsigned ga = 0; ga < 2; ++ga)
+      {
+        OpPack pack;
+        unsigned nops = 0, maxent = 0;
+        auto flush = [&]() {
+          if (!nops) return;
+          if (c->dna_fast)
+            launch_dna(c, pack, nops, maxent, kind, ga != 0);
+          else
+            switch (c->ich)
+            {
+              case 4: launch_generic<4>(c, pack, nops, maxent, kind, ga != 0); break;
+              case 8: launch_generic<8>(c, pack, nops, maxent, kind, ga != 0); break;
+              case 16: launch_generic<16>(c, pack, nops, maxent, kind, ga != 0); break;
+              default: launch_generic<20>(c, pack, nops, maxent, kind, ga != 0); break;
+            }
+          ++c->last_launches;
+          nops = 0;
+          maxent = 0;
+        };
+        for (unsigned o = i; o < j; ++o)
+        {
+          const unsigned f = ops[o].flags;
+          const unsigned tips = ((f & PLLGPU_OP_LEFT_TIP) ? 1u : 0u) + ((f & PLLGPU_OP_RIGHT_TIP) ? 1u : 0u);
+          if ((f & PLLGPU_OP_RIGHT_TIP) && !(f & PLLGPU_OP_LEFT_TIP))
+            return fail(PLLGPU_EINVAL, "tip-inner operations must carry the tip as the left child");
+          if (tips != kind || ((f & PLLGPU_OP_GATHER) ? 1u : 0u) != ga) continue;
+          if (ops[o].parent_entries == 0) continue;
+          if (int rc = resolve_op(c, ops[o], pack.ops[nops])) return rc;
+          maxent = std::max(maxent, ops[o].parent_entries);
+          if (++nops == (unsigned)kMaxOpsPerLaunch) flush();
+        }
+        flush();
+      }
+    i = j;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PLLGPU_ERUNTIME, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+// ---- log-likelihood ----------------------------------------------------------------------------
+template <int ICH>
+static void launch_edge_generic(pllgpu_ctx *c, const DevEdge &e, unsigned blocks, unsigned tpb, bool ctip, bool gather)
+{
+  const size_t lds = ((size_t)64 * c->gg.LSTR + 4 * 64) * sizeof(double);
+  const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
+#define EG(CT, GA) hipLaunchKernelGGL((k_edge_generic<ICH, CT, GA>), dim3(blocks), dim3(256), lds, c->stream, e, c->gg, tm, tpb)
+  if (ctip)
+  {
+    if (gather) EG(true, true); else EG(true, false);
+  }
+  else
+  {
+    if (gather) EG(false, true); else EG(false, false);
+  }
+#undef EG
+}
+
+static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsigned *freqs_indices,
+                   double *persite_host, double *lnl_out)
+{
+  const pllgpu_geometry_t &g = c->geo;
+  for (unsigned k = 0; k < g.rate_cats; ++k)
+  {
+    if (freqs_indices[k] >= g.rate_matrices) return fail(PLLGPU_EINVAL, "freqs_indices[%u] = %u out of range", k, freqs_indices[k]);
+    e.fidx[k] = (unsigned char)freqs_indices[k];
+  }
+  e.freqs = c->freqs.p;
+  e.rate_weights = c->rate_weights.p;
+  e.prop_invar = c->prop_invar.p;
+  e.pattern_weights = c->pattern_weights.p;
+  e.invariant = c->invariant_set ? c->invariant.p : nullptr;
+  e.persite = persite_host ? c->persite.p : nullptr;
+  e.block_sums = c->block_sums.p;
+  e.sites = g.sites;
+  e.per_rate = g.per_rate_scalers ? 1 : 0;
+
+  const unsigned tiles = (g.sites + 63) / 64;
+  const unsigned max_blocks = 1024;
+  const unsigned tpb = (tiles + max_blocks - 1) / max_blocks;
+  const unsigned blocks = (tiles + tpb - 1) / tpb;
+  if (c->dna_fast)
+  {
+    const unsigned spb = tpb * 64;
+#define ED(CT, GA) hipLaunchKernelGGL((k_edge_dna<CT, GA>), dim3(blocks), dim3(256), 0, c->stream, e, spb)
+    if (ctip)
+    {
+      if (gather) ED(true, true); else ED(true, false);
+    }
+    else
+    {
+      if (gather) ED(false, true); else ED(false, false);
+    }
+#undef ED
+  }
+  else
+    switch (c->ich)
+    {
+      case 4: launch_edge_generic<4>(c, e, blocks, tpb, ctip, gather); break;
+      case 8: launch_edge_generic<8>(c, e, blocks, tpb, ctip, gather); break;
+      case 16: launch_edge_generic<16>(c, e, blocks, tpb, ctip, gather); break;
+      default: launch_edge_generic<20>(c, e, blocks, tpb, ctip, gather); break;
+    }
+  hipLaunchKernelGGL(k_sum_blocks, dim3(1), dim3(256), 0, c->stream, c->block_sums.p, blocks, c->result.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(c->result_host, c->result.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (persite_host)
+    HIP_TRY(hipMemcpyAsync(persite_host, c->persite.p, g.sites * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *lnl_out = *c->result_host;
+  return 0;
+}
+
+static int scaler_ptr(pllgpu_ctx *c, int idx, const unsigned *&out)
+{
+  out = nullptr;
+  if (idx < 0) return 0;
+  if ((unsigned)idx >= c->geo.scale_buffers || !c->scaler[idx].p)
+    return fail(PLLGPU_EINVAL, "scale buffer %d unavailable on the device", idx);
+  out = c->scaler[idx].p;
+  return 0;
+}
+
+extern "C" int pllgpu_edge_loglikelihood(pllgpu_ctx_t *c, const pllgpu_edge_t *ed, double *persite_host, double *lnl_out)
+{
+  CHECK_CTX(c);
+  const pllgpu_geometry_t &g = c->geo;
+  if (ed->parent_clv >= g.nodes || ed->child_clv >= g.nodes || ed->matrix >= g.prob_matrices)
+    return fail(PLLGPU_EINVAL, "edge references an index out of range");
+  DevEdge e;
+  memset(&e, 0, sizeof e);
+  if (!c->clv[ed->parent_clv].p) return fail(PLLGPU_EINVAL, "CLV %u was never computed or uploaded", ed->parent_clv);
+  e.parent = c->clv[ed->parent_clv].p;
+  if (ed->child_is_tip)
+  {
+    if (ed->child_clv >= g.tips || !c->tipchars[ed->child_clv].p) return fail(PLLGPU_EINVAL, "tip %u has no codes on the device", ed->child_clv);
+    e.ctip = c->tipchars[ed->child_clv].p;
+  }
+  else
+  {
+    if (!c->clv[ed->child_clv].p) return fail(PLLGPU_EINVAL, "CLV %u was never computed or uploaded", ed->child_clv);
+    e.child = c->clv[ed->child_clv].p;
+  }
+  if (int rc = scaler_ptr(c, ed->parent_scaler, e.pscaler)) return rc;
+  if (int rc = scaler_ptr(c, ed->child_scaler, e.cscaler)) return rc;
+  e.mat = c->pmat.p + (size_t)ed->matrix * c->pm_stride;
+  if (ed->gather)
+  {
+    e.psid = c->ids[ed->parent_clv] ? c->site_id[ed->parent_clv].p : nullptr;
+    e.csid = c->ids[ed->child_clv] ? c->site_id[ed->child_clv].p : nullptr;
+  }
+  e.is_root = 0;
+  return run_lnl(c, e, ed->child_is_tip != 0, ed->gather != 0, ed->freqs_indices, persite_host, lnl_out);
+}
+
+extern "C" int pllgpu_root_loglikelihood(pllgpu_ctx_t *c, unsigned clv, int scaler, unsigned gather,
+                                         const unsigned *freqs_indices, double *persite_host, double *lnl_out)
+{
+  CHECK_CTX(c);
+  if (clv >= c->geo.nodes || !c->clv[clv].p) return fail(PLLGPU_EINVAL, "CLV %u unavailable on the device", clv);
+  DevEdge e;
+  memset(&e, 0, sizeof e);
+  e.parent = c->clv[clv].p;
+  if (int rc = scaler_ptr(c, scaler, e.pscaler)) return rc;
+  if (gather) e.psid = c->ids[clv] ? c->site_id[clv].p : nullptr;
+  e.is_root = 1;
+  return run_lnl(c, e, false, gather != 0, freqs_indices, persite_host, lnl_out);
+}
+
+// ---- stream / timing ---------------------------------------------------------------------------
+extern "C" int pllgpu_set_stream(pllgpu_ctx_t *c, void *s)
+{
+  CHECK_CTX(c);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  c->stream = (hipStream_t)s;
+  c->own_stream = false;
+  return 0;
+}
+
+extern "C" void *pllgpu_get_stream(const pllgpu_ctx_t *c) { return c ? (void *)c->stream : nullptr; }
+
+extern "C" int pllgpu_synchronize(pllgpu_ctx_t *c)
+{
+  CHECK_CTX(c);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int pllgpu_timer_start(pllgpu_ctx_t *c)
+{
+  CHECK_CTX(c);
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  return 0;
+}
+
+extern "C" double pllgpu_timer_stop(pllgpu_ctx_t *c)
+{
+  if (!c || use(c)) return -1.0;
+  float ms = 0;
+  if (hipEventRecord(c->ev1, c->stream) != hipSuccess || hipEventSynchronize(c->ev1) != hipSuccess ||
+      hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess)
+  {
+    fail(PLLGPU_ERUNTIME, "event timing failed");
+    return -1.0;
+  }
+  return (double)ms;
+}
+
+extern "C" unsigned pllgpu_last_launch_count(const pllgpu_ctx_t *c) { return c ? c->last_launches : 0; }

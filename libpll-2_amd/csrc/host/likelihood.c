@@ -1,0 +1,102 @@
+/* likelihood.c - pll_compute_edge_loglikelihood / pll_compute_root_loglikelihood.
+ *
+ * Case selection mirrors src/likelihood.c:586-636: site repeats on either end -> gather maps;
+ * PATTERN_TIP with a tip end -> the inner node becomes the "parent" and the tip is read as codes;
+ * otherwise two CLVs. One kernel evaluates all sites, a second sums the per-workgroup partials in
+ * a fixed order, the double comes back over PCIe (8 bytes) and the call returns it.
+ */
+#include <math.h>
+
+#include "pll_internal.h"
+
+static double fail_lnl(const char *what)
+{
+  fprintf(stderr, "libpll_amd: %s: [%d] %s\n", what, pll_errno, pll_errmsg);
+  return -INFINITY; /* the reference's failure value, src/core_likelihood.c:1384 */
+}
+
+static int prepare_end(pll_partition_t *p, pll_amd_ext_t *x, unsigned int clv, int scaler)
+{
+  if (!pll_flush_clv(p, x, clv)) return 0;
+  if (!pll_is_pattern_tip(p, clv) && !pll_flush_scaler(p, x, scaler)) return 0;
+  if (!pll_flush_repeats(p, x, clv)) return 0;
+  return 1;
+}
+
+double pll_compute_edge_loglikelihood(pll_partition_t *p, unsigned int parent_clv_index,
+                                      int parent_scaler_index, unsigned int child_clv_index,
+                                      int child_scaler_index, unsigned int matrix_index,
+                                      const unsigned int *freqs_indices, double *persite_lnl)
+{
+  pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
+  if (!x || !x->ctx)
+  {
+    pll_set_error(PLL_ERROR_GPU_UNAVAILABLE, "pll_compute_edge_loglikelihood: no MI355X context behind this partition; this library has no CPU path");
+    return fail_lnl("pll_compute_edge_loglikelihood");
+  }
+  if (parent_clv_index >= p->nodes || child_clv_index >= p->nodes || matrix_index >= p->prob_matrices ||
+      parent_scaler_index >= (int)p->scale_buffers || child_scaler_index >= (int)p->scale_buffers)
+  {
+    pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_compute_edge_loglikelihood: index out of range");
+    return fail_lnl("pll_compute_edge_loglikelihood");
+  }
+  const int ptip = pll_is_pattern_tip(p, parent_clv_index);
+  const int ctip = pll_is_pattern_tip(p, child_clv_index);
+  if (ptip && ctip)
+  {
+    pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_compute_edge_loglikelihood: both ends are pattern tips");
+    return fail_lnl("pll_compute_edge_loglikelihood");
+  }
+  if (!pll_flush_model(p, x) || !pll_flush_pmatrix(p, x, matrix_index, matrix_index) ||
+      !prepare_end(p, x, parent_clv_index, parent_scaler_index) ||
+      !prepare_end(p, x, child_clv_index, child_scaler_index))
+    return fail_lnl("pll_compute_edge_loglikelihood");
+
+  pllgpu_edge_t e;
+  memset(&e, 0, sizeof e);
+  /* the inner node plays "parent" when the other end is a tip given by codes
+   * (src/likelihood.c:612-624); P is symmetric in the reversible sense used there */
+  e.parent_clv = ptip ? child_clv_index : parent_clv_index;
+  e.parent_scaler = ptip ? child_scaler_index : parent_scaler_index;
+  e.child_clv = ptip ? parent_clv_index : child_clv_index;
+  e.child_scaler = (ptip || ctip) ? PLL_SCALE_BUFFER_NONE : child_scaler_index;
+  e.child_is_tip = (ptip || ctip);
+  e.matrix = matrix_index;
+  e.gather = pll_repeats_enabled(p) &&
+             (p->repeats->pernode_ids[parent_clv_index] || p->repeats->pernode_ids[child_clv_index]);
+  e.freqs_indices = freqs_indices;
+  e.want_persite = persite_lnl != NULL;
+  double lnl = 0;
+  if (pllgpu_edge_loglikelihood(x->ctx, &e, persite_lnl, &lnl) != 0)
+  {
+    pll_set_gpu_error("pll_compute_edge_loglikelihood");
+    return -INFINITY;
+  }
+  return lnl;
+}
+
+double pll_compute_root_loglikelihood(pll_partition_t *p, unsigned int clv_index, int scaler_index,
+                                      const unsigned int *freqs_indices, double *persite_lnl)
+{
+  pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
+  if (!x || !x->ctx)
+  {
+    pll_set_error(PLL_ERROR_GPU_UNAVAILABLE, "pll_compute_root_loglikelihood: no MI355X context behind this partition; this library has no CPU path");
+    return fail_lnl("pll_compute_root_loglikelihood");
+  }
+  if (clv_index >= p->nodes || scaler_index >= (int)p->scale_buffers || pll_is_pattern_tip(p, clv_index))
+  {
+    pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_compute_root_loglikelihood: invalid CLV/scaler index");
+    return fail_lnl("pll_compute_root_loglikelihood");
+  }
+  if (!pll_flush_model(p, x) || !prepare_end(p, x, clv_index, scaler_index))
+    return fail_lnl("pll_compute_root_loglikelihood");
+  const unsigned int gather = pll_repeats_enabled(p) && p->repeats->pernode_ids[clv_index];
+  double lnl = 0;
+  if (pllgpu_root_loglikelihood(x->ctx, clv_index, scaler_index, gather, freqs_indices, persite_lnl, &lnl) != 0)
+  {
+    pll_set_gpu_error("pll_compute_root_loglikelihood");
+    return -INFINITY;
+  }
+  return lnl;
+}

@@ -1,0 +1,67 @@
+/* pll_internal.h - host-side private state of libpll_amd.so.
+ *
+ * pll_partition_t has no spare field for a device handle, so the partition is
+ * over-allocated and the extension block below sits directly behind the public struct. */
+#ifndef PLL_INTERNAL_H_
+#define PLL_INTERNAL_H_
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../../include/pll_amd.h"
+#include "../../../include/pll_amd_device.h"
+
+#define PLL_AMD_MAGIC 0x504c4c414d443335ull /* "PLLAMD35" */
+
+/* which side holds the current copy of a mirrored buffer */
+enum
+{
+  SIDE_NONE = 0,   /* never written */
+  SIDE_HOST = 1,   /* host copy is newer: upload before the device reads it */
+  SIDE_DEVICE = 2, /* device copy is newer: download before the host reads it */
+  SIDE_BOTH = 3    /* in sync */
+};
+
+typedef struct pll_amd_ext
+{
+  unsigned long long magic;
+  pllgpu_ctx_t *ctx;            /* NULL only in host-only mode (PLL_AMD_HOST_ONLY=1, CPU tests) */
+  unsigned char *clv_side;      /* [nodes] */
+  unsigned char *scaler_side;   /* [scale_buffers] */
+  unsigned int *scaler_entries; /* [scale_buffers] entries last written */
+  unsigned char *tipchars_dirty; /* [tips] host codes not yet on the device */
+  unsigned char *repeats_dirty;  /* [nodes] class maps not yet on the device */
+  unsigned char *pmatrix_dirty;  /* [prob_matrices] */
+  unsigned char *freqs_dirty;    /* [rate_matrices] */
+  int rate_weights_dirty, pattern_weights_dirty, invariant_dirty, prop_invar_dirty, tipmap_dirty;
+  int eager_mirror;             /* PLL_AMD_EAGER_MIRROR=1: copy results back after every call */
+  int always_upload;            /* PLL_AMD_ALWAYS_UPLOAD=1: treat model arrays as dirty on every call */
+  unsigned int sites_alloc;
+  /* scheduler scratch (grown on demand) */
+  pllgpu_op_t *gops;
+  unsigned int gops_cap;
+  int *lvl_clv_w, *lvl_clv_r, *lvl_sc_w, *lvl_sc_r;
+} pll_amd_ext_t;
+
+static inline pll_amd_ext_t *pll_ext(const pll_partition_t *p)
+{
+  pll_amd_ext_t *x = (pll_amd_ext_t *)(p + 1);
+  return x->magic == PLL_AMD_MAGIC ? x : NULL;
+}
+
+/* error convention of the reference: code + message in thread-locals (src/pll.c:24-25) */
+void pll_set_error(int code, const char *fmt, ...);
+/* map the device layer's status + text onto pll_errno / pll_errmsg */
+void pll_set_gpu_error(const char *where);
+
+unsigned int pll_sites_alloc(const pll_partition_t *p);
+/* bring every input of the hot path that is stale on the device up to date; returns PLL_SUCCESS */
+int pll_flush_model(pll_partition_t *p, pll_amd_ext_t *x);
+int pll_flush_clv(pll_partition_t *p, pll_amd_ext_t *x, unsigned int clv_index);
+int pll_flush_scaler(pll_partition_t *p, pll_amd_ext_t *x, int scaler_index);
+int pll_flush_pmatrix(pll_partition_t *p, pll_amd_ext_t *x, unsigned int first, unsigned int last);
+int pll_flush_repeats(pll_partition_t *p, pll_amd_ext_t *x, unsigned int node);
+int pll_is_pattern_tip(const pll_partition_t *p, unsigned int clv_index);
+
+#endif

@@ -1,0 +1,246 @@
+/* repeats.c - site-repeats bookkeeping (integer work, stays on the host: SURVEY.md 8 row a8).
+ *
+ * Semantics of src/repeats.c: a node's CLV holds one entry per CLASS of sites that are
+ * indistinguishable in the subtree below it. pernode_site_id[node][site] is the class of a site,
+ * pernode_id_site[node][class] its first site; classes are numbered by first occurrence. A
+ * parent's classes are the distinct (left class, right class) pairs, found with a direct-address
+ * table that is wiped after use through a to-clean list (src/repeats.c:334-377). The maps are
+ * marked for upload; the gfx950 kernels gather through them.
+ */
+#include "pll_internal.h"
+
+#define EMPTY 0xFFFFFFFFu
+
+int pll_repeats_enabled(const pll_partition_t *p) { return (p->attributes & PLL_ATTRIB_SITE_REPEATS) != 0; }
+
+void pll_resize_repeats_lookup(pll_partition_t *p, unsigned int size)
+{
+  if (!size) return;
+  pll_repeats_t *r = p->repeats;
+  free(r->lookup_buffer);
+  r->lookup_buffer_size = size;
+  r->lookup_buffer = (unsigned int *)malloc((size_t)size * sizeof(unsigned int));
+  memset(r->lookup_buffer, 0xFF, (size_t)size * sizeof(unsigned int));
+}
+
+unsigned int pll_get_sites_number(const pll_partition_t *p, unsigned int clv_index)
+{
+  unsigned int n = pll_repeats_enabled(p) ? p->repeats->pernode_ids[clv_index] : 0;
+  if (!n) n = p->sites;
+  return n + (p->asc_bias_alloc ? p->states : 0);
+}
+
+unsigned int pll_get_clv_size(const pll_partition_t *p, unsigned int clv_index)
+{
+  return pll_get_sites_number(p, clv_index) * p->states_padded * p->rate_cats;
+}
+
+unsigned int *pll_get_site_id(const pll_partition_t *p, unsigned int clv_index)
+{
+  if (pll_repeats_enabled(p) && p->repeats->pernode_ids[clv_index]) return p->repeats->pernode_site_id[clv_index];
+  return NULL;
+}
+
+unsigned int *pll_get_id_site(const pll_partition_t *p, unsigned int clv_index)
+{
+  if (pll_repeats_enabled(p) && p->repeats->pernode_ids[clv_index]) return p->repeats->pernode_id_site[clv_index];
+  return NULL;
+}
+
+unsigned int pll_default_enable_repeats(pll_partition_t *p, unsigned int left, unsigned int right)
+{
+  /* src/repeats.c:100-110: compress only if the pair table fits and both children are
+   * themselves compressed to at most half the sites */
+  const pll_repeats_t *r = p->repeats;
+  const unsigned long long cells = (unsigned long long)r->pernode_ids[left] * r->pernode_ids[right];
+  if (!cells || cells >= r->lookup_buffer_size) return 0;
+  if (r->pernode_ids[left] > p->sites / 2 || r->pernode_ids[right] > p->sites / 2) return 0;
+  return 1;
+}
+
+unsigned int pll_no_enable_repeats(pll_partition_t *p, unsigned int left, unsigned int right)
+{
+  (void)p;
+  (void)left;
+  (void)right;
+  return 0;
+}
+
+int pll_repeats_initialize(pll_partition_t *p)
+{
+  const unsigned int n = pll_sites_alloc(p);
+  unsigned int i;
+  pll_repeats_t *r = (pll_repeats_t *)calloc(1, sizeof(pll_repeats_t));
+  p->repeats = r;
+  if (!r) goto oom;
+  r->enable_repeats = pll_default_enable_repeats;
+  r->reallocate_repeats = pll_default_reallocate_repeats;
+  r->pernode_site_id = (unsigned int **)calloc(p->nodes, sizeof(unsigned int *));
+  r->pernode_id_site = (unsigned int **)calloc(p->nodes, sizeof(unsigned int *));
+  if (!r->pernode_site_id || !r->pernode_id_site) goto oom;
+  for (i = 0; i < p->nodes; ++i)
+  {
+    r->pernode_site_id[i] = (unsigned int *)calloc(n, sizeof(unsigned int));
+    r->pernode_id_site[i] = (unsigned int *)calloc(n, sizeof(unsigned int));
+    if (!r->pernode_site_id[i] || !r->pernode_id_site[i]) goto oom;
+  }
+  r->pernode_ids = (unsigned int *)calloc(p->nodes, sizeof(unsigned int));
+  r->perscale_ids = (unsigned int *)calloc(p->scale_buffers ? p->scale_buffers : 1, sizeof(unsigned int));
+  r->pernode_allocated_clvs = (unsigned int *)calloc(p->nodes, sizeof(unsigned int));
+  r->toclean_buffer = (unsigned int *)malloc(n * sizeof(unsigned int));
+  r->id_site_buffer = (unsigned int *)malloc(n * sizeof(unsigned int));
+  /* bclv_buffer: the reference's scratch for a precomputed left term; the device kernels do not
+   * use it, a small non-NULL block keeps pll_disable_bclv and callers' NULL tests meaningful */
+  r->bclv_buffer = (double *)pll_aligned_alloc(64, p->alignment);
+  r->charmap = (char *)calloc(PLL_ASCII_SIZE, 1);
+  if (!r->pernode_ids || !r->perscale_ids || !r->pernode_allocated_clvs || !r->toclean_buffer ||
+      !r->id_site_buffer || !r->bclv_buffer || !r->charmap)
+    goto oom;
+  return PLL_SUCCESS;
+oom:
+  pll_set_error(PLL_ERROR_MEM_ALLOC, "Unable to allocate enough memory for repeats structure.");
+  return PLL_FAILURE;
+}
+
+void pll_disable_bclv(pll_partition_t *p)
+{
+  if (!pll_repeats_enabled(p)) return;
+  free(p->repeats->bclv_buffer);
+  p->repeats->bclv_buffer = NULL;
+}
+
+/* classes of a tip = distinct state masks of its sequence (src/repeats.c:189-254) */
+int pll_update_repeats_tips(pll_partition_t *p, unsigned int tip, const pll_state_t *map, const char *seq)
+{
+  pll_repeats_t *r = p->repeats;
+  unsigned int i, j, s, next = 0;
+  if (!r->lookup_buffer) pll_resize_repeats_lookup(p, PLL_REPEATS_LOOKUP_SIZE);
+
+  /* characters with equal masks must fall into one class: number the distinct masks 1,2,.. */
+  char label = 0;
+  for (i = 0; i < PLL_ASCII_SIZE; ++i)
+  {
+    for (j = 0; j < i; ++j)
+      if (map[i] == map[j])
+      {
+        r->charmap[i] = r->charmap[j];
+        break;
+      }
+    if (!r->charmap[i]) r->charmap[i] = ++label;
+  }
+
+  unsigned int *site_id = r->pernode_site_id[tip];
+  for (s = 0; s < p->sites; ++s)
+  {
+    const unsigned int cell = (unsigned int)r->charmap[(unsigned char)seq[s]];
+    if (r->lookup_buffer[cell] == EMPTY)
+    {
+      r->toclean_buffer[next] = cell;
+      r->id_site_buffer[next] = s;
+      r->lookup_buffer[cell] = next++;
+    }
+    site_id[s] = r->lookup_buffer[cell];
+  }
+  r->pernode_ids[tip] = next;
+  free(r->pernode_id_site[tip]);
+  r->pernode_id_site[tip] = (unsigned int *)malloc((next ? next : 1) * sizeof(unsigned int));
+  for (s = 0; s < next; ++s)
+  {
+    r->pernode_id_site[tip][s] = r->id_site_buffer[s];
+    r->lookup_buffer[r->toclean_buffer[s]] = EMPTY;
+  }
+  const size_t bytes = (size_t)next * p->states_padded * p->rate_cats * sizeof(double);
+  free(p->clv[tip]);
+  p->clv[tip] = (double *)pll_aligned_alloc(bytes ? bytes : 8, p->alignment);
+  if (!p->clv[tip])
+  {
+    pll_set_error(PLL_ERROR_MEM_ALLOC, "Unable to allocate enough memory for repeats structure.");
+    return PLL_FAILURE;
+  }
+  memset(p->clv[tip], 0, bytes);
+  r->pernode_allocated_clvs[tip] = next;
+  pll_amd_ext_t *x = pll_ext(p);
+  if (x) x->repeats_dirty[tip] = 1;
+  return PLL_SUCCESS;
+}
+
+/* host mirror sizing for a parent whose class count changed (src/repeats.c:256-296). The device
+ * buffers are sized by the launch code from the op's entry count. */
+void pll_default_reallocate_repeats(pll_partition_t *p, unsigned int parent, int scaler_index,
+                                    unsigned int sites_to_alloc)
+{
+  pll_repeats_t *r = p->repeats;
+  if (sites_to_alloc == r->pernode_allocated_clvs[parent]) return;
+  r->pernode_allocated_clvs[parent] = sites_to_alloc;
+  free(p->clv[parent]);
+  const size_t bytes = (size_t)sites_to_alloc * p->states_padded * p->rate_cats * sizeof(double);
+  p->clv[parent] = (double *)pll_aligned_alloc(bytes ? bytes : 8, p->alignment);
+  if (!p->clv[parent])
+  {
+    pll_set_error(PLL_ERROR_MEM_ALLOC, "Unable to allocate enough memory for repeats structure.");
+    return;
+  }
+  if (scaler_index != PLL_SCALE_BUFFER_NONE)
+  {
+    size_t n = sites_to_alloc;
+    if (p->attributes & PLL_ATTRIB_RATE_SCALERS) n *= p->rate_cats;
+    free(p->scale_buffer[scaler_index]);
+    p->scale_buffer[scaler_index] = (unsigned int *)calloc(n ? n : 1, sizeof(unsigned int));
+  }
+  free(r->pernode_id_site[parent]);
+  r->pernode_id_site[parent] = (unsigned int *)malloc((sites_to_alloc ? sites_to_alloc : 1) * sizeof(unsigned int));
+}
+
+void pll_update_repeats(pll_partition_t *p, const pll_operation_t *op)
+{
+  pll_repeats_t *r = p->repeats;
+  const unsigned int left = op->child1_clv_index, right = op->child2_clv_index, parent = op->parent_clv_index;
+  unsigned int s, classes = 0, to_alloc;
+  if (!r->lookup_buffer) pll_resize_repeats_lookup(p, PLL_REPEATS_LOOKUP_SIZE);
+
+  if (!r->enable_repeats(p, left, right))
+  {
+    to_alloc = p->sites;
+    r->pernode_ids[parent] = 0;
+    if (op->parent_scaler_index != PLL_SCALE_BUFFER_NONE) r->perscale_ids[op->parent_scaler_index] = 0;
+  }
+  else
+  {
+    const unsigned int *lid = r->pernode_site_id[left];
+    const unsigned int *rid = r->pernode_site_id[right];
+    unsigned int *pid = r->pernode_site_id[parent];
+    const unsigned int nleft = r->pernode_ids[left];
+    for (s = 0; s < p->sites; ++s)
+    {
+      const unsigned int cell = lid[s] + rid[s] * nleft;
+      unsigned int id = r->lookup_buffer[cell];
+      if (id == EMPTY)
+      {
+        r->toclean_buffer[classes] = cell;
+        r->id_site_buffer[classes] = s;
+        id = classes;
+        r->lookup_buffer[cell] = classes++;
+      }
+      pid[s] = id;
+    }
+    r->pernode_ids[parent] = classes;
+    if (op->parent_scaler_index != PLL_SCALE_BUFFER_NONE) r->perscale_ids[op->parent_scaler_index] = classes;
+    to_alloc = classes;
+  }
+
+  r->reallocate_repeats(p, parent, op->parent_scaler_index, to_alloc);
+
+  /* no compression gained: fall back to one entry per site (src/repeats.c:364-370) */
+  if (to_alloc >= p->sites)
+  {
+    r->pernode_ids[parent] = 0;
+    if (op->parent_scaler_index != PLL_SCALE_BUFFER_NONE) r->perscale_ids[op->parent_scaler_index] = 0;
+  }
+  for (s = 0; s < classes; ++s)
+  {
+    r->pernode_id_site[parent][s] = r->id_site_buffer[s];
+    r->lookup_buffer[r->toclean_buffer[s]] = EMPTY;
+  }
+  pll_amd_ext_t *x = pll_ext(p);
+  if (x) x->repeats_dirty[parent] = 1;
+}

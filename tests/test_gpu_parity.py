@@ -1,0 +1,176 @@
+"""GPU: the HIP path (through the C ABI of libpll_amd.so) against the golden vectors produced by
+the reference, the values pinned by the reference's own tests, and the CPU restatement (oracle/)
+on seeded inputs. Tolerance: 1e-10 relative on scaler-normalised CLV entries, per-site and total
+log-likelihoods (north_star); integer outputs (scalers where the decision is not borderline, class
+maps) exact."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_ids
+from compare import RTOL, assert_kat, assert_results_match, scalers_equal
+from oracle import oracle as O
+from pllamd import api, driver, fixtures, workload as W
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=golden_ids())
+def test_golden_avx2_layout(amd_lib, path):
+    case, exp, extra = fixtures.load(path)
+    got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    assert_results_match(got, exp, what=case.name)
+    assert_kat(got, extra, case.name)
+    if extra.get("scalings"):
+        assert scalers_equal(got, exp), "scaler vectors differ from the reference"
+
+
+@pytest.mark.parametrize("path", [g for g in GOLDEN if any(t in g for t in ("kat_", "s5_", "s7_", "s61_plain", "dna_deep_rate", "aa_tip"))],
+                         ids=lambda p: p.split("/")[-1][:-4])
+@pytest.mark.parametrize("arch", [api.ARCH_CPU, api.ARCH_SSE], ids=["cpu-layout", "sse-layout"])
+def test_golden_other_layouts(amd_lib, path, arch):
+    """states_padded = states (CPU) or even (SSE): odd strides, 8-byte aligned rows"""
+    case, exp, extra = fixtures.load(path)
+    got = driver.run_case(amd_lib, case, arch)
+    assert_results_match(got, exp, what=case.name)
+    assert_kat(got, extra, case.name)
+
+
+ORACLE_CASES = [
+    dict(states=4, tips=32, sites=1000, seed=21),
+    dict(states=4, tips=32, sites=1001, attributes=api.PATTERN_TIP, ambiguity_pct=8, seed=22),
+    dict(states=4, tips=32, sites=999, attributes=api.SITE_REPEATS, mutate_pct=6, seed=23),
+    dict(states=4, tips=16, sites=130, rate_cats=1, seed=24),
+    dict(states=4, tips=16, sites=130, rate_cats=2, attributes=api.PATTERN_TIP, seed=25),
+    dict(states=4, tips=16, sites=130, rate_cats=8, attributes=api.RATE_SCALERS, seed=26),
+    dict(states=4, tips=16, sites=70, rate_cats=16, seed=27),
+    dict(states=4, tips=256, sites=65, tree="caterpillar", brlen_scale=4, attributes=api.RATE_SCALERS | api.PATTERN_TIP, seed=28),
+    dict(states=4, tips=256, sites=200, tree="caterpillar", brlen_scale=4, attributes=api.SITE_REPEATS, mutate_pct=2, seed=29),
+    dict(states=20, tips=32, sites=333, seed=31),
+    dict(states=20, tips=32, sites=321, attributes=api.PATTERN_TIP, ambiguity_pct=8, seed=32),
+    dict(states=20, tips=32, sites=300, attributes=api.SITE_REPEATS | api.RATE_SCALERS, mutate_pct=4, seed=33),
+    dict(states=20, tips=128, sites=70, tree="caterpillar", brlen_scale=3, seed=34),
+    dict(states=20, tips=128, sites=70, tree="caterpillar", brlen_scale=3, attributes=api.RATE_SCALERS | api.PATTERN_TIP, seed=35),
+    dict(states=20, tips=8, sites=100, rate_cats=7, seed=36),
+    dict(states=2, tips=8, sites=100, seed=41),
+    dict(states=3, tips=8, sites=100, attributes=api.PATTERN_TIP, seed=42),
+    dict(states=9, tips=8, sites=129, attributes=api.RATE_SCALERS, seed=43),
+    dict(states=16, tips=8, sites=64, seed=44),
+    dict(states=21, tips=8, sites=65, seed=45),
+    dict(states=32, tips=8, sites=63, attributes=api.PATTERN_TIP, seed=46),
+    dict(states=48, tips=8, sites=66, seed=47),
+    dict(states=61, tips=16, sites=150, seed=48),
+    dict(states=61, tips=16, sites=150, attributes=api.PATTERN_TIP, ambiguity_pct=5, seed=49),
+    dict(states=61, tips=100, sites=64, tree="caterpillar", brlen_scale=3, seed=50),
+    dict(states=61, tips=100, sites=64, tree="caterpillar", brlen_scale=3, attributes=api.RATE_SCALERS, seed=51),
+    dict(states=61, tips=16, sites=100, attributes=api.SITE_REPEATS, mutate_pct=3, seed=52),
+    dict(states=64, tips=8, sites=70, rate_cats=2, seed=53),
+    dict(states=4, tips=16, sites=500, pinv=0.3, mutate_pct=4, seed=61),
+    dict(states=4, tips=200, sites=100, tree="caterpillar", brlen_scale=4, pinv=0.25, mutate_pct=2, attributes=api.RATE_SCALERS, seed=62),
+    dict(states=20, tips=16, sites=200, pinv=0.2, mutate_pct=3, attributes=api.PATTERN_TIP, seed=63),
+]
+
+
+def _id(k):
+    return "s%d-t%d-n%d-r%d-a%d" % (k["states"], k["tips"], k["sites"], k.get("rate_cats", 4), k.get("attributes", 0))
+
+
+@pytest.mark.parametrize("kw", ORACLE_CASES, ids=_id)
+def test_against_oracle(amd_lib, kw):
+    case = W.make_case("rnd", **kw)
+    exp = O.run_case(case)
+    got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    assert_results_match(got, exp, what=_id(kw))
+    assert scalers_equal(got, exp)
+
+
+def test_scaling_actually_happens(amd_lib):
+    """guards the deep-tree cases against becoming vacuous"""
+    case = W.make_case("deep", 61, 100, 64, tree="caterpillar", brlen_scale=3, seed=50)
+    got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    assert sum(int(v.sum()) for v in got["scaler"].values()) > 1000
+
+
+def test_partial_traversal_reorients_shared_clv(amd_lib):
+    """an op list that reads a CLV and later overwrites the same buffer (the three records of an
+    unrooted inner node share one clv_index): the level scheduler must honour
+    write-after-read, and a second call must pick up CLVs left in HBM by the first."""
+    base = W.make_case("pt", 4, 8, 300, seed=5)
+    ops = base.op_batches[0]  # parents 8..13
+    # second call: recompute 12 from (8, 9) again, then overwrite 8 from (12, 10), then 13 from (8, 11)
+    second = [(12, 4, 8, 8, 0, 9, 9, 1), (8, 0, 12, 3, 4, 10, 10, 2), (13, 5, 8, 6, 0, 11, 11, 3)]
+    case = driver.Case(name="pt2", states=4, rate_cats=4, tips=8, sites=300, pmatrix=base.pmatrix, freqs=base.freqs,
+                       op_batches=[ops, second], edges=[(13, 5, 12, 4, 2)], charmap=base.charmap,
+                       sequences=base.sequences, clv_buffers=6, scale_buffers=6, dump_clvs=[8, 12, 13])
+    exp = O.run_case(case)
+    got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    assert_results_match(got, exp, what="partial traversal")
+
+
+def test_host_edit_of_clv_is_picked_up(amd_lib):
+    """freshness: a CLV synced to the host, edited there and invalidated is re-uploaded"""
+    case = W.make_case("edit", 4, 4, 100, seed=9)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        l0, _ = s.edge_lnl(case.edges[0])
+        assert amd_lib.pll_gpu_sync_clv(s.p, 4)
+        a = api.as_np(s.part.clv[4], 100 * 16, np.float64)
+        a *= 0.5
+        amd_lib.pll_gpu_invalidate(s.p, api.DIRTY_CLV, 4)
+        l1, _ = s.edge_lnl(case.edges[0])
+        assert abs((l1 - l0) - 100 * np.log(0.5)) < 1e-9
+        # pattern weights through the setter
+        w = np.full(100, 3, dtype=np.uint32)
+        amd_lib.pll_set_pattern_weights(s.p, api.uptr(w))
+        l2, _ = s.edge_lnl(case.edges[0])
+        assert abs(l2 - 3 * l1) < 1e-9 * abs(l2)
+
+
+def test_repeats_reuse_without_update(amd_lib):
+    """pll_update_partials_rep(..., update_repeats=0) re-uses the class maps already in HBM"""
+    case = W.make_case("rep", 4, 16, 400, attributes=api.SITE_REPEATS, mutate_pct=5, seed=3)
+    exp = O.run_case(case)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials(update_repeats=1)
+        v1, _ = s.edge_lnl(case.edges[0])
+        s.update_partials(update_repeats=0)
+        v2, ps = s.edge_lnl(case.edges[0])
+        assert v1 == v2
+        assert abs(v2 - exp["lnl"][0]) <= RTOL * abs(v2)
+        assert any(s.entries(c) < 400 for c in range(16, 30)), "nothing was compressed"
+
+
+def test_lnl_is_deterministic(amd_lib):
+    case = W.make_case("det", 4, 16, 5000, seed=77)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        vals = set()
+        for _ in range(5):
+            s.update_partials()
+            vals.add(s.edge_lnl(case.edges[0], persite=False)[0])
+        assert len(vals) == 1
+
+
+def test_model_api_end_to_end(amd_lib):
+    """the reference's own call sequence (test/src/00010_NMDU_lkcalc.c:96-147) through the model
+    setters of this library: pinned lnL -58.887310"""
+    import ctypes as C
+    lib = amd_lib
+    p = lib.pll_partition_create(5, 4, 4, 12, 1, 7, 4, 0, api.ARCH_AVX2 | api.PATTERN_TIP)
+    assert p, lib.errmsg()
+    rates = np.zeros(4)
+    assert lib.pll_compute_gamma_cats(0.5, 4, api.dptr(rates), 0)
+    lib.pll_set_frequencies(p, 0, api.dptr(np.array([0.3, 0.4, 0.1, 0.2])))
+    lib.pll_set_subst_params(p, 0, api.dptr(np.array([1, 2.5, 1, 1, 2.5, 1.0])))
+    nt = lib.state_map("pll_map_nt")
+    for t, seq in enumerate([b"WAC-CTA-ATCT", b"CCC-TTA-ATGT", b"A-C-TAG-CTCT", b"CTCTTAA-A-CG", b"CAC-TCA-A-TG"]):
+        assert lib.pll_set_tip_states(p, t, nt, seq)
+    lib.pll_set_category_rates(p, api.dptr(rates))
+    pi = np.zeros(4, dtype=np.uint32)
+    assert lib.pll_update_prob_matrices(p, api.uptr(pi), api.uptr(np.arange(4, dtype=np.uint32)),
+                                        api.dptr(np.array([0.1, 0.2, 1.0, 1.0])), 4)
+    ops = api.make_ops([(5, -1, 0, 1, -1, 1, 1, -1), (6, -1, 5, 0, -1, 2, 1, -1), (7, -1, 3, 1, -1, 4, 1, -1)])
+    lib.pll_update_partials(p, ops, 3)
+    ps = np.zeros(12)
+    v = lib.pll_compute_edge_loglikelihood(p, 6, -1, 7, -1, 0, api.uptr(pi), api.dptr(ps))
+    assert abs(v - (-58.887310)) < 5.1e-7
+    assert abs(ps.sum() - v) < 1e-9
+    lib.pll_partition_destroy(p)

@@ -1,0 +1,285 @@
+"""CPU (no GPU): the C-ABI library loads, exports every symbol its headers declare, lays its
+structs out like the reference, and its host-side bookkeeping (tip encodings, site-repeats class
+maps, model matrices, invariant sites, error behaviour) matches the reference. Partitions are
+created as host-only shells (PLL_AMD_HOST_ONLY=1): no compute call is made - and the compute entry
+points are checked to FAIL LOUDLY rather than fall back to anything."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from pllamd import api, driver, workload as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(autouse=True)
+def host_only(monkeypatch):
+    monkeypatch.setenv("PLL_AMD_HOST_ONLY", "1")
+
+
+def declared_symbols():
+    names = set()
+    for hdr in ("pll_amd.h", "pll_amd_device.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(pll(?:gpu)?_[a-z0-9_]+)\s*\(", txt))
+        names |= set(re.findall(r"extern\s+[^;]*?\b(pll_[a-z0-9_]+)\s*(?:\[|;)", txt))
+    names -= {"pll_state_t", "pll_partition", "pll_repeats", "pll_operation"}
+    return sorted(names)
+
+
+def test_exports_every_declared_symbol(amd_lib):
+    missing = []
+    for name in declared_symbols():
+        try:
+            getattr(amd_lib.dll, name)
+        except AttributeError:
+            missing.append(name)
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+    assert len(declared_symbols()) > 70
+
+
+def test_no_cpu_fallback_compute_fails_loudly(amd_lib, capfd):
+    case = W.make_case("t", 4, 4, 32)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        assert amd_lib.errno() == 900  # PLL_ERROR_GPU_UNAVAILABLE
+        v, _ = s.edge_lnl(case.edges[0])
+        assert v == -np.inf and amd_lib.errno() == 900
+        assert not amd_lib.pll_gpu_sync_clv(s.p, 5)
+    err = capfd.readouterr().err
+    assert "no MI355X context" in err
+
+
+def test_create_without_device_is_refused(amd_lib, monkeypatch):
+    if amd_lib.pll_gpu_device_count() > 0:
+        pytest.skip("a GPU is present")
+    monkeypatch.delenv("PLL_AMD_HOST_ONLY")
+    p = amd_lib.pll_partition_create(4, 2, 4, 10, 1, 5, 4, 2, api.ARCH_AVX2)
+    assert not p
+    assert amd_lib.errno() == 900 and "MI355X" in amd_lib.errmsg()
+
+
+def test_invalid_attribute_combinations(amd_lib):
+    assert not amd_lib.pll_partition_create(4, 2, 4, 100, 1, 5, 4, 2, api.ARCH_AVX | api.ARCH_SSE)
+    assert amd_lib.errno() == 113
+    assert not amd_lib.pll_partition_create(4, 2, 4, 100, 1, 5, 4, 2, api.PATTERN_TIP | api.SITE_REPEATS)
+    assert amd_lib.errno() == 113
+    assert not amd_lib.pll_partition_create(4, 2, 4, 100, 1, 5, 4, 2, api.AB_LEWIS | api.AB_FLAG)
+    assert amd_lib.errno() == 902
+
+
+@pytest.mark.parametrize("states,arch,sp,align", [(4, 0, 4, 8), (5, api.ARCH_SSE, 6, 16), (7, api.ARCH_AVX, 8, 32),
+                                                    (20, api.ARCH_AVX2, 20, 32), (61, api.ARCH_AVX2, 64, 32),
+                                                    (61, 0, 61, 8)])
+def test_layout_follows_arch_bits(amd_lib, ref_lib, states, arch, sp, align):
+    for lib in (amd_lib, ref_lib):
+        p = lib.pll_partition_create(5, 3, states, 20, 2, 7, 4, 3, arch | api.RATE_SCALERS)
+        part = p.contents
+        assert (part.states_padded, part.alignment) == (sp, align)
+        assert (part.nodes, part.pattern_weight_sum) == (8, 20)
+        assert part.pmatrix[1] and (C.addressof(part.pmatrix[1].contents) - C.addressof(part.pmatrix[0].contents)) == 8 * 4 * states * sp
+        assert list(api.as_np(part.rate_weights, 4, np.float64)) == [0.25] * 4
+        assert list(api.as_np(part.pattern_weights, 20, np.uint32)) == [1] * 20
+        assert C.addressof(part.clv[7].contents) % align == 0
+        lib.pll_partition_destroy(p)
+
+
+def test_repeats_disabled_below_16_sites(amd_lib):
+    p = amd_lib.pll_partition_create(4, 2, 4, 15, 1, 5, 4, 2, api.SITE_REPEATS)
+    assert p and not amd_lib.pll_repeats_enabled(p) and not p.contents.repeats
+    amd_lib.pll_partition_destroy(p)
+
+
+@pytest.mark.parametrize("states", [4, 7, 20, 61])
+def test_tip_codes_match_reference(amd_lib, ref_lib, states):
+    case = W.make_case("t", states, 8, 80, attributes=api.PATTERN_TIP, ambiguity_pct=15, seed=states)
+    got = {}
+    for lib in (amd_lib, ref_lib):
+        with driver.Session(lib, case, api.ARCH_AVX2) as s:
+            part = s.part
+            got[lib.is_amd] = (part.maxstates, [api.as_np(part.tipchars[t], 80, np.uint8).copy() for t in range(8)],
+                               api.as_np(part.tipmap, 256, np.uint64).copy(), api.as_np(part.charmap, 256, np.uint8).copy(),
+                               [bool(part.clv[t]) for t in range(8)])
+    a, b = got[True], got[False]
+    assert a[0] == b[0]
+    assert all((x == y).all() for x, y in zip(a[1], b[1]))
+    assert (a[2] == b[2]).all() and (a[3] == b[3]).all() and a[4] == b[4] == [False] * 8
+
+
+def test_second_map_extends_code_table(amd_lib, ref_lib):
+    """src/pll.c:157-286: a later sequence with another map adds codes without disturbing old ones"""
+    m1 = W.map_generic(7)
+    m2 = m1.copy()
+    m2[ord("z")] = 0x3 | 0x40
+    m2[ord("y")] = 0x11
+    out = {}
+    for lib in (amd_lib, ref_lib):
+        p = lib.pll_partition_create(3, 1, 7, 16, 1, 3, 2, 0, api.PATTERN_TIP)
+        a1 = (C.c_ulonglong * 256)(*[int(v) for v in m1])
+        a2 = (C.c_ulonglong * 256)(*[int(v) for v in m2])
+        assert lib.pll_set_tip_states(p, 0, a1, b"0123456-01234560")
+        assert lib.pll_set_tip_states(p, 1, a2, b"zy23456-0123456z")
+        part = p.contents
+        out[lib.is_amd] = (part.maxstates, api.as_np(part.tipchars[0], 16, np.uint8).copy(),
+                           api.as_np(part.tipchars[1], 16, np.uint8).copy(), api.as_np(part.tipmap, 16, np.uint64).copy())
+        lib.pll_partition_destroy(p)
+    assert out[True][0] == out[False][0]
+    for i in (1, 2, 3):
+        assert (out[True][i] == out[False][i]).all()
+
+
+def test_illegal_state_is_reported(amd_lib):
+    p = amd_lib.pll_partition_create(2, 1, 4, 8, 1, 1, 1, 0, 0)
+    assert not amd_lib.pll_set_tip_states(p, 0, amd_lib.state_map("pll_map_nt"), b"ACGT!CGT")
+    assert amd_lib.errno() == 114
+    amd_lib.pll_partition_destroy(p)
+    p = amd_lib.pll_partition_create(2, 1, 4, 8, 1, 1, 1, 0, api.PATTERN_TIP)
+    clv = np.zeros(32)
+    assert not amd_lib.pll_set_tip_clv(p, 0, api.dptr(clv), 0)
+    assert amd_lib.errno() == 115
+    amd_lib.pll_partition_destroy(p)
+
+
+@pytest.mark.parametrize("name", ["pll_map_nt", "pll_map_aa", "pll_map_bin"])
+def test_state_maps_equal_reference(amd_lib, ref_lib, name):
+    assert list(amd_lib.state_map(name)) == list(ref_lib.state_map(name))
+
+
+def test_tip_clvs_match_reference(amd_lib, ref_lib):
+    case = W.make_case("t", 7, 8, 33, ambiguity_pct=20)
+    clv = {}
+    for lib in (amd_lib, ref_lib):
+        with driver.Session(lib, case, api.ARCH_AVX2) as s:
+            n = 33 * 4 * s.sp
+            clv[lib.is_amd] = [api.as_np(s.part.clv[t], n, np.float64).reshape(33, 4, s.sp)[:, :, :7].copy() for t in range(8)]
+    assert all((a == b).all() for a, b in zip(clv[True], clv[False]))
+
+
+@pytest.mark.parametrize("states,mut", [(4, 5), (4, 40), (20, 5)])
+def test_repeat_class_maps_match_reference(amd_lib, ref_lib, states, mut):
+    """integer work: bit-exact (src/repeats.c:189-254, :299-382), including the fall-back to
+    uncompressed nodes when compression does not pay"""
+    case = W.make_case("t", states, 16, 300, attributes=api.SITE_REPEATS, mutate_pct=mut, seed=7)
+    ops = api.make_ops(case.op_batches[0])
+    res = {}
+    for lib in (amd_lib, ref_lib):
+        with driver.Session(lib, case, api.ARCH_AVX2) as s:
+            for i in range(len(case.op_batches[0])):
+                lib.pll_update_repeats(s.p, C.byref(ops[i]))
+            rep = s.part.repeats.contents
+            rows = []
+            for node in range(s.part.nodes):
+                ids = rep.pernode_ids[node]
+                rows.append((ids, api.as_np(rep.pernode_site_id[node], 300, np.uint32).copy() if ids else None,
+                             api.as_np(rep.pernode_id_site[node], ids, np.uint32).copy() if ids else None,
+                             lib.pll_get_sites_number(s.p, node), lib.pll_get_clv_size(s.p, node)))
+            res[lib.is_amd] = rows
+    for a, b in zip(res[True], res[False]):
+        assert a[0] == b[0] and a[3] == b[3] and a[4] == b[4]
+        if a[0]:
+            assert (a[1] == b[1]).all() and (a[2] == b[2]).all()
+    assert any(r[0] for r in res[True][16:]), "no inner node was compressed - test is vacuous"
+
+
+def test_invariant_sites_match_reference(amd_lib, ref_lib):
+    for attr in (0, api.PATTERN_TIP):
+        case = W.make_case("t", 4, 8, 200, attributes=attr, mutate_pct=3, ambiguity_pct=10, pinv=0.2)
+        inv = {}
+        for lib in (amd_lib, ref_lib):
+            with driver.Session(lib, case, api.ARCH_AVX2) as s:
+                inv[lib.is_amd] = api.as_np(s.part.invariant, 200, np.int32).copy()
+                assert abs(s.part.prop_invar[0] - 0.2) < 1e-15
+        assert (inv[True] == inv[False]).all() and (inv[True] >= 0).any() and (inv[True] < 0).any()
+
+
+def model_pmatrices(lib, states, exch, freqs, alpha, cats, brlens, arch, pinv=0.0):
+    p = lib.pll_partition_create(2, 1, states, 16, 1, len(brlens), cats, 0, arch)
+    part = p.contents
+    sp = part.states_padded
+    rates = np.zeros(cats)
+    assert lib.pll_compute_gamma_cats(alpha, cats, api.dptr(rates), 0)
+    f = np.ascontiguousarray(freqs, dtype=np.float64)
+    e = np.ascontiguousarray(exch, dtype=np.float64)
+    lib.pll_set_frequencies(p, 0, api.dptr(f))
+    lib.pll_set_subst_params(p, 0, api.dptr(e))
+    part.prop_invar[0] = pinv
+    bl = np.ascontiguousarray(brlens, dtype=np.float64)
+    return p, part, sp, rates, bl
+
+
+@pytest.mark.parametrize("states,arch", [(4, api.ARCH_AVX2), (7, api.ARCH_AVX2), (20, api.ARCH_CPU), (61, api.ARCH_AVX2)])
+def test_prob_matrices_match_reference(amd_lib, ref_lib, states, arch):
+    """same category rates on both sides (the reference's own), then P(t) must agree to 1e-12"""
+    exch, freqs = (W.GTR_DNA["exch"], W.GTR_DNA["freqs"]) if states == 4 else W.synthetic_exch(states)
+    brlens = [0.0, 1e-6, 0.05, 0.5, 3.0]
+    out = {}
+    ref_rates = None
+    for lib in (ref_lib, amd_lib):
+        p, part, sp, rates, bl = model_pmatrices(lib, states, exch, freqs, 0.7, 4, brlens, arch, pinv=0.1)
+        if ref_rates is None:
+            ref_rates = rates
+        lib.pll_set_category_rates(p, api.dptr(ref_rates))
+        pi = np.zeros(4, dtype=np.uint32)
+        mi = np.arange(len(brlens), dtype=np.uint32)
+        assert lib.pll_update_prob_matrices(p, api.uptr(pi), api.uptr(mi), api.dptr(bl), len(brlens))
+        out[lib.is_amd] = np.stack([api.as_np(part.pmatrix[i], 4 * states * sp, np.float64).reshape(4, states, sp)[:, :, :states].copy()
+                                    for i in range(len(brlens))])
+        assert part.eigen_decomp_valid[0] == 1
+        lib.pll_partition_destroy(p)
+    a, b = out[True], out[False]
+    assert np.allclose(a.sum(-1), 1.0, atol=1e-12)
+    assert np.max(np.abs(a - b)) < 1e-12
+    assert (a[0] == np.eye(states)[None]).all()
+
+
+def test_zero_frequency_states_are_dropped(amd_lib, ref_lib):
+    """src/models.c:254-291,346-385"""
+    freqs = np.array([0.4, 0.0, 0.35, 0.25])
+    out = {}
+    for lib in (ref_lib, amd_lib):
+        p, part, sp, rates, bl = model_pmatrices(lib, 4, [1, 2, 3, 4, 5, 6], freqs, 1.0, 2, [0.3], api.ARCH_AVX2)
+        lib.pll_set_category_rates(p, api.dptr(np.array([0.5, 1.5])))
+        pi = np.zeros(2, dtype=np.uint32)
+        mi = np.zeros(1, dtype=np.uint32)
+        assert lib.pll_update_prob_matrices(p, api.uptr(pi), api.uptr(mi), api.dptr(bl), 1)
+        out[lib.is_amd] = api.as_np(part.pmatrix[0], 2 * 4 * sp, np.float64).copy()
+        lib.pll_partition_destroy(p)
+    assert np.max(np.abs(out[True] - out[False])) < 1e-12
+
+
+@pytest.mark.parametrize("alpha", [0.05, 0.5, 1.0, 4.2, 50.0])
+@pytest.mark.parametrize("cats", [1, 2, 4, 8, 16])
+def test_gamma_categories(amd_lib, ref_lib, alpha, cats):
+    """mean/median category rates: the reference's incomplete-gamma routine stops at 1e-8
+    (src/gamma.c:47), ours does not - agreement is to 1e-6, and against scipy to 1e-12"""
+    for mode in (0, 1):
+        a = np.zeros(cats)
+        b = np.zeros(cats)
+        assert amd_lib.pll_compute_gamma_cats(alpha, cats, api.dptr(a), mode)
+        assert ref_lib.pll_compute_gamma_cats(alpha, cats, api.dptr(b), mode)
+        assert np.allclose(a, b, rtol=2e-6, atol=1e-12)
+        assert abs(a.mean() - 1.0) < 1e-12
+    a = np.zeros(cats)
+    amd_lib.pll_compute_gamma_cats(alpha, cats, api.dptr(a), 0)
+    assert np.allclose(a, W.gamma_rates_mean(alpha, cats), rtol=1e-11, atol=1e-14)
+
+
+def test_gamma_rejects_bad_alpha(amd_lib):
+    a = np.zeros(4)
+    assert not amd_lib.pll_compute_gamma_cats(0.0, 4, api.dptr(a), 0)
+    assert amd_lib.errno() == 113
+
+
+def test_frequencies_are_normalised_like_reference(amd_lib, ref_lib):
+    for f in ([0.1, 0.2, 0.3, 0.4], [1.0, 2.0, 3.0, 4.0], [0.25, 0.25, 0.25, 0.25 + 5e-9]):
+        got = []
+        for lib in (amd_lib, ref_lib):
+            p = lib.pll_partition_create(2, 1, 4, 16, 1, 1, 1, 0, 0)
+            lib.pll_set_frequencies(p, 0, api.dptr(np.array(f)))
+            got.append(api.as_np(p.contents.frequencies[0], 4, np.float64).copy())
+            lib.pll_partition_destroy(p)
+        assert (got[0] == got[1]).all()
