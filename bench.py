@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the MI355X partial-likelihood hot path.
+
+One "step" = one pass of the hot path over one synthetic alignment that is already resident in
+HBM: pll_update_partials over the full post-order operation list (62 ops for the 64-taxon
+balanced tree) followed by pll_compute_edge_loglikelihood at the root edge, which synchronises and
+returns the log-likelihood (and, for N > 1, one all-reduce of that double over RCCL).
+
+    metric  M site-CLV-updates/s = sites * ops * steps / t / 1e6          (BASELINE.json)
+    config  configs[1]: 4-state DNA, 4 Gamma rates, 64-taxon balanced tree, 100k synthetic sites
+            (tips as ordinary 0/1 CLVs: every update is inner x inner, 384 B + scalers)
+
+Multi-GPU: one process per GPU (torch.distributed / RCCL), sites sharded - every rank owns an
+independent partition over its own 100k-site shard (weak scaling); the only exchange is the
+all-reduce of the final log-likelihood.
+
+Besides the contract fields the JSON line carries
+    roofline      HIP-event timing of the CLV-update kernel launches of one traversal on the
+                  partition's stream vs the 8 TB/s HBM3E peak; algorithmic bytes per DESIGN.md
+    cpu_baseline  the reference's own AVX2 path (oracle/_ref/libpll_ref.so, built from the
+                  reference sources) timed on this host's cores on the same workload, rank 0 only
+    lnl_rel_err   |lnL_gpu - lnL_reference| / |lnL_reference| on that workload
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "libpll-2_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+CONFIGS = {
+    # name: (states, tips, sites, attributes-as-names, description)
+    "c2": dict(states=4, tips=64, sites=100000, desc="4-state DNA GTR+G4, 64-taxon balanced tree, 100k sites"),
+    "c3": dict(states=20, tips=64, sites=50000, desc="20-state protein (LG)+G4, 64 taxa, 50k sites"),
+    "c5": dict(states=61, tips=32, sites=20000, desc="61-state codon stand-in +G4, 32 taxa, 20k sites"),
+}
+
+
+def build_case(cfg, sites, seed, attributes):
+    import numpy as np
+    from pllamd import workload as W
+    kw = {}
+    if cfg["states"] == 20:
+        lg = np.load(os.path.join(ROOT, "tests", "golden", "model_lg.npz"))
+        kw.update(exch=lg["rates"], freqs=lg["freqs"])
+    return W.make_case("bench", cfg["states"], cfg["tips"], sites, attributes=attributes, seed=seed, **kw)
+
+
+def op_bytes(case, api):
+    """algorithmic HBM bytes of one traversal: per update 3 CLV entries for
+    inner x inner, 2 + 1 B for tip x inner, 1 + 2 B for tip x tip, plus 4 B per scaler touched"""
+    s, r, n = case.states, case.rate_cats, case.sites
+    entry = s * r * 8
+    pattern_tip = bool(case.attributes & api.PATTERN_TIP)
+    per_rate = r if (case.attributes & api.RATE_SCALERS) else 1
+    total = 0
+    for (pc, psc, c1, m1, s1, c2, m2, s2) in case.op_batches[0]:
+        b = entry
+        for c, sc in ((c1, s1), (c2, s2)):
+            if pattern_tip and c < case.tips:
+                b += 1
+            else:
+                b += entry
+                if sc >= 0:
+                    b += 4 * per_rate
+        if psc >= 0:
+            b += 4 * per_rate
+        total += b * n
+    return total
+
+
+def cpu_baseline(case, api, driver, budget_s=12.0):
+    """reference AVX2 path on the host cores: T threads, each its own partition over sites/T
+    contiguous sites (how applications parallelise libpll), traversal repeated to fill ~budget_s
+    of CPU work. Falls back to the scalar restatement (kind 'port', 1 core, small sample)."""
+    import numpy as np
+    from oracle import oracle as O
+    ops = len(case.op_batches[0])
+    if os.path.exists(O.REF_LIB):
+        ref = api.PllLib(O.REF_LIB)
+        cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+        bounds = np.linspace(0, case.sites, cores + 1).astype(int)
+        shards = []
+        for t in range(cores):
+            lo, hi = int(bounds[t]), int(bounds[t + 1])
+            sub = driver.Case(name=f"shard{t}", states=case.states, rate_cats=case.rate_cats, tips=case.tips,
+                              sites=hi - lo, pmatrix=case.pmatrix, freqs=case.freqs, op_batches=case.op_batches,
+                              edges=case.edges, charmap=case.charmap,
+                              sequences=[sq[lo:hi] for sq in case.sequences], attributes=case.attributes,
+                              clv_buffers=case.clv_buffers, scale_buffers=case.scale_buffers)
+            shards.append(driver.Session(ref, sub, api.ARCH_AVX2))
+        # one traversal to size the sample, then reps traversals timed
+        t0 = time.perf_counter()
+        shards[0].update_partials()
+        one = (time.perf_counter() - t0) * cores  # core-seconds per full traversal (approx.)
+        reps = int(max(2, min(200, budget_s / max(one, 1e-4))))
+        lnls = [0.0] * cores
+
+        def work(i):
+            for _ in range(reps):
+                shards[i].update_partials()
+            lnls[i] = shards[i].edge_lnl(case.edges[0], persite=False)[0]
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        dt = time.perf_counter() - t0
+        for sh in shards:
+            sh.close()
+        return dict(value=case.sites * ops * reps / dt / 1e6, unit="M site-CLV-updates/s", cores=cores, kind="reference",
+                    sample=f"{reps} full traversals ({ops} ops) of the same {case.sites}-site alignment, reference "
+                           f"PLL_ATTRIB_ARCH_AVX2 path, {cores} threads x sites/{cores} partitions, {dt:.1f} s wall"), float(sum(lnls))
+    # no reference library on this host: time the scalar restatement on a small slice
+    n = min(case.sites, 2000)
+    sub = driver.Case(name="slice", states=case.states, rate_cats=case.rate_cats, tips=case.tips, sites=n,
+                      pmatrix=case.pmatrix, freqs=case.freqs, op_batches=case.op_batches, edges=case.edges,
+                      charmap=case.charmap, sequences=[sq[:n] for sq in case.sequences], attributes=case.attributes,
+                      clv_buffers=case.clv_buffers, scale_buffers=case.scale_buffers)
+    t0 = time.perf_counter()
+    O.run_case(sub)
+    dt = time.perf_counter() - t0
+    return dict(value=n * ops / dt / 1e6, unit="M site-CLV-updates/s", cores=1, kind="port",
+                sample=f"one traversal of the first {n} sites with the scalar C restatement (oracle/pll_oracle.c)"), None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--sites", type=int, default=0, help="override sites per GPU")
+    ap.add_argument("--pattern-tip", action="store_true", help="PLL_ATTRIB_PATTERN_TIP variant (tip codes instead of tip CLVs)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("PLL_AMD_DEVICE", str(local))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import numpy as np
+    from pllamd import api, driver
+
+    cfg = CONFIGS[args.config]
+    sites = args.sites or cfg["sites"]
+    attributes = api.PATTERN_TIP if args.pattern_tip else 0
+    case = build_case(cfg, sites, seed=1000 + rank, attributes=attributes)
+    nops = len(case.op_batches[0])
+    lib = api.PllLib()
+    sess = driver.Session(lib, case, api.ARCH_AVX2)  # uploads happen on first use (warm-up)
+    edge = case.edges[0]
+    red = torch.zeros(1, dtype=torch.float64, device=f"cuda:{local}") if dist else None
+
+    def step():
+        sess.update_partials()
+        v, _ = sess.edge_lnl(edge, persite=False)
+        if dist:
+            red[0] = v
+            dist.all_reduce(red)  # the path's one exchange: sum of the shards' log-likelihoods
+            v = float(red.item())
+        return v
+
+    def fence():
+        lib.pll_gpu_synchronize(sess.p)
+        if dist:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    lnl = None
+    for _ in range(args.warmup):
+        lnl = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lnl = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if not np.isfinite(lnl):
+        raise SystemExit(f"hot path failed: lnL = {lnl} [{lib.errno()}] {lib.errmsg()}")
+
+    total_sites = sites * world
+    value = total_sites * nops * args.steps / dt / 1e6
+
+    # ---- roofline leg: the CLV-update kernel launches of one traversal, HIP events on their stream
+    reps = 20
+    lib.pll_gpu_synchronize(sess.p)
+    lib.pll_gpu_timer_start(sess.p)
+    for _ in range(reps):
+        sess.update_partials()
+    ms = lib.pll_gpu_timer_stop(sess.p)
+    launches = lib.pll_gpu_last_launch_count(sess.p)
+    trav_bytes = op_bytes(case, api)
+    per_launch_bytes = trav_bytes / launches
+    per_launch_ms = ms / reps / launches
+    achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
+    if os.path.exists(tfile):  # PMC-derived HBM bytes per launch of the same command (profiles/README.md)
+        traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+    kernel = {4: "k_partials_dna", 20: "k_partials_generic<20>", 61: "k_partials_generic<16>"}[cfg["states"]]
+    roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, kernel=kernel,
+                    launches_per_traversal=launches, avg_launch_ms=round(per_launch_ms, 5),
+                    algorithmic_bytes_per_launch=int(per_launch_bytes),
+                    update_partials_only_M_per_s=round(sites * nops / (ms / reps * 1e-3) / 1e6, 1))
+
+    out = {
+        "metric": "M site-CLV-updates/s", "value": round(value, 1), "unit": "M site-CLV-updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": cfg["desc"] + (", PATTERN_TIP" if args.pattern_tip else ", tips as CLVs (all inner x inner)"),
+                   "sites_per_gpu": sites, "ops_per_traversal": nops, "states": cfg["states"], "rate_cats": 4,
+                   "taxa": cfg["tips"], "step": "pll_update_partials(full traversal) + pll_compute_edge_loglikelihood"
+                   + (" + all-reduce(lnL)" if world > 1 else ""), "parallelism": f"sites sharded x{world}"},
+        "lnl": lnl, "roofline": roofline,
+    }
+    sess.close()
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cb, ref_lnl = cpu_baseline(case, api, driver)
+        out["cpu_baseline"] = cb
+        if ref_lnl is not None and world == 1:
+            out["lnl_rel_err"] = abs(lnl - ref_lnl) / abs(ref_lnl)
+            out["lnl_reference"] = ref_lnl
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
