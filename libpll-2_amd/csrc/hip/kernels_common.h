@@ -1,8 +1,10 @@
 // kernels_common.h - device-side structures shared by the gfx950 kernels.
 //
 // Data layout in HBM (DESIGN.md "Data layout"):
-//   CLV      [entry][rate][states_padded] doubles - the reference's own site-major layout
-//            (src/pll.c:565-567), so one wavefront reads 64 consecutive 8/16/32-byte pieces.
+//   CLV      4 states x 4 rates: [entry][rate][state] doubles - the reference's own site-major
+//            layout (src/pll.c:565-567); a quad of lanes covers one site, a wavefront reads 64
+//            consecutive 32-byte pieces. Every other shape: tiled sites-contiguous
+//            [tile][rate][state][64 lanes] (kernels_generic.h).
 //   scaler   [entry] or [entry][rate] unsigned (src/pll.c:838-857)
 //   P matrix per branch, TRANSPOSED relative to the reference: PT[rate][col j][row i padded to
 //            SPT]; a kernel walking the contraction index j then finds the ICH parent-state
@@ -48,13 +50,11 @@ struct OpPack
 
 struct GenGeo
 {
-  unsigned S, SP, R;
-  unsigned SPT;      // padded row count of PT = nchunks * ICH
-  unsigned nchunks;  // parent-state chunks of ICH
-  unsigned RG;       // rate categories staged per LDS tile pass
-  unsigned ngroups;  // ceil(R / RG)
-  unsigned LSTR;     // LDS row stride in doubles (odd -> conflict-free ds_read_b64 by row)
-  int scale_mode;    // 0 none, 1 per site, 2 per rate
+  unsigned S, SP, R;  // states, host states_padded (frequencies / host mirror stride), rate categories
+  unsigned SPT;       // padded row count of PT = nchunks * ICH
+  unsigned nchunks;   // parent-state chunks of ICH
+  unsigned tile_sz;   // doubles per 64-entry tile of a tiled CLV = R * S * 64
+  int scale_mode;     // 0 none, 1 per site, 2 per rate
 };
 
 // one edge / root evaluation

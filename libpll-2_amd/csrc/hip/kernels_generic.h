@@ -1,190 +1,147 @@
 // kernels_generic.h - any number of states (<= 64) and rate categories.
 //
-// Thread mapping: a 256-thread workgroup owns a tile of 64 site entries; LANE = ENTRY in every
-// wave. The four waves split the (rate category, parent-state chunk) work items of the tile, so
-// the transition-matrix coefficients a wave needs are wave-uniform: they are fetched with scalar
-// loads from the transposed matrix PT (constant address space) and enter v_fma_f64 as SGPR
-// operands - no LDS or VGPR traffic for the matrix at all. The child CLV tile is staged through
-// LDS (coalesced row copies in, conflict-free per-lane row reads out: odd row stride), one child
-// at a time so the tile costs 64 x (RG*SP+1) x 8 B of LDS (41.5 KB for 20 states x 4 rates,
-// three workgroups per CU). Results are transposed back through the same LDS tile and stored
-// with coalesced row copies.
+// DEVICE LAYOUT for these kernels is "tiled sites-contiguous" (AoSoA), not the host's
+// [entry][rate][state]:   clv[tile][rate k][state j][lane],  tile = entry >> 6, lane = entry & 63,
+// i.e. the 64 sites of a tile are contiguous for every (rate, state). With LANE = SITE a wavefront
+// then reads x_j of its 64 sites as ONE contiguous 512-byte line-pair and writes every result the
+// same way: no LDS transposes, no barriers in the streaming part, occupancy bounded by VGPRs only.
+// The host mirror keeps the reference layout; k_aos_to_tiled / k_tiled_to_aos convert at upload /
+// sync time (never on the hot path). State padding is dropped on the device (stride S, not SP).
 //
-// Tips given as codes (PATTERN_TIP) use the same FMA stream with the 0/1 indicator of the tip
-// mask as the "CLV" value (bit j of tipmap[code], src/core_partials.c:478-486), so ti / tt need
-// no lookup table. Site repeats only change which rows are staged (GATHER).
+// Thread mapping: workgroup = one tile of 64 entries; wave w owns the rate categories
+// w, w+nw, ... of the tile (nw = min(R,4) waves). For its (tile, rate) a wave computes all parent
+// states in chunks of ICH accumulators: acc[i] += PT[k][j][c*ICH+i] * x_j, where the ICH
+// coefficients are WAVE-UNIFORM -> fetched by scalar loads from the transposed matrix (constant
+// address space) and fed to v_fma_f64 as SGPR operands: the matrix costs no LDS, no VGPRs.
+// x_j comes straight from HBM/L2 (coalesced), or - for tips given as codes (PATTERN_TIP) - is
+// the 0/1 indicator of bit j of tipmap[code] (src/core_partials.c:478-486), so tip-inner and
+// tip-tip updates need no lookup table. Site repeats turn x_j loads into per-lane gathers.
+//
+// Scaling (src/core_partials.c:729-763): results are stored unscaled as they are produced; each
+// lane keeps "all my entries < 2^-256" per rate. Per-rate mode: the wave rescales its own stored
+// column of that rate when the flag is set (rare). Per-site mode: flags of all rates meet in a
+// R x 64 byte LDS array behind one barrier, then every wave rescales the rates it produced.
 //
 // Arithmetic: src/core_partials.c:709-764 (ii), :465-507 (ti), :1166-1209 + :188-199 (tt),
-// :819-879 (repeats); scaling :729-763. Per-rate scaling is honoured for every child kind (the
-// reference's AVX2 kernels do, its generic ti does not - SURVEY 8a "quirks").
+// :819-879 (repeats). Per-rate scaling is honoured for every child kind (the reference's AVX2
+// kernels do, its generic non-4-state ti does not - SURVEY 8a "quirks").
 #pragma once
 #include "kernels_common.h"
 
-// copy rows of a CLV into the LDS tile: wave w copies rows w, w+4, ...; row e of the tile is
-// entry idx(e) of the source, columns [col0, col0+rowlen)
-__device__ __forceinline__ void stage_rows(double *tile, unsigned LSTR, const double *__restrict__ src,
-                                           unsigned idx_lane, unsigned span, unsigned col0,
-                                           unsigned rowlen, unsigned wave, unsigned lane)
-{
-  for (unsigned e = wave; e < 64; e += 4)
-  {
-    const unsigned ent = __shfl(idx_lane, e, 64);
-    const double *row = src + (size_t)ent * span + col0;
-    for (unsigned x = lane; x < rowlen; x += 64) tile[e * LSTR + x] = row[x];
-  }
-}
-
-// acc[i] += PT[k][j][c*ICH + i] * x_j for all contraction indices j
+// acc[i] = sum_j PT[k][j][c*ICH + i] * x_j ; x_j from a tiled CLV (stride 64 between states) or
+// from a tip mask
 template <int ICH, bool TIP>
 __device__ __forceinline__ void contract(double (&acc)[ICH], const double *pt, unsigned k, unsigned c,
-                                         const GenGeo &g, const double *tile_row, unsigned col,
+                                         const GenGeo &g, const double *__restrict__ x /* &clv[..][k][0][lane] */,
                                          unsigned long long mask)
 {
   cdouble_p p = as_const(pt) + ((size_t)k * g.S) * g.SPT + c * ICH;
 #pragma unroll
   for (int i = 0; i < ICH; ++i) acc[i] = 0.0;
-  for (unsigned j = 0; j < g.S; ++j, p += g.SPT)
+#pragma unroll 4
+  for (unsigned j = 0; j < g.S; ++j)
   {
-    double x;
+    double xj;
     if (TIP)
-      x = ((mask >> j) & 1ull) ? 1.0 : 0.0;
+      xj = ((mask >> j) & 1ull) ? 1.0 : 0.0;
     else
-      x = tile_row[col + j];
+      xj = x[(size_t)j * 64];
+    cdouble_p pj = p + (size_t)j * g.SPT;
 #pragma unroll
-    for (int i = 0; i < ICH; ++i) acc[i] = fma(p[i], x, acc[i]);
+    for (int i = 0; i < ICH; ++i) acc[i] = fma(pj[i], xj, acc[i]);
   }
 }
 
-template <int ICH, bool LTIP, bool RTIP, bool GATHER>
-__global__ __launch_bounds__(256) void k_partials_generic(const OpPack pack, const GenGeo g,
-                                                          const unsigned long long *__restrict__ tipmap,
-                                                          unsigned tiles_per_block)
+// tiled address of element 0 of (entry e, rate 0, state 0)
+__device__ __forceinline__ size_t tiled_base(unsigned e, unsigned tile_sz)
 {
-  extern __shared__ double lds[];
-  double *tile = lds;                                                    // [64][LSTR]
-  unsigned char *flags = reinterpret_cast<unsigned char *>(lds + 64 * g.LSTR); // [4][64]
+  return (size_t)(e >> 6) * tile_sz + (e & 63u);
+}
+
+template <int ICH, bool LTIP, bool RTIP, bool GATHER>
+__global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const GenGeo g,
+                                                        const unsigned long long *__restrict__ tipmap)
+{
+  __shared__ unsigned char flags[kMaxRates][64];
 
   const DevOp &op = pack.ops[blockIdx.y];
+  const unsigned tile = blockIdx.x;
+  if (tile * 64u >= op.entries) return; // whole workgroup
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const unsigned span = g.R * g.SP;
+  const unsigned nw = blockDim.x >> 6;
   const int mode = op.pscaler ? g.scale_mode : 0;
 
-  for (unsigned t = 0; t < tiles_per_block; ++t)
+  const unsigned n = tile * 64u + lane;
+  const bool valid = n < op.entries;
+  const unsigned nn = valid ? n : op.entries - 1; // tail lanes redo the last entry, store nothing
+  unsigned le = nn, re = nn;
+  if (GATHER)
   {
-    const unsigned tile0 = (blockIdx.x * tiles_per_block + t) * 64u;
-    if (tile0 >= op.entries) break; // uniform
-    const unsigned n = tile0 + lane;
-    const bool valid = n < op.entries;
-    const unsigned nn = valid ? n : op.entries - 1; // clamp: tail lanes redo the last entry
-    unsigned le = nn, re = nn;
-    if (GATHER)
+    const unsigned site = op.id_site ? op.id_site[nn] : nn;
+    le = op.lsid ? op.lsid[site] : site;
+    re = op.rsid ? op.rsid[site] : site;
+  }
+  unsigned long long lmask = 0, rmask = 0;
+  if (LTIP) lmask = tipmap ? tipmap[op.ltip[le]] : (unsigned long long)op.ltip[le];
+  if (RTIP) rmask = tipmap ? tipmap[op.rtip[re]] : (unsigned long long)op.rtip[re];
+  const double *__restrict__ lx = LTIP ? nullptr : op.left + tiled_base(le, g.tile_sz);
+  const double *__restrict__ rx = RTIP ? nullptr : op.right + tiled_base(re, g.tile_sz);
+  double *__restrict__ out = op.parent + (size_t)tile * g.tile_sz + lane;
+
+  auto rescale_rate = [&](unsigned k) {
+    // this lane's stored column of rate k: same lane wrote it; order the accesses explicitly
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    double *col = out + (size_t)k * g.S * 64;
+    for (unsigned s = 0; s < g.S; ++s)
     {
-      const unsigned site = op.id_site ? op.id_site[nn] : nn;
-      le = op.lsid ? op.lsid[site] : site;
-      re = op.rsid ? op.rsid[site] : site;
+      const double v = __builtin_nontemporal_load(col + (size_t)s * 64);
+      col[(size_t)s * 64] = v * PLLGPU_SCALE_FACTOR;
     }
-    unsigned long long lmask = 0, rmask = 0;
-    if (LTIP) lmask = tipmap ? tipmap[op.ltip[le]] : (unsigned long long)op.ltip[le];
-    if (RTIP) rmask = tipmap ? tipmap[op.rtip[re]] : (unsigned long long)op.rtip[re];
+  };
 
-    bool site_small = true;
-    for (unsigned grp = 0; grp < g.ngroups; ++grp)
+  for (unsigned k = wave; k < g.R; k += nw)
+  {
+    bool small = true;
+    for (unsigned c = 0; c < g.nchunks; ++c)
     {
-      const unsigned k0 = grp * g.RG;
-      const unsigned nk = min(g.RG, g.R - k0);
-      const unsigned rowlen = nk * g.SP;
-      const unsigned nitems = nk * g.nchunks;          // <= 4 by construction of RG
-      const bool has_item = wave < nitems;
-      const unsigned kk = has_item ? wave / g.nchunks : 0; // rate within the group
-      const unsigned c = has_item ? wave % g.nchunks : 0;  // parent-state chunk
-      const unsigned k = k0 + kk;
-
       double A[ICH], B[ICH];
-      if (!LTIP)
-      {
-        stage_rows(tile, g.LSTR, op.left, le, span, k0 * g.SP, rowlen, wave, lane);
-        __syncthreads();
-      }
-      if (has_item) contract<ICH, LTIP>(A, op.lmat, k, c, g, tile + lane * g.LSTR, kk * g.SP, lmask);
-      if (!RTIP)
-      {
-        if (!LTIP) __syncthreads(); // every wave is done reading the left tile
-        stage_rows(tile, g.LSTR, op.right, re, span, k0 * g.SP, rowlen, wave, lane);
-        __syncthreads();
-      }
-      if (has_item) contract<ICH, RTIP>(B, op.rmat, k, c, g, tile + lane * g.LSTR, kk * g.SP, rmask);
-
-      bool small = true;
-      if (has_item)
-      {
+      contract<ICH, LTIP>(A, op.lmat, k, c, g, LTIP ? nullptr : lx + (size_t)k * g.S * 64, lmask);
+      contract<ICH, RTIP>(B, op.rmat, k, c, g, RTIP ? nullptr : rx + (size_t)k * g.S * 64, rmask);
+      double *dst = out + ((size_t)k * g.S + c * ICH) * 64;
 #pragma unroll
-        for (int i = 0; i < ICH; ++i)
+      for (int i = 0; i < ICH; ++i)
+        if (c * ICH + i < g.S)
         {
-          A[i] *= B[i];
-          if (c * ICH + i < g.S) small = small && (A[i] < PLLGPU_SCALE_THRESHOLD);
+          const double v = A[i] * B[i];
+          small = small && (v < PLLGPU_SCALE_THRESHOLD);
+          if (valid) dst[(size_t)i * 64] = v;
         }
-        if (mode) flags[wave * 64 + lane] = small ? 1 : 0;
-      }
-      __syncthreads(); // flags visible; tile no longer read by anyone
-
-      if (mode == 2)
-      {
-        // all states of this (site, rate): AND over the chunks of the rate (src/core_partials.c:736-746)
-        bool rs = true;
-        for (unsigned cc = 0; cc < g.nchunks; ++cc) rs = rs && flags[(kk * g.nchunks + cc) * 64 + lane];
-        if (has_item)
-        {
-          if (rs)
-          {
-#pragma unroll
-            for (int i = 0; i < ICH; ++i) A[i] *= PLLGPU_SCALE_FACTOR;
-          }
-          if (c == 0 && valid)
-            op.pscaler[(size_t)n * g.R + k] = (op.lscaler ? op.lscaler[(size_t)le * g.R + k] : 0u) +
-                                              (op.rscaler ? op.rscaler[(size_t)re * g.R + k] : 0u) +
-                                              (rs ? 1u : 0u);
-        }
-      }
-      else if (mode == 1)
-      {
-        for (unsigned it = 0; it < nitems; ++it) site_small = site_small && flags[it * 64 + lane];
-        if (g.ngroups == 1 && site_small && has_item)
-        {
-#pragma unroll
-          for (int i = 0; i < ICH; ++i) A[i] *= PLLGPU_SCALE_FACTOR;
-        }
-      }
-
-      if (has_item)
-      {
-        double *row = tile + lane * g.LSTR + kk * g.SP + c * ICH;
-#pragma unroll
-        for (int i = 0; i < ICH; ++i)
-          if (c * ICH + i < g.SP) row[i] = (c * ICH + i < g.S) ? A[i] : 0.0; // padding lanes := 0
-      }
-      __syncthreads();
-      for (unsigned e = wave; e < 64 && tile0 + e < op.entries; e += 4)
-      {
-        double *dst = op.parent + (size_t)(tile0 + e) * span + k0 * g.SP;
-        for (unsigned x = lane; x < rowlen; x += 64) dst[x] = tile[e * g.LSTR + x];
-      }
-      __syncthreads(); // tile free for the next group / tile
     }
-
-    if (mode == 1)
+    if (mode == 2)
     {
-      if (g.ngroups > 1 && site_small)
+      if (valid)
       {
-        // rare: the site's rate groups were already stored unscaled - rescale the stored row
-        // (this workgroup's own stores, ordered by the barrier above)
-        if (wave == 0 && valid)
-        {
-          double *row = op.parent + (size_t)n * span;
-          for (unsigned x = 0; x < span; ++x) row[x] = row[x] * PLLGPU_SCALE_FACTOR;
-        }
+        if (small) rescale_rate(k);
+        op.pscaler[(size_t)n * g.R + k] = (op.lscaler ? op.lscaler[(size_t)le * g.R + k] : 0u) +
+                                          (op.rscaler ? op.rscaler[(size_t)re * g.R + k] : 0u) +
+                                          (small ? 1u : 0u);
       }
-      if (wave == 0 && valid)
+    }
+    else if (mode == 1)
+      flags[k][lane] = small ? 1 : 0;
+  }
+
+  if (mode == 1)
+  {
+    __syncthreads();
+    bool site_small = true;
+    for (unsigned k = 0; k < g.R; ++k) site_small = site_small && flags[k][lane];
+    if (valid)
+    {
+      if (site_small)
+        for (unsigned k = wave; k < g.R; k += nw) rescale_rate(k);
+      if (wave == 0)
         op.pscaler[n] = (op.lscaler ? op.lscaler[le] : 0u) + (op.rscaler ? op.rscaler[re] : 0u) +
                         (site_small ? 1u : 0u);
     }
@@ -192,28 +149,27 @@ __global__ __launch_bounds__(256) void k_partials_generic(const OpPack pack, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// edge / root log-likelihood, any states/rates. Same tile/lane mapping: work item (rate, chunk)
-// per wave gives the partial sum_i p_i pi_i (P c)_i of its chunk; wave 0 then mixes rates, undoes
-// scaling, takes the log and accumulates the block sum in site order.
+// edge / root log-likelihood, any states/rates, tiled layout. One WAVE per tile of 64 sites: it
+// walks the rate categories, forms (P c)_i in chunks exactly like the update kernel, dots it with
+// p_i * pi_i, mixes the categories (per-rate scaler excess, invariant sites), takes the log and
+// keeps a running sum in site order; 4 waves = 4 tiles per workgroup, one partial per workgroup.
 // Arithmetic: src/core_likelihood.c:1388-1490 (ii), :812-915 (ti), :1077-1183 (repeats), :163-207 (root).
 template <int ICH, bool CTIP, bool GATHER>
-__global__ __launch_bounds__(256) void k_edge_generic(const DevEdge e, const GenGeo g,
-                                                      const unsigned long long *__restrict__ tipmap,
-                                                      unsigned tiles_per_block)
+__global__ __launch_bounds__(256) void k_edge_tiled(const DevEdge e, const GenGeo g,
+                                                    const unsigned long long *__restrict__ tipmap,
+                                                    unsigned tiles_per_wave)
 {
-  extern __shared__ double lds[];
-  double *tile = lds;                       // [64][LSTR]
-  double *part = lds + 64 * g.LSTR;         // [4][64] chunk partials
+  __shared__ double wsum[4];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const unsigned span = g.R * g.SP;
+  const unsigned ntiles = (e.sites + 63u) / 64u;
   double acc = 0.0;
 
-  for (unsigned t = 0; t < tiles_per_block; ++t)
+  for (unsigned t = 0; t < tiles_per_wave; ++t)
   {
-    const unsigned tile0 = (blockIdx.x * tiles_per_block + t) * 64u;
-    if (tile0 >= e.sites) break;
-    const unsigned n = tile0 + lane;
+    const unsigned tile = (blockIdx.x * 4u + wave) * tiles_per_wave + t;
+    if (tile >= ntiles) break; // wave-uniform
+    const unsigned n = tile * 64u + lane;
     const bool valid = n < e.sites;
     const unsigned nn = valid ? n : e.sites - 1;
     unsigned pe = nn, ce = nn;
@@ -224,105 +180,108 @@ __global__ __launch_bounds__(256) void k_edge_generic(const DevEdge e, const Gen
     }
     unsigned long long cmask = 0;
     if (CTIP) cmask = tipmap ? tipmap[e.ctip[ce]] : (unsigned long long)e.ctip[ce];
+    const double *__restrict__ px = e.parent + tiled_base(pe, g.tile_sz);
+    const double *__restrict__ cx = (CTIP || e.is_root) ? nullptr : e.child + tiled_base(ce, g.tile_sz);
 
-    // wave 0 owns the per-site epilogue state
-    unsigned scal = 0;
-    if (wave == 0)
+    unsigned scal;
+    if (e.per_rate)
     {
-      if (e.per_rate)
+      scal = 0xFFFFFFFFu;
+      for (unsigned k = 0; k < g.R; ++k)
       {
-        scal = 0xFFFFFFFFu;
-        for (unsigned k = 0; k < g.R; ++k)
-        {
-          unsigned rs = (e.pscaler ? e.pscaler[(size_t)pe * g.R + k] : 0u) +
-                        (e.cscaler ? e.cscaler[(size_t)ce * g.R + k] : 0u);
-          scal = min(scal, rs);
-        }
+        const unsigned rs = (e.pscaler ? e.pscaler[(size_t)pe * g.R + k] : 0u) +
+                            (e.cscaler ? e.cscaler[(size_t)ce * g.R + k] : 0u);
+        scal = min(scal, rs);
       }
-      else
-        scal = (e.pscaler ? e.pscaler[pe] : 0u) + (e.cscaler ? e.cscaler[ce] : 0u);
     }
+    else
+      scal = (e.pscaler ? e.pscaler[pe] : 0u) + (e.cscaler ? e.cscaler[ce] : 0u);
+
     double terma = 0.0, terminv = 0.0;
-
-    for (unsigned grp = 0; grp < g.ngroups; ++grp)
+    for (unsigned k = 0; k < g.R; ++k)
     {
-      const unsigned k0 = grp * g.RG;
-      const unsigned nk = min(g.RG, g.R - k0);
-      const unsigned rowlen = nk * g.SP;
-      const unsigned nitems = nk * g.nchunks;
-      const bool has_item = wave < nitems;
-      const unsigned kk = has_item ? wave / g.nchunks : 0;
-      const unsigned c = has_item ? wave % g.nchunks : 0;
-      const unsigned k = k0 + kk;
-
-      double B[ICH];
-      if (e.is_root)
+      const unsigned fi = e.fidx[k];
+      double tr = 0.0;
+      for (unsigned c = 0; c < g.nchunks; ++c)
       {
-#pragma unroll
-        for (int i = 0; i < ICH; ++i) B[i] = 1.0;
-      }
-      else
-      {
-        if (!CTIP)
+        double B[ICH];
+        if (e.is_root)
         {
-          stage_rows(tile, g.LSTR, e.child, ce, span, k0 * g.SP, rowlen, wave, lane);
-          __syncthreads();
+#pragma unroll
+          for (int i = 0; i < ICH; ++i) B[i] = 1.0;
         }
-        if (has_item) contract<ICH, CTIP>(B, e.mat, k, c, g, tile + lane * g.LSTR, kk * g.SP, cmask);
-        if (!CTIP) __syncthreads();
-      }
-      stage_rows(tile, g.LSTR, e.parent, pe, span, k0 * g.SP, rowlen, wave, lane);
-      __syncthreads();
-      if (has_item)
-      {
-        cdouble_p pi = as_const(e.freqs) + (size_t)e.fidx[k] * g.SP + c * ICH;
-        const double *row = tile + lane * g.LSTR + kk * g.SP + c * ICH;
-        double s = 0.0;
+        else
+          contract<ICH, CTIP>(B, e.mat, k, c, g, CTIP ? nullptr : cx + (size_t)k * g.S * 64, cmask);
+        cdouble_p pi = as_const(e.freqs) + (size_t)fi * g.SP + c * ICH;
+        const double *pk = px + ((size_t)k * g.S + c * ICH) * 64;
 #pragma unroll
         for (int i = 0; i < ICH; ++i)
-          if (c * ICH + i < g.S) s = fma(row[i] * pi[i], B[i], s);
-        part[wave * 64 + lane] = s;
+          if (c * ICH + i < g.S) tr = fma(pk[(size_t)i * 64] * pi[i], B[i], tr);
       }
-      __syncthreads();
-      if (wave == 0)
+      if (e.per_rate)
       {
-        for (unsigned r = 0; r < nk; ++r)
-        {
-          const unsigned kr = k0 + r;
-          double tr = 0.0;
-          for (unsigned cc = 0; cc < g.nchunks; ++cc) tr += part[(r * g.nchunks + cc) * 64 + lane];
-          if (e.per_rate)
-          {
-            unsigned rs = (e.pscaler ? e.pscaler[(size_t)pe * g.R + kr] : 0u) +
-                          (e.cscaler ? e.cscaler[(size_t)ce * g.R + kr] : 0u);
-            const unsigned ex = min(rs - scal, PLLGPU_RATE_MAXDIFF);
-            if (ex) tr *= minlh(ex);
-          }
-          const unsigned fi = e.fidx[kr];
-          const double pinv = e.prop_invar ? e.prop_invar[fi] : 0.0;
-          const double w = e.rate_weights[kr];
-          if (pinv > 0.0)
-          {
-            terma += w * tr * (1.0 - pinv);
-            const int inv = e.invariant ? e.invariant[nn] : -1;
-            if (inv >= 0) terminv += w * e.freqs[(size_t)fi * g.SP + inv] * pinv;
-          }
-          else
-            terma += tr * w;
-        }
+        const unsigned rs = (e.pscaler ? e.pscaler[(size_t)pe * g.R + k] : 0u) +
+                            (e.cscaler ? e.cscaler[(size_t)ce * g.R + k] : 0u);
+        const unsigned ex = min(rs - scal, PLLGPU_RATE_MAXDIFF);
+        if (ex) tr *= minlh(ex);
       }
-      __syncthreads(); // part / tile reusable
+      const double pinv = e.prop_invar ? e.prop_invar[fi] : 0.0;
+      const double w = e.rate_weights[k];
+      if (pinv > 0.0)
+      {
+        terma += w * tr * (1.0 - pinv);
+        const int inv = e.invariant ? e.invariant[nn] : -1;
+        if (inv >= 0) terminv += w * e.freqs[(size_t)fi * g.SP + inv] * pinv;
+      }
+      else
+        terma += tr * w;
     }
-    if (wave == 0 && valid)
+    if (valid)
     {
-      double site = finish_site(terma, terminv, scal, e.is_root) * (double)e.pattern_weights[n];
+      const double site = finish_site(terma, terminv, scal, e.is_root) * (double)e.pattern_weights[n];
       if (e.persite) e.persite[n] = site;
       acc += site;
     }
   }
-  if (wave == 0)
+  acc = wave_sum(acc);
+  if (lane == 0) wsum[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) e.block_sums[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout converters between the host mirror [entry][rate][SP] and the tiled device layout. One
+// thread per tiled element (coalesced on the tiled side). Not on the hot path.
+__global__ __launch_bounds__(256) void k_aos_to_tiled(const double *__restrict__ aos, double *__restrict__ tiled,
+                                                      unsigned entries, unsigned S, unsigned SP, unsigned R)
+{
+  const size_t total = (size_t)((entries + 63u) / 64u) * R * S * 64u;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256)
   {
-    acc = wave_sum(acc);
-    if (lane == 0) e.block_sums[blockIdx.x] = acc;
+    const unsigned lane = idx & 63u;
+    size_t r = idx >> 6;
+    const unsigned j = r % S;
+    r /= S;
+    const unsigned k = r % R;
+    const size_t tile = r / R;
+    const size_t ent = tile * 64 + lane;
+    tiled[idx] = ent < entries ? aos[(ent * R + k) * SP + j] : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_tiled_to_aos(const double *__restrict__ tiled, double *__restrict__ aos,
+                                                      unsigned entries, unsigned S, unsigned SP, unsigned R)
+{
+  const size_t total = (size_t)((entries + 63u) / 64u) * R * SP * 64u;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256)
+  {
+    const unsigned lane = idx & 63u;
+    size_t r = idx >> 6;
+    const unsigned j = r % SP;
+    r /= SP;
+    const unsigned k = r % R;
+    const size_t tile = r / R;
+    const size_t ent = tile * 64 + lane;
+    if (ent < entries) aos[(ent * R + k) * SP + j] = j < S ? tiled[((tile * R + k) * S + j) * 64 + lane] : 0.0;
   }
 }

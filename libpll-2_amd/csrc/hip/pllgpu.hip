@@ -75,6 +75,8 @@ struct pllgpu_ctx
   GenGeo gg;
   int ich = 0;
   bool dna_fast = false;
+  bool tiled = false;       // generic shapes keep CLVs in the tiled sites-contiguous layout
+  DevBuf<double> scratch;   // host-layout staging for mirror copies of tiled CLVs
   size_t pm_stride = 0; // doubles per matrix in PT layout
   unsigned span = 0;
 
@@ -112,21 +114,29 @@ extern "C" int pllgpu_device_count(void)
 static void derive_geometry(pllgpu_ctx *c)
 {
   const pllgpu_geometry_t &g = c->geo;
-  int ich = g.states <= 4 ? 4 : g.states <= 8 ? 8 : g.states <= 16 ? 16 : g.states <= 20 ? 20 : 16;
+  int ich = g.states <= 4 ? 4 : g.states <= 8 ? 8 : g.states <= 16 ? 16 : g.states <= 20 ? 20 : 32;
   GenGeo &gg = c->gg;
   gg.S = g.states;
   gg.SP = g.states_padded;
   gg.R = g.rate_cats;
   gg.nchunks = (g.states + ich - 1) / ich;
   gg.SPT = gg.nchunks * ich;
-  gg.RG = gg.nchunks == 1 ? std::min(g.rate_cats, 4u) : gg.nchunks == 2 ? std::min(g.rate_cats, 2u) : 1u;
-  gg.ngroups = (g.rate_cats + gg.RG - 1) / gg.RG;
-  gg.LSTR = (gg.RG * gg.SP) | 1u;
+  gg.tile_sz = g.rate_cats * g.states * 64u;
   gg.scale_mode = g.per_rate_scalers ? 2 : 1;
   c->ich = ich;
   c->dna_fast = (g.states == 4 && g.states_padded == 4 && g.rate_cats == 4);
+  if (const char *v = getenv("PLL_AMD_FORCE_TILED")) // experiment switch: route DNA through the tiled kernels
+    if (*v && *v != '0') c->dna_fast = false;
+  c->tiled = !c->dna_fast;
   c->pm_stride = (size_t)g.rate_cats * g.states * gg.SPT;
   c->span = g.rate_cats * g.states_padded;
+}
+
+// doubles of device storage for `entries` entries of one CLV
+static inline size_t clv_elems(const pllgpu_ctx *c, unsigned entries)
+{
+  if (c->tiled) return (size_t)((entries + 63u) / 64u) * c->gg.tile_sz;
+  return (size_t)entries * c->span;
 }
 
 extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
@@ -213,6 +223,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   for (auto &b : c->site_id) b.release();
   for (auto &b : c->id_site) b.release();
   c->tipmap.release();
+  c->scratch.release();
   c->pmat.release();
   c->freqs.release();
   c->rate_weights.release();
@@ -240,24 +251,42 @@ extern "C" int pllgpu_clv_reserve(pllgpu_ctx_t *c, unsigned node, unsigned entri
 {
   CHECK_CTX(c);
   if (node >= c->geo.nodes) return fail(PLLGPU_EINVAL, "clv index %u out of range", node);
-  return c->clv[node].ensure((size_t)entries * c->span);
+  return c->clv[node].ensure(clv_elems(c, entries));
 }
 
 extern "C" int pllgpu_clv_upload(pllgpu_ctx_t *c, unsigned node, const double *host, unsigned entries)
 {
   if (int rc = pllgpu_clv_reserve(c, node, entries)) return rc;
-  HIP_TRY(hipMemcpyAsync(c->clv[node].p, host, (size_t)entries * c->span * sizeof(double),
-                         hipMemcpyHostToDevice, c->stream));
+  const size_t bytes = (size_t)entries * c->span * sizeof(double);
+  if (!c->tiled)
+  {
+    HIP_TRY(hipMemcpyAsync(c->clv[node].p, host, bytes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+  }
+  if (int rc = c->scratch.ensure((size_t)entries * c->span)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->scratch.p, host, bytes, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_aos_to_tiled, dim3(1024), dim3(256), 0, c->stream, c->scratch.p, c->clv[node].p, entries,
+                     c->gg.S, c->gg.SP, c->gg.R);
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 
 extern "C" int pllgpu_clv_download(pllgpu_ctx_t *c, unsigned node, double *host, unsigned entries)
 {
   CHECK_CTX(c);
-  if (node >= c->geo.nodes || (size_t)entries * c->span > c->clv[node].cap)
+  if (node >= c->geo.nodes || clv_elems(c, entries) > c->clv[node].cap)
     return fail(PLLGPU_EINVAL, "clv %u: download of %u entries exceeds the device buffer", node, entries);
-  HIP_TRY(hipMemcpyAsync(host, c->clv[node].p, (size_t)entries * c->span * sizeof(double),
-                         hipMemcpyDeviceToHost, c->stream));
+  const size_t bytes = (size_t)entries * c->span * sizeof(double);
+  const double *src = c->clv[node].p;
+  if (c->tiled)
+  {
+    if (int rc = c->scratch.ensure((size_t)entries * c->span)) return rc;
+    hipLaunchKernelGGL(k_tiled_to_aos, dim3(1024), dim3(256), 0, c->stream, c->clv[node].p, c->scratch.p, entries,
+                       c->gg.S, c->gg.SP, c->gg.R);
+    HIP_TRY(hipGetLastError());
+    src = c->scratch.p;
+  }
+  HIP_TRY(hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -409,7 +438,7 @@ static int resolve_op(pllgpu_ctx *c, const pllgpu_op_t &o, DevOp &d)
   if (o.left_matrix >= g.prob_matrices || o.right_matrix >= g.prob_matrices)
     return fail(PLLGPU_EINVAL, "operation references a p-matrix out of range");
   memset(&d, 0, sizeof d);
-  if (int rc = c->clv[o.parent_clv].ensure((size_t)o.parent_entries * c->span)) return rc;
+  if (int rc = c->clv[o.parent_clv].ensure(clv_elems(c, o.parent_entries))) return rc;
   d.parent = c->clv[o.parent_clv].p;
   d.entries = o.parent_entries;
   if (o.flags & PLLGPU_OP_LEFT_TIP)
@@ -464,13 +493,12 @@ static int resolve_op(pllgpu_ctx *c, const pllgpu_op_t &o, DevOp &d)
 template <int ICH>
 static void launch_generic(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
 {
+  // one workgroup per 64-entry tile; min(R,4) waves share the tile's rate categories
   const unsigned tiles = (maxent + 63) / 64;
-  unsigned tpb = std::max(1u, (tiles * nops) / 2048u);
-  dim3 grid((tiles + tpb - 1) / tpb, nops), block(256);
-  const size_t lds = (size_t)64 * c->gg.LSTR * sizeof(double) + 4 * 64;
+  dim3 grid(tiles, nops), block(64u * std::min(c->gg.R, 4u));
   const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
 #define GEN_LAUNCH(LT, RT, GA) \
-  hipLaunchKernelGGL((k_partials_generic<ICH, LT, RT, GA>), grid, block, lds, c->stream, pack, c->gg, tm, tpb)
+  hipLaunchKernelGGL((k_partials_tiled<ICH, LT, RT, GA>), grid, block, 0, c->stream, pack, c->gg, tm)
   if (kind == 0)
   {
     if (gather) GEN_LAUNCH(false, false, true); else GEN_LAUNCH(false, false, false);
@@ -536,7 +564,8 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
               case 4: launch_generic<4>(c, pack, nops, maxent, kind, ga != 0); break;
               case 8: launch_generic<8>(c, pack, nops, maxent, kind, ga != 0); break;
               case 16: launch_generic<16>(c, pack, nops, maxent, kind, ga != 0); break;
-              default: launch_generic<20>(c, pack, nops, maxent, kind, ga != 0); break;
+              case 20: launch_generic<20>(c, pack, nops, maxent, kind, ga != 0); break;
+              default: launch_generic<32>(c, pack, nops, maxent, kind, ga != 0); break;
             }
           ++c->last_launches;
           nops = 0;
@@ -565,11 +594,10 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
 
 // ---- log-likelihood ----------------------------------------------------------------------------
 template <int ICH>
-static void launch_edge_generic(pllgpu_ctx *c, const DevEdge &e, unsigned blocks, unsigned tpb, bool ctip, bool gather)
+static void launch_edge_generic(pllgpu_ctx *c, const DevEdge &e, unsigned blocks, unsigned tpw, bool ctip, bool gather)
 {
-  const size_t lds = ((size_t)64 * c->gg.LSTR + 4 * 64) * sizeof(double);
   const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
-#define EG(CT, GA) hipLaunchKernelGGL((k_edge_generic<ICH, CT, GA>), dim3(blocks), dim3(256), lds, c->stream, e, c->gg, tm, tpb)
+#define EG(CT, GA) hipLaunchKernelGGL((k_edge_tiled<ICH, CT, GA>), dim3(blocks), dim3(256), 0, c->stream, e, c->gg, tm, tpw)
   if (ctip)
   {
     if (gather) EG(true, true); else EG(true, false);
@@ -602,10 +630,11 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
 
   const unsigned tiles = (g.sites + 63) / 64;
   const unsigned max_blocks = 1024;
-  const unsigned tpb = (tiles + max_blocks - 1) / max_blocks;
-  const unsigned blocks = (tiles + tpb - 1) / tpb;
+  unsigned blocks;
   if (c->dna_fast)
   {
+    const unsigned tpb = (tiles + max_blocks - 1) / max_blocks;
+    blocks = (tiles + tpb - 1) / tpb;
     const unsigned spb = tpb * 64;
 #define ED(CT, GA) hipLaunchKernelGGL((k_edge_dna<CT, GA>), dim3(blocks), dim3(256), 0, c->stream, e, spb)
     if (ctip)
@@ -619,13 +648,19 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
 #undef ED
   }
   else
+  {
+    // 4 waves = 4 tiles per workgroup, tpw consecutive tiles per wave
+    const unsigned tpw = (tiles + 4 * max_blocks - 1) / (4 * max_blocks);
+    blocks = (tiles + 4 * tpw - 1) / (4 * tpw);
     switch (c->ich)
     {
-      case 4: launch_edge_generic<4>(c, e, blocks, tpb, ctip, gather); break;
-      case 8: launch_edge_generic<8>(c, e, blocks, tpb, ctip, gather); break;
-      case 16: launch_edge_generic<16>(c, e, blocks, tpb, ctip, gather); break;
-      default: launch_edge_generic<20>(c, e, blocks, tpb, ctip, gather); break;
+      case 4: launch_edge_generic<4>(c, e, blocks, tpw, ctip, gather); break;
+      case 8: launch_edge_generic<8>(c, e, blocks, tpw, ctip, gather); break;
+      case 16: launch_edge_generic<16>(c, e, blocks, tpw, ctip, gather); break;
+      case 20: launch_edge_generic<20>(c, e, blocks, tpw, ctip, gather); break;
+      default: launch_edge_generic<32>(c, e, blocks, tpw, ctip, gather); break;
     }
+  }
   hipLaunchKernelGGL(k_sum_blocks, dim3(1), dim3(256), 0, c->stream, c->block_sums.p, blocks, c->result.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(c->result_host, c->result.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
