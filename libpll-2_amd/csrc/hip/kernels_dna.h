@@ -1,228 +1,234 @@
-// kernels_dna.h - 4-state x 4-rate kernels (the headline DNA/Gamma4 configuration).
+// kernels_dna.h - 4 states x 4 rate categories (the headline DNA + Gamma4 configuration), tiled
+// sites-contiguous layout clv[tile][rate][state][64 lanes] (kernels_generic.h explains the layout).
 //
-// Thread mapping: one lane per (entry, rate). The four lanes of a DPP quad hold the four rate
-// categories of one site; lane t of the grid touches bytes [32 t, 32 t + 32) of a CLV, so every
-// wave-wide load/store is 64 x 16 B fully coalesced (two global_load_dwordx4 per CLV per lane).
-// The two 4x4 transition matrices of the lane's rate category live in registers for the whole
-// kernel (64 VGPRs); per-site reductions (scaling test, rate mixing) are DPP quad exchanges.
+// Thread mapping: LANE = SITE, one WAVE per 64-site tile, all four rate categories in the lane:
+//   * every load/store is a dense 512-byte wave access (64 x 8 B): 32 loads + 16 stores per tile;
+//   * the 2 x 4 x 16 transition coefficients of the op are wave-uniform -> scalar loads (1 KB per
+//     op, resident in the scalar cache), SGPR operands of v_fma_f64; no LDS, no barriers;
+//   * a site's 16 results stay in registers until the per-site scaling decision
+//     (src/core_partials.c:729-763) is known: no cross-lane traffic at all.
+// An earlier variant with the reference's [site][rate][state] layout and one lane per (site, rate)
+// (DPP quad reductions, matrices in VGPRs) measured 64 % of HBM peak on C2; this one is faster
+// (profiles/README.md) because each wave instruction touches 4 full cache lines instead of 16 half
+// ones and the matrices cost no vector registers.
 //
-// Algorithmic traffic per site-CLV-update: ii 3*128 B (+12 B scalers), ti 2*128+1, tt 128+2.
-// Arithmetic: src/core_partials.c:709-764 (ii), :290-351 (ti), :1032-1070 + :68-79 (tt, the
-// lookup table is replaced by 8 masked adds in registers), :819-879 (repeats: gathers).
+// Algorithmic traffic per site-CLV-update: ii 3*128 B (+4 B per scaler vector touched),
+// ti 2*128+1, tt 128+2. Arithmetic: src/core_partials.c:709-764 (ii), :290-351 (ti),
+// :1032-1070 + :68-79 (tt; the lookup table is replaced by masked sums), :819-879 (repeats).
 #pragma once
 #include "kernels_common.h"
 
-struct Mat4
-{
-  double m[4][4]; // m[i][j]: parent state i, child state j
-};
+constexpr unsigned kDnaTile = 16 * 64; // doubles per tile
 
-// PT layout for SPT == 4: pt[(k*4 + j)*4 + i]
-__device__ __forceinline__ void load_mat4(const double *__restrict__ pt, unsigned k, Mat4 &M)
+// x[j] of one (entry, rate): four dense loads, or the bits of a tip code
+template <bool TIP>
+__device__ __forceinline__ void dna_fetch(double (&x)[4], const double *__restrict__ base, unsigned k, unsigned code)
 {
-  const double4 *p = reinterpret_cast<const double4 *>(pt) + k * 4;
+  if (TIP)
+  {
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) x[j] = (code >> j) & 1u ? 1.0 : 0.0;
+  }
+  else
   {
-    double4 v = p[j];
-    M.m[0][j] = v.x;
-    M.m[1][j] = v.y;
-    M.m[2][j] = v.z;
-    M.m[3][j] = v.w;
+    // child CLVs are read exactly once per traversal: streaming (nt) loads keep them from
+    // displacing the freshly written parent lines the next level will want from L2/MALL.
+    // Measured on C2: 5.4 -> 6.3 TB/s (profiles/README.md); nt on the STORES as well loses it again.
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = __builtin_nontemporal_load(base + (k * 4 + j) * 64);
   }
 }
 
-__device__ __forceinline__ double4 matvec4(const Mat4 &M, const double4 x)
+// r[i] = sum_j PT[k][j][i] * x[j], coefficients through the scalar path
+__device__ __forceinline__ void dna_matvec(double (&r)[4], cdouble_p pt_k, const double (&x)[4])
 {
-  double4 r;
-  r.x = fma(M.m[0][3], x.w, fma(M.m[0][2], x.z, fma(M.m[0][1], x.y, M.m[0][0] * x.x)));
-  r.y = fma(M.m[1][3], x.w, fma(M.m[1][2], x.z, fma(M.m[1][1], x.y, M.m[1][0] * x.x)));
-  r.z = fma(M.m[2][3], x.w, fma(M.m[2][2], x.z, fma(M.m[2][1], x.y, M.m[2][0] * x.x)));
-  r.w = fma(M.m[3][3], x.w, fma(M.m[3][2], x.z, fma(M.m[3][1], x.y, M.m[3][0] * x.x)));
-  return r;
-}
-
-// row sums over the states present in a 4-bit tip code (src/core_partials.c:304-312)
-__device__ __forceinline__ double4 masksum4(const Mat4 &M, unsigned code)
-{
-  double4 x;
-  x.x = (code & 1u) ? 1.0 : 0.0;
-  x.y = (code & 2u) ? 1.0 : 0.0;
-  x.z = (code & 4u) ? 1.0 : 0.0;
-  x.w = (code & 8u) ? 1.0 : 0.0;
-  return matvec4(M, x);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    r[i] = fma(pt_k[12 + i], x[3], fma(pt_k[8 + i], x[2], fma(pt_k[4 + i], x[1], pt_k[i] * x[0])));
 }
 
 template <bool LTIP, bool RTIP, bool GATHER>
-__device__ __forceinline__ void dna_site(const DevOp &op, const Mat4 &L, const Mat4 &R, unsigned n,
-                                         unsigned k, int scale_mode)
-{
-  const double4 *__restrict__ left = reinterpret_cast<const double4 *>(op.left);
-  const double4 *__restrict__ right = reinterpret_cast<const double4 *>(op.right);
-  double4 *__restrict__ parent = reinterpret_cast<double4 *>(op.parent);
-
-  unsigned le = n, re = n;
-  if (GATHER)
-  {
-    const unsigned site = op.id_site ? op.id_site[n] : n;
-    le = op.lsid ? op.lsid[site] : site;
-    re = op.rsid ? op.rsid[site] : site;
-  }
-  double4 a, b;
-  if (LTIP)
-    a = masksum4(L, op.ltip[le]);
-  else
-    a = matvec4(L, left[(size_t)le * 4 + k]);
-  if (RTIP)
-    b = masksum4(R, op.rtip[re]);
-  else
-    b = matvec4(R, right[(size_t)re * 4 + k]);
-  double4 v;
-  v.x = a.x * b.x;
-  v.y = a.y * b.y;
-  v.z = a.z * b.z;
-  v.w = a.w * b.w;
-
-  if (scale_mode)
-  {
-    int small = (v.x < PLLGPU_SCALE_THRESHOLD) & (v.y < PLLGPU_SCALE_THRESHOLD) &
-                (v.z < PLLGPU_SCALE_THRESHOLD) & (v.w < PLLGPU_SCALE_THRESHOLD);
-    if (scale_mode == 1)
-    {
-      // all 16 entries of the site: AND across the quad (src/core_partials.c:754-763)
-      small &= dpp_i32<0xB1>(small);
-      small &= dpp_i32<0x4E>(small);
-      if (k == 0)
-        op.pscaler[n] = (op.lscaler ? op.lscaler[le] : 0u) + (op.rscaler ? op.rscaler[re] : 0u) +
-                        (unsigned)small;
-    }
-    else
-    {
-      op.pscaler[(size_t)n * 4 + k] = (op.lscaler ? op.lscaler[(size_t)le * 4 + k] : 0u) +
-                                      (op.rscaler ? op.rscaler[(size_t)re * 4 + k] : 0u) +
-                                      (unsigned)small;
-    }
-    if (small)
-    {
-      v.x *= PLLGPU_SCALE_FACTOR;
-      v.y *= PLLGPU_SCALE_FACTOR;
-      v.z *= PLLGPU_SCALE_FACTOR;
-      v.w *= PLLGPU_SCALE_FACTOR;
-    }
-  }
-  parent[(size_t)n * 4 + k] = v;
-}
-
-// grid: x = entry chunks of `epb` (multiple of 64), y = op within the pack
-template <bool LTIP, bool RTIP, bool GATHER>
-__global__ __launch_bounds__(256) void k_partials_dna(const OpPack pack, int scale_mode, unsigned epb)
+__global__ __launch_bounds__(256) void k_partials_dna(const OpPack pack, int scale_mode, unsigned tiles_per_wave)
 {
   const DevOp &op = pack.ops[blockIdx.y];
-  const unsigned begin = blockIdx.x * epb;
-  if (begin >= op.entries) return;
-  const unsigned end = min(op.entries, begin + epb);
-  const unsigned k = threadIdx.x & 3u;
-  const unsigned q = threadIdx.x >> 2;
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned ntiles = (op.entries + 63u) / 64u;
   const int mode = op.pscaler ? scale_mode : 0;
+  cdouble_p lm = as_const(op.lmat), rm = as_const(op.rmat);
 
-  Mat4 L, R;
-  load_mat4(op.lmat, k, L);
-  load_mat4(op.rmat, k, R);
-
-  unsigned n = begin + q;
-  // two sites per trip: twice the loads in flight per lane
-  for (; n + 64 < end; n += 128)
+  for (unsigned t = 0; t < tiles_per_wave; ++t)
   {
-    dna_site<LTIP, RTIP, GATHER>(op, L, R, n, k, mode);
-    dna_site<LTIP, RTIP, GATHER>(op, L, R, n + 64, k, mode);
+    const unsigned tile = (blockIdx.x * 4u + wave) * tiles_per_wave + t;
+    if (tile >= ntiles) break; // wave-uniform
+    const unsigned n = tile * 64u + lane;
+    const bool valid = n < op.entries;
+    const unsigned nn = valid ? n : op.entries - 1;
+    unsigned le = nn, re = nn;
+    if (GATHER)
+    {
+      const unsigned site = op.id_site ? op.id_site[nn] : nn;
+      le = op.lsid ? op.lsid[site] : site;
+      re = op.rsid ? op.rsid[site] : site;
+    }
+    const unsigned lcode = LTIP ? op.ltip[le] : 0u;
+    const unsigned rcode = RTIP ? op.rtip[re] : 0u;
+    const double *__restrict__ lx = LTIP ? nullptr : op.left + (size_t)(le >> 6) * kDnaTile + (le & 63u);
+    const double *__restrict__ rx = RTIP ? nullptr : op.right + (size_t)(re >> 6) * kDnaTile + (re & 63u);
+    double *__restrict__ out = op.parent + (size_t)tile * kDnaTile + lane;
+
+    double v[4][4];
+    bool small[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      double xl[4], xr[4], a[4], b[4];
+      dna_fetch<LTIP>(xl, lx, k, lcode);
+      dna_fetch<RTIP>(xr, rx, k, rcode);
+      dna_matvec(a, lm + k * 16, xl);
+      dna_matvec(b, rm + k * 16, xr);
+      small[k] = true;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+      {
+        v[k][i] = a[i] * b[i];
+        small[k] = small[k] && (v[k][i] < PLLGPU_SCALE_THRESHOLD);
+      }
+    }
+    if (mode == 1)
+    {
+      const bool s = small[0] && small[1] && small[2] && small[3];
+      if (s)
+      {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[k][i] *= PLLGPU_SCALE_FACTOR;
+      }
+      if (valid)
+        op.pscaler[n] = (op.lscaler ? op.lscaler[le] : 0u) + (op.rscaler ? op.rscaler[re] : 0u) + (s ? 1u : 0u);
+    }
+    else if (mode == 2)
+    {
+      uint4 sc = make_uint4(0, 0, 0, 0);
+      if (op.lscaler)
+      {
+        const uint4 l = reinterpret_cast<const uint4 *>(op.lscaler)[le];
+        sc.x += l.x; sc.y += l.y; sc.z += l.z; sc.w += l.w;
+      }
+      if (op.rscaler)
+      {
+        const uint4 r = reinterpret_cast<const uint4 *>(op.rscaler)[re];
+        sc.x += r.x; sc.y += r.y; sc.z += r.z; sc.w += r.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (small[k])
+        {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[k][i] *= PLLGPU_SCALE_FACTOR;
+        }
+      sc.x += small[0]; sc.y += small[1]; sc.z += small[2]; sc.w += small[3];
+      if (valid) reinterpret_cast<uint4 *>(op.pscaler)[n] = sc;
+    }
+    if (valid)
+    {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[(k * 4 + i) * 64] = v[k][i];
+    }
   }
-  if (n < end) dna_site<LTIP, RTIP, GATHER>(op, L, R, n, k, mode);
 }
 
 // ------------------------------------------------------------------------------------------------
-// edge / root log-likelihood, 4 states x 4 rates. Same quad mapping; the quad's rate terms are
-// mixed with two DPP adds, lane k==0 finishes the site (log, scaler undo, pattern weight), then a
-// wave shuffle tree and an LDS step give one partial sum per block (fixed order: deterministic).
+// edge / root log-likelihood, 4 x 4, tiled. One wave per tile; the lane mixes its site's four rate
+// categories in registers, takes the log and accumulates in site order; wave shuffle tree + LDS
+// give one partial per workgroup (fixed order: deterministic).
 // Arithmetic: src/core_likelihood.c:1388-1490 (ii), :470-578 (ti 4x4), :1077-1183 (repeats),
 // :163-207 (root).
 template <bool CTIP, bool GATHER>
-__global__ __launch_bounds__(256) void k_edge_dna(const DevEdge e, unsigned spb /* sites per block */)
+__global__ __launch_bounds__(256) void k_edge_dna(const DevEdge e, unsigned tiles_per_wave)
 {
   __shared__ double wsum[4];
-  const unsigned k = threadIdx.x & 3u;
-  const unsigned q = threadIdx.x >> 2;
-  const unsigned begin = blockIdx.x * spb;
-  const unsigned end = min(e.sites, begin + spb);
-
-  Mat4 P;
-  if (!e.is_root) load_mat4(e.mat, k, P);
-  const unsigned fi = e.fidx[k];
-  const double4 pi = reinterpret_cast<const double4 *>(e.freqs)[fi];
-  const double w = e.rate_weights[k];
-  const double pinv = e.prop_invar ? e.prop_invar[fi] : 0.0;
-  const double4 *__restrict__ parent = reinterpret_cast<const double4 *>(e.parent);
-  const double4 *__restrict__ child = reinterpret_cast<const double4 *>(e.child);
-
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned ntiles = (e.sites + 63u) / 64u;
+  cdouble_p pm = as_const(e.mat);
   double acc = 0.0;
-  for (unsigned n = begin + q; n < end; n += 64)
+
+  for (unsigned t = 0; t < tiles_per_wave; ++t)
   {
-    unsigned pe = n, ce = n;
+    const unsigned tile = (blockIdx.x * 4u + wave) * tiles_per_wave + t;
+    if (tile >= ntiles) break;
+    const unsigned n = tile * 64u + lane;
+    const bool valid = n < e.sites;
+    const unsigned nn = valid ? n : e.sites - 1;
+    unsigned pe = nn, ce = nn;
     if (GATHER)
     {
-      pe = e.psid ? e.psid[n] : n;
-      ce = e.csid ? e.csid[n] : n;
+      pe = e.psid ? e.psid[nn] : nn;
+      ce = e.csid ? e.csid[nn] : nn;
     }
-    const double4 x = parent[(size_t)pe * 4 + k];
-    double4 tb;
-    if (e.is_root)
-      tb = make_double4(1.0, 1.0, 1.0, 1.0);
-    else if (CTIP)
-      tb = masksum4(P, e.ctip[ce]);
-    else
-      tb = matvec4(P, child[(size_t)ce * 4 + k]);
-    double t = fma(x.w * pi.w, tb.w, fma(x.z * pi.z, tb.z, fma(x.y * pi.y, tb.y, (x.x * pi.x) * tb.x)));
+    const unsigned ccode = CTIP ? e.ctip[ce] : 0u;
+    const double *__restrict__ px = e.parent + (size_t)(pe >> 6) * kDnaTile + (pe & 63u);
+    const double *__restrict__ cx = (CTIP || e.is_root) ? nullptr : e.child + (size_t)(ce >> 6) * kDnaTile + (ce & 63u);
 
-    unsigned scal;
+    unsigned rs[4] = {0, 0, 0, 0}, scal;
     if (e.per_rate)
     {
-      unsigned rs = (e.pscaler ? e.pscaler[(size_t)pe * 4 + k] : 0u) +
-                    (e.cscaler ? e.cscaler[(size_t)ce * 4 + k] : 0u);
-      unsigned mn = min(rs, (unsigned)dpp_i32<0xB1>((int)rs));
-      mn = min(mn, (unsigned)dpp_i32<0x4E>((int)mn));
-      const unsigned ex = min(rs - mn, PLLGPU_RATE_MAXDIFF);
-      if (ex) t *= minlh(ex);
-      scal = mn;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        rs[k] = (e.pscaler ? e.pscaler[(size_t)pe * 4 + k] : 0u) + (e.cscaler ? e.cscaler[(size_t)ce * 4 + k] : 0u);
+      scal = min(min(rs[0], rs[1]), min(rs[2], rs[3]));
     }
     else
       scal = (e.pscaler ? e.pscaler[pe] : 0u) + (e.cscaler ? e.cscaler[ce] : 0u);
+    const int inv = e.invariant ? e.invariant[nn] : -1;
 
-    double ta, ti = 0.0;
-    if (pinv > 0.0)
+    double terma = 0.0, terminv = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
     {
-      ta = w * t * (1.0 - pinv);
-      const int inv = e.invariant ? e.invariant[n] : -1;
-      if (inv >= 0)
+      double xp[4], xc[4], tb[4];
+      dna_fetch<false>(xp, px, k, 0u);
+      if (e.is_root)
       {
-        const double f = inv == 0 ? pi.x : inv == 1 ? pi.y : inv == 2 ? pi.z : pi.w;
-        ti = w * f * pinv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tb[i] = 1.0;
       }
+      else
+      {
+        dna_fetch<CTIP>(xc, cx, k, ccode);
+        dna_matvec(tb, pm + k * 16, xc);
+      }
+      const unsigned fi = e.fidx[k];
+      cdouble_p pi = as_const(e.freqs) + (size_t)fi * 4;
+      double tr = fma(xp[3] * pi[3], tb[3], fma(xp[2] * pi[2], tb[2], fma(xp[1] * pi[1], tb[1], (xp[0] * pi[0]) * tb[0])));
+      if (e.per_rate)
+      {
+        const unsigned ex = min(rs[k] - scal, PLLGPU_RATE_MAXDIFF);
+        if (ex) tr *= minlh(ex);
+      }
+      const double pinv = e.prop_invar ? e.prop_invar[fi] : 0.0;
+      const double w = e.rate_weights[k];
+      if (pinv > 0.0)
+      {
+        terma += w * tr * (1.0 - pinv);
+        if (inv >= 0) terminv += w * e.freqs[(size_t)fi * 4 + inv] * pinv;
+      }
+      else
+        terma += tr * w;
     }
-    else
-      ta = t * w;
-    // mix the four categories in category order: ((t0 + t1) + (t2 + t3))
-    ta += dpp_f64_xor1(ta);
-    ta += dpp_f64_xor2(ta);
-    ti += dpp_f64_xor1(ti);
-    ti += dpp_f64_xor2(ti);
-    if (k == 0)
+    if (valid)
     {
-      double site = finish_site(ta, ti, scal, e.is_root) * (double)e.pattern_weights[n];
+      const double site = finish_site(terma, terminv, scal, e.is_root) * (double)e.pattern_weights[n];
       if (e.persite) e.persite[n] = site;
       acc += site;
     }
   }
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = acc;
+  if (lane == 0) wsum[wave] = acc;
   __syncthreads();
   if (threadIdx.x == 0) e.block_sums[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }

@@ -45,7 +45,7 @@ __device__ __forceinline__ void contract(double (&acc)[ICH], const double *pt, u
     if (TIP)
       xj = ((mask >> j) & 1ull) ? 1.0 : 0.0;
     else
-      xj = x[(size_t)j * 64];
+      xj = __builtin_nontemporal_load(x + (size_t)j * 64); // read-once stream, see kernels_dna.h
     cdouble_p pj = p + (size_t)j * g.SPT;
 #pragma unroll
     for (int i = 0; i < ICH; ++i) acc[i] = fma(pj[i], xj, acc[i]);

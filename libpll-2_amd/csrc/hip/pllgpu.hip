@@ -124,10 +124,10 @@ static void derive_geometry(pllgpu_ctx *c)
   gg.tile_sz = g.rate_cats * g.states * 64u;
   gg.scale_mode = g.per_rate_scalers ? 2 : 1;
   c->ich = ich;
-  c->dna_fast = (g.states == 4 && g.states_padded == 4 && g.rate_cats == 4);
-  if (const char *v = getenv("PLL_AMD_FORCE_TILED")) // experiment switch: route DNA through the tiled kernels
+  c->dna_fast = (g.states == 4 && g.rate_cats == 4);
+  if (const char *v = getenv("PLL_AMD_GENERIC_ONLY")) // experiment switch: route DNA through the generic kernels
     if (*v && *v != '0') c->dna_fast = false;
-  c->tiled = !c->dna_fast;
+  c->tiled = true; // every shape keeps CLVs in the tiled sites-contiguous layout
   c->pm_stride = (size_t)g.rate_cats * g.states * gg.SPT;
   c->span = g.rate_cats * g.states_padded;
 }
@@ -516,13 +516,14 @@ static void launch_generic(pllgpu_ctx *c, const OpPack &pack, unsigned nops, uns
 
 static void launch_dna(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
 {
-  // entries per block: enough blocks to fill 256 CUs several times over, at least 64 entries
-  const unsigned want_blocks = 2048;
-  unsigned epb = (unsigned)(((size_t)maxent * nops + want_blocks - 1) / want_blocks);
-  epb = std::max(64u, (epb + 63u) & ~63u);
-  dim3 grid((maxent + epb - 1) / epb, nops), block(256);
+  // one wave per 64-site tile; a wave takes tpw consecutive tiles so that ~4096 workgroups exist
+  const unsigned tiles = (maxent + 63) / 64;
+  const unsigned want_blocks = 4096;
+  unsigned tpw = (unsigned)(((size_t)tiles * nops + 4 * want_blocks - 1) / (4 * want_blocks));
+  tpw = std::max(1u, std::min(tpw, 8u));
+  dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), nops), block(256);
   const int mode = c->gg.scale_mode;
-#define DNA_LAUNCH(LT, RT, GA) hipLaunchKernelGGL((k_partials_dna<LT, RT, GA>), grid, block, 0, c->stream, pack, mode, epb)
+#define DNA_LAUNCH(LT, RT, GA) hipLaunchKernelGGL((k_partials_dna<LT, RT, GA>), grid, block, 0, c->stream, pack, mode, tpw)
   if (kind == 0)
   {
     if (gather) DNA_LAUNCH(false, false, true); else DNA_LAUNCH(false, false, false);
@@ -631,12 +632,12 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
   const unsigned tiles = (g.sites + 63) / 64;
   const unsigned max_blocks = 1024;
   unsigned blocks;
+  // 4 waves = 4 tiles per workgroup, tpw consecutive tiles per wave
+  const unsigned tpw = (tiles + 4 * max_blocks - 1) / (4 * max_blocks);
+  blocks = (tiles + 4 * tpw - 1) / (4 * tpw);
   if (c->dna_fast)
   {
-    const unsigned tpb = (tiles + max_blocks - 1) / max_blocks;
-    blocks = (tiles + tpb - 1) / tpb;
-    const unsigned spb = tpb * 64;
-#define ED(CT, GA) hipLaunchKernelGGL((k_edge_dna<CT, GA>), dim3(blocks), dim3(256), 0, c->stream, e, spb)
+#define ED(CT, GA) hipLaunchKernelGGL((k_edge_dna<CT, GA>), dim3(blocks), dim3(256), 0, c->stream, e, tpw)
     if (ctip)
     {
       if (gather) ED(true, true); else ED(true, false);
@@ -649,9 +650,6 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
   }
   else
   {
-    // 4 waves = 4 tiles per workgroup, tpw consecutive tiles per wave
-    const unsigned tpw = (tiles + 4 * max_blocks - 1) / (4 * max_blocks);
-    blocks = (tiles + 4 * tpw - 1) / (4 * tpw);
     switch (c->ich)
     {
       case 4: launch_edge_generic<4>(c, e, blocks, tpw, ctip, gather); break;

@@ -158,6 +158,8 @@ _GPU_PROTOS = {
 
 
 def default_library_path():
+    if os.environ.get("PLL_AMD_LIB"):  # A/B builds of the same library (tools/, not the product default)
+        return os.environ["PLL_AMD_LIB"]
     here = os.path.dirname(os.path.abspath(__file__))
     return os.path.join(os.path.dirname(here), "csrc", "libpll_amd.so")
 

@@ -174,3 +174,14 @@ def test_model_api_end_to_end(amd_lib):
     assert abs(v - (-58.887310)) < 5.1e-7
     assert abs(ps.sum() - v) < 1e-9
     lib.pll_partition_destroy(p)
+
+
+@pytest.mark.parametrize("kw", [k for k in ORACLE_CASES if k["states"] == 4 and k.get("rate_cats", 4) == 4], ids=_id)
+def test_dna_through_generic_kernels(amd_lib, kw, monkeypatch):
+    """the 4x4 shape also has to be right in the any-shape kernels (PLL_AMD_GENERIC_ONLY=1)"""
+    monkeypatch.setenv("PLL_AMD_GENERIC_ONLY", "1")
+    case = W.make_case("rnd", **kw)
+    exp = O.run_case(case)
+    got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    assert_results_match(got, exp, what=_id(kw))
+    assert scalers_equal(got, exp)
