@@ -39,6 +39,9 @@ CONFIGS = {
     "c2": dict(states=4, tips=64, sites=100000, desc="4-state DNA GTR+G4, 64-taxon balanced tree, 100k sites"),
     "c3": dict(states=20, tips=64, sites=50000, desc="20-state protein (LG)+G4, 64 taxa, 50k sites"),
     "c5": dict(states=61, tips=32, sites=20000, desc="61-state codon stand-in +G4, 32 taxa, 20k sites"),
+    # configs[3]: 1M sites over 8 GPUs = 125k sites per GPU, PLL_ATTRIB_SITE_REPEATS
+    "c4": dict(states=4, tips=128, sites=125000, repeats=True,
+               desc="4-state DNA GTR+G4, 128 taxa, 125k-site shard of the 1M-site alignment, SITE_REPEATS"),
 }
 
 
@@ -52,9 +55,11 @@ def build_case(cfg, sites, seed, attributes):
     return W.make_case("bench", cfg["states"], cfg["tips"], sites, attributes=attributes, seed=seed, **kw)
 
 
-def op_bytes(case, api):
+def op_bytes(case, api, entries=None):
     """algorithmic HBM bytes of one traversal: per update 3 CLV entries for
-    inner x inner, 2 + 1 B for tip x inner, 1 + 2 B for tip x tip, plus 4 B per scaler touched"""
+    inner x inner, 2 + 1 B for tip x inner, 1 + 2 B for tip x tip, plus 4 B per scaler touched.
+    entries: {parent clv: class count} under site repeats (only that many updates are computed;
+    the 12 B of class-map gathers per update are not counted)"""
     s, r, n = case.states, case.rate_cats, case.sites
     entry = s * r * 8
     pattern_tip = bool(case.attributes & api.PATTERN_TIP)
@@ -71,7 +76,7 @@ def op_bytes(case, api):
                     b += 4 * per_rate
         if psc >= 0:
             b += 4 * per_rate
-        total += b * n
+        total += b * (entries[pc] if entries else n)
     return total
 
 
@@ -102,9 +107,14 @@ def cpu_baseline(case, api, driver, budget_s=12.0):
         reps = int(max(2, min(200, budget_s / max(one, 1e-4))))
         lnls = [0.0] * cores
 
+        rep_mode = bool(case.attributes & api.SITE_REPEATS)
+        if rep_mode:  # class maps once, outside the timed region (same policy as the GPU leg)
+            for sh in shards:
+                sh.update_partials(update_repeats=1)
+
         def work(i):
             for _ in range(reps):
-                shards[i].update_partials()
+                shards[i].update_partials(update_repeats=0 if rep_mode else 1)
             lnls[i] = shards[i].edge_lnl(case.edges[0], persite=False)[0]
 
         th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
@@ -141,19 +151,30 @@ def main():
     ap.add_argument("--sites", type=int, default=0, help="override sites per GPU")
     ap.add_argument("--pattern-tip", action="store_true", help="PLL_ATTRIB_PATTERN_TIP variant (tip codes instead of tip CLVs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo + PLL_BENCH_SAME_DEVICE=1 rehearses the N>1 flow on a one-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    os.environ.setdefault("PLL_AMD_DEVICE", str(local))
+    same_device = os.environ.get("PLL_BENCH_SAME_DEVICE") == "1"
+    os.environ.setdefault("PLL_AMD_DEVICE", "0" if same_device else str(local))
     dist = None
     torch = None
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+    tdev = f"cuda:{local}" if (dist and args.backend == "nccl") else "cpu"
+
+    def tsync():
+        if dist and args.backend == "nccl":
+            torch.cuda.synchronize()
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import numpy as np
@@ -162,15 +183,23 @@ def main():
     cfg = CONFIGS[args.config]
     sites = args.sites or cfg["sites"]
     attributes = api.PATTERN_TIP if args.pattern_tip else 0
+    if cfg.get("repeats"):
+        attributes |= api.SITE_REPEATS
     case = build_case(cfg, sites, seed=1000 + rank, attributes=attributes)
     nops = len(case.op_batches[0])
     lib = api.PllLib()
     sess = driver.Session(lib, case, api.ARCH_AVX2)  # uploads happen on first use (warm-up)
     edge = case.edges[0]
-    red = torch.zeros(1, dtype=torch.float64, device=f"cuda:{local}") if dist else None
+    red = torch.zeros(1, dtype=torch.float64, device=tdev) if dist else None
+
+    # site repeats: class maps are computed once (host, integer) and re-used, as applications do
+    # between topology changes: pll_update_partials_rep(..., update_repeats = 0)
+    upd = [1]
 
     def step():
-        sess.update_partials()
+        sess.update_partials(update_repeats=upd[0])
+        if cfg.get("repeats"):
+            upd[0] = 0
         v, _ = sess.edge_lnl(edge, persite=False)
         if dist:
             red[0] = v
@@ -181,9 +210,9 @@ def main():
     def fence():
         lib.pll_gpu_synchronize(sess.p)
         if dist:
-            torch.cuda.synchronize()
+            tsync()
             dist.barrier()
-            torch.cuda.synchronize()
+            tsync()
 
     lnl = None
     for _ in range(args.warmup):
@@ -195,7 +224,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     if not np.isfinite(lnl):
@@ -209,16 +238,17 @@ def main():
     lib.pll_gpu_synchronize(sess.p)
     lib.pll_gpu_timer_start(sess.p)
     for _ in range(reps):
-        sess.update_partials()
+        sess.update_partials(update_repeats=upd[0])
     ms = lib.pll_gpu_timer_stop(sess.p)
     launches = lib.pll_gpu_last_launch_count(sess.p)
-    trav_bytes = op_bytes(case, api)
+    entries = {op[0]: sess.entries(op[0]) for op in case.op_batches[0]} if cfg.get("repeats") else None
+    trav_bytes = op_bytes(case, api, entries)
     per_launch_bytes = trav_bytes / launches
     per_launch_ms = ms / reps / launches
     achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
-    if os.path.exists(tfile):  # PMC-derived HBM bytes per launch of the same command (profiles/README.md)
+    if os.path.exists(tfile) and not args.pattern_tip and not args.sites:  # PMC-derived HBM bytes per launch of the same command (profiles/README.md)
         traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
     kernel = {4: "k_partials_dna", 20: "k_partials_generic<20>", 61: "k_partials_generic<16>"}[cfg["states"]]
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",

@@ -1,0 +1,98 @@
+"""GPU, BASELINE.json's full configurations. Where the prebuilt reference (oracle/_ref, shipped
+with the repo snapshot) is present the HIP path is compared with the reference's AVX2 path directly
+at full size; independent of that, size-independent properties are checked: agreement between the
+three data paths (tip CLVs / PATTERN_TIP / SITE_REPEATS), linearity in the pattern weights,
+invariance under a permutation of the sites, per-site values summing to the total."""
+import os
+
+import numpy as np
+import pytest
+
+from compare import RTOL
+from oracle import oracle as O
+from pllamd import api, driver, workload as W
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def lg():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "model_lg.npz"))
+    return dict(exch=z["rates"], freqs=z["freqs"])
+
+
+CONFIGS = {
+    "C2-dna-64x100k": dict(states=4, tips=64, sites=100000, seed=1000),
+    "C3-lg-64x50k": dict(states=20, tips=64, sites=50000, seed=1000, **lg()),
+    "C5-codon61-32x20k": dict(states=61, tips=32, sites=20000, seed=1000),
+    "C4shard-dna-128x125k": dict(states=4, tips=128, sites=125000, seed=1000),
+}
+
+
+def run(lib, case, arch=api.ARCH_AVX2, clvs=()):
+    with driver.Session(lib, case, arch) as s:
+        s.update_partials()
+        lnl, ps = s.edge_lnl(case.edges[0])
+        got = {c: (s.read_clv(c), s.read_scaler(c - case.tips, c)) for c in clvs}
+        ids = [s.entries(c) for c in range(case.tips, case.tips + case.clv_buffers)]
+    return lnl, ps, got, ids
+
+
+@pytest.fixture(scope="module")
+def reference():
+    if not os.path.exists(O.REF_LIB):
+        pytest.skip("oracle/_ref/libpll_ref.so not shipped")
+    return api.PllLib(O.REF_LIB)
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_full_size_against_reference_avx2(amd_lib, reference, name):
+    kw = CONFIGS[name]
+    attrs = api.SITE_REPEATS if name.startswith("C4") else 0
+    case = W.make_case(name, attributes=attrs, **kw)
+    a, b = case.edges[0][0], case.edges[0][2]
+    r_lnl, r_ps, r_clv, r_ids = run(reference, case, clvs=(a, b))
+    g_lnl, g_ps, g_clv, g_ids = run(amd_lib, case, clvs=(a, b))
+    assert abs(g_lnl - r_lnl) <= RTOL * abs(r_lnl), (g_lnl, r_lnl)
+    assert np.all(np.abs(g_ps - r_ps) <= RTOL * np.maximum(np.abs(r_ps), 1.0))
+    for c in (a, b):
+        err = driver.rel_err_normalised(g_clv[c][0], g_clv[c][1], r_clv[c][0], r_clv[c][1])
+        assert err <= RTOL, (name, c, err)
+    assert g_ids == r_ids  # class counts per inner node (site repeats) are integers: exact
+
+
+@pytest.mark.parametrize("name", ["C2-dna-64x100k", "C3-lg-64x50k", "C5-codon61-32x20k"])
+def test_data_paths_agree_at_full_size(amd_lib, name):
+    """tip CLVs, tip codes and site repeats are three routes to the same numbers"""
+    kw = CONFIGS[name]
+    vals = {}
+    for tag, attrs in (("clv", 0), ("tip", api.PATTERN_TIP), ("rep", api.SITE_REPEATS), ("tip+rs", api.PATTERN_TIP | api.RATE_SCALERS)):
+        case = W.make_case(name, attributes=attrs, **kw)
+        lnl, ps, _, ids = run(amd_lib, case)
+        vals[tag] = (lnl, ps)
+        if tag == "rep":
+            assert min(ids) < kw["sites"], "site repeats compressed nothing"
+    base = vals["clv"]
+    for tag, (lnl, ps) in vals.items():
+        assert abs(lnl - base[0]) <= 1e-12 * abs(base[0]), tag
+        assert np.all(np.abs(ps - base[1]) <= 1e-11 * np.maximum(np.abs(base[1]), 1.0)), tag
+    assert abs(base[1].sum() - base[0]) <= 1e-11 * abs(base[0])
+
+
+def test_linearity_and_permutation_at_full_size(amd_lib):
+    kw = CONFIGS["C2-dna-64x100k"]
+    case = W.make_case("w1", **kw)
+    lnl1, ps1, _, _ = run(amd_lib, case)
+    rng = np.random.Generator(np.random.PCG64(4))
+    w = rng.integers(1, 9, size=kw["sites"]).astype(np.uint32)
+    case_w = W.make_case("w", pattern_weights=w, **kw)
+    lnl_w, ps_w, _, _ = run(amd_lib, case_w)
+    assert np.all(np.abs(ps_w - ps1 * w) <= 1e-12 * np.abs(ps_w) + 1e-300)
+    assert abs(lnl_w - float(np.dot(ps1, w))) <= 1e-11 * abs(lnl_w)
+    # permute the sites: per-site values permute, the total is unchanged up to summation order
+    perm = rng.permutation(kw["sites"])
+    case_p = W.make_case("p", **kw)
+    case_p.sequences = [np.frombuffer(s, dtype=np.uint8)[perm].tobytes() for s in case.sequences]
+    lnl_p, ps_p, _, _ = run(amd_lib, case_p)
+    assert np.array_equal(ps_p, ps1[perm])
+    assert abs(lnl_p - lnl1) <= 1e-12 * abs(lnl1)
