@@ -75,6 +75,9 @@ struct DevEdge
   const int *invariant;        // or null
   double *persite;             // or null
   double *block_sums;          // [gridDim.x]
+  unsigned *counter;           // arrival ticket of the workgroups (0 between calls)
+  double *result;              // host-mapped: [0] the total, [1] sequence number of the call
+  double sequence;             // written to result[1] after result[0] (host polls it)
   unsigned sites;
   int per_rate;
   int is_root;
@@ -134,4 +137,52 @@ __device__ __forceinline__ double finish_site(double terma, double terminv, unsi
 __device__ __forceinline__ double minlh(unsigned d)
 {
   return ldexp(1.0, -256 * (int)d);
+}
+
+// Every workgroup leaves its partial sum; the workgroup that arrives last adds all partials in
+// index order (fixed tree: the result does not depend on arrival order) and writes the total to
+// host-mapped memory. One launch, no separate reduction kernel, no D2H copy. Hand-off follows the
+// agent-scope release/acquire recipe (cdna_hip_programming.md guideline 16): release fence before the
+// ticket, one acquire fence in the last workgroup before it reads the other workgroups' partials.
+// nsum_waves: how many of the calling workgroup's waves contribute a value (wave index < nsum_waves).
+__device__ __forceinline__ void publish_block_sum(const DevEdge &e, double wave_value, unsigned nsum_waves)
+{
+  __shared__ double ws[4];
+  __shared__ unsigned last;
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) ws[wave] = wave < nsum_waves ? wave_value : 0.0;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    double s = ws[0];
+    for (unsigned w = 1; w < nw; ++w) s += ws[w];
+    e.block_sums[blockIdx.x] = s;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(e.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (ticket == gridDim.x - 1) ? 1u : 0u;
+    if (last)
+    {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (!last) return;
+  double a = 0.0;
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) a += e.block_sums[i];
+  a = wave_sum(a);
+  __syncthreads();
+  if (lane == 0) ws[wave] = a;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    double s = ws[0];
+    for (unsigned w = 1; w < nw; ++w) s += ws[w];
+    __hip_atomic_store(e.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // result[0] = value, then result[1] = this call's sequence number with system-scope release:
+    // the host polls the sequence word in mapped memory instead of paying a stream synchronise
+    __hip_atomic_store(e.result, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(e.result + 1, e.sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }

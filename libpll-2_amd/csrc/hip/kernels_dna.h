@@ -144,13 +144,13 @@ __global__ __launch_bounds__(256) void k_partials_dna(const OpPack pack, int sca
 // ------------------------------------------------------------------------------------------------
 // edge / root log-likelihood, 4 x 4, tiled. One wave per tile; the lane mixes its site's four rate
 // categories in registers, takes the log and accumulates in site order; wave shuffle tree + LDS
-// give one partial per workgroup (fixed order: deterministic).
+// give one partial per workgroup; the last workgroup to arrive adds the partials in index order
+// (publish_block_sum: deterministic, single launch).
 // Arithmetic: src/core_likelihood.c:1388-1490 (ii), :470-578 (ti 4x4), :1077-1183 (repeats),
 // :163-207 (root).
 template <bool CTIP, bool GATHER>
 __global__ __launch_bounds__(256) void k_edge_dna(const DevEdge e, unsigned tiles_per_wave)
 {
-  __shared__ double wsum[4];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned ntiles = (e.sites + 63u) / 64u;
@@ -227,21 +227,5 @@ __global__ __launch_bounds__(256) void k_edge_dna(const DevEdge e, unsigned tile
       acc += site;
     }
   }
-  acc = wave_sum(acc);
-  if (lane == 0) wsum[wave] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) e.block_sums[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-}
-
-// final fixed-order sum of the per-block partials (one block)
-__global__ __launch_bounds__(256) void k_sum_blocks(const double *__restrict__ part, unsigned count,
-                                                    double *__restrict__ out)
-{
-  __shared__ double wsum[4];
-  double acc = 0.0;
-  for (unsigned i = threadIdx.x; i < count; i += 256) acc += part[i];
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) *out = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  publish_block_sum(e, wave_sum(acc), 4u);
 }

@@ -149,26 +149,30 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// edge / root log-likelihood, any states/rates, tiled layout. One WAVE per tile of 64 sites: it
-// walks the rate categories, forms (P c)_i in chunks exactly like the update kernel, dots it with
-// p_i * pi_i, mixes the categories (per-rate scaler excess, invariant sites), takes the log and
-// keeps a running sum in site order; 4 waves = 4 tiles per workgroup, one partial per workgroup.
+// edge / root log-likelihood, any states/rates, tiled layout. Workgroup = one tile at a time; wave
+// w of min(R,4) owns the rate categories w, w+nw, ... : it forms (P c)_i in chunks exactly like the
+// update kernel, dots it with p_i * pi_i, applies the per-rate scaler excess, the rate weight and
+// the invariant-site share, and leaves its partial (terma, terminv) in LDS. Wave 0 adds the waves'
+// partials in wave order, undoes the scaling, takes the log and keeps the running sum in site
+// order. Splitting the rates over the waves keeps the dependent chain of one evaluation short
+// (an lnL call on a small partition is latency-, not bandwidth-bound).
 // Arithmetic: src/core_likelihood.c:1388-1490 (ii), :812-915 (ti), :1077-1183 (repeats), :163-207 (root).
 template <int ICH, bool CTIP, bool GATHER>
 __global__ __launch_bounds__(256) void k_edge_tiled(const DevEdge e, const GenGeo g,
                                                     const unsigned long long *__restrict__ tipmap,
-                                                    unsigned tiles_per_wave)
+                                                    unsigned tiles_per_block)
 {
-  __shared__ double wsum[4];
+  __shared__ double part[2][4][64];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned nw = blockDim.x >> 6;
   const unsigned ntiles = (e.sites + 63u) / 64u;
   double acc = 0.0;
 
-  for (unsigned t = 0; t < tiles_per_wave; ++t)
+  for (unsigned t = 0; t < tiles_per_block; ++t)
   {
-    const unsigned tile = (blockIdx.x * 4u + wave) * tiles_per_wave + t;
-    if (tile >= ntiles) break; // wave-uniform
+    const unsigned tile = blockIdx.x * tiles_per_block + t;
+    if (tile >= ntiles) break; // whole workgroup
     const unsigned n = tile * 64u + lane;
     const bool valid = n < e.sites;
     const unsigned nn = valid ? n : e.sites - 1;
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256) void k_edge_tiled(const DevEdge e, const GenGe
       scal = (e.pscaler ? e.pscaler[pe] : 0u) + (e.cscaler ? e.cscaler[ce] : 0u);
 
     double terma = 0.0, terminv = 0.0;
-    for (unsigned k = 0; k < g.R; ++k)
+    for (unsigned k = wave; k < g.R; k += nw)
     {
       const unsigned fi = e.fidx[k];
       double tr = 0.0;
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void k_edge_tiled(const DevEdge e, const GenGe
         const double *pk = px + ((size_t)k * g.S + c * ICH) * 64;
 #pragma unroll
         for (int i = 0; i < ICH; ++i)
-          if (c * ICH + i < g.S) tr = fma(pk[(size_t)i * 64] * pi[i], B[i], tr);
+          if (c * ICH + i < g.S) tr = fma(__builtin_nontemporal_load(pk + (size_t)i * 64) * pi[i], B[i], tr);
       }
       if (e.per_rate)
       {
@@ -236,17 +240,25 @@ __global__ __launch_bounds__(256) void k_edge_tiled(const DevEdge e, const GenGe
       else
         terma += tr * w;
     }
-    if (valid)
+    part[0][wave][lane] = terma;
+    part[1][wave][lane] = terminv;
+    __syncthreads();
+    if (wave == 0 && valid)
     {
-      const double site = finish_site(terma, terminv, scal, e.is_root) * (double)e.pattern_weights[n];
+      double ta = part[0][0][lane], ti = part[1][0][lane];
+      for (unsigned w = 1; w < nw; ++w)
+      {
+        ta += part[0][w][lane];
+        ti += part[1][w][lane];
+      }
+      const double site = finish_site(ta, ti, scal, e.is_root) * (double)e.pattern_weights[n];
       if (e.persite) e.persite[n] = site;
       acc += site;
     }
+    __syncthreads(); // part[] is reused by the next tile
   }
-  acc = wave_sum(acc);
-  if (lane == 0) wsum[wave] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) e.block_sums[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  // only wave 0 holds a sum
+  publish_block_sum(e, wave == 0 ? wave_sum(acc) : 0.0, 1u);
 }
 
 // ------------------------------------------------------------------------------------------------

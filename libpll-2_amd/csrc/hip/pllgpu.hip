@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -87,11 +88,14 @@ struct pllgpu_ctx
   std::vector<unsigned> ids;
   DevBuf<unsigned long long> tipmap;
   bool tipmap_set = false;
-  DevBuf<double> pmat, freqs, rate_weights, prop_invar, persite, block_sums, result;
+  DevBuf<double> pmat, freqs, rate_weights, prop_invar, persite, block_sums;
+  DevBuf<unsigned> counter;
+  double *result_dev = nullptr;  // device alias of result_host
   DevBuf<unsigned> pattern_weights;
   DevBuf<int> invariant;
   bool invariant_set = false;
-  double *result_host = nullptr; // pinned
+  double *result_host = nullptr; // pinned + mapped: [0] lnL, [1] sequence of the call that wrote it
+  double seq = 0.0;
   std::vector<double> stage;     // host staging for the P-matrix re-layout
   unsigned last_launches = 0;
 };
@@ -185,7 +189,8 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   bool ok = hipSetDevice(device) == hipSuccess &&
             hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
-            hipHostMalloc((void **)&c->result_host, 64, hipHostMallocDefault) == hipSuccess;
+            hipHostMalloc((void **)&c->result_host, 64, hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer((void **)&c->result_dev, c->result_host, 0) == hipSuccess;
   if (!ok)
   {
     fail(PLLGPU_ERUNTIME, "stream/event creation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -193,6 +198,7 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
     return nullptr;
   }
   c->own_stream = true;
+  c->result_host[0] = c->result_host[1] = 0.0;
   c->clv.resize(geo->nodes);
   c->scaler.resize(geo->scale_buffers);
   c->tipchars.resize(geo->tips);
@@ -202,13 +208,14 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   if (c->pmat.ensure(c->pm_stride * geo->prob_matrices) || c->freqs.ensure((size_t)geo->rate_matrices * geo->states_padded) ||
       c->rate_weights.ensure(geo->rate_cats) || c->prop_invar.ensure(geo->rate_matrices) ||
       c->pattern_weights.ensure(geo->sites_alloc) || c->persite.ensure(geo->sites_alloc) ||
-      c->block_sums.ensure(4096) || c->result.ensure(8))
+      c->block_sums.ensure(4096) || c->counter.ensure(4))
   {
     pllgpu_destroy(c);
     return nullptr;
   }
   (void)hipMemsetAsync(c->pmat.p, 0, c->pmat.cap * sizeof(double), c->stream);
   (void)hipMemsetAsync(c->prop_invar.p, 0, c->prop_invar.cap * sizeof(double), c->stream);
+  (void)hipMemsetAsync(c->counter.p, 0, c->counter.cap * sizeof(unsigned), c->stream);
   return c;
 }
 
@@ -230,7 +237,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->prop_invar.release();
   c->persite.release();
   c->block_sums.release();
-  c->result.release();
+  c->counter.release();
   c->pattern_weights.release();
   c->invariant.release();
   if (c->result_host) (void)hipHostFree(c->result_host);
@@ -598,7 +605,8 @@ template <int ICH>
 static void launch_edge_generic(pllgpu_ctx *c, const DevEdge &e, unsigned blocks, unsigned tpw, bool ctip, bool gather)
 {
   const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
-#define EG(CT, GA) hipLaunchKernelGGL((k_edge_tiled<ICH, CT, GA>), dim3(blocks), dim3(256), 0, c->stream, e, c->gg, tm, tpw)
+  const unsigned threads = 64u * std::min(c->gg.R, 4u); // one wave per rate category of the tile, up to 4
+#define EG(CT, GA) hipLaunchKernelGGL((k_edge_tiled<ICH, CT, GA>), dim3(blocks), dim3(threads), 0, c->stream, e, c->gg, tm, tpw)
   if (ctip)
   {
     if (gather) EG(true, true); else EG(true, false);
@@ -626,17 +634,23 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
   e.invariant = c->invariant_set ? c->invariant.p : nullptr;
   e.persite = persite_host ? c->persite.p : nullptr;
   e.block_sums = c->block_sums.p;
+  e.counter = c->counter.p;
+  e.result = c->result_dev;
+  c->seq += 1.0;
+  e.sequence = c->seq;
+  unsigned long long seq_bits;
+  memcpy(&seq_bits, &c->seq, sizeof seq_bits);
   e.sites = g.sites;
   e.per_rate = g.per_rate_scalers ? 1 : 0;
 
   const unsigned tiles = (g.sites + 63) / 64;
   const unsigned max_blocks = 1024;
-  unsigned blocks;
-  // 4 waves = 4 tiles per workgroup, tpw consecutive tiles per wave
-  const unsigned tpw = (tiles + 4 * max_blocks - 1) / (4 * max_blocks);
-  blocks = (tiles + 4 * tpw - 1) / (4 * tpw);
+  unsigned blocks, tpw;
   if (c->dna_fast)
   {
+    // 4 waves = 4 tiles per workgroup, tpw consecutive tiles per wave
+    tpw = (tiles + 4 * max_blocks - 1) / (4 * max_blocks);
+    blocks = (tiles + 4 * tpw - 1) / (4 * tpw);
 #define ED(CT, GA) hipLaunchKernelGGL((k_edge_dna<CT, GA>), dim3(blocks), dim3(256), 0, c->stream, e, tpw)
     if (ctip)
     {
@@ -650,6 +664,9 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
   }
   else
   {
+    // one tile per workgroup pass (the waves split its rate categories), tpw tiles per workgroup
+    tpw = (tiles + max_blocks - 1) / max_blocks;
+    blocks = (tiles + tpw - 1) / tpw;
     switch (c->ich)
     {
       case 4: launch_edge_generic<4>(c, e, blocks, tpw, ctip, gather); break;
@@ -659,13 +676,31 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
       default: launch_edge_generic<32>(c, e, blocks, tpw, ctip, gather); break;
     }
   }
-  hipLaunchKernelGGL(k_sum_blocks, dim3(1), dim3(256), 0, c->stream, c->block_sums.p, blocks, c->result.p);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(c->result_host, c->result.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (persite_host)
+  {
     HIP_TRY(hipMemcpyAsync(persite_host, c->persite.p, g.sites * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  *lnl_out = *c->result_host;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  else
+  {
+    // the last workgroup stores {lnL, sequence} into mapped host memory: poll the sequence word for
+    // a bounded time (a stream synchronise costs ~15 us of wake-up latency on a ~5 us kernel), then
+    // fall back to the synchronise so a failed launch cannot hang the caller
+    volatile double *res = c->result_host;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n((const unsigned long long *)&res[1], __ATOMIC_ACQUIRE) != seq_bits)
+    {
+      if ((++spins & 1023u) == 0 &&
+          std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+      {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        break;
+      }
+    }
+  }
+  *lnl_out = c->result_host[0];
   return 0;
 }
 
