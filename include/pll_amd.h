@@ -218,6 +218,21 @@ double pll_compute_root_loglikelihood(pll_partition_t *partition, unsigned int c
                                       int scaler_index, const unsigned int *freqs_indices,
                                       double *persite_lnl);
 
+/* ---- branch-length derivatives (src/pll.h:834-852, src/derivatives.c:239-418; SURVEY section 8
+ * row f1). `sumtable` is the caller's buffer of sites*rate_cats*states_padded doubles, as in the
+ * reference, but it is used as a HANDLE: pll_update_sumtable computes the table into HBM and
+ * remembers which host buffer it stands for; pll_compute_likelihood_derivatives given the same
+ * pointer streams the device copy. The host buffer itself is only filled by
+ * pll_gpu_sync_sumtable() (or under PLL_AMD_EAGER_MIRROR=1); a table the library has never seen
+ * (written by the caller) is uploaded from the host buffer. */
+int pll_update_sumtable(pll_partition_t *partition, unsigned int parent_clv_index,
+                        unsigned int child_clv_index, int parent_scaler_index,
+                        int child_scaler_index, const unsigned int *params_indices, double *sumtable);
+int pll_compute_likelihood_derivatives(pll_partition_t *partition, int parent_scaler_index,
+                                       int child_scaler_index, double branch_length,
+                                       const unsigned int *params_indices, const double *sumtable,
+                                       double *d_f, double *dd_f);
+
 /* ---- site repeats bookkeeping (src/pll.h:682-742, src/repeats.c) --------------------------- */
 #define PLL_GET_ID(site_id, site) ((site_id) ? ((site_id)[(site)]) : (site))
 #define PLL_GET_SITE(id_site, site) ((id_site) ? ((id_site)[(site)]) : (site))
@@ -259,7 +274,10 @@ int pll_gpu_sync_all(pll_partition_t *partition);
 #define PLL_GPU_DIRTY_SCALER 64u
 #define PLL_GPU_DIRTY_TIPCHARS 128u
 #define PLL_GPU_DIRTY_REPEATS 256u
+#define PLL_GPU_DIRTY_EIGEN 512u /* eigenvecs / inv_eigenvecs / eigenvals / rates written directly */
 void pll_gpu_invalidate(pll_partition_t *partition, unsigned int what, int index);
+/* download the device sumtable that stands for this host buffer into it (reference layout) */
+int pll_gpu_sync_sumtable(pll_partition_t *partition, double *sumtable);
 /* stream plumbing: by default each partition owns a stream; a harness may substitute its own
  * (a hipStream_t passed as void*) so that its events see the kernels. */
 int pll_gpu_set_stream(pll_partition_t *partition, void *hip_stream);

@@ -120,6 +120,29 @@ int pllgpu_root_loglikelihood(pllgpu_ctx_t *ctx, unsigned int clv, int scaler, u
                               const unsigned int *freqs_indices, double *persite_host,
                               double *lnl_out);
 
+/* ---- branch-length derivatives ---------------------------------- */
+/* the two contraction matrices of the sumtable, one block [rate][row j][states_padded] each:
+ * slot 0: M1[j][i] = pi_i * inv_eigenvecs[i][j] (applied to the left end), slot 1: M2[j][i] =
+ * eigenvecs[j][i] (right end) - src/core_derivatives.c:446-456 */
+int pllgpu_aux_matrix_upload(pllgpu_ctx_t *ctx, unsigned int slot, const double *host_block);
+int pllgpu_eigenvals_upload(pllgpu_ctx_t *ctx, unsigned int index, const double *host);
+int pllgpu_rates_upload(pllgpu_ctx_t *ctx, const double *host); /* category rates [rate_cats] */
+typedef struct pllgpu_sumtable
+{
+  unsigned int left_clv, right_clv; /* a tip given by codes must be the left end */
+  int left_scaler, right_scaler;
+  unsigned int left_is_tip;
+  unsigned int gather;
+} pllgpu_sumtable_t;
+/* replaces pll_core_update_sumtable_{ii,ti,repeats} (src/core_derivatives.c:25-641); the table
+ * stays in HBM in one of 4 slots */
+int pllgpu_update_sumtable(pllgpu_ctx_t *ctx, const pllgpu_sumtable_t *st, unsigned int slot);
+int pllgpu_sumtable_upload(pllgpu_ctx_t *ctx, unsigned int slot, const double *host);
+int pllgpu_sumtable_download(pllgpu_ctx_t *ctx, unsigned int slot, double *host);
+/* replaces pll_core_likelihood_derivatives (src/core_derivatives.c:696-849). Synchronises. */
+int pllgpu_likelihood_derivatives(pllgpu_ctx_t *ctx, unsigned int slot, double branch_length,
+                                  const unsigned int *params_indices, double *d_f, double *dd_f);
+
 /* ---- stream / timing ---------------------------------------------------------------------- */
 int pllgpu_set_stream(pllgpu_ctx_t *ctx, void *hip_stream);
 void *pllgpu_get_stream(const pllgpu_ctx_t *ctx);

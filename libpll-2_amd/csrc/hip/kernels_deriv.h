@@ -1,0 +1,202 @@
+// kernels_deriv.h - branch-length derivatives (pll_update_sumtable /
+// pll_compute_likelihood_derivatives, src/derivatives.c, src/core_derivatives.c).
+//
+// The sumtable   sum[n][k][j] = (sum_i p_i pi_i Vinv[i][j]) * (sum_i V[j][i] c_i)
+// has exactly the shape of a CLV update (two matrix-vector products per (site, rate), multiplied
+// element-wise), so it is produced by the CLV-update kernels themselves with the two "transition
+// matrices" replaced by M1[j][i] = pi_i Vinv[i][j] and M2[j][i] = V[j][i] (uploaded in the same
+// transposed layout) and the table - resident in HBM, tiled like a CLV - as the "parent". Only the
+// per-rate-scaler variant needs an extra pass (k_sumtable_excess, src/core_derivatives.c:420-460).
+//
+// Derivatives at a branch length t: a one-workgroup pre-kernel fills diag[k][j] = (e, l e, l^2 e)
+// with e = exp(lambda_j r_k t / (1 - pinv)), l = lambda_j r_k / (1 - pinv) (:757-772); the main kernel
+// streams the table once (lane = site, one wave per tile, diag through the scalar path), forms the
+// site's (L, L', L'') and accumulates pattern_weight * (-L'/L) and pattern_weight *
+// ((L'/L)^2 - L''/L) (:643-694, :843-847); the last workgroup to arrive adds the partials in index
+// order and writes {d_f, dd_f, sequence} to mapped host memory.
+#pragma once
+#include "kernels_common.h"
+
+struct DevDeriv
+{
+  const double *table;          // tiled [tile][k][j][64]
+  const double *diag;           // [k][j][4]
+  const double *freqs;          // [rate_matrices][SP]
+  const double *rate_weights;   // [R]
+  const double *prop_invar;     // [rate_matrices]
+  const unsigned *pattern_weights;
+  const int *invariant;         // or null
+  double *block_sums;           // [2][1024]
+  unsigned *counter;
+  double *result;               // mapped: [0] d_f, [1] sequence, [2] dd_f
+  double sequence;
+  unsigned sites;
+  unsigned char fidx[kMaxRates];
+};
+
+struct DevDiag
+{
+  double *diag;                 // [k][j][4]
+  const double *eigenvals;      // [rate_matrices][SP]
+  const double *rates;          // [R]
+  const double *prop_invar;     // [rate_matrices]
+  double branch_length;
+  unsigned S, SP, R;
+  unsigned char fidx[kMaxRates];
+};
+
+__global__ __launch_bounds__(256) void k_diagtable(const DevDiag d)
+{
+  for (unsigned idx = threadIdx.x; idx < d.R * d.S; idx += blockDim.x)
+  {
+    const unsigned k = idx / d.S, j = idx % d.S;
+    const unsigned fi = d.fidx[k];
+    const double ki = d.rates[k] / (1.0 - d.prop_invar[fi]);
+    const double lam = d.eigenvals[(size_t)fi * d.SP + j];
+    const double e = exp(lam * ki * d.branch_length);
+    double *o = d.diag + (size_t)idx * 4;
+    o[0] = e;
+    o[1] = lam * ki * e;
+    o[2] = lam * ki * lam * ki * e;
+    o[3] = 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_derivatives(const DevDeriv d, const GenGeo g, unsigned tiles_per_wave)
+{
+  __shared__ double ws[2][4];
+  __shared__ unsigned last;
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned ntiles = (d.sites + 63u) / 64u;
+  cdouble_p diag = as_const(d.diag);
+  double a1 = 0.0, a2 = 0.0;
+
+  for (unsigned t = 0; t < tiles_per_wave; ++t)
+  {
+    const unsigned tile = (blockIdx.x * 4u + wave) * tiles_per_wave + t;
+    if (tile >= ntiles) break; // wave-uniform
+    const unsigned n = tile * 64u + lane;
+    const bool valid = n < d.sites;
+    const unsigned nn = valid ? n : d.sites - 1;
+    const double *x = d.table + tiled_base(nn, g.tile_sz);
+    const int inv = d.invariant ? d.invariant[nn] : -1;
+    double lk0 = 0.0, lk1 = 0.0, lk2 = 0.0;
+    for (unsigned k = 0; k < g.R; ++k)
+    {
+      double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+      cdouble_p dk = diag + (size_t)k * g.S * 4;
+      const double *xk = x + (size_t)k * g.S * 64;
+#pragma unroll 4
+      for (unsigned j = 0; j < g.S; ++j)
+      {
+        const double s = __builtin_nontemporal_load(xk + (size_t)j * 64);
+        c0 = fma(s, dk[j * 4 + 0], c0);
+        c1 = fma(s, dk[j * 4 + 1], c1);
+        c2 = fma(s, dk[j * 4 + 2], c2);
+      }
+      const unsigned fi = d.fidx[k];
+      const double pinv = d.prop_invar ? d.prop_invar[fi] : 0.0;
+      if (pinv > 0.0)
+      {
+        const double isl = inv >= 0 ? d.freqs[(size_t)fi * g.SP + inv] * pinv : 0.0;
+        c0 = c0 * (1.0 - pinv) + isl;
+        c1 = c1 * (1.0 - pinv);
+        c2 = c2 * (1.0 - pinv);
+      }
+      const double w = d.rate_weights[k];
+      lk0 += c0 * w;
+      lk1 += c1 * w;
+      lk2 += c2 * w;
+    }
+    if (valid)
+    {
+      const double d1 = -lk1 / lk0;
+      const double d2 = d1 * d1 - lk2 / lk0;
+      const double pw = (double)d.pattern_weights[n];
+      a1 += pw * d1;
+      a2 += pw * d2;
+    }
+  }
+  a1 = wave_sum(a1);
+  a2 = wave_sum(a2);
+  if (lane == 0)
+  {
+    ws[0][wave] = a1;
+    ws[1][wave] = a2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    d.block_sums[blockIdx.x] = (ws[0][0] + ws[0][1]) + (ws[0][2] + ws[0][3]);
+    d.block_sums[1024 + blockIdx.x] = (ws[1][0] + ws[1][1]) + (ws[1][2] + ws[1][3]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (ticket == gridDim.x - 1) ? 1u : 0u;
+    if (last)
+    {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (!last) return;
+  double b1 = 0.0, b2 = 0.0;
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += 256)
+  {
+    b1 += d.block_sums[i];
+    b2 += d.block_sums[1024 + i];
+  }
+  b1 = wave_sum(b1);
+  b2 = wave_sum(b2);
+  __syncthreads();
+  if (lane == 0)
+  {
+    ws[0][wave] = b1;
+    ws[1][wave] = b2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d.result, (ws[0][0] + ws[0][1]) + (ws[0][2] + ws[0][3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(d.result + 2, (ws[1][0] + ws[1][1]) + (ws[1][2] + ws[1][3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(d.result + 1, d.sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// per-rate scalers only: multiply column k of every site by 2^(-256 * min(rs_k - min_k rs, 4))
+// (src/core_derivatives.c:420-460). One wave per tile.
+struct DevExcess
+{
+  double *table;
+  const unsigned *pscaler, *cscaler; // [entry][R] or null
+  const unsigned *psid, *csid;       // site -> entry or null
+  unsigned sites;
+};
+
+__global__ __launch_bounds__(256) void k_sumtable_excess(const DevExcess e, const GenGeo g)
+{
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const unsigned n = tile * 64u + lane;
+  if (n >= e.sites) return;
+  const unsigned pe = e.psid ? e.psid[n] : n;
+  const unsigned ce = e.csid ? e.csid[n] : n;
+  unsigned mn = 0xFFFFFFFFu;
+  for (unsigned k = 0; k < g.R; ++k)
+  {
+    const unsigned rs = (e.pscaler ? e.pscaler[(size_t)pe * g.R + k] : 0u) + (e.cscaler ? e.cscaler[(size_t)ce * g.R + k] : 0u);
+    mn = min(mn, rs);
+  }
+  double *x = e.table + tiled_base(n, g.tile_sz);
+  for (unsigned k = 0; k < g.R; ++k)
+  {
+    const unsigned rs = (e.pscaler ? e.pscaler[(size_t)pe * g.R + k] : 0u) + (e.cscaler ? e.cscaler[(size_t)ce * g.R + k] : 0u);
+    const unsigned ex = min(rs - mn, PLLGPU_RATE_MAXDIFF);
+    if (!ex) continue;
+    const double f = minlh(ex);
+    for (unsigned j = 0; j < g.S; ++j) x[((size_t)k * g.S + j) * 64] *= f;
+  }
+}

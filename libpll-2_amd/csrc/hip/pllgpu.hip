@@ -16,6 +16,7 @@
 #include "kernels_common.h"
 #include "kernels_dna.h"
 #include "kernels_generic.h"
+#include "kernels_deriv.h"
 
 // ---------------------------------------------------------------------------------------------
 static thread_local char g_err[256] = "";
@@ -90,6 +91,8 @@ struct pllgpu_ctx
   bool tipmap_set = false;
   DevBuf<double> pmat, freqs, rate_weights, prop_invar, persite, block_sums;
   DevBuf<unsigned> counter;
+  DevBuf<double> eigenvals, rates, diag; // derivatives: [rate_matrices][SP], [R], [R][S][4]
+  DevBuf<double> sumtable[4];            // device-resident sumtables (tiled like a CLV)
   double *result_dev = nullptr;  // device alias of result_host
   DevBuf<unsigned> pattern_weights;
   DevBuf<int> invariant;
@@ -205,7 +208,7 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   c->site_id.resize(geo->nodes);
   c->id_site.resize(geo->nodes);
   c->ids.assign(geo->nodes, 0);
-  if (c->pmat.ensure(c->pm_stride * geo->prob_matrices) || c->freqs.ensure((size_t)geo->rate_matrices * geo->states_padded) ||
+  if (c->pmat.ensure(c->pm_stride * (geo->prob_matrices + 2)) || c->freqs.ensure((size_t)geo->rate_matrices * geo->states_padded) ||
       c->rate_weights.ensure(geo->rate_cats) || c->prop_invar.ensure(geo->rate_matrices) ||
       c->pattern_weights.ensure(geo->sites_alloc) || c->persite.ensure(geo->sites_alloc) ||
       c->block_sums.ensure(4096) || c->counter.ensure(4))
@@ -238,6 +241,10 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->persite.release();
   c->block_sums.release();
   c->counter.release();
+  c->eigenvals.release();
+  c->rates.release();
+  c->diag.release();
+  for (auto &b : c->sumtable) b.release();
   c->pattern_weights.release();
   c->invariant.release();
   if (c->result_host) (void)hipHostFree(c->result_host);
@@ -353,11 +360,12 @@ extern "C" int pllgpu_tipmap_upload(pllgpu_ctx_t *c, const unsigned long long *h
   return 0;
 }
 
-extern "C" int pllgpu_pmatrix_upload(pllgpu_ctx_t *c, unsigned first, unsigned count, const double *host)
+// matrices [first, first+count) of the device block; slots prob_matrices and prob_matrices+1 hold the
+// two sumtable contraction matrices (kernels_deriv.h)
+static int upload_matrices(pllgpu_ctx *c, unsigned first, unsigned count, const double *host, unsigned limit)
 {
-  CHECK_CTX(c);
   const pllgpu_geometry_t &g = c->geo;
-  if (first + count > g.prob_matrices) return fail(PLLGPU_EINVAL, "p-matrix range [%u,%u) out of range", first, first + count);
+  if (first + count > limit) return fail(PLLGPU_EINVAL, "matrix range [%u,%u) out of range", first, first + count);
   const unsigned S = g.states, SP = g.states_padded, R = g.rate_cats, SPT = c->gg.SPT;
   const size_t host_stride = (size_t)R * S * SP;
   // the previous async copy may still be reading the staging vector
@@ -374,6 +382,19 @@ extern "C" int pllgpu_pmatrix_upload(pllgpu_ctx_t *c, unsigned first, unsigned c
   HIP_TRY(hipMemcpyAsync(c->pmat.p + (size_t)first * c->pm_stride, c->stage.data(),
                          c->stage.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
   return 0;
+}
+
+extern "C" int pllgpu_pmatrix_upload(pllgpu_ctx_t *c, unsigned first, unsigned count, const double *host)
+{
+  CHECK_CTX(c);
+  return upload_matrices(c, first, count, host, c->geo.prob_matrices);
+}
+
+extern "C" int pllgpu_aux_matrix_upload(pllgpu_ctx_t *c, unsigned slot, const double *host)
+{
+  CHECK_CTX(c);
+  if (slot > 1) return fail(PLLGPU_EINVAL, "aux matrix slot %u out of range", slot);
+  return upload_matrices(c, c->geo.prob_matrices + slot, 1, host, c->geo.prob_matrices + 2);
 }
 
 extern "C" int pllgpu_frequencies_upload(pllgpu_ctx_t *c, unsigned index, const double *host)
@@ -801,3 +822,177 @@ extern "C" double pllgpu_timer_stop(pllgpu_ctx_t *c)
 }
 
 extern "C" unsigned pllgpu_last_launch_count(const pllgpu_ctx_t *c) { return c ? c->last_launches : 0; }
+
+// ---- branch-length derivatives ------------------------------------------------------------------
+extern "C" int pllgpu_eigenvals_upload(pllgpu_ctx_t *c, unsigned index, const double *host)
+{
+  CHECK_CTX(c);
+  if (index >= c->geo.rate_matrices) return fail(PLLGPU_EINVAL, "eigenvalue set %u out of range", index);
+  if (int rc = c->eigenvals.ensure((size_t)c->geo.rate_matrices * c->geo.states_padded)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->eigenvals.p + (size_t)index * c->geo.states_padded, host,
+                         c->geo.states_padded * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+extern "C" int pllgpu_rates_upload(pllgpu_ctx_t *c, const double *host)
+{
+  CHECK_CTX(c);
+  if (int rc = c->rates.ensure(c->geo.rate_cats)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->rates.p, host, c->geo.rate_cats * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+static int sumtable_slot(pllgpu_ctx *c, unsigned slot)
+{
+  if (slot >= 4) return fail(PLLGPU_EINVAL, "sumtable slot %u out of range", slot);
+  return c->sumtable[slot].ensure(clv_elems(c, c->geo.sites));
+}
+
+extern "C" int pllgpu_update_sumtable(pllgpu_ctx_t *c, const pllgpu_sumtable_t *st, unsigned slot)
+{
+  CHECK_CTX(c);
+  if (int rc = sumtable_slot(c, slot)) return rc;
+  const pllgpu_geometry_t &g = c->geo;
+  if (st->left_clv >= g.nodes || st->right_clv >= g.nodes) return fail(PLLGPU_EINVAL, "sumtable references a CLV out of range");
+  OpPack pack;
+  DevOp &d = pack.ops[0];
+  memset(&d, 0, sizeof d);
+  d.parent = c->sumtable[slot].p;
+  d.entries = g.sites;
+  if (st->left_is_tip)
+  {
+    if (st->left_clv >= g.tips || !c->tipchars[st->left_clv].p) return fail(PLLGPU_EINVAL, "tip %u has no codes on the device", st->left_clv);
+    d.ltip = c->tipchars[st->left_clv].p;
+  }
+  else
+  {
+    if (!c->clv[st->left_clv].p) return fail(PLLGPU_EINVAL, "CLV %u unavailable on the device", st->left_clv);
+    d.left = c->clv[st->left_clv].p;
+  }
+  if (!c->clv[st->right_clv].p) return fail(PLLGPU_EINVAL, "CLV %u unavailable on the device", st->right_clv);
+  d.right = c->clv[st->right_clv].p;
+  d.lmat = c->pmat.p + (size_t)g.prob_matrices * c->pm_stride;
+  d.rmat = c->pmat.p + (size_t)(g.prob_matrices + 1) * c->pm_stride;
+  if (st->gather)
+  {
+    d.lsid = c->ids[st->left_clv] ? c->site_id[st->left_clv].p : nullptr;
+    d.rsid = c->ids[st->right_clv] ? c->site_id[st->right_clv].p : nullptr;
+  }
+  const unsigned kind = st->left_is_tip ? 1u : 0u;
+  if (c->dna_fast)
+    launch_dna(c, pack, 1, g.sites, kind, st->gather != 0);
+  else
+    switch (c->ich)
+    {
+      case 4: launch_generic<4>(c, pack, 1, g.sites, kind, st->gather != 0); break;
+      case 8: launch_generic<8>(c, pack, 1, g.sites, kind, st->gather != 0); break;
+      case 16: launch_generic<16>(c, pack, 1, g.sites, kind, st->gather != 0); break;
+      case 20: launch_generic<20>(c, pack, 1, g.sites, kind, st->gather != 0); break;
+      default: launch_generic<32>(c, pack, 1, g.sites, kind, st->gather != 0); break;
+    }
+  if (g.per_rate_scalers && (st->left_scaler >= 0 || st->right_scaler >= 0))
+  {
+    DevExcess e;
+    memset(&e, 0, sizeof e);
+    e.table = c->sumtable[slot].p;
+    if (int rc = scaler_ptr(c, st->left_is_tip ? -1 : st->left_scaler, e.pscaler)) return rc;
+    if (int rc = scaler_ptr(c, st->right_scaler, e.cscaler)) return rc;
+    e.psid = d.lsid;
+    e.csid = d.rsid;
+    e.sites = g.sites;
+    const unsigned tiles = (g.sites + 63) / 64;
+    hipLaunchKernelGGL(k_sumtable_excess, dim3((tiles + 3) / 4), dim3(256), 0, c->stream, e, c->gg);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pllgpu_sumtable_upload(pllgpu_ctx_t *c, unsigned slot, const double *host)
+{
+  CHECK_CTX(c);
+  if (int rc = sumtable_slot(c, slot)) return rc;
+  const size_t n = (size_t)c->geo.sites * c->span;
+  if (int rc = c->scratch.ensure(n)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->scratch.p, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_aos_to_tiled, dim3(1024), dim3(256), 0, c->stream, c->scratch.p, c->sumtable[slot].p, c->geo.sites,
+                     c->gg.S, c->gg.SP, c->gg.R);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pllgpu_sumtable_download(pllgpu_ctx_t *c, unsigned slot, double *host)
+{
+  CHECK_CTX(c);
+  if (slot >= 4 || !c->sumtable[slot].p) return fail(PLLGPU_EINVAL, "sumtable slot %u is empty", slot);
+  const size_t n = (size_t)c->geo.sites * c->span;
+  if (int rc = c->scratch.ensure(n)) return rc;
+  hipLaunchKernelGGL(k_tiled_to_aos, dim3(1024), dim3(256), 0, c->stream, c->sumtable[slot].p, c->scratch.p, c->geo.sites,
+                     c->gg.S, c->gg.SP, c->gg.R);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(host, c->scratch.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int pllgpu_likelihood_derivatives(pllgpu_ctx_t *c, unsigned slot, double branch_length,
+                                             const unsigned *params_indices, double *d_f, double *dd_f)
+{
+  CHECK_CTX(c);
+  const pllgpu_geometry_t &g = c->geo;
+  if (slot >= 4 || !c->sumtable[slot].p) return fail(PLLGPU_EINVAL, "sumtable slot %u is empty", slot);
+  if (!c->eigenvals.p || !c->rates.p) return fail(PLLGPU_EINVAL, "eigenvalues / category rates were not uploaded");
+  if (int rc = c->diag.ensure((size_t)g.rate_cats * g.states * 4)) return rc;
+  DevDiag dg;
+  DevDeriv dv;
+  memset(&dg, 0, sizeof dg);
+  memset(&dv, 0, sizeof dv);
+  for (unsigned k = 0; k < g.rate_cats; ++k)
+  {
+    if (params_indices[k] >= g.rate_matrices) return fail(PLLGPU_EINVAL, "params_indices[%u] out of range", k);
+    dg.fidx[k] = dv.fidx[k] = (unsigned char)params_indices[k];
+  }
+  dg.diag = c->diag.p;
+  dg.eigenvals = c->eigenvals.p;
+  dg.rates = c->rates.p;
+  dg.prop_invar = c->prop_invar.p;
+  dg.branch_length = branch_length;
+  dg.S = g.states;
+  dg.SP = g.states_padded;
+  dg.R = g.rate_cats;
+  hipLaunchKernelGGL(k_diagtable, dim3(1), dim3(256), 0, c->stream, dg);
+
+  dv.table = c->sumtable[slot].p;
+  dv.diag = c->diag.p;
+  dv.freqs = c->freqs.p;
+  dv.rate_weights = c->rate_weights.p;
+  dv.prop_invar = c->prop_invar.p;
+  dv.pattern_weights = c->pattern_weights.p;
+  dv.invariant = c->invariant_set ? c->invariant.p : nullptr;
+  dv.block_sums = c->block_sums.p;
+  dv.counter = c->counter.p;
+  dv.result = c->result_dev;
+  c->seq += 1.0;
+  dv.sequence = c->seq;
+  dv.sites = g.sites;
+  unsigned long long seq_bits;
+  memcpy(&seq_bits, &c->seq, sizeof seq_bits);
+  const unsigned tiles = (g.sites + 63) / 64;
+  const unsigned tpw = (tiles + 4 * 1024 - 1) / (4 * 1024);
+  const unsigned blocks = (tiles + 4 * tpw - 1) / (4 * tpw);
+  hipLaunchKernelGGL(k_derivatives, dim3(blocks), dim3(256), 0, c->stream, dv, c->gg, tpw);
+  HIP_TRY(hipGetLastError());
+  volatile double *res = c->result_host;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (__atomic_load_n((const unsigned long long *)&res[1], __ATOMIC_ACQUIRE) != seq_bits)
+  {
+    if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+    {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      break;
+    }
+  }
+  *d_f = c->result_host[0];
+  *dd_f = c->result_host[2];
+  return 0;
+}

@@ -1,0 +1,235 @@
+/* derivatives.c - pll_update_sumtable / pll_compute_likelihood_derivatives (SURVEY.md section 8
+ * row f1; reference: src/derivatives.c:239-418 over src/core_derivatives.c).
+ *
+ * Case selection as in the reference (:264-321): site repeats on either end -> gather maps;
+ * PATTERN_TIP with one tip end -> the tip is read as codes and plays the "left" role (:67-79);
+ * tip-tip is refused (:278-286). The table is computed into HBM by the CLV-update kernels with the
+ * two contraction matrices
+ *     M1[k][j][i] = pi_i * inv_eigenvecs[i][j]      (left end)
+ *     M2[k][j][i] = eigenvecs[j][i]                 (right end)
+ * per rate category k = params_indices[k]; they are rebuilt and uploaded only when an
+ * eigensystem, a frequency vector or params_indices changed. The caller's `sumtable` pointer is a
+ * handle to one of four device slots (least recently used is recycled).
+ */
+#include "pll_internal.h"
+
+static int fail_loudly(const char *what)
+{
+  fprintf(stderr, "libpll_amd: %s: [%d] %s\n", what, pll_errno, pll_errmsg);
+  return PLL_FAILURE;
+}
+
+static int slot_of(pll_amd_ext_t *x, const double *key, int create)
+{
+  int i, victim = 0;
+  for (i = 0; i < 4; ++i)
+    if (x->sumtable_key[i] == key)
+    {
+      x->sumtable_age[i] = ++x->sumtable_clock;
+      return i;
+    }
+  if (!create) return -1;
+  for (i = 0; i < 4; ++i)
+  {
+    if (!x->sumtable_key[i])
+    {
+      victim = i;
+      break;
+    }
+    if (x->sumtable_age[i] < x->sumtable_age[victim]) victim = i;
+  }
+  x->sumtable_key[victim] = key;
+  x->sumtable_age[victim] = ++x->sumtable_clock;
+  return victim;
+}
+
+/* eigenvalues, category rates, prop_invar, frequencies: whatever is stale */
+static int flush_deriv_model(pll_partition_t *p, pll_amd_ext_t *x)
+{
+  unsigned int i;
+  if (!pll_flush_model(p, x)) return PLL_FAILURE;
+  for (i = 0; i < p->rate_matrices; ++i)
+    if (x->eigen_dirty[i] || x->always_upload)
+    {
+      if (pllgpu_eigenvals_upload(x->ctx, i, p->eigenvals[i]) != 0)
+      {
+        pll_set_gpu_error("eigenvalues upload");
+        return PLL_FAILURE;
+      }
+      x->eigen_dirty[i] = 0;
+    }
+  if (x->rates_dirty || x->always_upload)
+  {
+    if (pllgpu_rates_upload(x->ctx, p->rates) != 0)
+    {
+      pll_set_gpu_error("category rates upload");
+      return PLL_FAILURE;
+    }
+    x->rates_dirty = 0;
+  }
+  return PLL_SUCCESS;
+}
+
+static int flush_aux_matrices(pll_partition_t *p, pll_amd_ext_t *x, const unsigned int *params_indices)
+{
+  const unsigned int s = p->states, sp = p->states_padded, r = p->rate_cats;
+  unsigned int k, i, j;
+  int same = (x->aux_version == x->eigen_version) && !x->always_upload;
+  for (k = 0; same && k < r; ++k) same = (x->aux_params[k] == params_indices[k]);
+  if (same) return PLL_SUCCESS;
+
+  double *m = (double *)calloc((size_t)2 * r * s * sp, sizeof(double));
+  if (!m)
+  {
+    pll_set_error(PLL_ERROR_MEM_ALLOC, "Unable to allocate enough memory.");
+    return PLL_FAILURE;
+  }
+  double *m1 = m, *m2 = m + (size_t)r * s * sp;
+  for (k = 0; k < r; ++k)
+  {
+    const double *ev = p->eigenvecs[params_indices[k]];
+    const double *iev = p->inv_eigenvecs[params_indices[k]];
+    const double *pi = p->frequencies[params_indices[k]];
+    for (j = 0; j < s; ++j)
+      for (i = 0; i < s; ++i)
+      {
+        m1[((size_t)k * s + j) * sp + i] = pi[i] * iev[(size_t)i * sp + j];
+        m2[((size_t)k * s + j) * sp + i] = ev[(size_t)j * sp + i];
+      }
+  }
+  int rc = pllgpu_aux_matrix_upload(x->ctx, 0, m1) || pllgpu_aux_matrix_upload(x->ctx, 1, m2);
+  free(m);
+  if (rc)
+  {
+    pll_set_gpu_error("sumtable matrices upload");
+    return PLL_FAILURE;
+  }
+  x->aux_version = x->eigen_version;
+  memcpy(x->aux_params, params_indices, sizeof(unsigned int) * r);
+  return PLL_SUCCESS;
+}
+
+int pll_update_sumtable(pll_partition_t *p, unsigned int parent_clv_index, unsigned int child_clv_index,
+                        int parent_scaler_index, int child_scaler_index,
+                        const unsigned int *params_indices, double *sumtable)
+{
+  pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
+  unsigned int k;
+  if (!x || !x->ctx)
+  {
+    pll_set_error(PLL_ERROR_GPU_UNAVAILABLE, "pll_update_sumtable: no MI355X context behind this partition; this library has no CPU path");
+    return fail_loudly("pll_update_sumtable");
+  }
+  if (parent_clv_index >= p->nodes || child_clv_index >= p->nodes || parent_scaler_index >= (int)p->scale_buffers ||
+      child_scaler_index >= (int)p->scale_buffers || !sumtable)
+  {
+    pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_update_sumtable: index out of range");
+    return fail_loudly("pll_update_sumtable");
+  }
+  const int ptip = pll_is_pattern_tip(p, parent_clv_index);
+  const int ctip = pll_is_pattern_tip(p, child_clv_index);
+  if (ptip && ctip)
+  {
+    pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_update_sumtable() was called for the tip-tip case!");
+    return PLL_FAILURE;
+  }
+  for (k = 0; k < p->rate_cats; ++k)
+  {
+    if (params_indices[k] >= p->rate_matrices)
+    {
+      pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_update_sumtable: params_indices[%u] out of range", k);
+      return fail_loudly("pll_update_sumtable");
+    }
+    /* the reference reads whatever eigensystem is stored; an invalid one is computed here */
+    if (!p->eigen_decomp_valid[params_indices[k]] && !pll_update_eigen(p, params_indices[k])) return PLL_FAILURE;
+  }
+  if (!flush_deriv_model(p, x) || !flush_aux_matrices(p, x, params_indices)) return fail_loudly("pll_update_sumtable");
+  if (!pll_flush_clv(p, x, parent_clv_index) || !pll_flush_clv(p, x, child_clv_index) ||
+      (!ptip && !pll_flush_scaler(p, x, parent_scaler_index)) || (!ctip && !pll_flush_scaler(p, x, child_scaler_index)) ||
+      !pll_flush_repeats(p, x, parent_clv_index) || !pll_flush_repeats(p, x, child_clv_index))
+    return fail_loudly("pll_update_sumtable");
+
+  pllgpu_sumtable_t st;
+  memset(&st, 0, sizeof st);
+  /* a tip given by codes is the left end; otherwise parent left, child right (:142-153) */
+  st.left_clv = ctip ? child_clv_index : parent_clv_index;
+  st.right_clv = ctip ? parent_clv_index : child_clv_index;
+  st.left_scaler = (ptip || ctip) ? PLL_SCALE_BUFFER_NONE : parent_scaler_index;
+  st.right_scaler = ctip ? parent_scaler_index : child_scaler_index;
+  st.left_is_tip = (ptip || ctip);
+  st.gather = pll_repeats_enabled(p) &&
+              (p->repeats->pernode_ids[parent_clv_index] || p->repeats->pernode_ids[child_clv_index]);
+  const int slot = slot_of(x, sumtable, 1);
+  if (pllgpu_update_sumtable(x->ctx, &st, (unsigned)slot) != 0)
+  {
+    x->sumtable_key[slot] = NULL;
+    pll_set_gpu_error("pll_update_sumtable");
+    return PLL_FAILURE;
+  }
+  if (x->eager_mirror && pllgpu_sumtable_download(x->ctx, (unsigned)slot, sumtable) != 0)
+  {
+    pll_set_gpu_error("pll_update_sumtable (mirror)");
+    return PLL_FAILURE;
+  }
+  return PLL_SUCCESS;
+}
+
+int pll_gpu_sync_sumtable(pll_partition_t *p, double *sumtable)
+{
+  pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
+  if (!x || !x->ctx)
+  {
+    pll_set_error(PLL_ERROR_GPU_UNAVAILABLE, "pll_gpu_sync_sumtable: no MI355X context behind this partition");
+    return fail_loudly("pll_gpu_sync_sumtable");
+  }
+  const int slot = slot_of(x, sumtable, 0);
+  if (slot < 0)
+  {
+    pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_gpu_sync_sumtable: no device table stands for this buffer");
+    return PLL_FAILURE;
+  }
+  if (pllgpu_sumtable_download(x->ctx, (unsigned)slot, sumtable) != 0)
+  {
+    pll_set_gpu_error("pll_gpu_sync_sumtable");
+    return PLL_FAILURE;
+  }
+  return PLL_SUCCESS;
+}
+
+int pll_compute_likelihood_derivatives(pll_partition_t *p, int parent_scaler_index, int child_scaler_index,
+                                       double branch_length, const unsigned int *params_indices,
+                                       const double *sumtable, double *d_f, double *dd_f)
+{
+  pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
+  (void)parent_scaler_index; /* only the ascertainment-bias terms use the scalers (:851-924): out of scope */
+  (void)child_scaler_index;
+  if (!x || !x->ctx)
+  {
+    pll_set_error(PLL_ERROR_GPU_UNAVAILABLE, "pll_compute_likelihood_derivatives: no MI355X context behind this partition; this library has no CPU path");
+    return fail_loudly("pll_compute_likelihood_derivatives");
+  }
+  if (!sumtable || !d_f || !dd_f || !(branch_length >= 0))
+  {
+    pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_compute_likelihood_derivatives: invalid argument");
+    return fail_loudly("pll_compute_likelihood_derivatives");
+  }
+  if (!flush_deriv_model(p, x)) return fail_loudly("pll_compute_likelihood_derivatives");
+  int slot = slot_of(x, sumtable, 0);
+  if (slot < 0)
+  {
+    /* a table this library did not produce: the caller's buffer is the truth */
+    slot = slot_of(x, sumtable, 1);
+    if (pllgpu_sumtable_upload(x->ctx, (unsigned)slot, sumtable) != 0)
+    {
+      x->sumtable_key[slot] = NULL;
+      pll_set_gpu_error("pll_compute_likelihood_derivatives (table upload)");
+      return PLL_FAILURE;
+    }
+  }
+  if (pllgpu_likelihood_derivatives(x->ctx, (unsigned)slot, branch_length, params_indices, d_f, dd_f) != 0)
+  {
+    pll_set_gpu_error("pll_compute_likelihood_derivatives");
+    return PLL_FAILURE;
+  }
+  return PLL_SUCCESS;
+}

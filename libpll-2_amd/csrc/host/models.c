@@ -227,6 +227,14 @@ int pll_update_eigen(pll_partition_t *p, unsigned int idx)
     }
   }
   p->eigen_decomp_valid[idx] = 1;
+  {
+    pll_amd_ext_t *x = pll_ext(p);
+    if (x)
+    {
+      x->eigen_dirty[idx] = 1;
+      x->eigen_version++;
+    }
+  }
   free(keep); free(a); free(v); free(d); free(full);
   return PLL_SUCCESS;
 }

@@ -68,6 +68,8 @@ static void free_ext(pll_amd_ext_t *x)
   free(x->repeats_dirty);
   free(x->pmatrix_dirty);
   free(x->freqs_dirty);
+  free(x->eigen_dirty);
+  free(x->aux_params);
   free(x->gops);
   free(x->lvl_clv_w);
   free(x->lvl_clv_r);
@@ -294,8 +296,14 @@ pll_partition_t *pll_partition_create(unsigned int tips, unsigned int clv_buffer
   x->repeats_dirty = (unsigned char *)calloc(p->nodes ? p->nodes : 1, 1);
   x->pmatrix_dirty = (unsigned char *)malloc(prob_matrices ? prob_matrices : 1);
   x->freqs_dirty = (unsigned char *)malloc(rate_matrices ? rate_matrices : 1);
+  x->eigen_dirty = (unsigned char *)malloc(rate_matrices ? rate_matrices : 1);
+  x->aux_params = (unsigned int *)malloc(sizeof(unsigned int) * rate_cats);
   NEED(x->clv_side && x->scaler_side && x->scaler_entries && x->tipchars_dirty && x->repeats_dirty &&
-       x->pmatrix_dirty && x->freqs_dirty);
+       x->pmatrix_dirty && x->freqs_dirty && x->eigen_dirty && x->aux_params);
+  memset(x->eigen_dirty, 1, rate_matrices ? rate_matrices : 1);
+  x->rates_dirty = 1;
+  x->eigen_version = 1;
+  x->aux_version = 0;
   memset(x->pmatrix_dirty, 1, prob_matrices ? prob_matrices : 1);
   memset(x->freqs_dirty, 1, rate_matrices ? rate_matrices : 1);
   x->rate_weights_dirty = x->pattern_weights_dirty = x->prop_invar_dirty = 1;
@@ -383,7 +391,11 @@ void pll_set_frequencies(pll_partition_t *p, unsigned int idx, const double *f)
     for (i = 0; i < p->states; ++i) dst[i] /= sum;
   p->eigen_decomp_valid[idx] = 0;
   pll_amd_ext_t *x = pll_ext(p);
-  if (x) x->freqs_dirty[idx] = 1;
+  if (x)
+  {
+    x->freqs_dirty[idx] = 1;
+    x->eigen_version++;
+  }
 }
 
 void pll_set_subst_params(pll_partition_t *p, unsigned int idx, const double *params)
@@ -395,6 +407,8 @@ void pll_set_subst_params(pll_partition_t *p, unsigned int idx, const double *pa
 void pll_set_category_rates(pll_partition_t *p, const double *rates)
 {
   memcpy(p->rates, rates, p->rate_cats * sizeof(double));
+  pll_amd_ext_t *x = pll_ext(p);
+  if (x) x->rates_dirty = 1;
 }
 
 void pll_set_category_weights(pll_partition_t *p, const double *w)
@@ -628,6 +642,12 @@ void pll_gpu_invalidate(pll_partition_t *p, unsigned int what, int index)
     x->tipmap_dirty = 1;
   }
   if (what & PLL_GPU_DIRTY_REPEATS) MARK(repeats_dirty, p->nodes, 1);
+  if (what & PLL_GPU_DIRTY_EIGEN)
+  {
+    MARK(eigen_dirty, p->rate_matrices, 1);
+    x->eigen_version++;
+    x->rates_dirty = 1;
+  }
 #undef MARK
 }
 

@@ -38,6 +38,17 @@ typedef struct pll_amd_ext
   int eager_mirror;             /* PLL_AMD_EAGER_MIRROR=1: copy results back after every call */
   int always_upload;            /* PLL_AMD_ALWAYS_UPLOAD=1: treat model arrays as dirty on every call */
   unsigned int sites_alloc;
+  /* derivatives: eigenvalues / category rates on the device, the two sumtable contraction
+   * matrices (rebuilt when the eigensystem, the frequencies or params_indices change), and which
+   * caller-owned host sumtable each device slot stands for */
+  unsigned char *eigen_dirty;   /* [rate_matrices] eigenvalues not yet on the device */
+  int rates_dirty;
+  unsigned int eigen_version;   /* bumped whenever an eigensystem or frequency vector changes */
+  unsigned int aux_version;     /* eigen_version the device contraction matrices were built from */
+  unsigned int *aux_params;     /* [rate_cats] params_indices they were built for */
+  const double *sumtable_key[4];
+  unsigned int sumtable_age[4];
+  unsigned int sumtable_clock;
   /* scheduler scratch (grown on demand) */
   pllgpu_op_t *gops;
   unsigned int gops_cap;

@@ -27,6 +27,7 @@ SCALE_BUFFER_NONE = -1
 
 DIRTY_PMATRIX, DIRTY_FREQS, DIRTY_RATE_WEIGHTS, DIRTY_PATTERN_WEIGHTS = 1, 2, 4, 8
 DIRTY_INVARIANT, DIRTY_CLV, DIRTY_SCALER, DIRTY_TIPCHARS, DIRTY_REPEATS = 16, 32, 64, 128, 256
+DIRTY_EIGEN = 512
 
 
 class Repeats(C.Structure):
@@ -130,6 +131,11 @@ _PROTOS = {
         C.c_double,
         [PartitionP, C.c_uint, C.c_int, c_uint_p, c_double_p],
     ),
+    "pll_update_sumtable": (C.c_int, [PartitionP, C.c_uint, C.c_uint, C.c_int, C.c_int, c_uint_p, c_double_p]),
+    "pll_compute_likelihood_derivatives": (
+        C.c_int,
+        [PartitionP, C.c_int, C.c_int, C.c_double, c_uint_p, c_double_p, c_double_p, c_double_p],
+    ),
     "pll_repeats_enabled": (C.c_int, [PartitionP]),
     "pll_get_sites_number": (C.c_uint, [PartitionP, C.c_uint]),
     "pll_get_clv_size": (C.c_uint, [PartitionP, C.c_uint]),
@@ -146,6 +152,7 @@ _GPU_PROTOS = {
     "pll_gpu_sync_scaler": (C.c_int, [PartitionP, C.c_uint]),
     "pll_gpu_sync_all": (C.c_int, [PartitionP]),
     "pll_gpu_invalidate": (None, [PartitionP, C.c_uint, C.c_int]),
+    "pll_gpu_sync_sumtable": (C.c_int, [PartitionP, c_double_p]),
     "pll_gpu_set_stream": (C.c_int, [PartitionP, C.c_void_p]),
     "pll_gpu_get_stream": (C.c_void_p, [PartitionP]),
     "pll_gpu_synchronize": (C.c_int, [PartitionP]),

@@ -38,6 +38,9 @@ class Case:
     roots: List[Tuple[int, int]] = field(default_factory=list)  # (clv, scaler) root lnL
     dump_clvs: Optional[Sequence[int]] = None  # default: every op parent
     update_repeats: int = 1
+    # optional model description for the derivative tests: exch (upper triangle), rates (category
+    # rates), and the list of branch lengths at which derivatives are evaluated
+    model: Optional[dict] = None
 
     def __post_init__(self):
         self.pmatrix = np.ascontiguousarray(self.pmatrix, dtype=np.float64)
@@ -185,6 +188,78 @@ class Session:
             if sid:
                 a = a[api.as_np(sid, c.sites, np.uint32)]
         return a
+
+    # ---- branch-length derivatives ---------------------------------
+    def set_model(self, exch, freqs, rates):
+        """substitution parameters, frequencies and category rates through the model setters; the
+        library computes its own eigensystem on demand (pll_update_eigen)"""
+        c = self.case
+        e = np.ascontiguousarray(exch, dtype=np.float64)
+        for m in range(c.rate_matrices):
+            f = np.ascontiguousarray(np.atleast_2d(freqs)[m], dtype=np.float64)
+            self.lib.pll_set_frequencies(self.p, m, api.dptr(f))
+            self.lib.pll_set_subst_params(self.p, m, api.dptr(e))
+        r = np.ascontiguousarray(rates, dtype=np.float64)
+        self.lib.pll_set_category_rates(self.p, api.dptr(r))
+
+    def update_eigen(self):
+        for m in range(self.case.rate_matrices):
+            if not self.lib.pll_update_eigen(self.p, m):
+                raise RuntimeError(f"pll_update_eigen: [{self.lib.errno()}] {self.lib.errmsg()}")
+
+    def read_eigen(self):
+        c, sp, part = self.case, self.sp, self.part
+        out = {"eigenvecs": [], "inv_eigenvecs": [], "eigenvals": []}
+        for m in range(c.rate_matrices):
+            out["eigenvecs"].append(api.as_np(part.eigenvecs[m], c.states * sp, np.float64).reshape(c.states, sp)[:, :c.states].copy())
+            out["inv_eigenvecs"].append(api.as_np(part.inv_eigenvecs[m], c.states * sp, np.float64).reshape(c.states, sp)[:, :c.states].copy())
+            out["eigenvals"].append(api.as_np(part.eigenvals[m], c.states, np.float64).copy())
+        return {k: np.stack(v) for k, v in out.items()}
+
+    def inject_eigen(self, eig, rates):
+        """write a given eigensystem into the partition's arrays (callers may do that: the arrays are
+        public) and mark it valid, so both libraries work in the same eigenbasis"""
+        c, sp, part = self.case, self.sp, self.part
+        for m in range(c.rate_matrices):
+            for name in ("eigenvecs", "inv_eigenvecs"):
+                dst = api.as_np(getattr(part, name)[m], c.states * sp, np.float64).reshape(c.states, sp)
+                dst[:, :] = 0.0
+                dst[:, :c.states] = eig[name][m]
+            api.as_np(part.eigenvals[m], sp, np.float64)[:c.states] = eig["eigenvals"][m]
+            part.eigen_decomp_valid[m] = 1
+        r = np.ascontiguousarray(rates, dtype=np.float64)
+        self.lib.pll_set_category_rates(self.p, api.dptr(r))
+        if self.lib.is_amd:
+            self.lib.pll_gpu_invalidate(self.p, api.DIRTY_EIGEN, -1)
+
+    def new_sumtable(self):
+        """caller-owned table, aligned like pll_aligned_alloc(.., partition->alignment) in the
+        reference's tests (its AVX kernels use aligned stores)"""
+        n = self.case.sites * self.case.rate_cats * self.sp
+        raw = np.zeros(n + 8, dtype=np.float64)
+        off = (-raw.ctypes.data // 8) % 8  # doubles up to the next 64-byte boundary
+        return raw[off:off + n]
+
+    def update_sumtable(self, edge, sumtable):
+        ok = self.lib.pll_update_sumtable(self.p, edge[0], edge[2], edge[1], edge[3], api.uptr(self._fi), api.dptr(sumtable))
+        if not ok:
+            raise RuntimeError(f"pll_update_sumtable: [{self.lib.errno()}] {self.lib.errmsg()}")
+
+    def read_sumtable(self, sumtable):
+        """[sites][rate][states]; the AMD library keeps the table in HBM until asked for it"""
+        c = self.case
+        if self.lib.is_amd:
+            if not self.lib.pll_gpu_sync_sumtable(self.p, api.dptr(sumtable)):
+                raise RuntimeError(f"pll_gpu_sync_sumtable: [{self.lib.errno()}] {self.lib.errmsg()}")
+        return sumtable.reshape(c.sites, c.rate_cats, self.sp)[:, :, :c.states].copy()
+
+    def derivatives(self, edge, sumtable, t):
+        d1, d2 = C.c_double(0), C.c_double(0)
+        ok = self.lib.pll_compute_likelihood_derivatives(self.p, edge[1], edge[3], float(t), api.uptr(self._fi),
+                                                         api.dptr(sumtable), C.byref(d1), C.byref(d2))
+        if not ok:
+            raise RuntimeError(f"pll_compute_likelihood_derivatives: [{self.lib.errno()}] {self.lib.errmsg()}")
+        return d1.value, d2.value
 
     def close(self):
         if self.p:

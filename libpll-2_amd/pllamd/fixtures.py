@@ -12,7 +12,9 @@ _SCALARS = ("name", "states", "rate_cats", "tips", "sites", "attributes", "clv_b
             "update_repeats")
 
 
-def save(path, case: Case, expected: dict, extra: dict = None):
+def save(path, case: Case, expected: dict, extra: dict = None, arrays: dict = None):
+    """arrays: additional named numpy arrays (e.g. an eigensystem, expected derivatives); they come
+    back from load() as extra['arrays']"""
     meta = {k: getattr(case, k) for k in _SCALARS}
     meta["op_batches"] = [[list(map(int, op)) for op in b] for b in case.op_batches]
     meta["edges"] = [list(map(int, e)) for e in case.edges]
@@ -41,6 +43,8 @@ def save(path, case: Case, expected: dict, extra: dict = None):
     arrs["out_root_lnl"] = np.asarray(expected.get("root_lnl", []), dtype=np.float64)
     if expected.get("root_persite"):
         arrs["out_root_persite"] = np.stack(expected["root_persite"])
+    for k, v in (arrays or {}).items():
+        arrs["x_" + k] = np.asarray(v)
     arrs["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(path, **arrs)
 
@@ -71,4 +75,6 @@ def load(path):
         exp["persite"] = list(z["out_persite"])
     if "out_root_persite" in z:
         exp["root_persite"] = list(z["out_root_persite"])
-    return case, exp, meta["extra"]
+    extra = dict(meta["extra"])
+    extra["arrays"] = {k[2:]: z[k] for k in z.files if k.startswith("x_")}
+    return case, exp, extra

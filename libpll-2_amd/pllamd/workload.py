@@ -166,6 +166,20 @@ def pmatrices(exch, freqs, rates, brlens, pinv=0.0):
     return np.clip(out, 0.0, None)
 
 
+def eigensystem(exch, freqs):
+    """eigen-decomposition of the reversible rate matrix in the array conventions of
+    pll_partition_t (src/models.c:346-398): eigenvecs[m][k] = U[k][m] sqrt(pi_k),
+    inv_eigenvecs[j][m] = U[j][m] / sqrt(pi_j), so that P(t) = inv_eigenvecs . diag(exp(lambda t)) .
+    eigenvecs. Returns arrays with a leading rate-matrix axis of length 1."""
+    freqs = np.asarray(freqs, dtype=np.float64)
+    q = reversible_q(np.asarray(exch, dtype=np.float64), freqs)
+    sq = np.sqrt(freqs)
+    sym = q * sq[:, None] / sq[None, :]
+    sym = 0.5 * (sym + sym.T)
+    w, u = np.linalg.eigh(sym)
+    return dict(eigenvecs=(u.T * sq[None, :])[None], inv_eigenvecs=(u / sq[:, None])[None], eigenvals=w[None])
+
+
 GTR_DNA = dict(exch=[1, 2, 1, 1, 2, 1], freqs=[0.3, 0.2, 0.2, 0.3])
 
 
@@ -222,4 +236,5 @@ def make_case(name, states, tips, sites, rate_cats=4, tree="balanced", attribute
     return Case(name=name, states=states, rate_cats=rate_cats, tips=tips, sites=sites, pmatrix=pm,
                 freqs=freqs[None, :], op_batches=[ops], edges=[edge], attributes=attributes,
                 clv_buffers=tips - 2, scale_buffers=(tips - 2) if scalers else 0,
-                prop_invar=np.array([pinv]), pattern_weights=pattern_weights, **kw)
+                prop_invar=np.array([pinv]), pattern_weights=pattern_weights,
+                model=dict(exch=np.asarray(exch, dtype=np.float64), rates=rates), **kw)

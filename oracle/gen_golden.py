@@ -158,6 +158,129 @@ def synthetic_cases():
     yield W.make_case("s64_plain", 64, 4, 16)
 
 
+DERIV_BRLENS = [0.1, 0.2, 0.5, 0.9, 1.5, 5, 10, 50, 90]  # test/src/derivatives.c:48
+
+
+def parse_deriv_out():
+    """test/out/derivatives.out: {(alpha, ncats, pinv): {'inner': [(f, d, dd) x 9], 'tip': [...]}}"""
+    txt = open(os.path.join(REF_ROOT, "test", "out", "derivatives.out")).read()
+    out = {}
+    for blk in re.split(r"\n\s*TEST alpha\(ncats\) =", txt)[1:]:
+        m = re.match(r"\s*([0-9.]+)\(\s*(\d+)\) ; pinv = ([0-9.]+)", blk)
+        key = (float(m.group(1)), int(m.group(2)), float(m.group(3)))
+        rows = {"inner": [], "tip": []}
+        for tag, pat in (("inner", r"Branch\s+([0-9.]+) :\s+(\S+)\s+(\S+)\s+(\S+)"),
+                         ("tip", r"Branch\(Tip\)\s+([0-9.]+) :\s+(\S+)\s+(\S+)\s+(\S+)")):
+            rows[tag] = [(float(a), float(b), float(c)) for _, a, b, c in re.findall(pat, blk)]
+        out[key] = rows
+    return out
+
+
+def record_derivatives(ref, case, eigen_from_model, deriv_edges, brlens, arch=api.ARCH_AVX2):
+    """run the reference: partials, then per (edge, after-batch) the sumtable and (d_f, dd_f) at every
+    branch length; also hands back the reference's eigensystem and category rates"""
+    res = dict(d=[], sumtable=[])
+    with driver.Session(ref, case, arch) as s:
+        s.set_model(case.model["exch"], case.freqs, case.model["rates"])
+        for m in range(case.rate_matrices):  # set_frequencies reset nothing else; pinv is already in place
+            pass
+        s.update_eigen()
+        eig = s.read_eigen()
+        done = 0
+        for (edge, after) in deriv_edges:
+            while done <= after:
+                arr, batch = s._op_arrays[done], case.op_batches[done]
+                ref.pll_update_partials(s.p, arr, len(batch))
+                done += 1
+            st = s.new_sumtable()
+            s.update_sumtable(edge, st)
+            res["sumtable"].append(s.read_sumtable(st))
+            res["d"].append([s.derivatives(edge, st, t) for t in brlens])
+    return eig, res
+
+
+def derivative_fixtures(ref, outdir):
+    n = 0
+    pinned = parse_deriv_out()
+    seqs = [b"WAACTCGCTA--ATTCTAAT", b"CACCATGCTA--ATTGTCTT", b"AG-C-TGCAG--CTTCTACT", b"CGTCTTGCAA--AT-C-AAG",
+            b"CGACTTGCCA--AT-T-AAG"]
+    ops3 = [(5, -1, 0, 1, -1, 1, 1, -1), (6, -1, 5, 0, -1, 2, 1, -1), (7, -1, 3, 1, -1, 4, 1, -1)]
+    op4 = [(7, -1, 6, 0, -1, 3, 0, -1)]
+    exch, freqs = [1, 2.5, 1, 1, 2.5, 1], [0.3, 0.4, 0.1, 0.2]
+    # replay of test/src/derivatives.c for three of its 36 parameter blocks
+    for (alpha, ncat, pinv) in ((0.1, 1, 0.0), (0.75, 4, 0.3), (1.5, 2, 0.6)):
+        for attr, tag in ((0, "plain"), (api.PATTERN_TIP, "tip")):
+            rates = np.zeros(ncat)
+            assert ref.pll_compute_gamma_cats(alpha, ncat, api.dptr(rates), 0)
+            # P-matrices with the proportion of invariant sites folded in, through the reference
+            p = ref.pll_partition_create(2, 1, 4, 16, 1, 4, ncat, 0, api.ARCH_AVX2)
+            part = p.contents
+            ref.pll_set_frequencies(p, 0, api.dptr(np.array(freqs)))
+            ref.pll_set_subst_params(p, 0, api.dptr(np.array(exch, dtype=np.float64)))
+            ref.pll_set_category_rates(p, api.dptr(rates))
+            part.prop_invar[0] = pinv
+            pi = np.zeros(ncat, dtype=np.uint32)
+            assert ref.pll_update_prob_matrices(p, api.uptr(pi), api.uptr(np.arange(4, dtype=np.uint32)),
+                                                api.dptr(np.array([0.1, 0.2, 0.3, 0.4])), 4)
+            pm = np.zeros((7, ncat, 4, 4))
+            for i in range(4):
+                pm[i] = api.as_np(part.pmatrix[i], ncat * 16, np.float64).reshape(ncat, 4, 4)
+            ref.pll_partition_destroy(p)
+            case = driver.Case(name=f"kat_deriv_a{alpha}_c{ncat}_p{pinv}_{tag}", states=4, rate_cats=ncat, tips=5,
+                               sites=20, pmatrix=pm, freqs=np.array([freqs]), op_batches=[ops3, op4], edges=[],
+                               charmap=W.map_nt(), sequences=seqs, attributes=attr, clv_buffers=4, scale_buffers=0,
+                               prop_invar=np.array([pinv]), model=dict(exch=np.array(exch, dtype=np.float64), rates=rates))
+            dedges = [((6, -1, 7, -1), 0), ((4, -1, 7, -1), 1)]
+            eig, res = record_derivatives(ref, case, True, dedges, DERIV_BRLENS)
+            pin = pinned[(alpha, ncat, pinv)]
+            for which, rows in zip(("inner", "tip"), res["d"]):
+                for (d1, d2), (_, pd1, pd2) in zip(rows, pin[which]):
+                    # printed with %12.4e: 5 significant digits (tiny values only to absolute 1e-13)
+                    assert abs(d1 - pd1) <= 6e-5 * abs(pd1) + 1e-13, (case.name, which, d1, pd1)
+                    assert abs(d2 - pd2) <= 6e-5 * abs(pd2) + 1e-13, (case.name, which, d2, pd2)
+            exp = dict(clv={}, scaler={}, lnl=[], persite=[])
+            fixtures.save(os.path.join(outdir, case.name + ".npz"), case, exp,
+                          dict(source="test/out/derivatives.out", deriv_edges=[[list(e), a] for e, a in dedges],
+                               brlens=DERIV_BRLENS, exch=list(map(float, exch)),
+                               kat=[[list(r) for r in pin["inner"]], [list(r) for r in pin["tip"]]]),
+                          arrays=dict(eigenvecs=eig["eigenvecs"], inv_eigenvecs=eig["inv_eigenvecs"],
+                                      eigenvals=eig["eigenvals"], rates=rates, d=np.array(res["d"]),
+                                      sumtable=np.stack(res["sumtable"])))
+            n += 1
+    # synthetic shapes
+    A = api
+    specs = [
+        ("deriv_dna", dict(states=4, tips=16, sites=150)),
+        ("deriv_dna_tip_rs", dict(states=4, tips=16, sites=150, attributes=A.PATTERN_TIP | A.RATE_SCALERS, ambiguity_pct=5)),
+        ("deriv_dna_repeats", dict(states=4, tips=16, sites=300, attributes=A.SITE_REPEATS, mutate_pct=5)),
+        ("deriv_dna_pinv", dict(states=4, tips=16, sites=200, pinv=0.25, mutate_pct=4)),
+        ("deriv_dna_deep_rate", dict(states=4, tips=300, sites=48, tree="caterpillar", brlen_scale=3, attributes=A.RATE_SCALERS)),
+        ("deriv_dna_deep_site", dict(states=4, tips=300, sites=48, tree="caterpillar", brlen_scale=3)),
+        ("deriv_aa", dict(states=20, tips=8, sites=64)),
+        ("deriv_aa_tip", dict(states=20, tips=8, sites=64, attributes=A.PATTERN_TIP, ambiguity_pct=5)),
+        ("deriv_s7_rates8", dict(states=7, tips=8, sites=64, rate_cats=8)),
+        ("deriv_s61", dict(states=61, tips=8, sites=24)),
+    ]
+    brl = [0.001, 0.05, 0.3, 1.0, 4.0, 30.0]
+    for name, kw in specs:
+        case = W.make_case(name, **kw)
+        e = case.edges[0]
+        dedges = [((e[0], e[1], e[2], e[3]), 0)]
+        # a second edge: last op's parent against one of its children is not a tree edge; use a tip
+        # edge for the tip-inner path where the tree has one at the root (caterpillar)
+        eig, res = record_derivatives(ref, case, True, dedges, brl)
+        case.edges = []
+        case.dump_clvs = []
+        exp = dict(clv={}, scaler={}, lnl=[], persite=[])
+        fixtures.save(os.path.join(outdir, name + ".npz"), case, exp,
+                      dict(source="oracle/_ref AVX2", deriv_edges=[[list(e), a] for e, a in dedges], brlens=brl,
+                           exch=[float(v) for v in case.model["exch"]]),
+                      arrays=dict(eigenvecs=eig["eigenvecs"], inv_eigenvecs=eig["inv_eigenvecs"], eigenvals=eig["eigenvals"],
+                                  rates=case.model["rates"], d=np.array(res["d"]), sumtable=np.stack(res["sumtable"])))
+        n += 1
+    return n
+
+
 def main():
     outdir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
@@ -186,6 +309,7 @@ def main():
         case.dump_clvs = keep
         fixtures.save(os.path.join(outdir, case.name + ".npz"), case, exp, dict(scalings=nscal, source="oracle/_ref AVX2"))
         n += 1
+    n += derivative_fixtures(ref, outdir)
     # model constants the synthetic protein workload uses (data exported by the reference library)
     np.savez_compressed(os.path.join(outdir, "model_lg.npz"), rates=ref.const_doubles("pll_aa_rates_lg", 190),
                         freqs=ref.const_doubles("pll_aa_freqs_lg", 20))

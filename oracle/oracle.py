@@ -121,6 +121,11 @@ class _Node:
         return c
 
 
+def dense_nodes(case):
+    """(nodes, scalers) after all op batches: per node a dense [sites][r][s] CLV or tip codes"""
+    return run_case(case)["_nodes"]
+
+
 def run_case(case, states_padded=None, pattern_tip=None):
     """Evaluate `case` with the restatement. pattern_tip: None -> follow case.attributes."""
     from pllamd import api  # constants only
@@ -182,6 +187,7 @@ def run_case(case, states_padded=None, pattern_tip=None):
                 scalers[psc] = pscal
             parents[pc] = psc
 
+    out["_nodes"] = (nodes, scalers)  # dense per-node state, for oracle_deriv
     dump = case.dump_clvs if case.dump_clvs is not None else sorted(parents)
     for idx in dump:
         out["clv"][idx] = nodes[idx].clv[:, :, :s].copy()

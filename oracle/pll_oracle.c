@@ -308,3 +308,110 @@ unsigned int orc_repeat_classes(unsigned int sites, const unsigned int *site_id_
   free(table);
   return next;
 }
+
+/* ---- branch-length derivatives -------------------------------------- */
+
+/* sumtable[n][k][j] = (sum_i p_i pi_i Vinv[i][j]) * (sum_i V[j][i] c_i), times the capped per-rate
+ * scaler excess (src/core_derivatives.c:417-465 ii, :587-635 ti, :215-319 repeats). The arrays
+ * follow the reference's naming: eigenvecs[j*sp+i], inv_eigenvecs[i*sp+j], one set per category. */
+void orc_update_sumtable(unsigned int states, unsigned int sp, unsigned int rate_cats, unsigned int sites,
+                         const orc_child_t *parent, const orc_child_t *child,
+                         const double *const *eigenvecs, const double *const *inv_eigenvecs,
+                         const double *const *freqs, double *sumtable, int per_rate)
+{
+  const unsigned int span = rate_cats * sp;
+  unsigned int *excess = (unsigned int *)calloc(rate_cats ? rate_cats : 1, sizeof(unsigned int));
+  double minlh[ORC_RATE_MAXDIFF];
+  unsigned int n, k, i, j;
+  fill_minlh(minlh);
+  for (n = 0; n < sites; ++n)
+  {
+    const unsigned int pe = entry_of(parent->site_id, n);
+    const unsigned int ce = entry_of(child->site_id, n);
+    if (per_rate) (void)site_scalings(parent, pe, child, ce, rate_cats, 1, excess);
+    for (k = 0; k < rate_cats; ++k)
+    {
+      const double *V = eigenvecs[k], *Vi = inv_eigenvecs[k], *pi = freqs[k];
+      double *sum = sumtable + (size_t)n * span + (size_t)k * sp;
+      orc_state_t pm = parent->clv ? 0 : tip_mask(parent, pe);
+      orc_state_t cm = child->clv ? 0 : tip_mask(child, ce);
+      const double *xp = parent->clv ? parent->clv + (size_t)pe * span + (size_t)k * sp : NULL;
+      const double *xc = child->clv ? child->clv + (size_t)ce * span + (size_t)k * sp : NULL;
+      for (j = 0; j < states; ++j)
+      {
+        double l = 0, r = 0;
+        for (i = 0; i < states; ++i)
+        {
+          const double p = xp ? xp[i] : (double)((pm >> i) & 1);
+          const double c = xc ? xc[i] : (double)((cm >> i) & 1);
+          l += p * pi[i] * Vi[(size_t)i * sp + j];
+          r += V[(size_t)j * sp + i] * c;
+        }
+        sum[j] = l * r;
+        if (per_rate && excess[k] > 0) sum[j] *= minlh[excess[k] - 1];
+      }
+      for (j = states; j < sp; ++j) sum[j] = 0.0;
+    }
+  }
+  free(excess);
+}
+
+/* first and second derivative of -lnL with respect to the branch length
+ * (src/core_derivatives.c:643-694, :757-772, :825-848) */
+void orc_likelihood_derivatives(unsigned int states, unsigned int sp, unsigned int rate_cats,
+                                unsigned int sites, const double *rate_weights, const int *invariant,
+                                const unsigned int *pattern_weights, double branch_length,
+                                const double *prop_invar /* per category */,
+                                const double *const *freqs, const double *rates,
+                                const double *const *eigenvals, const double *sumtable, double *d_f,
+                                double *dd_f)
+{
+  double *diag = (double *)malloc(sizeof(double) * 3 * rate_cats * states);
+  unsigned int n, k, j;
+  *d_f = 0;
+  *dd_f = 0;
+  for (k = 0; k < rate_cats; ++k)
+  {
+    const double ki = rates[k] / (1.0 - prop_invar[k]);
+    for (j = 0; j < states; ++j)
+    {
+      double *d = diag + 3 * ((size_t)k * states + j);
+      d[0] = exp(eigenvals[k][j] * ki * branch_length);
+      d[1] = eigenvals[k][j] * ki * d[0];
+      d[2] = eigenvals[k][j] * ki * eigenvals[k][j] * ki * d[0];
+    }
+  }
+  for (n = 0; n < sites; ++n)
+  {
+    double lk[3] = {0, 0, 0};
+    for (k = 0; k < rate_cats; ++k)
+    {
+      const double *sum = sumtable + ((size_t)n * rate_cats + k) * sp;
+      double c[3] = {0, 0, 0};
+      for (j = 0; j < states; ++j)
+      {
+        const double *d = diag + 3 * ((size_t)k * states + j);
+        c[0] += sum[j] * d[0];
+        c[1] += sum[j] * d[1];
+        c[2] += sum[j] * d[2];
+      }
+      if (prop_invar[k] > 0)
+      {
+        const double inv = (invariant && invariant[n] != -1) ? freqs[k][invariant[n]] * prop_invar[k] : 0;
+        c[0] = c[0] * (1. - prop_invar[k]) + inv;
+        c[1] = c[1] * (1. - prop_invar[k]);
+        c[2] = c[2] * (1. - prop_invar[k]);
+      }
+      lk[0] += c[0] * rate_weights[k];
+      lk[1] += c[1] * rate_weights[k];
+      lk[2] += c[2] * rate_weights[k];
+    }
+    {
+      const double d1 = -lk[1] / lk[0];
+      const double d2 = d1 * d1 - lk[2] / lk[0];
+      *d_f += pattern_weights[n] * d1;
+      *dd_f += pattern_weights[n] * d2;
+    }
+  }
+  free(diag);
+}

@@ -78,6 +78,21 @@ unsigned int orc_repeat_classes(unsigned int sites, const unsigned int *site_id_
                                 unsigned int ids_right, unsigned int *site_id_parent,
                                 unsigned int *id_site_parent);
 
+/* Branch-length derivatives: the table of branch-independent terms,
+ * src/core_derivatives.c:321-471 (ii), :473-641 (ti), :215-319 (repeats), and the first/second
+ * derivative of -lnL at a branch length, :643-694 + :696-848. Arrays per RATE CATEGORY (the
+ * caller resolves params_indices), reference naming: eigenvecs[j*sp+i], inv_eigenvecs[i*sp+j]. */
+void orc_update_sumtable(unsigned int states, unsigned int states_padded, unsigned int rate_cats,
+                         unsigned int sites, const orc_child_t *parent, const orc_child_t *child,
+                         const double *const *eigenvecs, const double *const *inv_eigenvecs,
+                         const double *const *freqs, double *sumtable, int per_rate_scaling);
+void orc_likelihood_derivatives(unsigned int states, unsigned int states_padded, unsigned int rate_cats,
+                                unsigned int sites, const double *rate_weights, const int *invariant,
+                                const unsigned int *pattern_weights, double branch_length,
+                                const double *prop_invar, const double *const *freqs,
+                                const double *rates, const double *const *eigenvals,
+                                const double *sumtable, double *d_f, double *dd_f);
+
 #ifdef __cplusplus
 }
 #endif
