@@ -55,17 +55,25 @@ def build_case(cfg, sites, seed, attributes):
     return W.make_case("bench", cfg["states"], cfg["tips"], sites, attributes=attributes, seed=seed, **kw)
 
 
-def op_bytes(case, api, entries=None):
-    """algorithmic HBM bytes of one traversal: per update 3 CLV entries for
+def tips_are_codes(case, api):
+    """tips set from sequences reach the device as one-byte codes (PATTERN_TIP, or the library's
+    compact form of an indicator CLV) unless PLL_AMD_NO_TIP_CODES=1 forces dense tip CLVs"""
+    if case.attributes & api.PATTERN_TIP:
+        return True
+    return case.sequences is not None and os.environ.get("PLL_AMD_NO_TIP_CODES", "0") in ("", "0")
+
+
+def op_bytes(case, api, ops, entries=None):
+    """algorithmic HBM bytes of the given ops: per update 3 CLV entries for
     inner x inner, 2 + 1 B for tip x inner, 1 + 2 B for tip x tip, plus 4 B per scaler touched.
     entries: {parent clv: class count} under site repeats (only that many updates are computed;
     the 12 B of class-map gathers per update are not counted)"""
     s, r, n = case.states, case.rate_cats, case.sites
     entry = s * r * 8
-    pattern_tip = bool(case.attributes & api.PATTERN_TIP)
+    pattern_tip = tips_are_codes(case, api)
     per_rate = r if (case.attributes & api.RATE_SCALERS) else 1
     total = 0
-    for (pc, psc, c1, m1, s1, c2, m2, s2) in case.op_batches[0]:
+    for (pc, psc, c1, m1, s1, c2, m2, s2) in ops:
         b = entry
         for c, sc in ((c1, s1), (c2, s2)):
             if pattern_tip and c < case.tips:
@@ -233,16 +241,33 @@ def main():
     total_sites = sites * world
     value = total_sites * nops * args.steps / dt / 1e6
 
-    # ---- roofline leg: the CLV-update kernel launches of one traversal, HIP events on their stream
+    # ---- full traversal alone (no lnL), HIP events on the partition's stream
     reps = 20
     lib.pll_gpu_synchronize(sess.p)
     lib.pll_gpu_timer_start(sess.p)
     for _ in range(reps):
         sess.update_partials(update_repeats=upd[0])
+    ms_full = lib.pll_gpu_timer_stop(sess.p)
+    launches_full = lib.pll_gpu_last_launch_count(sess.p)
+    # ---- roofline leg: the DOMINANT kernel = the inner x inner CLV update. Its launches are timed by
+    # re-running the part of the traversal whose children are both inner CLVs (a valid partial
+    # traversal: the tip-level parents it reads are already in HBM)
+    all_ops = case.op_batches[0]
+    codes = tips_are_codes(case, api)
+    ii_ops = [op for op in all_ops if op[2] >= case.tips and op[5] >= case.tips] if codes else list(all_ops)
+    if not ii_ops:
+        ii_ops = list(all_ops)
+    ii_arr = api.make_ops(ii_ops)
+    for _ in range(3):
+        lib.pll_update_partials_rep(sess.p, ii_arr, len(ii_ops), 0)
+    lib.pll_gpu_synchronize(sess.p)
+    lib.pll_gpu_timer_start(sess.p)
+    for _ in range(reps):
+        lib.pll_update_partials_rep(sess.p, ii_arr, len(ii_ops), 0)
     ms = lib.pll_gpu_timer_stop(sess.p)
     launches = lib.pll_gpu_last_launch_count(sess.p)
-    entries = {op[0]: sess.entries(op[0]) for op in case.op_batches[0]} if cfg.get("repeats") else None
-    trav_bytes = op_bytes(case, api, entries)
+    entries = {op[0]: sess.entries(op[0]) for op in all_ops} if cfg.get("repeats") else None
+    trav_bytes = op_bytes(case, api, ii_ops, entries)
     per_launch_bytes = trav_bytes / launches
     per_launch_ms = ms / reps / launches
     achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
@@ -250,18 +275,23 @@ def main():
     tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
     if os.path.exists(tfile) and not args.pattern_tip and not args.sites:  # PMC-derived HBM bytes per launch of the same command (profiles/README.md)
         traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-    kernel = {4: "k_partials_dna", 20: "k_partials_generic<20>", 61: "k_partials_generic<16>"}[cfg["states"]]
+    kernel = {4: "k_partials_dna<false,false,%s>", 20: "k_partials_tiled<20,false,false,%s>",
+              61: "k_partials_tiled<32,false,false,%s>"}[cfg["states"]] % ("true" if cfg.get("repeats") else "false")
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, kernel=kernel,
-                    launches_per_traversal=launches, avg_launch_ms=round(per_launch_ms, 5),
+                    launches=launches, ops_in_those_launches=len(ii_ops), avg_launch_ms=round(per_launch_ms, 5),
                     algorithmic_bytes_per_launch=int(per_launch_bytes),
-                    update_partials_only_M_per_s=round(sites * nops / (ms / reps * 1e-3) / 1e6, 1))
+                    full_traversal=dict(launches=launches_full, ms=round(ms_full / reps, 5),
+                                        algorithmic_GBps=round(op_bytes(case, api, all_ops, entries) / (ms_full / reps * 1e-3) / 1e9, 1),
+                                        update_partials_only_M_per_s=round(sites * nops / (ms_full / reps * 1e-3) / 1e6, 1)))
 
     out = {
         "metric": "M site-CLV-updates/s", "value": round(value, 1), "unit": "M site-CLV-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": cfg["desc"] + (", PATTERN_TIP" if args.pattern_tip else ", tips as CLVs (all inner x inner)"),
+        "config": {"workload": cfg["desc"] + (", PLL_ATTRIB_PATTERN_TIP" if args.pattern_tip else
+                                              (", tips set with pll_set_tip_states (device reads 1-byte codes: tip x tip / tip x inner kernels at the leaves)"
+                                               if codes else ", tips as dense 0/1 CLVs (every update inner x inner)")),
                    "sites_per_gpu": sites, "ops_per_traversal": nops, "states": cfg["states"], "rate_cats": 4,
                    "taxa": cfg["tips"], "step": "pll_update_partials(full traversal) + pll_compute_edge_loglikelihood"
                    + (" + all-reduce(lnL)" if world > 1 else ""), "parallelism": f"sites sharded x{world}"},

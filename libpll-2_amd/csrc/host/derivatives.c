@@ -126,13 +126,17 @@ int pll_update_sumtable(pll_partition_t *p, unsigned int parent_clv_index, unsig
     pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_update_sumtable: index out of range");
     return fail_loudly("pll_update_sumtable");
   }
-  const int ptip = pll_is_pattern_tip(p, parent_clv_index);
-  const int ctip = pll_is_pattern_tip(p, child_clv_index);
-  if (ptip && ctip)
+  if (pll_tip_by_codes(p, parent_clv_index) && pll_tip_by_codes(p, child_clv_index))
   {
-    pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_update_sumtable() was called for the tip-tip case!");
-    return PLL_FAILURE;
+    if (p->attributes & PLL_ATTRIB_PATTERN_TIP)
+    {
+      pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_update_sumtable() was called for the tip-tip case!");
+      return PLL_FAILURE;
+    }
+    pll_tip_densify(p, parent_clv_index);
   }
+  const int ptip = pll_tip_by_codes(p, parent_clv_index);
+  const int ctip = pll_tip_by_codes(p, child_clv_index);
   for (k = 0; k < p->rate_cats; ++k)
   {
     if (params_indices[k] >= p->rate_matrices)

@@ -18,7 +18,7 @@ static double fail_lnl(const char *what)
 static int prepare_end(pll_partition_t *p, pll_amd_ext_t *x, unsigned int clv, int scaler)
 {
   if (!pll_flush_clv(p, x, clv)) return 0;
-  if (!pll_is_pattern_tip(p, clv) && !pll_flush_scaler(p, x, scaler)) return 0;
+  if (!pll_tip_by_codes(p, clv) && !pll_flush_scaler(p, x, scaler)) return 0;
   if (!pll_flush_repeats(p, x, clv)) return 0;
   return 1;
 }
@@ -40,13 +40,17 @@ double pll_compute_edge_loglikelihood(pll_partition_t *p, unsigned int parent_cl
     pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_compute_edge_loglikelihood: index out of range");
     return fail_lnl("pll_compute_edge_loglikelihood");
   }
-  const int ptip = pll_is_pattern_tip(p, parent_clv_index);
-  const int ctip = pll_is_pattern_tip(p, child_clv_index);
-  if (ptip && ctip)
+  if (pll_tip_by_codes(p, parent_clv_index) && pll_tip_by_codes(p, child_clv_index))
   {
-    pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_compute_edge_loglikelihood: both ends are pattern tips");
-    return fail_lnl("pll_compute_edge_loglikelihood");
+    if (p->attributes & PLL_ATTRIB_PATTERN_TIP)
+    {
+      pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_compute_edge_loglikelihood: both ends are pattern tips");
+      return fail_lnl("pll_compute_edge_loglikelihood");
+    }
+    pll_tip_densify(p, parent_clv_index); /* two compact tips: one of them becomes a dense CLV */
   }
+  const int ptip = pll_tip_by_codes(p, parent_clv_index);
+  const int ctip = pll_tip_by_codes(p, child_clv_index);
   if (!pll_flush_model(p, x) || !pll_flush_pmatrix(p, x, matrix_index, matrix_index) ||
       !prepare_end(p, x, parent_clv_index, parent_scaler_index) ||
       !prepare_end(p, x, child_clv_index, child_scaler_index))
@@ -84,6 +88,7 @@ double pll_compute_root_loglikelihood(pll_partition_t *p, unsigned int clv_index
     pll_set_error(PLL_ERROR_GPU_UNAVAILABLE, "pll_compute_root_loglikelihood: no MI355X context behind this partition; this library has no CPU path");
     return fail_lnl("pll_compute_root_loglikelihood");
   }
+  pll_tip_densify(p, clv_index); /* a root at a compact tip needs the dense CLV */
   if (clv_index >= p->nodes || scaler_index >= (int)p->scale_buffers || pll_is_pattern_tip(p, clv_index))
   {
     pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_compute_root_loglikelihood: invalid CLV/scaler index");

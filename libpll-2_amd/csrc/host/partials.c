@@ -153,7 +153,7 @@ void pll_update_partials_rep(pll_partition_t *p, const pll_operation_t *ops, uns
     for (int c = 0; c < 2; ++c)
     {
       if (!x->lvl_clv_r[kids[c]] && !pll_flush_clv(p, x, kids[c])) BAIL();
-      if (ksc[c] >= 0 && !pll_is_pattern_tip(p, kids[c]) && !x->lvl_sc_r[ksc[c]] && !pll_flush_scaler(p, x, ksc[c])) BAIL();
+      if (ksc[c] >= 0 && !pll_tip_by_codes(p, kids[c]) && !x->lvl_sc_r[ksc[c]] && !pll_flush_scaler(p, x, ksc[c])) BAIL();
       if (rep && !pll_flush_repeats(p, x, kids[c])) BAIL();
     }
     if (rep && !pll_flush_repeats(p, x, o->parent_clv_index)) BAIL();
@@ -174,8 +174,8 @@ void pll_update_partials_rep(pll_partition_t *p, const pll_operation_t *ops, uns
   {
     const pll_operation_t *o = &ops[i];
     pllgpu_op_t *g = &x->gops[start[level[i]]++];
-    const int t1 = pll_is_pattern_tip(p, o->child1_clv_index);
-    const int t2 = pll_is_pattern_tip(p, o->child2_clv_index);
+    const int t1 = pll_tip_by_codes(p, o->child1_clv_index);
+    const int t2 = pll_tip_by_codes(p, o->child2_clv_index);
     /* the tip goes left in a tip-inner pair (src/partials.c:90-112) */
     const int swap = (!t1 && t2);
     g->parent_clv = o->parent_clv_index;

@@ -58,9 +58,30 @@ int pll_is_pattern_tip(const pll_partition_t *p, unsigned int clv_index)
   return (p->attributes & PLL_ATTRIB_PATTERN_TIP) && clv_index < p->tips;
 }
 
+int pll_tip_by_codes(const pll_partition_t *p, unsigned int clv_index)
+{
+  if (clv_index >= p->tips) return 0;
+  if (p->attributes & PLL_ATTRIB_PATTERN_TIP) return 1;
+  const pll_amd_ext_t *x = pll_ext(p);
+  return x && x->tip_compact && x->tip_compact[clv_index];
+}
+
+void pll_tip_densify(pll_partition_t *p, unsigned int clv_index)
+{
+  pll_amd_ext_t *x = pll_ext(p);
+  if (!x || clv_index >= p->tips || (p->attributes & PLL_ATTRIB_PATTERN_TIP)) return;
+  if (x->tip_compact[clv_index])
+  {
+    x->tip_compact[clv_index] = 0;
+    x->clv_side[clv_index] = SIDE_HOST; /* the host mirror holds the indicator CLV */
+  }
+}
+
 static void free_ext(pll_amd_ext_t *x)
 {
   if (x->ctx) pllgpu_destroy(x->ctx);
+  free(x->tip_compact);
+  free(x->ctipmap);
   free(x->clv_side);
   free(x->scaler_side);
   free(x->scaler_entries);
@@ -83,6 +104,12 @@ void pll_partition_destroy(pll_partition_t *p)
   unsigned int i;
   if (!p) return;
   pll_amd_ext_t *x = pll_ext(p);
+  if (x && x->tipcodes)
+  {
+    for (i = 0; i < p->tips; ++i) free(x->tipcodes[i]);
+    free(x->tipcodes);
+    x->tipcodes = NULL;
+  }
   if (x) free_ext(x);
 
   free(p->rates);
@@ -296,6 +323,11 @@ pll_partition_t *pll_partition_create(unsigned int tips, unsigned int clv_buffer
   x->repeats_dirty = (unsigned char *)calloc(p->nodes ? p->nodes : 1, 1);
   x->pmatrix_dirty = (unsigned char *)malloc(prob_matrices ? prob_matrices : 1);
   x->freqs_dirty = (unsigned char *)malloc(rate_matrices ? rate_matrices : 1);
+  x->tip_compact = (unsigned char *)calloc(tips ? tips : 1, 1);
+  x->tipcodes = (unsigned char **)calloc(tips ? tips : 1, sizeof(unsigned char *));
+  x->ctipmap = (pll_state_t *)calloc(PLL_ASCII_SIZE, sizeof(pll_state_t));
+  x->no_tip_codes = env_flag("PLL_AMD_NO_TIP_CODES");
+  NEED(x->tip_compact && x->tipcodes && x->ctipmap);
   x->eigen_dirty = (unsigned char *)malloc(rate_matrices ? rate_matrices : 1);
   x->aux_params = (unsigned int *)malloc(sizeof(unsigned int) * rate_cats);
   NEED(x->clv_side && x->scaler_side && x->scaler_entries && x->tipchars_dirty && x->repeats_dirty &&
@@ -477,7 +509,8 @@ int pll_flush_model(pll_partition_t *p, pll_amd_ext_t *x)
   if (x->tipmap_dirty)
   {
     /* 4-state codes are the masks themselves (src/pll.c:893-895) */
-    GPU_TRY(pllgpu_tipmap_upload(x->ctx, p->states == 4 ? NULL : p->tipmap, PLL_ASCII_SIZE), "tipmap upload");
+    const pll_state_t *tm = (p->attributes & PLL_ATTRIB_PATTERN_TIP) ? p->tipmap : x->ctipmap;
+    GPU_TRY(pllgpu_tipmap_upload(x->ctx, p->states == 4 ? NULL : tm, PLL_ASCII_SIZE), "tipmap upload");
     x->tipmap_dirty = 0;
   }
   return PLL_SUCCESS;
@@ -485,11 +518,14 @@ int pll_flush_model(pll_partition_t *p, pll_amd_ext_t *x)
 
 int pll_flush_clv(pll_partition_t *p, pll_amd_ext_t *x, unsigned int idx)
 {
-  if (pll_is_pattern_tip(p, idx))
+  if (pll_tip_by_codes(p, idx))
   {
     if (x->tipchars_dirty[idx])
     {
-      GPU_TRY(pllgpu_tipchars_upload(x->ctx, idx, p->tipchars[idx], x->sites_alloc), "tip codes upload");
+      const int pattern = (p->attributes & PLL_ATTRIB_PATTERN_TIP) != 0;
+      GPU_TRY(pllgpu_tipchars_upload(x->ctx, idx, pattern ? p->tipchars[idx] : x->tipcodes[idx],
+                                     pattern ? x->sites_alloc : pll_get_sites_number(p, idx)),
+              "tip codes upload");
       x->tipchars_dirty[idx] = 0;
     }
     return PLL_SUCCESS;
@@ -580,7 +616,7 @@ int pll_gpu_sync_clv(pll_partition_t *p, unsigned int idx)
 {
   pll_amd_ext_t *x = need_ctx(p, "pll_gpu_sync_clv");
   if (!x) return PLL_FAILURE;
-  if (idx >= p->nodes || pll_is_pattern_tip(p, idx)) return PLL_SUCCESS;
+  if (idx >= p->nodes || pll_tip_by_codes(p, idx)) return PLL_SUCCESS; /* host copy is the original */
   if (x->clv_side[idx] == SIDE_DEVICE)
   {
     if (!p->clv[idx])
@@ -634,7 +670,11 @@ void pll_gpu_invalidate(pll_partition_t *p, unsigned int what, int index)
   if (what & PLL_GPU_DIRTY_RATE_WEIGHTS) x->rate_weights_dirty = x->prop_invar_dirty = 1;
   if (what & PLL_GPU_DIRTY_PATTERN_WEIGHTS) x->pattern_weights_dirty = 1;
   if (what & PLL_GPU_DIRTY_INVARIANT) x->invariant_dirty = x->prop_invar_dirty = 1;
-  if (what & PLL_GPU_DIRTY_CLV) MARK(clv_side, p->nodes, SIDE_HOST);
+  if (what & PLL_GPU_DIRTY_CLV)
+  {
+    MARK(clv_side, p->nodes, SIDE_HOST);
+    if (!(p->attributes & PLL_ATTRIB_PATTERN_TIP)) MARK(tip_compact, p->tips, 0); /* arbitrary values now */
+  }
   if (what & PLL_GPU_DIRTY_SCALER) MARK(scaler_side, p->scale_buffers, SIDE_HOST);
   if (what & PLL_GPU_DIRTY_TIPCHARS)
   {

@@ -35,6 +35,14 @@ typedef struct pll_amd_ext
   unsigned char *pmatrix_dirty;  /* [prob_matrices] */
   unsigned char *freqs_dirty;    /* [rate_matrices] */
   int rate_weights_dirty, pattern_weights_dirty, invariant_dirty, prop_invar_dirty, tipmap_dirty;
+  /* tips set through pll_set_tip_states WITHOUT PLL_ATTRIB_PATTERN_TIP are 0/1 indicator CLVs of a
+   * state mask: the device is handed the one-byte code per entry instead of the dense CLV and the
+   * tip-inner / tip-tip kernels are used for them (PLL_AMD_NO_TIP_CODES=1 switches this off) */
+  unsigned char *tip_compact;   /* [tips] 1 = device holds codes, not a dense CLV */
+  unsigned char **tipcodes;     /* [tips] code per entry (NULL until set) */
+  pll_state_t *ctipmap;         /* code -> mask for compact tips (unused for 4 states: code = mask) */
+  unsigned int ctip_count;
+  int no_tip_codes;
   int eager_mirror;             /* PLL_AMD_EAGER_MIRROR=1: copy results back after every call */
   int always_upload;            /* PLL_AMD_ALWAYS_UPLOAD=1: treat model arrays as dirty on every call */
   unsigned int sites_alloc;
@@ -74,5 +82,9 @@ int pll_flush_scaler(pll_partition_t *p, pll_amd_ext_t *x, int scaler_index);
 int pll_flush_pmatrix(pll_partition_t *p, pll_amd_ext_t *x, unsigned int first, unsigned int last);
 int pll_flush_repeats(pll_partition_t *p, pll_amd_ext_t *x, unsigned int node);
 int pll_is_pattern_tip(const pll_partition_t *p, unsigned int clv_index);
+/* the device reads this node as tip codes (PATTERN_TIP tip, or a compact indicator tip) */
+int pll_tip_by_codes(const pll_partition_t *p, unsigned int clv_index);
+/* give a compact tip a dense device CLV again (someone needs it as an ordinary CLV) */
+void pll_tip_densify(pll_partition_t *p, unsigned int clv_index);
 
 #endif

@@ -146,6 +146,19 @@ static void spread_mask(const pll_partition_t *p, pll_state_t m, double *dst)
   for (k = 1; k < p->rate_cats; ++k) memcpy(dst + (size_t)k * p->states_padded, dst, p->states * sizeof(double));
 }
 
+/* one-byte code of a state mask for the device: the mask itself for 4 states, otherwise its
+ * index in a per-partition table of the masks seen so far; -1 when the table is full */
+static int compact_code(pll_partition_t *p, pll_amd_ext_t *x, pll_state_t m)
+{
+  unsigned int c;
+  if (p->states == 4) return (int)m;
+  for (c = 0; c < x->ctip_count; ++c)
+    if (x->ctipmap[c] == m) return (int)c;
+  if (x->ctip_count >= PLL_ASCII_SIZE) return -1;
+  x->ctipmap[x->ctip_count] = m;
+  return (int)x->ctip_count++;
+}
+
 static int encode_tipclv(pll_partition_t *p, unsigned int tip, const pll_state_t *map, const char *seq)
 {
   const int rep = pll_repeats_enabled(p);
@@ -153,13 +166,28 @@ static int encode_tipclv(pll_partition_t *p, unsigned int tip, const pll_state_t
   const size_t span = (size_t)p->rate_cats * p->states_padded;
   unsigned int i;
   double *clv = p->clv[tip];
+  pll_amd_ext_t *x = pll_ext(p);
+  int compact = x && !x->no_tip_codes;
+  if (compact)
+  {
+    free(x->tipcodes[tip]);
+    x->tipcodes[tip] = (unsigned char *)malloc(n ? n : 1);
+    compact = x->tipcodes[tip] != NULL;
+  }
   for (i = 0; i < n; ++i)
   {
     const unsigned int site = rep ? p->repeats->pernode_id_site[tip][i] : i;
     const pll_state_t m = map[(unsigned char)seq[site]];
     if (!m) return illegal_state(seq[site]);
     spread_mask(p, m, clv + i * span);
+    if (compact)
+    {
+      const int code = compact_code(p, x, m);
+      if (code < 0) compact = 0;
+      else x->tipcodes[tip][i] = (unsigned char)code;
+    }
   }
+  if (x) x->tip_compact[tip] = (unsigned char)compact;
   return PLL_SUCCESS;
 }
 
@@ -187,7 +215,15 @@ int pll_set_tip_states(pll_partition_t *p, unsigned int tip, const pll_state_t *
   else
   {
     rc = encode_tipclv(p, tip, map, seq);
-    if (rc && x) x->clv_side[tip] = SIDE_HOST;
+    if (rc && x)
+    {
+      x->clv_side[tip] = SIDE_HOST; /* the dense indicator CLV lives in the host mirror either way */
+      if (x->tip_compact[tip])
+      {
+        x->tipchars_dirty[tip] = 1;
+        x->tipmap_dirty = 1;
+      }
+    }
   }
   return rc;
 }
@@ -212,6 +248,10 @@ int pll_set_tip_clv(pll_partition_t *p, unsigned int tip, const double *clv, int
     const double *src = clv + (size_t)site * in_stride;
     for (k = 0; k < p->rate_cats; ++k, dst += p->states_padded) memcpy(dst, src, p->states * sizeof(double));
   }
-  if (x) x->clv_side[tip] = SIDE_HOST;
+  if (x)
+  {
+    x->clv_side[tip] = SIDE_HOST;
+    x->tip_compact[tip] = 0; /* arbitrary values: a dense CLV on the device */
+  }
   return PLL_SUCCESS;
 }

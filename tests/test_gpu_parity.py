@@ -176,6 +176,50 @@ def test_model_api_end_to_end(amd_lib):
     lib.pll_partition_destroy(p)
 
 
+@pytest.mark.parametrize("kw", [k for k in ORACLE_CASES if not (k.get("attributes", 0) & api.PATTERN_TIP)][::2], ids=_id)
+def test_dense_tip_clvs(amd_lib, kw, monkeypatch):
+    """tips set by pll_set_tip_states without PATTERN_TIP normally reach the device as one-byte codes
+    (the tip kernels run); PLL_AMD_NO_TIP_CODES=1 uploads them as dense 0/1 CLVs - same numbers"""
+    monkeypatch.setenv("PLL_AMD_NO_TIP_CODES", "1")
+    case = W.make_case("rnd", **kw)
+    exp = O.run_case(case)
+    got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    assert_results_match(got, exp, what=_id(kw))
+    assert scalers_equal(got, exp)
+
+
+def test_compact_tips_become_dense_when_needed(amd_lib):
+    """root lnL at a tip, an edge between two tips, and a host edit of a tip CLV all need the dense
+    CLV of a tip that the device only holds as codes"""
+    case = W.make_case("ct", 4, 4, 200, seed=12, ambiguity_pct=10)
+    exp = O.run_case(case)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        v0, _ = s.edge_lnl(case.edges[0])
+        assert abs(v0 - exp["lnl"][0]) <= RTOL * abs(v0)
+        # edge between tips 0 and 1 over matrix 0: compare with the oracle on a two-tip "tree"
+        two = driver.Case(name="two", states=4, rate_cats=4, tips=4, sites=200, pmatrix=case.pmatrix, freqs=case.freqs,
+                          op_batches=[case.op_batches[0]], edges=[(0, -1, 1, -1, 0)], charmap=case.charmap,
+                          sequences=case.sequences, clv_buffers=2, scale_buffers=2)
+        e2 = O.run_case(two)["lnl"][0]
+        v2, _ = s.edge_lnl((0, -1, 1, -1, 0))
+        assert abs(v2 - e2) <= RTOL * abs(e2)
+        # root at tip 2
+        r = driver.Case(name="r", states=4, rate_cats=4, tips=4, sites=200, pmatrix=case.pmatrix, freqs=case.freqs,
+                        op_batches=[case.op_batches[0]], edges=[], roots=[(2, -1)], charmap=case.charmap,
+                        sequences=case.sequences, clv_buffers=2, scale_buffers=2)
+        er = O.run_case(r)["root_lnl"][0]
+        vr, _ = s.root_lnl((2, -1))
+        assert abs(vr - er) <= RTOL * abs(er)
+        # host edit of tip 3's CLV: halve it, invalidate, the traversal must see it
+        a = api.as_np(s.part.clv[3], 200 * 16, np.float64)
+        a *= 0.5
+        amd_lib.pll_gpu_invalidate(s.p, api.DIRTY_CLV, 3)
+        s.update_partials()
+        v1, _ = s.edge_lnl(case.edges[0])
+        assert abs((v1 - v0) - 200 * np.log(0.5)) < 1e-8
+
+
 @pytest.mark.parametrize("kw", [k for k in ORACLE_CASES if k["states"] == 4 and k.get("rate_cats", 4) == 4], ids=_id)
 def test_dna_through_generic_kernels(amd_lib, kw, monkeypatch):
     """the 4x4 shape also has to be right in the any-shape kernels (PLL_AMD_GENERIC_ONLY=1)"""
