@@ -17,6 +17,7 @@
 #include "kernels_dna.h"
 #include "kernels_generic.h"
 #include "kernels_deriv.h"
+#include "kernels_mfma.h"
 
 // ---------------------------------------------------------------------------------------------
 static thread_local char g_err[256] = "";
@@ -77,6 +78,7 @@ struct pllgpu_ctx
   GenGeo gg;
   int ich = 0;
   bool dna_fast = false;
+  bool use_mfma = false;
   bool tiled = false;       // generic shapes keep CLVs in the tiled sites-contiguous layout
   DevBuf<double> scratch;   // host-layout staging for mirror copies of tiled CLVs
   size_t pm_stride = 0; // doubles per matrix in PT layout
@@ -135,6 +137,10 @@ static void derive_geometry(pllgpu_ctx *c)
   if (const char *v = getenv("PLL_AMD_GENERIC_ONLY")) // experiment switch: route DNA through the generic kernels
     if (*v && *v != '0') c->dna_fast = false;
   c->tiled = true; // every shape keeps CLVs in the tiled sites-contiguous layout
+  // 33..64 states: CLV updates on the fp64 matrix pipe (kernels_mfma.h); PLL_AMD_NO_MFMA=1 keeps the FMA kernel
+  c->use_mfma = (g.states > 32 && g.rate_cats <= 16);
+  if (const char *v = getenv("PLL_AMD_NO_MFMA"))
+    if (*v && *v != '0') c->use_mfma = false;
   c->pm_stride = (size_t)g.rate_cats * g.states * gg.SPT;
   c->span = g.rate_cats * g.states_padded;
 }
@@ -567,6 +573,58 @@ static void launch_dna(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigne
 #undef DNA_LAUNCH
 }
 
+// large state spaces: fp64 MFMA 4x4x4 kernel, matrices staged in LDS (kernels_mfma.h)
+static void launch_mfma(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
+{
+  const unsigned items = (maxent + 31) / 32; // 32 sites per item
+  unsigned ipw = (unsigned)(((size_t)items * nops + 4 * 512 - 1) / (4 * 512));
+  ipw = std::max(1u, std::min(ipw, (unsigned)kMfmaItemsMax));
+  dim3 grid((items + 4 * ipw - 1) / (4 * ipw), nops), block(256);
+  const size_t lds = 8192 * sizeof(double) + (size_t)4 * kMfmaItemsMax * c->gg.R * 32;
+  const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
+#define MF_LAUNCH(LT, RT, GA)                                                                                   \
+  do                                                                                                            \
+  {                                                                                                             \
+    static bool attr_set = false;                                                                               \
+    if (!attr_set)                                                                                              \
+    {                                                                                                           \
+      (void)hipFuncSetAttribute((const void *)k_partials_mfma<LT, RT, GA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    hipLaunchKernelGGL((k_partials_mfma<LT, RT, GA>), grid, block, lds, c->stream, pack, c->gg, tm, ipw);       \
+  } while (0)
+  if (kind == 0)
+  {
+    if (gather) MF_LAUNCH(false, false, true); else MF_LAUNCH(false, false, false);
+  }
+  else if (kind == 1)
+  {
+    if (gather) MF_LAUNCH(true, false, true); else MF_LAUNCH(true, false, false);
+  }
+  else
+  {
+    if (gather) MF_LAUNCH(true, true, true); else MF_LAUNCH(true, true, false);
+  }
+#undef MF_LAUNCH
+}
+
+static void launch_partials(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
+{
+  if (c->dna_fast)
+    launch_dna(c, pack, nops, maxent, kind, gather);
+  else if (c->use_mfma)
+    launch_mfma(c, pack, nops, maxent, kind, gather);
+  else
+    switch (c->ich)
+    {
+      case 4: launch_generic<4>(c, pack, nops, maxent, kind, gather); break;
+      case 8: launch_generic<8>(c, pack, nops, maxent, kind, gather); break;
+      case 16: launch_generic<16>(c, pack, nops, maxent, kind, gather); break;
+      case 20: launch_generic<20>(c, pack, nops, maxent, kind, gather); break;
+      default: launch_generic<32>(c, pack, nops, maxent, kind, gather); break;
+    }
+}
+
 extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, unsigned count)
 {
   CHECK_CTX(c);
@@ -585,17 +643,7 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
         unsigned nops = 0, maxent = 0;
         auto flush = [&]() {
           if (!nops) return;
-          if (c->dna_fast)
-            launch_dna(c, pack, nops, maxent, kind, ga != 0);
-          else
-            switch (c->ich)
-            {
-              case 4: launch_generic<4>(c, pack, nops, maxent, kind, ga != 0); break;
-              case 8: launch_generic<8>(c, pack, nops, maxent, kind, ga != 0); break;
-              case 16: launch_generic<16>(c, pack, nops, maxent, kind, ga != 0); break;
-              case 20: launch_generic<20>(c, pack, nops, maxent, kind, ga != 0); break;
-              default: launch_generic<32>(c, pack, nops, maxent, kind, ga != 0); break;
-            }
+          launch_partials(c, pack, nops, maxent, kind, ga != 0);
           ++c->last_launches;
           nops = 0;
           maxent = 0;
@@ -879,17 +927,7 @@ extern "C" int pllgpu_update_sumtable(pllgpu_ctx_t *c, const pllgpu_sumtable_t *
     d.rsid = c->ids[st->right_clv] ? c->site_id[st->right_clv].p : nullptr;
   }
   const unsigned kind = st->left_is_tip ? 1u : 0u;
-  if (c->dna_fast)
-    launch_dna(c, pack, 1, g.sites, kind, st->gather != 0);
-  else
-    switch (c->ich)
-    {
-      case 4: launch_generic<4>(c, pack, 1, g.sites, kind, st->gather != 0); break;
-      case 8: launch_generic<8>(c, pack, 1, g.sites, kind, st->gather != 0); break;
-      case 16: launch_generic<16>(c, pack, 1, g.sites, kind, st->gather != 0); break;
-      case 20: launch_generic<20>(c, pack, 1, g.sites, kind, st->gather != 0); break;
-      default: launch_generic<32>(c, pack, 1, g.sites, kind, st->gather != 0); break;
-    }
+  launch_partials(c, pack, 1, g.sites, kind, st->gather != 0);
   if (g.per_rate_scalers && (st->left_scaler >= 0 || st->right_scaler >= 0))
   {
     DevExcess e;
