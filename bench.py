@@ -33,6 +33,10 @@ sys.path.insert(0, os.path.join(ROOT, "libpll-2_amd"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# fp64 matrix pipe: 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz (v_mfma_f64_4x4x4: 512 flop / 16 clk).
+# The guide lists no fp64 row; tools/mfma_f64_probe.hip measures 70.6 TF on this part
+# (profiles/r1_fp64_issue_rates.md) - the spec figure is the one priced against.
+FP64_MFMA_PEAK_TF = 78.6
 
 CONFIGS = {
     # name: (states, tips, sites, attributes-as-names, description)
@@ -275,12 +279,30 @@ def main():
     tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
     if os.path.exists(tfile) and not args.pattern_tip and not args.sites:  # PMC-derived HBM bytes per launch of the same command (profiles/README.md)
         traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+    mfma = cfg["states"] > 32 and not os.environ.get("PLL_AMD_NO_MFMA", "0").strip("0")
     kernel = {4: "k_partials_dna<false,false,%s>", 20: "k_partials_tiled<20,false,false,%s>",
-              61: "k_partials_tiled<32,false,false,%s>"}[cfg["states"]] % ("true" if cfg.get("repeats") else "false")
-    roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, kernel=kernel,
-                    launches=launches, ops_in_those_launches=len(ii_ops), avg_launch_ms=round(per_launch_ms, 5),
-                    algorithmic_bytes_per_launch=int(per_launch_bytes),
+              61: "k_partials_mfma<false,false,%s>" if mfma else "k_partials_tiled<32,false,false,%s>"
+              }[cfg["states"]] % ("true" if cfg.get("repeats") else "false")
+    if mfma:
+        # 33..64 states sit past the fp64 ridge: the bounding line is the fp64 matrix pipe.
+        # Algorithmic flop per update = the two 64-padded matrix-vector products the MFMA tiles
+        # perform per (site, rate) would overstate it; count the reference's own arithmetic:
+        # 2 children x S x S multiply-adds + S products per (site, rate)  (core_partials.c:739-757)
+        S, R = cfg["states"], 4
+        flop_per_update = R * (2 * 2 * S * S + S)
+        per_launch_flop = flop_per_update * sum((entries[op[0]] if entries else sites) for op in ii_ops) / launches
+        tf = per_launch_flop / (per_launch_ms * 1e-3) / 1e12
+        roofline = dict(bound="mfma", achieved=round(tf, 2), peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
+                        frac=round(tf / FP64_MFMA_PEAK_TF, 4), traffic=None, kernel=kernel,
+                        launches=launches, ops_in_those_launches=len(ii_ops), avg_launch_ms=round(per_launch_ms, 5),
+                        algorithmic_flop_per_launch=int(per_launch_flop), algorithmic_bytes_per_launch=int(per_launch_bytes),
+                        hbm_GBps=round(achieved, 1))
+    else:
+        roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, kernel=kernel,
+                        launches=launches, ops_in_those_launches=len(ii_ops), avg_launch_ms=round(per_launch_ms, 5),
+                        algorithmic_bytes_per_launch=int(per_launch_bytes))
+    roofline.update(
                     full_traversal=dict(launches=launches_full, ms=round(ms_full / reps, 5),
                                         algorithmic_GBps=round(op_bytes(case, api, all_ops, entries) / (ms_full / reps * 1e-3) / 1e9, 1),
                                         update_partials_only_M_per_s=round(sites * nops / (ms_full / reps * 1e-3) / 1e6, 1)))

@@ -14,124 +14,231 @@
 // the D side. The A operand (the 4x4 block P[4ig..+3][4jg..+3]) is the same in all four blocks:
 // lane l reads element (k = l>>4, i = l&3) of a 128-byte fragment in LDS.
 //
-// Work split: a workgroup (4 waves) walks the rate categories; for each it stages both children's
-// matrices as fragments in LDS (2 x 32 KB) and then every wave processes its items of 32 sites
-// (2 MFMA site groups): x fragments of one child live in registers (32 loads of 4 x 128-byte
-// segments from the tiled CLV, no re-reads), D_left for all 16 state groups stays in registers
-// while D_right is formed 4 state groups at a time, multiplied, range-checked and stored.
-// Scaling decisions are kept as per-(item, rate, site) flags in LDS and applied after the rate loop
-// by rescaling the (rare) affected stored entries - same policy as kernels_generic.h.
+// Work split: grid = (item blocks, ops, rate categories). A workgroup (4 waves) stages the two
+// children's matrices of ITS rate category once as fragments in LDS (2 x 32 KB, two workgroups per
+// CU) and every wave then walks its items of 32 sites (2 MFMA site groups). Per item the x
+// fragments of one child live in 64 VGPRs, D_left for all 16 state groups in another 64; D_right is
+// formed 4 state groups at a time, multiplied, range-checked and stored. The loop is software
+// pipelined by hand: the right child's x[jg] is requested as soon as the left pass is done with
+// x[jg], and the next item's left x[jg] while the last D_right chunk runs, so that HBM latency
+// hides behind ~120 MFMAs with only two waves per SIMD.
+//
+// Tip children (1-byte codes -> state masks): when every site of an item is a single state or a
+// full gap, P x is a column of P (or its row sum) - 16 LDS reads instead of 256 MFMAs per site
+// group; other ambiguity patterns take the MFMA route with a 0/1 x.
+//
+// Scaling: each rate category is a different workgroup, so the "all entries below 2^-256" bits go to
+// a byte buffer in HBM ([op][rate][entry]) and k_mfma_scale_epilogue applies them afterwards
+// (rescales the - rare - affected entries, fills the parent scaler). Same policy as
+// kernels_generic.h; the epilogue is launched only when the level has ops with a parent scaler.
 //
 // Arithmetic: src/core_partials.c:709-764 (ii), :465-507 (ti), :1166-1209 (tt), :819-879 (repeats).
 #pragma once
 #include "kernels_common.h"
 
-constexpr int kMfmaItemsMax = 8; // items (32 sites each) per wave and launch
+constexpr int kMfmaRowsumOff = 8192; // doubles: after the two fragment arrays come 2 x 64 row sums
 
-// x fragment of (state group jg, site group sg) for this lane: CLV value or tip-mask bit
+struct MfmaItem
+{
+  unsigned e[2];           // parent entry of the lane's site in site group 0 / 1
+  bool valid[2];
+  const double *lb[2];     // child entry base (+ rate offset) in the tiled CLV, or null for tips
+  const double *rb[2];
+  unsigned long long lm[2], rm[2]; // tip state masks
+};
+
+template <bool LTIP, bool RTIP, bool GATHER>
+__device__ __forceinline__ MfmaItem mfma_item(const DevOp &op, const GenGeo &g, const unsigned long long *__restrict__ tipmap,
+                                              unsigned item, unsigned col, unsigned k)
+{
+  MfmaItem m;
+#pragma unroll
+  for (int sg = 0; sg < 2; ++sg)
+  {
+    m.e[sg] = item * 32u + sg * 16u + col;
+    m.valid[sg] = m.e[sg] < op.entries;
+    const unsigned nn = m.valid[sg] ? m.e[sg] : op.entries - 1;
+    unsigned le = nn, re = nn;
+    if (GATHER)
+    {
+      const unsigned site = op.id_site ? op.id_site[nn] : nn;
+      le = op.lsid ? op.lsid[site] : site;
+      re = op.rsid ? op.rsid[site] : site;
+    }
+    m.lm[sg] = m.rm[sg] = 0;
+    if (LTIP) m.lm[sg] = tipmap ? tipmap[op.ltip[le]] : (unsigned long long)op.ltip[le];
+    if (RTIP) m.rm[sg] = tipmap ? tipmap[op.rtip[re]] : (unsigned long long)op.rtip[re];
+    m.lb[sg] = LTIP ? nullptr : op.left + (size_t)(le >> 6) * g.tile_sz + (le & 63u) + (size_t)k * g.S * 64;
+    m.rb[sg] = RTIP ? nullptr : op.right + (size_t)(re >> 6) * g.tile_sz + (re & 63u) + (size_t)k * g.S * 64;
+  }
+  return m;
+}
+
+// x fragment value for contraction index j: CLV entry or tip-mask bit
 template <bool TIP>
-__device__ __forceinline__ double mfma_x(const double *__restrict__ base /* entry base of the lane's site in group sg */,
-                                         unsigned long long mask, unsigned k, unsigned S, unsigned j)
+__device__ __forceinline__ double mfma_x(const double *__restrict__ base, unsigned long long mask, unsigned S, unsigned j)
 {
   if (TIP) return (j < S && ((mask >> j) & 1ull)) ? 1.0 : 0.0;
   const unsigned jj = j < S ? j : S - 1; // rows beyond S meet zero matrix columns; stay in bounds
-  return __builtin_nontemporal_load(base + ((size_t)k * S + jj) * 64);
+  return __builtin_nontemporal_load(base + (size_t)jj * 64);
+}
+
+// is every site of the item a single state or a full gap? (wave-uniform answer)
+__device__ __forceinline__ bool mfma_simple_tips(const unsigned long long m[2], unsigned long long full)
+{
+  const bool ok = (__popcll(m[0]) == 1 || m[0] == full) && (__popcll(m[1]) == 1 || m[1] == full);
+  return __all(ok);
+}
+
+// (P x)[4 ig + row] for a simple tip: column `code` of P, or the row sum for a gap - one LDS read.
+// frag[ig][jg][kk][ii] = P[4ig+ii][4jg+kk]; the lane wants P[4ig + row][code]: not this lane's own
+// fragment element, so a per-lane address.
+__device__ __forceinline__ double mfma_tip_column(const double *__restrict__ frag, const double *__restrict__ rowsum,
+                                                  unsigned long long m, unsigned long long full, unsigned row, int ig)
+{
+  const unsigned code = (unsigned)__ffsll((long long)m) - 1u;
+  const double *p = m == full ? rowsum + 4 * ig + row : frag + ig * 256 + (code >> 2) * 16u + (code & 3u) * 4u + row;
+  return *p;
 }
 
 template <bool LTIP, bool RTIP, bool GATHER>
 __global__ __launch_bounds__(256, 2) void k_partials_mfma(const OpPack pack, const GenGeo g,
                                                           const unsigned long long *__restrict__ tipmap,
-                                                          unsigned items_per_wave)
+                                                          unsigned items_per_wave, unsigned char *__restrict__ flagbuf,
+                                                          unsigned flag_stride /* bytes per (op, rate) */)
 {
   extern __shared__ double lds[];
   double *PL = lds;                 // [16 ig][16 jg][4 k][4 i]
   double *PR = lds + 4096;
-  unsigned char *flags = reinterpret_cast<unsigned char *>(lds + 8192); // [4 waves][items][R<=?][32 sites]
+  double *RS = lds + kMfmaRowsumOff; // row sums of P_left [64], P_right [64]
 
   const DevOp &op = pack.ops[blockIdx.y];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned row = lane >> 4;   // k on the input side, i on the output side
   const unsigned col = lane & 15u;  // site within a 16-site group
-  const unsigned S = g.S, R = g.R;
+  const unsigned S = g.S;
+  const unsigned k = blockIdx.z;
   const unsigned nitems = (op.entries + 31u) / 32u;
-  const unsigned item0 = (blockIdx.x * 4u + wave) * items_per_wave;
   if (blockIdx.x * 4u * items_per_wave >= nitems) return; // whole workgroup
   const int mode = op.pscaler ? g.scale_mode : 0;
   const unsigned fragoff = (row * 4u + (lane & 3u));
+  const unsigned long long full = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
 
-  for (unsigned k = 0; k < R; ++k)
+  // stage fragments: frag[ig][jg][kk][ii] = P[4ig+ii][4jg+kk] = PT[k][4jg+kk][4ig+ii]
+  for (unsigned idx = threadIdx.x; idx < 4096; idx += 256)
   {
-    __syncthreads(); // previous rate's fragments no longer read
-    // stage fragments: frag[ig][jg][kk][ii] = P[4ig+ii][4jg+kk] = PT[k][4jg+kk][4ig+ii]
-    for (unsigned idx = threadIdx.x; idx < 4096; idx += 256)
+    const unsigned ii = idx & 3u, kk = (idx >> 2) & 3u, jg = (idx >> 4) & 15u, ig = idx >> 8;
+    const unsigned j = 4 * jg + kk, i = 4 * ig + ii;
+    double l = 0.0, r = 0.0;
+    if (j < S && i < g.SPT)
     {
-      const unsigned ii = idx & 3u, kk = (idx >> 2) & 3u, jg = (idx >> 4) & 15u, ig = idx >> 8;
-      const unsigned j = 4 * jg + kk, i = 4 * ig + ii;
-      double l = 0.0, r = 0.0;
-      if (j < S && i < g.SPT)
-      {
-        l = op.lmat[((size_t)k * S + j) * g.SPT + i];
-        r = op.rmat[((size_t)k * S + j) * g.SPT + i];
-      }
-      PL[idx] = l;
-      PR[idx] = r;
+      l = op.lmat[((size_t)k * S + j) * g.SPT + i];
+      r = op.rmat[((size_t)k * S + j) * g.SPT + i];
+    }
+    PL[idx] = l;
+    PR[idx] = r;
+  }
+  __syncthreads();
+  if (LTIP || RTIP)
+  {
+    if (threadIdx.x < 128)
+    {
+      // row sums in ascending j like the reference's set-bit walk (core_partials.c:480-489)
+      const double *F = threadIdx.x < 64 ? PL : PR;
+      const unsigned i = threadIdx.x & 63u;
+      double s = 0.0;
+      for (unsigned j = 0; j < S; ++j) s += F[((i >> 2) * 16 + (j >> 2)) * 16 + (j & 3u) * 4 + (i & 3u)];
+      RS[threadIdx.x] = s;
     }
     __syncthreads();
+  }
 
-    for (unsigned it = 0; it < items_per_wave; ++it)
+  const unsigned item0 = (blockIdx.x * 4u + wave) * items_per_wave;
+  if (item0 >= nitems) return; // no barriers below
+  const unsigned nmine = min(items_per_wave, nitems - item0);
+
+  // x: CLV fragments of the inner child in flight - the left one, then the right one (ii), or
+  // the right one only (ti); tip children take their 0/1 x from the mask on the fly
+  MfmaItem cur = mfma_item<LTIP, RTIP, GATHER>(op, g, tipmap, item0, col, k);
+  double x[16][2];
+  if (!LTIP || !RTIP)
+  {
+#pragma unroll
+    for (int jg = 0; jg < 16; ++jg)
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg) x[jg][sg] = mfma_x<false>(LTIP ? cur.rb[sg] : cur.lb[sg], 0, S, 4 * jg + row);
+  }
+
+  for (unsigned it = 0; it < nmine; ++it)
+  {
+    const bool has_next = it + 1 < nmine;
+    MfmaItem nxt = cur;
+    if (has_next) nxt = mfma_item<LTIP, RTIP, GATHER>(op, g, tipmap, item0 + it + 1, col, k);
+
+    double DL[16][2];
+    // ---- left child: all 16 parent state groups
+    const bool lsimple = LTIP && mfma_simple_tips(cur.lm, full);
+    if (lsimple)
     {
-      const unsigned item = item0 + it;
-      if (item >= nitems) break; // wave-uniform
-      // the lane's two sites (site group 0 and 1 of the item)
-      unsigned e[2], le[2], re[2];
-      bool valid[2];
-      const double *lb[2], *rb[2];
-      unsigned long long lm[2] = {0, 0}, rm[2] = {0, 0};
 #pragma unroll
-      for (int sg = 0; sg < 2; ++sg)
-      {
-        e[sg] = item * 32u + sg * 16u + col;
-        valid[sg] = e[sg] < op.entries;
-        const unsigned nn = valid[sg] ? e[sg] : op.entries - 1;
-        le[sg] = re[sg] = nn;
-        if (GATHER)
-        {
-          const unsigned site = op.id_site ? op.id_site[nn] : nn;
-          le[sg] = op.lsid ? op.lsid[site] : site;
-          re[sg] = op.rsid ? op.rsid[site] : site;
-        }
-        if (LTIP) lm[sg] = tipmap ? tipmap[op.ltip[le[sg]]] : (unsigned long long)op.ltip[le[sg]];
-        if (RTIP) rm[sg] = tipmap ? tipmap[op.rtip[re[sg]]] : (unsigned long long)op.rtip[re[sg]];
-        lb[sg] = LTIP ? nullptr : op.left + (size_t)(le[sg] >> 6) * g.tile_sz + (le[sg] & 63u);
-        rb[sg] = RTIP ? nullptr : op.right + (size_t)(re[sg] >> 6) * g.tile_sz + (re[sg] & 63u);
-      }
-
-      double x[16][2];
-      double DL[16][2];
-      // ---- left child: all 16 state groups
+      for (int ig = 0; ig < 16; ++ig)
 #pragma unroll
-      for (int jg = 0; jg < 16; ++jg)
-#pragma unroll
-        for (int sg = 0; sg < 2; ++sg) x[jg][sg] = mfma_x<LTIP>(lb[sg], lm[sg], k, S, 4 * jg + row);
+        for (int sg = 0; sg < 2; ++sg) DL[ig][sg] = mfma_tip_column(PL, RS, cur.lm[sg], full, row, ig);
+    }
+    else
+    {
 #pragma unroll
       for (int ig = 0; ig < 16; ++ig) DL[ig][0] = DL[ig][1] = 0.0;
 #pragma unroll
       for (int jg = 0; jg < 16; ++jg)
+      {
+        const double x0 = LTIP ? mfma_x<true>(nullptr, cur.lm[0], S, 4 * jg + row) : x[jg][0];
+        const double x1 = LTIP ? mfma_x<true>(nullptr, cur.lm[1], S, 4 * jg + row) : x[jg][1];
 #pragma unroll
         for (int ig = 0; ig < 16; ++ig)
         {
           const double a = PL[(ig * 16 + jg) * 16 + fragoff];
-          DL[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][0], DL[ig][0], 0, 0, 0);
-          DL[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][1], DL[ig][1], 0, 0, 0);
-          if ((ig & 7) == 7) __builtin_amdgcn_sched_barrier(0); // bound the fragment look-ahead (registers)
+          DL[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x0, DL[ig][0], 0, 0, 0);
+          DL[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x1, DL[ig][1], 0, 0, 0);
         }
-      // ---- right child, 4 state groups at a time; product, range test, store
+        // ii: x[jg] of the left child is dead, request the right child's
+        if (!LTIP)
+        {
+          x[jg][0] = mfma_x<false>(cur.rb[0], 0, S, 4 * jg + row);
+          x[jg][1] = mfma_x<false>(cur.rb[1], 0, S, 4 * jg + row);
+        }
+        __builtin_amdgcn_sched_barrier(0); // keep the request here and the fragment look-ahead bounded
+      }
+    }
+
+    // ---- right child, 4 parent state groups at a time; product, range test, store
+    const bool rsimple = RTIP && mfma_simple_tips(cur.rm, full);
+    bool small[2] = {true, true};
+    double *pb[2];
 #pragma unroll
-      for (int jg = 0; jg < 16; ++jg)
+    for (int sg = 0; sg < 2; ++sg)
+      pb[sg] = op.parent + (size_t)(cur.e[sg] >> 6) * g.tile_sz + (cur.e[sg] & 63u) + (size_t)k * S * 64;
+    if (rsimple)
+    {
 #pragma unroll
-        for (int sg = 0; sg < 2; ++sg) x[jg][sg] = mfma_x<RTIP>(rb[sg], rm[sg], k, S, 4 * jg + row);
-      bool small[2] = {true, true};
+      for (int ig = 0; ig < 16; ++ig)
+      {
+        const unsigned i = 4 * ig + row;
+        if (i < S)
+        {
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg)
+          {
+            const double v = DL[ig][sg] * mfma_tip_column(PR, RS, cur.rm[sg], full, row, ig);
+            small[sg] = small[sg] && (v < PLLGPU_SCALE_THRESHOLD);
+            if (cur.valid[sg]) pb[sg][(size_t)i * 64] = v;
+          }
+        }
+      }
+    }
+    else
+    {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
       {
@@ -140,14 +247,24 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma(const OpPack pack, con
         for (int q = 0; q < 4; ++q) DR[q][0] = DR[q][1] = 0.0;
 #pragma unroll
         for (int jg = 0; jg < 16; ++jg)
+        {
+          const double x0 = RTIP ? mfma_x<true>(nullptr, cur.rm[0], S, 4 * jg + row) : x[jg][0];
+          const double x1 = RTIP ? mfma_x<true>(nullptr, cur.rm[1], S, 4 * jg + row) : x[jg][1];
 #pragma unroll
           for (int q = 0; q < 4; ++q)
           {
             const double a = PR[((c * 4 + q) * 16 + jg) * 16 + fragoff];
-            DR[q][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][0], DR[q][0], 0, 0, 0);
-            DR[q][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][1], DR[q][1], 0, 0, 0);
-            if (q == 3 && (jg & 1)) __builtin_amdgcn_sched_barrier(0);
+            DR[q][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x0, DR[q][0], 0, 0, 0);
+            DR[q][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x1, DR[q][1], 0, 0, 0);
           }
+          // last chunk: x[jg] of this item is dead, request the next item's first inner child
+          if (c == 3 && !RTIP && has_next)
+          {
+            x[jg][0] = mfma_x<false>(LTIP ? nxt.rb[0] : nxt.lb[0], 0, S, 4 * jg + row);
+            x[jg][1] = mfma_x<false>(LTIP ? nxt.rb[1] : nxt.lb[1], 0, S, 4 * jg + row);
+          }
+          if (c == 3 || (jg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
         {
@@ -159,70 +276,65 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma(const OpPack pack, con
             {
               const double v = DL[c * 4 + q][sg] * DR[q][sg];
               small[sg] = small[sg] && (v < PLLGPU_SCALE_THRESHOLD);
-              if (valid[sg]) op.parent[(size_t)(e[sg] >> 6) * g.tile_sz + (e[sg] & 63u) + ((size_t)k * S + i) * 64] = v;
+              if (cur.valid[sg]) pb[sg][(size_t)i * 64] = v;
             }
           }
         }
       }
-      if (mode)
-      {
-        // a site's states are spread over the four row groups of the wave: AND them together
+    }
+    if (mode)
+    {
+      // a site's states are spread over the four row groups of the wave: AND them together
 #pragma unroll
-        for (int sg = 0; sg < 2; ++sg)
-        {
-          int s = small[sg] ? 1 : 0;
-          s &= __shfl_xor(s, 16, 64);
-          s &= __shfl_xor(s, 32, 64);
-          if (row == 0) flags[((wave * kMfmaItemsMax + it) * R + k) * 32 + sg * 16 + col] = (unsigned char)s;
-        }
+      for (int sg = 0; sg < 2; ++sg)
+      {
+        int s = small[sg] ? 1 : 0;
+        s &= __shfl_xor(s, 16, 64);
+        s &= __shfl_xor(s, 32, 64);
+        if (row == 0 && cur.valid[sg])
+          flagbuf[((size_t)blockIdx.y * g.R + k) * flag_stride + cur.e[sg]] = (unsigned char)s;
       }
     }
+    cur = nxt;
   }
+}
 
-  if (!mode) return;
-  // ---- scaling epilogue: row group 0 owns the sites; flags were written by this same wave
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  if (row != 0) return;
-  for (unsigned it = 0; it < items_per_wave; ++it)
+// applies the scaling decisions k_partials_mfma left in flagbuf: one thread per parent entry
+template <bool GATHER>
+__global__ __launch_bounds__(256) void k_mfma_scale_epilogue(const OpPack pack, const GenGeo g,
+                                                             const unsigned char *__restrict__ flagbuf, unsigned flag_stride)
+{
+  const DevOp &op = pack.ops[blockIdx.y];
+  if (!op.pscaler || !g.scale_mode) return;
+  const unsigned n = blockIdx.x * 256u + threadIdx.x;
+  if (n >= op.entries) return;
+  const unsigned S = g.S, R = g.R;
+  unsigned le = n, re = n;
+  if (GATHER)
   {
-    const unsigned item = item0 + it;
-    if (item >= nitems) break;
-    for (int sg = 0; sg < 2; ++sg)
+    const unsigned site = op.id_site ? op.id_site[n] : n;
+    le = op.lsid ? op.lsid[site] : site;
+    re = op.rsid ? op.rsid[site] : site;
+  }
+  double *base = op.parent + (size_t)(n >> 6) * g.tile_sz + (n & 63u);
+  const unsigned char *f = flagbuf + (size_t)blockIdx.y * R * flag_stride + n;
+  if (g.scale_mode == 1)
+  {
+    bool all = true;
+    for (unsigned k = 0; k < R; ++k) all = all && f[(size_t)k * flag_stride];
+    if (all)
+      for (unsigned q = 0; q < R * S; ++q) base[(size_t)q * 64] *= PLLGPU_SCALE_FACTOR;
+    op.pscaler[n] = (op.lscaler ? op.lscaler[le] : 0u) + (op.rscaler ? op.rscaler[re] : 0u) + (all ? 1u : 0u);
+  }
+  else
+  {
+    for (unsigned k = 0; k < R; ++k)
     {
-      const unsigned n = item * 32u + sg * 16u + col;
-      if (n >= op.entries) continue;
-      unsigned le = n, re = n;
-      if (GATHER)
-      {
-        const unsigned site = op.id_site ? op.id_site[n] : n;
-        le = op.lsid ? op.lsid[site] : site;
-        re = op.rsid ? op.rsid[site] : site;
-      }
-      double *base = op.parent + (size_t)(n >> 6) * g.tile_sz + (n & 63u);
-      const unsigned char *f = flags + ((wave * kMfmaItemsMax + it) * R) * 32 + sg * 16 + col;
-      if (mode == 1)
-      {
-        bool all = true;
-        for (unsigned k = 0; k < R; ++k) all = all && f[k * 32];
-        if (all)
-          for (unsigned q = 0; q < R * S; ++q) base[(size_t)q * 64] = __builtin_nontemporal_load(base + (size_t)q * 64) * PLLGPU_SCALE_FACTOR;
-        op.pscaler[n] = (op.lscaler ? op.lscaler[le] : 0u) + (op.rscaler ? op.rscaler[re] : 0u) + (all ? 1u : 0u);
-      }
-      else
-      {
-        for (unsigned k = 0; k < R; ++k)
-        {
-          const bool sm = f[k * 32] != 0;
-          if (sm)
-            for (unsigned q = 0; q < S; ++q)
-            {
-              double *p = base + ((size_t)k * S + q) * 64;
-              *p = __builtin_nontemporal_load(p) * PLLGPU_SCALE_FACTOR;
-            }
-          op.pscaler[(size_t)n * R + k] = (op.lscaler ? op.lscaler[(size_t)le * R + k] : 0u) +
-                                          (op.rscaler ? op.rscaler[(size_t)re * R + k] : 0u) + (sm ? 1u : 0u);
-        }
-      }
+      const bool sm = f[(size_t)k * flag_stride] != 0;
+      if (sm)
+        for (unsigned q = 0; q < S; ++q) base[((size_t)k * S + q) * 64] *= PLLGPU_SCALE_FACTOR;
+      op.pscaler[(size_t)n * R + k] = (op.lscaler ? op.lscaler[(size_t)le * R + k] : 0u) +
+                                      (op.rscaler ? op.rscaler[(size_t)re * R + k] : 0u) + (sm ? 1u : 0u);
     }
   }
 }

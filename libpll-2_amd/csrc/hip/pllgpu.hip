@@ -93,6 +93,7 @@ struct pllgpu_ctx
   bool tipmap_set = false;
   DevBuf<double> pmat, freqs, rate_weights, prop_invar, persite, block_sums;
   DevBuf<unsigned> counter;
+  DevBuf<unsigned char> mfma_flags;      // [op in launch][rate][entry] scaling decisions (kernels_mfma.h)
   DevBuf<double> eigenvals, rates, diag; // derivatives: [rate_matrices][SP], [R], [R][S][4]
   DevBuf<double> sumtable[4];            // device-resident sumtables (tiled like a CLV)
   double *result_dev = nullptr;  // device alias of result_host
@@ -247,6 +248,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->persite.release();
   c->block_sums.release();
   c->counter.release();
+  c->mfma_flags.release();
   c->eigenvals.release();
   c->rates.release();
   c->diag.release();
@@ -574,14 +576,22 @@ static void launch_dna(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigne
 }
 
 // large state spaces: fp64 MFMA 4x4x4 kernel, matrices staged in LDS (kernels_mfma.h)
-static void launch_mfma(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
+static int launch_mfma(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
 {
+  const unsigned R = c->gg.R;
   const unsigned items = (maxent + 31) / 32; // 32 sites per item
-  unsigned ipw = (unsigned)(((size_t)items * nops + 4 * 512 - 1) / (4 * 512));
-  ipw = std::max(1u, std::min(ipw, (unsigned)kMfmaItemsMax));
-  dim3 grid((items + 4 * ipw - 1) / (4 * ipw), nops), block(256);
-  const size_t lds = 8192 * sizeof(double) + (size_t)4 * kMfmaItemsMax * c->gg.R * 32;
+  // aim at two workgroups of four waves on every CU (2048 waves); more work -> more items per wave
+  unsigned ipw = (unsigned)(((size_t)items * nops * R + 2047) / 2048);
+  ipw = std::max(1u, ipw);
+  dim3 grid((items + 4 * ipw - 1) / (4 * ipw), nops, R), block(256);
+  const size_t lds = (kMfmaRowsumOff + 128) * sizeof(double);
   const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
+  bool scaling = false;
+  for (unsigned i = 0; i < nops; ++i) scaling = scaling || pack.ops[i].pscaler != nullptr;
+  scaling = scaling && c->gg.scale_mode != 0;
+  const unsigned fstride = (maxent + 63u) & ~63u;
+  if (scaling && c->mfma_flags.ensure((size_t)kMaxOpsPerLaunch * R * fstride)) return PLLGPU_ENOMEM;
+  unsigned char *fb = c->mfma_flags.p;
 #define MF_LAUNCH(LT, RT, GA)                                                                                   \
   do                                                                                                            \
   {                                                                                                             \
@@ -591,7 +601,7 @@ static void launch_mfma(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsign
       (void)hipFuncSetAttribute((const void *)k_partials_mfma<LT, RT, GA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       attr_set = true;                                                                                          \
     }                                                                                                           \
-    hipLaunchKernelGGL((k_partials_mfma<LT, RT, GA>), grid, block, lds, c->stream, pack, c->gg, tm, ipw);       \
+    hipLaunchKernelGGL((k_partials_mfma<LT, RT, GA>), grid, block, lds, c->stream, pack, c->gg, tm, ipw, fb, fstride); \
   } while (0)
   if (kind == 0)
   {
@@ -606,14 +616,23 @@ static void launch_mfma(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsign
     if (gather) MF_LAUNCH(true, true, true); else MF_LAUNCH(true, true, false);
   }
 #undef MF_LAUNCH
+  if (scaling)
+  {
+    dim3 eg((maxent + 255) / 256, nops);
+    if (gather)
+      hipLaunchKernelGGL((k_mfma_scale_epilogue<true>), eg, dim3(256), 0, c->stream, pack, c->gg, fb, fstride);
+    else
+      hipLaunchKernelGGL((k_mfma_scale_epilogue<false>), eg, dim3(256), 0, c->stream, pack, c->gg, fb, fstride);
+  }
+  return 0;
 }
 
-static void launch_partials(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
+static int launch_partials(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
 {
   if (c->dna_fast)
     launch_dna(c, pack, nops, maxent, kind, gather);
   else if (c->use_mfma)
-    launch_mfma(c, pack, nops, maxent, kind, gather);
+    return launch_mfma(c, pack, nops, maxent, kind, gather);
   else
     switch (c->ich)
     {
@@ -623,6 +642,7 @@ static void launch_partials(pllgpu_ctx *c, const OpPack &pack, unsigned nops, un
       case 20: launch_generic<20>(c, pack, nops, maxent, kind, gather); break;
       default: launch_generic<32>(c, pack, nops, maxent, kind, gather); break;
     }
+  return 0;
 }
 
 extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, unsigned count)
@@ -641,9 +661,10 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
       {
         OpPack pack;
         unsigned nops = 0, maxent = 0;
+        int lrc = 0;
         auto flush = [&]() {
           if (!nops) return;
-          launch_partials(c, pack, nops, maxent, kind, ga != 0);
+          if (int rc = launch_partials(c, pack, nops, maxent, kind, ga != 0)) lrc = rc;
           ++c->last_launches;
           nops = 0;
           maxent = 0;
@@ -661,6 +682,7 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
           if (++nops == (unsigned)kMaxOpsPerLaunch) flush();
         }
         flush();
+        if (lrc) return lrc;
       }
     i = j;
   }

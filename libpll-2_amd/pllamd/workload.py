@@ -46,6 +46,10 @@ def map_generic(states, first=48):
     for i in range(states):
         m[first + i] = np.uint64(1) << np.uint64(i)
     m[ord("-")] = np.uint64((1 << states) - 1) if states < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    # partial ambiguities: '!' = first two states, '#' = upper half, '$' = second and last state
+    m[ord("!")] = np.uint64(3)
+    m[ord("#")] = np.uint64(sum(1 << i for i in range(states // 2, states)))
+    m[ord("$")] = np.uint64((1 << 1) | (1 << (states - 1)))
     return m
 
 
@@ -194,7 +198,7 @@ def synthetic_exch(states):
 
 def make_case(name, states, tips, sites, rate_cats=4, tree="balanced", attributes=0, seed=1,
               mutate_pct=30, alpha=0.5, scalers=True, tips_as="states", exch=None, freqs=None,
-              brlen_scale=1.0, pinv=0.0, pattern_weights=None, ambiguity_pct=0):
+              brlen_scale=1.0, pinv=0.0, pattern_weights=None, ambiguity_pct=0, partial_pct=0):
     """One synthetic configuration of SURVEY 8d (C2: states=4,tips=64,sites=100000; C3: 20/64/
     50000; C5: 61/32/20000)."""
     if exch is None:
@@ -228,6 +232,17 @@ def make_case(name, states, tips, sites, rate_cats=4, tree="balanced", attribute
             for sq in seqs:
                 a = np.frombuffer(sq, dtype=np.uint8).copy()
                 a[rng.integers(0, 100, size=sites) < ambiguity_pct] = amb
+                seqs2.append(a.tobytes())
+            seqs = seqs2
+        if partial_pct:
+            # partially ambiguous characters of the alphabet (IUPAC for DNA / protein)
+            pool = np.frombuffer({4: b"RYSWKMBDHV", 20: b"BZJ"}.get(states, b"!#$"), dtype=np.uint8)
+            rng = np.random.Generator(np.random.PCG64(seed + 78))
+            seqs2 = []
+            for sq in seqs:
+                a = np.frombuffer(sq, dtype=np.uint8).copy()
+                hit = rng.integers(0, 100, size=sites) < partial_pct
+                a[hit] = pool[rng.integers(0, len(pool), size=int(hit.sum()))]
                 seqs2.append(a.tobytes())
             seqs = seqs2
         kw.update(charmap=cmap, sequences=seqs)

@@ -64,6 +64,12 @@ ORACLE_CASES = [
     dict(states=61, tips=100, sites=64, tree="caterpillar", brlen_scale=3, attributes=api.RATE_SCALERS, seed=51),
     dict(states=61, tips=16, sites=100, attributes=api.SITE_REPEATS, mutate_pct=3, seed=52),
     dict(states=64, tips=8, sites=70, rate_cats=2, seed=53),
+    dict(states=61, tips=16, sites=200, ambiguity_pct=4, partial_pct=6, seed=54),
+    dict(states=64, tips=8, sites=100, attributes=api.PATTERN_TIP | api.RATE_SCALERS, partial_pct=10, seed=55),
+    dict(states=40, tips=64, sites=97, tree="caterpillar", brlen_scale=4, partial_pct=3, attributes=api.RATE_SCALERS, seed=56),
+    dict(states=61, tips=16, sites=4100, rate_cats=3, seed=57),
+    dict(states=20, tips=16, sites=150, partial_pct=10, ambiguity_pct=3, seed=58),
+    dict(states=4, tips=16, sites=300, partial_pct=15, seed=59),
     dict(states=4, tips=16, sites=500, pinv=0.3, mutate_pct=4, seed=61),
     dict(states=4, tips=200, sites=100, tree="caterpillar", brlen_scale=4, pinv=0.25, mutate_pct=2, attributes=api.RATE_SCALERS, seed=62),
     dict(states=20, tips=16, sites=200, pinv=0.2, mutate_pct=3, attributes=api.PATTERN_TIP, seed=63),
@@ -224,6 +230,18 @@ def test_compact_tips_become_dense_when_needed(amd_lib):
 def test_dna_through_generic_kernels(amd_lib, kw, monkeypatch):
     """the 4x4 shape also has to be right in the any-shape kernels (PLL_AMD_GENERIC_ONLY=1)"""
     monkeypatch.setenv("PLL_AMD_GENERIC_ONLY", "1")
+    case = W.make_case("rnd", **kw)
+    exp = O.run_case(case)
+    got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    assert_results_match(got, exp, what=_id(kw))
+    assert scalers_equal(got, exp)
+
+
+@pytest.mark.parametrize("kw", [k for k in ORACLE_CASES if k["states"] > 32], ids=_id)
+def test_large_states_through_fma_kernels(amd_lib, kw, monkeypatch):
+    """33..64 states normally run on the fp64 matrix pipe (kernels_mfma.h); PLL_AMD_NO_MFMA=1 sends
+    them through the any-shape FMA kernels, which must stay right as well"""
+    monkeypatch.setenv("PLL_AMD_NO_MFMA", "1")
     case = W.make_case("rnd", **kw)
     exp = O.run_case(case)
     got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
