@@ -182,6 +182,13 @@ int pll_set_tip_states(pll_partition_t *partition, unsigned int tip_index,
 int pll_set_tip_clv(pll_partition_t *partition, unsigned int tip_index, const double *clv,
                     int padding);
 void pll_set_pattern_weights(pll_partition_t *partition, const unsigned int *pattern_weights);
+/* ascertainment-bias correction (src/pll.h:663-667, src/pll.c:1145-1200): the partition must have
+ * been created with PLL_ATTRIB_AB_FLAG or an AB type; type = 0 | PLL_ATTRIB_AB_{LEWIS,FELSENSTEIN,
+ * STAMATAKIS}. The correction enters pll_compute_{edge,root}_loglikelihood and
+ * pll_compute_likelihood_derivatives (src/likelihood.c:24-120,191-268,342-440;
+ * src/core_derivatives.c:851-924). Not combinable with PLL_ATTRIB_SITE_REPEATS (refused at creation). */
+int pll_set_asc_bias_type(pll_partition_t *partition, int asc_bias_type);
+void pll_set_asc_state_weights(pll_partition_t *partition, const unsigned int *state_weights);
 void pll_set_frequencies(pll_partition_t *partition, unsigned int params_index,
                          const double *frequencies);
 void pll_set_subst_params(pll_partition_t *partition, unsigned int params_index,

@@ -120,6 +120,15 @@ int pllgpu_root_loglikelihood(pllgpu_ctx_t *ctx, unsigned int clv, int scaler, u
                               const unsigned int *freqs_indices, double *persite_host,
                               double *lnl_out);
 
+/* ascertainment-bias correction (src/likelihood.c:50-120, :191-268,
+ * :342-440): for each state n the likelihood of the per-state extra entry `sites + n` of the same
+ * edge (is_root = 0; edge->child_is_tip honoured) or root (is_root = 1; only parent_clv /
+ * parent_scaler / freqs_indices of `edge` are read) and the number of scalings it carries.
+ * With per-rate scalers the term is already brought to the smallest per-rate count, which is the
+ * count reported. Synchronises. */
+int pllgpu_asc_terms(pllgpu_ctx_t *ctx, const pllgpu_edge_t *edge, int is_root, double *terms /* [states] */,
+                     unsigned int *scalings /* [states] */);
+
 /* ---- branch-length derivatives ---------------------------------- */
 /* the two contraction matrices of the sumtable, one block [rate][row j][states_padded] each:
  * slot 0: M1[j][i] = pi_i * inv_eigenvecs[i][j] (applied to the left end), slot 1: M2[j][i] =
@@ -140,8 +149,17 @@ int pllgpu_update_sumtable(pllgpu_ctx_t *ctx, const pllgpu_sumtable_t *st, unsig
 int pllgpu_sumtable_upload(pllgpu_ctx_t *ctx, unsigned int slot, const double *host);
 int pllgpu_sumtable_download(pllgpu_ctx_t *ctx, unsigned int slot, double *host);
 /* replaces pll_core_likelihood_derivatives (src/core_derivatives.c:696-849). Synchronises. */
+/* eval_sites: how many leading table entries enter the sums (sites, or sites + states for the
+ * Stamatakis correction, src/core_derivatives.c:733-742) */
 int pllgpu_likelihood_derivatives(pllgpu_ctx_t *ctx, unsigned int slot, double branch_length,
-                                  const unsigned int *params_indices, double *d_f, double *dd_f);
+                                  const unsigned int *params_indices, unsigned int eval_sites, double *d_f,
+                                  double *dd_f);
+/* (L, L', L'') of the per-state extra entries at the branch length of the LAST
+ * pllgpu_likelihood_derivatives call on this context, and their scaling counts
+ * (src/core_derivatives.c:864-891). Synchronises. */
+int pllgpu_asc_derivative_terms(pllgpu_ctx_t *ctx, unsigned int slot, int parent_scaler, int child_scaler,
+                                const unsigned int *params_indices, double *lk /* [states][3] */,
+                                unsigned int *scalings /* [states] */);
 
 /* ---- stream / timing ---------------------------------------------------------------------- */
 int pllgpu_set_stream(pllgpu_ctx_t *ctx, void *hip_stream);

@@ -200,3 +200,118 @@ __global__ __launch_bounds__(256) void k_sumtable_excess(const DevExcess e, cons
     for (unsigned j = 0; j < g.S; ++j) x[((size_t)k * g.S + j) * 64] *= f;
   }
 }
+
+// ---- ascertainment-bias terms (src/likelihood.c:50-120, :191-268, :342-440; src/core_derivatives.c:
+// 864-891): the per-state extra entries sites + n. A handful of entries: one wave per state, lanes
+// over the parent state j; results go to mapped host memory, the host applies the correction formula.
+struct DevAsc
+{
+  const double *parent;         // tiled CLV
+  const double *child;          // tiled CLV or null (tip codes / root)
+  const unsigned char *ctip;
+  const unsigned *pscaler, *cscaler;
+  const double *mat;            // PT layout; unused for root
+  const double *freqs;          // [rate_matrices][SP]
+  const double *rate_weights;
+  double *out;                  // mapped: [S] terms, then [S] scaling counts (as doubles)
+  unsigned first;               // entry of state 0 (= sites)
+  int per_rate;
+  int is_root;
+  unsigned char fidx[kMaxRates];
+};
+
+__global__ __launch_bounds__(64) void k_asc_terms(const DevAsc a, const GenGeo g, const unsigned long long *__restrict__ tipmap)
+{
+  const unsigned n = blockIdx.x, j = threadIdx.x;
+  const unsigned S = g.S, R = g.R;
+  const unsigned e = a.first + n;
+  const double *xp = a.parent + tiled_base(e, g.tile_sz);
+  const double *xc = a.child ? a.child + tiled_base(e, g.tile_sz) : nullptr;
+  unsigned long long mask = 0;
+  if (a.ctip) mask = tipmap ? tipmap[a.ctip[e]] : (unsigned long long)a.ctip[e];
+  unsigned mn = 0xFFFFFFFFu;
+  if (a.per_rate)
+    for (unsigned i = 0; i < R; ++i)
+      mn = min(mn, (a.pscaler ? a.pscaler[(size_t)e * R + i] : 0u) + (a.cscaler ? a.cscaler[(size_t)e * R + i] : 0u));
+  double term = 0.0;
+  for (unsigned i = 0; i < R; ++i)
+  {
+    double v = 0.0;
+    if (j < S)
+    {
+      double termb = 1.0;
+      if (!a.is_root)
+      {
+        termb = 0.0;
+        const double *col = a.mat + (size_t)i * S * g.SPT + j; // PT[i][k][j] = P_i[j][k]
+        if (a.ctip)
+        {
+          for (unsigned k = 0; k < S; ++k)
+            if ((mask >> k) & 1ull) termb += col[(size_t)k * g.SPT];
+        }
+        else
+          for (unsigned k = 0; k < S; ++k) termb += col[(size_t)k * g.SPT] * xc[((size_t)i * S + k) * 64];
+      }
+      v = xp[((size_t)i * S + j) * 64] * a.freqs[(size_t)a.fidx[i] * g.SP + j] * termb;
+    }
+    v = wave_sum(v);
+    if (a.per_rate)
+    {
+      const unsigned rs = (a.pscaler ? a.pscaler[(size_t)e * R + i] : 0u) + (a.cscaler ? a.cscaler[(size_t)e * R + i] : 0u);
+      const unsigned d = min(rs - mn, PLLGPU_RATE_MAXDIFF);
+      if (d) v *= minlh(d);
+    }
+    term += v * a.rate_weights[i];
+  }
+  if (j == 0)
+  {
+    const unsigned sc = a.per_rate ? mn : (a.pscaler ? a.pscaler[e] : 0u) + (a.cscaler ? a.cscaler[e] : 0u);
+    a.out[n] = term;
+    a.out[S + n] = (double)sc;
+  }
+}
+
+struct DevAscDeriv
+{
+  const double *table;          // tiled sumtable
+  const double *diag;           // [k][j][4], left by the last derivative evaluation
+  const double *rate_weights;
+  const unsigned *pscaler, *cscaler;
+  double *out;                  // mapped: [S][3] then [S] scaling counts
+  unsigned first;
+  int per_rate;
+};
+
+__global__ __launch_bounds__(64) void k_asc_deriv_terms(const DevAscDeriv a, const GenGeo g)
+{
+  const unsigned n = threadIdx.x;
+  if (n >= g.S) return;
+  const unsigned e = a.first + n;
+  const double *x = a.table + tiled_base(e, g.tile_sz);
+  double lk0 = 0.0, lk1 = 0.0, lk2 = 0.0;
+  unsigned mn = 0xFFFFFFFFu;
+  for (unsigned k = 0; k < g.R; ++k)
+  {
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    for (unsigned j = 0; j < g.S; ++j)
+    {
+      const double s = x[((size_t)k * g.S + j) * 64];
+      const double *dk = a.diag + ((size_t)k * g.S + j) * 4;
+      c0 = fma(s, dk[0], c0);
+      c1 = fma(s, dk[1], c1);
+      c2 = fma(s, dk[2], c2);
+    }
+    const double w = a.rate_weights[k];
+    lk0 += c0 * w;
+    lk1 += c1 * w;
+    lk2 += c2 * w;
+    if (a.per_rate)
+      mn = min(mn, (a.pscaler ? a.pscaler[(size_t)e * g.R + k] : 0u) + (a.cscaler ? a.cscaler[(size_t)e * g.R + k] : 0u));
+  }
+  // per-rate scalers: the table columns were already brought to the smallest count (k_sumtable_excess)
+  const unsigned sc = a.per_rate ? mn : (a.pscaler ? a.pscaler[e] : 0u) + (a.cscaler ? a.cscaler[e] : 0u);
+  a.out[n * 3 + 0] = lk0;
+  a.out[n * 3 + 1] = lk1;
+  a.out[n * 3 + 2] = lk2;
+  a.out[3 * g.S + n] = (double)sc;
+}

@@ -66,6 +66,10 @@ struct DevBuf
   }
 };
 
+// mapped result block: [0..7] lnL / derivative words, [8..) ascertainment-bias terms (up to 64 x 4 doubles)
+constexpr size_t kResultBytes = (8 + 4 * 64) * sizeof(double);
+constexpr unsigned kAscOff = 8;
+
 struct pllgpu_ctx
 {
   pllgpu_geometry_t geo;
@@ -199,7 +203,7 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   bool ok = hipSetDevice(device) == hipSuccess &&
             hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
-            hipHostMalloc((void **)&c->result_host, 64, hipHostMallocMapped) == hipSuccess &&
+            hipHostMalloc((void **)&c->result_host, kResultBytes, hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void **)&c->result_dev, c->result_host, 0) == hipSuccess;
   if (!ok)
   {
@@ -915,7 +919,7 @@ extern "C" int pllgpu_rates_upload(pllgpu_ctx_t *c, const double *host)
 static int sumtable_slot(pllgpu_ctx *c, unsigned slot)
 {
   if (slot >= 4) return fail(PLLGPU_EINVAL, "sumtable slot %u out of range", slot);
-  return c->sumtable[slot].ensure(clv_elems(c, c->geo.sites));
+  return c->sumtable[slot].ensure(clv_elems(c, c->geo.sites_alloc));
 }
 
 extern "C" int pllgpu_update_sumtable(pllgpu_ctx_t *c, const pllgpu_sumtable_t *st, unsigned slot)
@@ -928,7 +932,7 @@ extern "C" int pllgpu_update_sumtable(pllgpu_ctx_t *c, const pllgpu_sumtable_t *
   DevOp &d = pack.ops[0];
   memset(&d, 0, sizeof d);
   d.parent = c->sumtable[slot].p;
-  d.entries = g.sites;
+  d.entries = g.sites_alloc; // with ascertainment bias the per-state extra entries belong to the table
   if (st->left_is_tip)
   {
     if (st->left_clv >= g.tips || !c->tipchars[st->left_clv].p) return fail(PLLGPU_EINVAL, "tip %u has no codes on the device", st->left_clv);
@@ -949,7 +953,7 @@ extern "C" int pllgpu_update_sumtable(pllgpu_ctx_t *c, const pllgpu_sumtable_t *
     d.rsid = c->ids[st->right_clv] ? c->site_id[st->right_clv].p : nullptr;
   }
   const unsigned kind = st->left_is_tip ? 1u : 0u;
-  launch_partials(c, pack, 1, g.sites, kind, st->gather != 0);
+  if (int rc = launch_partials(c, pack, 1, g.sites_alloc, kind, st->gather != 0)) return rc;
   if (g.per_rate_scalers && (st->left_scaler >= 0 || st->right_scaler >= 0))
   {
     DevExcess e;
@@ -959,8 +963,8 @@ extern "C" int pllgpu_update_sumtable(pllgpu_ctx_t *c, const pllgpu_sumtable_t *
     if (int rc = scaler_ptr(c, st->right_scaler, e.cscaler)) return rc;
     e.psid = d.lsid;
     e.csid = d.rsid;
-    e.sites = g.sites;
-    const unsigned tiles = (g.sites + 63) / 64;
+    e.sites = g.sites_alloc;
+    const unsigned tiles = (g.sites_alloc + 63) / 64;
     hipLaunchKernelGGL(k_sumtable_excess, dim3((tiles + 3) / 4), dim3(256), 0, c->stream, e, c->gg);
   }
   HIP_TRY(hipGetLastError());
@@ -971,10 +975,10 @@ extern "C" int pllgpu_sumtable_upload(pllgpu_ctx_t *c, unsigned slot, const doub
 {
   CHECK_CTX(c);
   if (int rc = sumtable_slot(c, slot)) return rc;
-  const size_t n = (size_t)c->geo.sites * c->span;
+  const size_t n = (size_t)c->geo.sites_alloc * c->span;
   if (int rc = c->scratch.ensure(n)) return rc;
   HIP_TRY(hipMemcpyAsync(c->scratch.p, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_aos_to_tiled, dim3(1024), dim3(256), 0, c->stream, c->scratch.p, c->sumtable[slot].p, c->geo.sites,
+  hipLaunchKernelGGL(k_aos_to_tiled, dim3(1024), dim3(256), 0, c->stream, c->scratch.p, c->sumtable[slot].p, c->geo.sites_alloc,
                      c->gg.S, c->gg.SP, c->gg.R);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -984,9 +988,9 @@ extern "C" int pllgpu_sumtable_download(pllgpu_ctx_t *c, unsigned slot, double *
 {
   CHECK_CTX(c);
   if (slot >= 4 || !c->sumtable[slot].p) return fail(PLLGPU_EINVAL, "sumtable slot %u is empty", slot);
-  const size_t n = (size_t)c->geo.sites * c->span;
+  const size_t n = (size_t)c->geo.sites_alloc * c->span;
   if (int rc = c->scratch.ensure(n)) return rc;
-  hipLaunchKernelGGL(k_tiled_to_aos, dim3(1024), dim3(256), 0, c->stream, c->sumtable[slot].p, c->scratch.p, c->geo.sites,
+  hipLaunchKernelGGL(k_tiled_to_aos, dim3(1024), dim3(256), 0, c->stream, c->sumtable[slot].p, c->scratch.p, c->geo.sites_alloc,
                      c->gg.S, c->gg.SP, c->gg.R);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(host, c->scratch.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -995,11 +999,12 @@ extern "C" int pllgpu_sumtable_download(pllgpu_ctx_t *c, unsigned slot, double *
 }
 
 extern "C" int pllgpu_likelihood_derivatives(pllgpu_ctx_t *c, unsigned slot, double branch_length,
-                                             const unsigned *params_indices, double *d_f, double *dd_f)
+                                             const unsigned *params_indices, unsigned eval_sites, double *d_f, double *dd_f)
 {
   CHECK_CTX(c);
   const pllgpu_geometry_t &g = c->geo;
   if (slot >= 4 || !c->sumtable[slot].p) return fail(PLLGPU_EINVAL, "sumtable slot %u is empty", slot);
+  if (eval_sites == 0 || eval_sites > g.sites_alloc) return fail(PLLGPU_EINVAL, "eval_sites %u out of range", eval_sites);
   if (!c->eigenvals.p || !c->rates.p) return fail(PLLGPU_EINVAL, "eigenvalues / category rates were not uploaded");
   if (int rc = c->diag.ensure((size_t)g.rate_cats * g.states * 4)) return rc;
   DevDiag dg;
@@ -1027,16 +1032,16 @@ extern "C" int pllgpu_likelihood_derivatives(pllgpu_ctx_t *c, unsigned slot, dou
   dv.rate_weights = c->rate_weights.p;
   dv.prop_invar = c->prop_invar.p;
   dv.pattern_weights = c->pattern_weights.p;
-  dv.invariant = c->invariant_set ? c->invariant.p : nullptr;
+  dv.invariant = (c->invariant_set && eval_sites <= g.sites) ? c->invariant.p : nullptr;
   dv.block_sums = c->block_sums.p;
   dv.counter = c->counter.p;
   dv.result = c->result_dev;
   c->seq += 1.0;
   dv.sequence = c->seq;
-  dv.sites = g.sites;
+  dv.sites = eval_sites;
   unsigned long long seq_bits;
   memcpy(&seq_bits, &c->seq, sizeof seq_bits);
-  const unsigned tiles = (g.sites + 63) / 64;
+  const unsigned tiles = (eval_sites + 63) / 64;
   const unsigned tpw = (tiles + 4 * 1024 - 1) / (4 * 1024);
   const unsigned blocks = (tiles + 4 * tpw - 1) / (4 * tpw);
   hipLaunchKernelGGL(k_derivatives, dim3(blocks), dim3(256), 0, c->stream, dv, c->gg, tpw);
@@ -1054,5 +1059,86 @@ extern "C" int pllgpu_likelihood_derivatives(pllgpu_ctx_t *c, unsigned slot, dou
   }
   *d_f = c->result_host[0];
   *dd_f = c->result_host[2];
+  return 0;
+}
+
+// ---- ascertainment-bias terms --------------------------------------------------------------------
+extern "C" int pllgpu_asc_terms(pllgpu_ctx_t *c, const pllgpu_edge_t *ed, int is_root, double *terms, unsigned *scalings)
+{
+  CHECK_CTX(c);
+  const pllgpu_geometry_t &g = c->geo;
+  if (g.sites_alloc < g.sites + g.states) return fail(PLLGPU_EINVAL, "the partition has no per-state extra entries");
+  if (ed->parent_clv >= g.nodes || !c->clv[ed->parent_clv].p) return fail(PLLGPU_EINVAL, "CLV %u unavailable on the device", ed->parent_clv);
+  DevAsc a;
+  memset(&a, 0, sizeof a);
+  a.parent = c->clv[ed->parent_clv].p;
+  if (int rc = scaler_ptr(c, ed->parent_scaler, a.pscaler)) return rc;
+  if (!is_root)
+  {
+    if (ed->child_clv >= g.nodes || ed->matrix >= g.prob_matrices) return fail(PLLGPU_EINVAL, "edge references an index out of range");
+    if (ed->child_is_tip)
+    {
+      if (ed->child_clv >= g.tips || !c->tipchars[ed->child_clv].p) return fail(PLLGPU_EINVAL, "tip %u has no codes on the device", ed->child_clv);
+      a.ctip = c->tipchars[ed->child_clv].p;
+    }
+    else
+    {
+      if (!c->clv[ed->child_clv].p) return fail(PLLGPU_EINVAL, "CLV %u unavailable on the device", ed->child_clv);
+      a.child = c->clv[ed->child_clv].p;
+      if (int rc = scaler_ptr(c, ed->child_scaler, a.cscaler)) return rc;
+    }
+    a.mat = c->pmat.p + (size_t)ed->matrix * c->pm_stride;
+  }
+  for (unsigned k = 0; k < g.rate_cats; ++k)
+  {
+    if (ed->freqs_indices[k] >= g.rate_matrices) return fail(PLLGPU_EINVAL, "freqs_indices[%u] out of range", k);
+    a.fidx[k] = (unsigned char)ed->freqs_indices[k];
+  }
+  a.freqs = c->freqs.p;
+  a.rate_weights = c->rate_weights.p;
+  a.out = c->result_dev + kAscOff;
+  a.first = g.sites;
+  a.per_rate = g.per_rate_scalers ? 1 : 0;
+  a.is_root = is_root;
+  const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
+  hipLaunchKernelGGL(k_asc_terms, dim3(g.states), dim3(64), 0, c->stream, a, c->gg, tm);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (unsigned n = 0; n < g.states; ++n)
+  {
+    terms[n] = c->result_host[kAscOff + n];
+    scalings[n] = (unsigned)c->result_host[kAscOff + g.states + n];
+  }
+  return 0;
+}
+
+extern "C" int pllgpu_asc_derivative_terms(pllgpu_ctx_t *c, unsigned slot, int parent_scaler, int child_scaler,
+                                           const unsigned *params_indices, double *lk, unsigned *scalings)
+{
+  CHECK_CTX(c);
+  (void)params_indices; // the diag table of the last evaluation already carries them
+  const pllgpu_geometry_t &g = c->geo;
+  if (g.sites_alloc < g.sites + g.states) return fail(PLLGPU_EINVAL, "the partition has no per-state extra entries");
+  if (slot >= 4 || !c->sumtable[slot].p || !c->diag.p) return fail(PLLGPU_EINVAL, "no derivative evaluation precedes the ascertainment terms");
+  DevAscDeriv a;
+  memset(&a, 0, sizeof a);
+  a.table = c->sumtable[slot].p;
+  a.diag = c->diag.p;
+  a.rate_weights = c->rate_weights.p;
+  if (int rc = scaler_ptr(c, parent_scaler, a.pscaler)) return rc;
+  if (int rc = scaler_ptr(c, child_scaler, a.cscaler)) return rc;
+  a.out = c->result_dev + kAscOff;
+  a.first = g.sites;
+  a.per_rate = g.per_rate_scalers ? 1 : 0;
+  hipLaunchKernelGGL(k_asc_deriv_terms, dim3(1), dim3(64), 0, c->stream, a, c->gg);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (unsigned n = 0; n < g.states; ++n)
+  {
+    lk[3 * n + 0] = c->result_host[kAscOff + 3 * n + 0];
+    lk[3 * n + 1] = c->result_host[kAscOff + 3 * n + 1];
+    lk[3 * n + 2] = c->result_host[kAscOff + 3 * n + 2];
+    scalings[n] = (unsigned)c->result_host[kAscOff + 3 * g.states + n];
+  }
   return 0;
 }

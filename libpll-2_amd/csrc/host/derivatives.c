@@ -11,6 +11,8 @@
  * eigensystem, a frequency vector or params_indices changed. The caller's `sumtable` pointer is a
  * handle to one of four device slots (least recently used is recycled).
  */
+#include <math.h>
+
 #include "pll_internal.h"
 
 static int fail_loudly(const char *what)
@@ -205,8 +207,7 @@ int pll_compute_likelihood_derivatives(pll_partition_t *p, int parent_scaler_ind
                                        const double *sumtable, double *d_f, double *dd_f)
 {
   pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
-  (void)parent_scaler_index; /* only the ascertainment-bias terms use the scalers (:851-924): out of scope */
-  (void)child_scaler_index;
+  const int asc_type = (int)(p->attributes & PLL_ATTRIB_AB_MASK);
   if (!x || !x->ctx)
   {
     pll_set_error(PLL_ERROR_GPU_UNAVAILABLE, "pll_compute_likelihood_derivatives: no MI355X context behind this partition; this library has no CPU path");
@@ -230,10 +231,53 @@ int pll_compute_likelihood_derivatives(pll_partition_t *p, int parent_scaler_ind
       return PLL_FAILURE;
     }
   }
-  if (pllgpu_likelihood_derivatives(x->ctx, (unsigned)slot, branch_length, params_indices, d_f, dd_f) != 0)
+  /* Stamatakis: the per-state extra entries are ordinary weighted sites (src/core_derivatives.c:733-742) */
+  const unsigned int eval_sites = p->sites + (asc_type == PLL_ATTRIB_AB_STAMATAKIS ? p->states : 0);
+  if (pllgpu_likelihood_derivatives(x->ctx, (unsigned)slot, branch_length, params_indices, eval_sites, d_f, dd_f) != 0)
   {
     pll_set_gpu_error("pll_compute_likelihood_derivatives");
     return PLL_FAILURE;
+  }
+  if (asc_type && asc_type != PLL_ATTRIB_AB_STAMATAKIS)
+  {
+    /* Lewis / Felsenstein (src/core_derivatives.c:851-924): (L, L', L'') of the extra entries with
+     * their scaling undone, summed over the states. pattern_weight_sum stands for the reference's
+     * on-the-spot sum of pattern_weights[0..sites) (:900-902): equal whenever the weights were set
+     * through pll_set_pattern_weights. */
+    double lk[3 * 64], asc[3] = {0.0, 0.0, 0.0};
+    unsigned int sc[64], n, sum_w_inv = 0;
+    if (parent_scaler_index >= (int)p->scale_buffers || child_scaler_index >= (int)p->scale_buffers ||
+        !pll_flush_scaler(p, x, parent_scaler_index) || !pll_flush_scaler(p, x, child_scaler_index))
+      return fail_loudly("pll_compute_likelihood_derivatives");
+    if (pllgpu_asc_derivative_terms(x->ctx, (unsigned)slot, parent_scaler_index, child_scaler_index, params_indices, lk, sc) != 0)
+    {
+      pll_set_gpu_error("pll_compute_likelihood_derivatives (ascertainment terms)");
+      return PLL_FAILURE;
+    }
+    for (n = 0; n < p->states; ++n)
+    {
+      const double f = pow(PLL_SCALE_THRESHOLD, (double)sc[n]);
+      asc[0] += lk[3 * n + 0] * f;
+      asc[1] += lk[3 * n + 1] * f;
+      asc[2] += lk[3 * n + 2] * f;
+      sum_w_inv += p->pattern_weights[p->sites + n];
+    }
+    if (asc_type == PLL_ATTRIB_AB_LEWIS)
+    {
+      const double w = (double)p->pattern_weight_sum;
+      *d_f += w * (asc[1] / (asc[0] - 1.0));
+      *dd_f += w * (((asc[0] - 1.0) * asc[2] - asc[1] * asc[1]) / ((asc[0] - 1.0) * (asc[0] - 1.0)));
+    }
+    else if (asc_type == PLL_ATTRIB_AB_FELSENSTEIN)
+    {
+      *d_f -= sum_w_inv * (asc[1] / asc[0]);
+      *dd_f -= sum_w_inv * (((asc[2] * asc[0]) - asc[1] * asc[1]) / (asc[0] * asc[0]));
+    }
+    else
+    {
+      pll_set_error(PLL_ERROR_AB_INVALIDMETHOD, "Illegal ascertainment bias algorithm");
+      return PLL_FAILURE;
+    }
   }
   return PLL_SUCCESS;
 }

@@ -15,6 +15,53 @@ static double fail_lnl(const char *what)
   return -INFINITY; /* the reference's failure value, src/core_likelihood.c:1384 */
 }
 
+/* Ascertainment-bias correction (src/likelihood.c:24-48 and the three *_asc_bias functions): the
+ * device returns, per state n, the likelihood of the extra entry sites + n and its scaling count;
+ * the correction formula runs here in the reference's order.
+ * Deliberate differences from the reference, both in code it gets wrong:
+ *  - with PLL_ATTRIB_RATE_SCALERS it indexes the [entry][rate] scaler array as if it were per site
+ *    (:219,241,376-379,411-412); here the per-rate counts are honoured (min + capped differences,
+ *    like the main kernel);
+ *  - pll_compute_root_loglikelihood locates the extra entries at sites_number - rate_cats (:180),
+ *    which is only right when rate_cats == states; here they are taken where they are stored.
+ * Kept as is: the Stamatakis term adds scale_factors * log(2^-256) unweighted (:98-100). */
+static double asc_correction(pll_partition_t *p, pll_amd_ext_t *x, const pllgpu_edge_t *e, int is_root)
+{
+  double terms[64];
+  unsigned int sc[64];
+  unsigned int n, sum_w_inv = 0;
+  const int type = (int)(p->attributes & PLL_ATTRIB_AB_MASK);
+  const unsigned int *w = p->pattern_weights + p->sites;
+  double base = 0.0;
+  if (pllgpu_asc_terms(x->ctx, e, is_root, terms, sc) != 0)
+  {
+    pll_set_gpu_error("ascertainment bias terms");
+    return -INFINITY;
+  }
+  for (n = 0; n < p->states; ++n)
+  {
+    double site_lk;
+    sum_w_inv += w[n];
+    if (type == PLL_ATTRIB_AB_STAMATAKIS)
+    {
+      site_lk = log(terms[n]) * w[n];
+      if (sc[n]) site_lk += sc[n] * log(PLL_SCALE_THRESHOLD);
+    }
+    else
+      site_lk = terms[n] * pow(PLL_SCALE_THRESHOLD, (double)sc[n]);
+    base += site_lk;
+  }
+  switch (type)
+  {
+    case PLL_ATTRIB_AB_LEWIS: return -(p->pattern_weight_sum * log(1 - base));
+    case PLL_ATTRIB_AB_STAMATAKIS: return base;
+    case PLL_ATTRIB_AB_FELSENSTEIN: return sum_w_inv * log(base);
+    default:
+      pll_set_error(PLL_ERROR_AB_INVALIDMETHOD, "Illegal ascertainment bias algorithm");
+      return -INFINITY;
+  }
+}
+
 static int prepare_end(pll_partition_t *p, pll_amd_ext_t *x, unsigned int clv, int scaler)
 {
   if (!pll_flush_clv(p, x, clv)) return 0;
@@ -76,6 +123,7 @@ double pll_compute_edge_loglikelihood(pll_partition_t *p, unsigned int parent_cl
     pll_set_gpu_error("pll_compute_edge_loglikelihood");
     return -INFINITY;
   }
+  if (p->attributes & PLL_ATTRIB_AB_MASK) lnl += asc_correction(p, x, &e, 0);
   return lnl;
 }
 
@@ -102,6 +150,15 @@ double pll_compute_root_loglikelihood(pll_partition_t *p, unsigned int clv_index
   {
     pll_set_gpu_error("pll_compute_root_loglikelihood");
     return -INFINITY;
+  }
+  if (p->attributes & PLL_ATTRIB_AB_MASK)
+  {
+    pllgpu_edge_t e;
+    memset(&e, 0, sizeof e);
+    e.parent_clv = clv_index;
+    e.parent_scaler = scaler_index;
+    e.freqs_indices = freqs_indices;
+    lnl += asc_correction(p, x, &e, 1);
   }
   return lnl;
 }

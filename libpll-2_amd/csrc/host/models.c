@@ -343,6 +343,11 @@ int pll_update_invariant_sites(pll_partition_t *p)
 int pll_update_invariant_sites_proportion(pll_partition_t *p, unsigned int idx, double pinv)
 {
   pll_amd_ext_t *x = pll_ext(p);
+  if (pinv != 0.0 && (p->attributes & PLL_ATTRIB_AB_MASK)) /* src/models.c:500-508 */
+  {
+    pll_set_error(PLL_ERROR_INVAR_INCOMPAT, "Invariant sites are not compatible with asc bias correction");
+    return PLL_FAILURE;
+  }
   if (pinv < 0 || pinv >= 1)
   {
     pll_set_error(PLL_ERROR_INVAR_PROPORTION, "Invalid proportion of invariant sites (%f)", pinv);

@@ -192,9 +192,16 @@ pll_partition_t *pll_partition_create(unsigned int tips, unsigned int clv_buffer
     pll_set_error(PLL_ERROR_PARAM_INVALID, "PLL_ATTRIB_PATTERN_TIP and PLL_ATTRIB_SITE_REPEATS are mutually exclusive.");
     return NULL;
   }
-  if (attributes & (PLL_ATTRIB_AB_MASK | PLL_ATTRIB_AB_FLAG))
+  if ((attributes & (PLL_ATTRIB_AB_MASK | PLL_ATTRIB_AB_FLAG)) && (attributes & PLL_ATTRIB_SITE_REPEATS))
   {
-    pll_set_error(PLL_ERROR_GPU_UNSUPPORTED, "ascertainment-bias correction is outside the MI355X hot path (SURVEY.md section 8: out of scope).");
+    /* the reference's repeats update never computes the per-state extra sites
+     * (src/partials.c:183-235 has no asc_bias_alloc branch): the combination has no defined result */
+    pll_set_error(PLL_ERROR_GPU_UNSUPPORTED, "ascertainment-bias correction cannot be combined with PLL_ATTRIB_SITE_REPEATS.");
+    return NULL;
+  }
+  if ((attributes & PLL_ATTRIB_AB_MASK) > PLL_ATTRIB_AB_STAMATAKIS)
+  {
+    pll_set_error(PLL_ERROR_AB_INVALIDMETHOD, "Illegal ascertainment bias algorithm \"%d\"", (int)(attributes & PLL_ATTRIB_AB_MASK));
     return NULL;
   }
   if (states < 2 || states > 64 || rate_cats < 1)
@@ -237,9 +244,10 @@ pll_partition_t *pll_partition_create(unsigned int tips, unsigned int clv_buffer
   p->prob_matrices = prob_matrices;
   p->rate_cats = rate_cats;
   p->scale_buffers = scale_buffers;
-  p->asc_bias_alloc = 0;
-  p->asc_additional_sites = 0;
-  const unsigned int sites_alloc = sites;
+  /* one extra "site" per state behind the real ones (src/pll.c:525-531) */
+  p->asc_bias_alloc = (attributes & (PLL_ATTRIB_AB_MASK | PLL_ATTRIB_AB_FLAG)) != 0;
+  p->asc_additional_sites = p->asc_bias_alloc ? (int)states : 0;
+  const unsigned int sites_alloc = sites + (unsigned int)p->asc_additional_sites;
   x->sites_alloc = sites_alloc;
   const int repeats = (attributes & PLL_ATTRIB_SITE_REPEATS) != 0;
   const size_t span = (size_t)rate_cats * sp;
@@ -302,7 +310,8 @@ pll_partition_t *pll_partition_create(unsigned int tips, unsigned int clv_buffer
   NEED(p->prop_invar);
   p->pattern_weights = (unsigned int *)malloc((sites_alloc ? sites_alloc : 1) * sizeof(unsigned int));
   NEED(p->pattern_weights);
-  for (i = 0; i < sites_alloc; ++i) p->pattern_weights[i] = 1;
+  for (i = 0; i < sites; ++i) p->pattern_weights[i] = 1;
+  for (i = sites; i < sites_alloc; ++i) p->pattern_weights[i] = 0; /* src/pll.c:822-824 */
   p->scale_buffer = (unsigned int **)calloc(scale_buffers ? scale_buffers : 1, sizeof(unsigned int *));
   NEED(p->scale_buffer);
   if (!repeats)
@@ -412,6 +421,42 @@ void pll_set_pattern_weights(pll_partition_t *p, const unsigned int *w)
   if (x) x->pattern_weights_dirty = 1;
 }
 
+/* src/pll.c:1145-1191 */
+int pll_set_asc_bias_type(pll_partition_t *p, int asc_bias_type)
+{
+  unsigned int i;
+  int prop_invar = 0;
+  const int attr = asc_bias_type & PLL_ATTRIB_AB_MASK;
+  if (!p->asc_bias_alloc)
+  {
+    pll_set_error(PLL_ERROR_AB_NOSUPPORT, "Partition was not created with ascertainment bias support");
+    return PLL_FAILURE;
+  }
+  for (i = 0; i < p->rate_matrices; ++i) prop_invar |= (p->prop_invar[i] > 0);
+  if (asc_bias_type != 0 && prop_invar)
+  {
+    pll_set_error(PLL_ERROR_INVAR_INCOMPAT, "Invariant sites are not compatible with asc bias correction");
+    return PLL_FAILURE;
+  }
+  if (attr != asc_bias_type || (unsigned int)attr > PLL_ATTRIB_AB_STAMATAKIS)
+  {
+    pll_set_error(PLL_ERROR_AB_INVALIDMETHOD, "Illegal ascertainment bias algorithm \"%d\"", asc_bias_type);
+    return PLL_FAILURE;
+  }
+  p->attributes &= ~(unsigned int)PLL_ATTRIB_AB_MASK;
+  p->attributes |= (unsigned int)attr;
+  return PLL_SUCCESS;
+}
+
+/* src/pll.c:1193-1200 */
+void pll_set_asc_state_weights(pll_partition_t *p, const unsigned int *state_weights)
+{
+  if (!p->asc_bias_alloc) return; /* the reference asserts */
+  memcpy(p->pattern_weights + p->sites, state_weights, sizeof(unsigned int) * p->states);
+  pll_amd_ext_t *x = pll_ext(p);
+  if (x) x->pattern_weights_dirty = 1;
+}
+
 void pll_set_frequencies(pll_partition_t *p, unsigned int idx, const double *f)
 {
   unsigned int i;
@@ -498,7 +543,7 @@ int pll_flush_model(pll_partition_t *p, pll_amd_ext_t *x)
   }
   if (x->pattern_weights_dirty)
   {
-    GPU_TRY(pllgpu_pattern_weights_upload(x->ctx, p->pattern_weights, p->sites), "pattern weights upload");
+    GPU_TRY(pllgpu_pattern_weights_upload(x->ctx, p->pattern_weights, x->sites_alloc), "pattern weights upload");
     x->pattern_weights_dirty = 0;
   }
   if (x->invariant_dirty)

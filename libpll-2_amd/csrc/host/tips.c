@@ -135,7 +135,33 @@ static int encode_tipchars(pll_partition_t *p, unsigned int tip, const pll_state
     if (!m) return illegal_state(seq[i]);
     dst[i] = (p->states == 4) ? (unsigned char)m : p->charmap[(unsigned char)seq[i]];
   }
+  if (p->asc_bias_alloc)
+  {
+    /* the per-state extra sites: state i at position sites + i (src/pll.c:897-905, :935-953) */
+    dst += p->sites;
+    memset(dst, 0, p->states);
+    if (p->states == 4)
+      for (i = 0; i < 4; ++i) dst[i] = (unsigned char)(1u << i);
+    else
+      for (i = 0; i < p->maxstates; ++i)
+      {
+        const pll_state_t st = p->tipmap[i];
+        if (__builtin_popcountll(st) == 1 && (unsigned int)__builtin_ctzll(st) < p->states)
+          dst[__builtin_ctzll(st)] = (unsigned char)i;
+      }
+  }
   return PLL_SUCCESS;
+}
+
+/* the per-state extra sites of a tip CLV: indicator of state i at entry first + i
+ * (src/pll.c:1003-1021, :1113-1126) */
+static void asc_tip_entries(const pll_partition_t *p, double *clv, unsigned int first)
+{
+  const size_t span = (size_t)p->rate_cats * p->states_padded;
+  unsigned int i, j, k;
+  for (i = 0; i < p->states; ++i)
+    for (k = 0; k < p->rate_cats; ++k)
+      for (j = 0; j < p->states; ++j) clv[(first + i) * span + (size_t)k * p->states_padded + j] = (j == i) ? 1.0 : 0.0;
 }
 
 static void spread_mask(const pll_partition_t *p, pll_state_t m, double *dst)
@@ -171,7 +197,7 @@ static int encode_tipclv(pll_partition_t *p, unsigned int tip, const pll_state_t
   if (compact)
   {
     free(x->tipcodes[tip]);
-    x->tipcodes[tip] = (unsigned char *)malloc(n ? n : 1);
+    x->tipcodes[tip] = (unsigned char *)malloc((size_t)n + p->states);
     compact = x->tipcodes[tip] != NULL;
   }
   for (i = 0; i < n; ++i)
@@ -185,6 +211,16 @@ static int encode_tipclv(pll_partition_t *p, unsigned int tip, const pll_state_t
       const int code = compact_code(p, x, m);
       if (code < 0) compact = 0;
       else x->tipcodes[tip][i] = (unsigned char)code;
+    }
+  }
+  if (p->asc_bias_alloc)
+  {
+    asc_tip_entries(p, clv, n);
+    for (i = 0; compact && i < p->states; ++i)
+    {
+      const int code = compact_code(p, x, (pll_state_t)1 << i);
+      if (code < 0) compact = 0;
+      else x->tipcodes[tip][n + i] = (unsigned char)code;
     }
   }
   if (x) x->tip_compact[tip] = (unsigned char)compact;
@@ -248,6 +284,7 @@ int pll_set_tip_clv(pll_partition_t *p, unsigned int tip, const double *clv, int
     const double *src = clv + (size_t)site * in_stride;
     for (k = 0; k < p->rate_cats; ++k, dst += p->states_padded) memcpy(dst, src, p->states * sizeof(double));
   }
+  if (p->asc_bias_alloc) asc_tip_entries(p, p->clv[tip], n);
   if (x)
   {
     x->clv_side[tip] = SIDE_HOST;

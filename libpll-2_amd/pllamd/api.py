@@ -112,6 +112,8 @@ _PROTOS = {
     "pll_set_tip_states": (C.c_int, [PartitionP, C.c_uint, c_state_p, C.c_char_p]),
     "pll_set_tip_clv": (C.c_int, [PartitionP, C.c_uint, c_double_p, C.c_int]),
     "pll_set_pattern_weights": (None, [PartitionP, c_uint_p]),
+    "pll_set_asc_bias_type": (C.c_int, [PartitionP, C.c_int]),
+    "pll_set_asc_state_weights": (None, [PartitionP, c_uint_p]),
     "pll_set_frequencies": (None, [PartitionP, C.c_uint, c_double_p]),
     "pll_set_subst_params": (None, [PartitionP, C.c_uint, c_double_p]),
     "pll_set_category_rates": (None, [PartitionP, c_double_p]),

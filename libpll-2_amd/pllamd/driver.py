@@ -41,6 +41,11 @@ class Case:
     # optional model description for the derivative tests: exch (upper triangle), rates (category
     # rates), and the list of branch lengths at which derivatives are evaluated
     model: Optional[dict] = None
+    # ascertainment-bias correction: attributes must carry api.AB_FLAG (extra per-state entries);
+    # asc_type 0 none, 1 Lewis, 2 Felsenstein, 3 Stamatakis (PLL_ATTRIB_AB_* >> 5), set through
+    # pll_set_asc_bias_type; asc_weights[states] through pll_set_asc_state_weights
+    asc_type: int = 0
+    asc_weights: Optional[np.ndarray] = None
 
     def __post_init__(self):
         self.pmatrix = np.ascontiguousarray(self.pmatrix, dtype=np.float64)
@@ -55,6 +60,15 @@ class Case:
             self.prop_invar = np.zeros(self.freqs.shape[0])
         if self.freqs_indices is None:
             self.freqs_indices = np.zeros(self.rate_cats, dtype=np.uint32)
+
+    @property
+    def asc_alloc(self):
+        return bool(self.attributes & (api.AB_FLAG | (7 << 5)))
+
+    @property
+    def entries_alloc(self):
+        """site entries per (uncompressed) CLV: the sites plus one extra entry per state"""
+        return self.sites + (self.states if self.asc_alloc else 0)
 
     @property
     def prob_matrices(self):
@@ -126,6 +140,12 @@ class Session:
                 a = np.ascontiguousarray(c.tip_clvs[t], dtype=np.float64)
                 if not lib.pll_set_tip_clv(self.p, t, api.dptr(a), 0):
                     raise RuntimeError(f"pll_set_tip_clv: [{lib.errno()}] {lib.errmsg()}")
+        if c.asc_weights is not None:
+            w = np.ascontiguousarray(c.asc_weights, dtype=np.uint32)
+            lib.pll_set_asc_state_weights(self.p, api.uptr(w))
+        if c.asc_type:
+            if not lib.pll_set_asc_bias_type(self.p, c.asc_type << 5):
+                raise RuntimeError(f"pll_set_asc_bias_type: [{lib.errno()}] {lib.errmsg()}")
         for m in range(c.rate_matrices):
             if c.prop_invar[m] > 0:
                 if not lib.pll_update_invariant_sites_proportion(self.p, m, float(c.prop_invar[m])):
@@ -174,13 +194,17 @@ class Session:
             a = a[ids]
         return a
 
+    def set_asc_type(self, asc_type):
+        if not self.lib.pll_set_asc_bias_type(self.p, asc_type << 5):
+            raise RuntimeError(f"pll_set_asc_bias_type: [{self.lib.errno()}] {self.lib.errmsg()}")
+
     def read_scaler(self, scaler_index, clv_index=None, expand=True):
         c = self.case
         if scaler_index < 0:
             return None
         if self.lib.is_amd:
             self.lib.pll_gpu_sync_scaler(self.p, scaler_index)
-        n = self.entries(clv_index) if clv_index is not None else c.sites
+        n = self.entries(clv_index) if clv_index is not None else c.entries_alloc
         per = c.rate_cats if (c.attributes & api.RATE_SCALERS) else 1
         a = api.as_np(self.part.scale_buffer[scaler_index], n * per, np.uint32).reshape(n, per).copy()
         if clv_index is not None and expand:
@@ -235,7 +259,7 @@ class Session:
     def new_sumtable(self):
         """caller-owned table, aligned like pll_aligned_alloc(.., partition->alignment) in the
         reference's tests (its AVX kernels use aligned stores)"""
-        n = self.case.sites * self.case.rate_cats * self.sp
+        n = self.case.entries_alloc * self.case.rate_cats * self.sp
         raw = np.zeros(n + 8, dtype=np.float64)
         off = (-raw.ctypes.data // 8) % 8  # doubles up to the next 64-byte boundary
         return raw[off:off + n]
@@ -246,12 +270,13 @@ class Session:
             raise RuntimeError(f"pll_update_sumtable: [{self.lib.errno()}] {self.lib.errmsg()}")
 
     def read_sumtable(self, sumtable):
-        """[sites][rate][states]; the AMD library keeps the table in HBM until asked for it"""
+        """[sites (+ states with ascertainment bias)][rate][states]; the AMD library keeps the table
+        in HBM until asked for it"""
         c = self.case
         if self.lib.is_amd:
             if not self.lib.pll_gpu_sync_sumtable(self.p, api.dptr(sumtable)):
                 raise RuntimeError(f"pll_gpu_sync_sumtable: [{self.lib.errno()}] {self.lib.errmsg()}")
-        return sumtable.reshape(c.sites, c.rate_cats, self.sp)[:, :, :c.states].copy()
+        return sumtable.reshape(c.entries_alloc, c.rate_cats, self.sp)[:, :, :c.states].copy()
 
     def derivatives(self, edge, sumtable, t):
         d1, d2 = C.c_double(0), C.c_double(0)

@@ -7,9 +7,9 @@ import numpy as np
 from .driver import Case
 
 _ARRAYS = ("pmatrix", "freqs", "charmap", "tip_clvs", "rate_weights", "pattern_weights", "prop_invar",
-           "freqs_indices")
+           "freqs_indices", "asc_weights")
 _SCALARS = ("name", "states", "rate_cats", "tips", "sites", "attributes", "clv_buffers", "scale_buffers",
-            "update_repeats")
+            "update_repeats", "asc_type")
 
 
 def save(path, case: Case, expected: dict, extra: dict = None, arrays: dict = None):
@@ -52,7 +52,7 @@ def save(path, case: Case, expected: dict, extra: dict = None, arrays: dict = No
 def load(path):
     z = np.load(path)
     meta = json.loads(bytes(z["meta"]).decode())
-    kw = {k: meta[k] for k in _SCALARS}
+    kw = {k: meta[k] for k in _SCALARS if k in meta}
     for k in _ARRAYS:
         if "in_" + k in z:
             kw[k] = z["in_" + k]

@@ -198,7 +198,8 @@ def synthetic_exch(states):
 
 def make_case(name, states, tips, sites, rate_cats=4, tree="balanced", attributes=0, seed=1,
               mutate_pct=30, alpha=0.5, scalers=True, tips_as="states", exch=None, freqs=None,
-              brlen_scale=1.0, pinv=0.0, pattern_weights=None, ambiguity_pct=0, partial_pct=0):
+              brlen_scale=1.0, pinv=0.0, pattern_weights=None, ambiguity_pct=0, partial_pct=0,
+              asc_type=None, asc_weights=None):
     """One synthetic configuration of SURVEY 8d (C2: states=4,tips=64,sites=100000; C3: 20/64/
     50000; C5: 61/32/20000)."""
     if exch is None:
@@ -248,6 +249,11 @@ def make_case(name, states, tips, sites, rate_cats=4, tree="balanced", attribute
         kw.update(charmap=cmap, sequences=seqs)
     else:
         kw.update(tip_clvs=onehot_clvs(st, states))
+    if asc_type is not None:
+        # ascertainment-bias partition (extra per-state entries); asc_type 0 keeps the correction off
+        from . import api
+        attributes |= api.AB_FLAG
+        kw.update(asc_type=asc_type, asc_weights=None if asc_weights is None else np.asarray(asc_weights, dtype=np.uint32))
     return Case(name=name, states=states, rate_cats=rate_cats, tips=tips, sites=sites, pmatrix=pm,
                 freqs=freqs[None, :], op_batches=[ops], edges=[edge], attributes=attributes,
                 clv_buffers=tips - 2, scale_buffers=(tips - 2) if scalers else 0,

@@ -156,6 +156,26 @@ def synthetic_cases():
     yield W.make_case("s61_tip", 61, 8, 24, attributes=A.PATTERN_TIP)
     yield W.make_case("s61_clvtips", 61, 8, 24, tips_as="clv")
     yield W.make_case("s64_plain", 64, 4, 16)
+    # ascertainment-bias correction (test/src/asc-bias.c exercises it on testdata/2000.fas, which the
+    # reference snapshot does not carry: pinned by the reference library's own output instead).
+    # Root evaluations only where states == rate_cats: src/likelihood.c:180 subtracts rate_cats
+    # where it means states.
+    def with_root(c):
+        c.roots = [(c.edges[0][0], c.edges[0][1])]
+        return c
+    yield with_root(W.make_case("asc_dna_lewis", 4, 16, 200, asc_type=1))
+    yield with_root(W.make_case("asc_dna_fels_tip", 4, 16, 200, asc_type=2, asc_weights=[50, 40, 60, 20],
+                                attributes=A.PATTERN_TIP, ambiguity_pct=5))
+    yield with_root(W.make_case("asc_dna_stam", 4, 16, 200, asc_type=3, asc_weights=[5, 4, 6, 2]))
+    yield W.make_case("asc_dna_off", 4, 16, 200, asc_type=0)
+    yield with_root(W.make_case("asc_dna_deep_fels", 4, 300, 48, tree="caterpillar", brlen_scale=3, asc_type=2,
+                                asc_weights=[5, 4, 6, 2]))
+    yield with_root(W.make_case("asc_dna_deep_stam_tip", 4, 300, 48, tree="caterpillar", brlen_scale=3, asc_type=3,
+                                asc_weights=[5, 4, 6, 2], attributes=A.PATTERN_TIP))
+    yield with_root(W.make_case("asc_dna_deep_lewis", 4, 300, 48, tree="caterpillar", brlen_scale=3, asc_type=1))
+    yield W.make_case("asc_aa_lewis", 20, 8, 64, asc_type=1)
+    yield W.make_case("asc_aa_fels_tip", 20, 8, 64, asc_type=2, asc_weights=list(range(1, 21)), attributes=A.PATTERN_TIP)
+    yield with_root(W.make_case("asc_s7_stam_r7", 7, 8, 64, rate_cats=7, asc_type=3, asc_weights=list(range(1, 8))))
 
 
 DERIV_BRLENS = [0.1, 0.2, 0.5, 0.9, 1.5, 5, 10, 50, 90]  # test/src/derivatives.c:48
@@ -260,6 +280,13 @@ def derivative_fixtures(ref, outdir):
         ("deriv_aa_tip", dict(states=20, tips=8, sites=64, attributes=A.PATTERN_TIP, ambiguity_pct=5)),
         ("deriv_s7_rates8", dict(states=7, tips=8, sites=64, rate_cats=8)),
         ("deriv_s61", dict(states=61, tips=8, sites=24)),
+        ("deriv_asc_lewis", dict(states=4, tips=16, sites=150, asc_type=1)),
+        ("deriv_asc_fels_deep", dict(states=4, tips=300, sites=48, tree="caterpillar", brlen_scale=3, asc_type=2,
+                                     asc_weights=[5, 4, 6, 2])),
+        ("deriv_asc_stam_tip", dict(states=4, tips=16, sites=150, asc_type=3, asc_weights=[5, 4, 6, 2],
+                                    attributes=A.PATTERN_TIP)),
+        ("deriv_asc_lewis_deep", dict(states=4, tips=300, sites=48, tree="caterpillar", brlen_scale=3, asc_type=1)),
+        ("deriv_asc_aa_fels", dict(states=20, tips=8, sites=64, asc_type=2, asc_weights=list(range(1, 21)))),
     ]
     brl = [0.001, 0.05, 0.3, 1.0, 4.0, 30.0]
     for name, kw in specs:

@@ -50,6 +50,10 @@ def dll():
         d.orc_root_loglikelihood.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.POINTER(Child),
                                              C.POINTER(c_double_p), c_double_p, c_uint_p, c_double_p,
                                              C.POINTER(C.c_int), c_uint_p, c_double_p, C.c_int]
+        d.orc_asc_bias_correction.restype = C.c_double
+        d.orc_asc_bias_correction.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.POINTER(Child),
+                                              C.POINTER(Child), c_double_p, C.POINTER(c_double_p), c_double_p,
+                                              c_uint_p, C.c_uint, c_uint_p, C.c_int, C.c_int]
         d.orc_repeat_classes.restype = C.c_uint
         d.orc_repeat_classes.argtypes = [C.c_uint, c_uint_p, C.c_uint, c_uint_p, C.c_uint, c_uint_p,
                                          c_uint_p]
@@ -132,6 +136,9 @@ def run_case(case, states_padded=None, pattern_tip=None):
 
     d = dll()
     s, r, n = case.states, case.rate_cats, case.sites
+    # ascertainment bias: one extra entry per state behind the sites (src/pll.c:525-531); every CLV
+    # update covers them, the lnL loops do not
+    na = n + (s if case.asc_alloc else 0)
     sp = states_padded or s
     per_rate = bool(case.attributes & api.RATE_SCALERS)
     if pattern_tip is None:
@@ -139,6 +146,9 @@ def run_case(case, states_padded=None, pattern_tip=None):
     span = r * sp
 
     masks = tip_masks(case)
+    if masks is not None and na > n:
+        onehot = np.uint64(1) << np.arange(s, dtype=np.uint64)
+        masks = np.concatenate([masks, np.broadcast_to(onehot, (case.tips, s))], axis=1)
     nodes = {}
     for t in range(case.tips):
         nd = _Node()
@@ -151,12 +161,14 @@ def run_case(case, states_padded=None, pattern_tip=None):
                 nd.tipmap = np.zeros(256, dtype=np.uint64)
                 nd.tipmap[:len(uniq)] = uniq
         else:
-            clv = np.zeros((n, r, sp))
+            clv = np.zeros((na, r, sp))
             if masks is not None:
                 bits = ((masks[t][:, None] >> np.arange(s, dtype=np.uint64)[None, :]) & np.uint64(1))
                 clv[:, :, :s] = bits[:, None, :].astype(np.float64)
             else:
-                clv[:, :, :s] = np.asarray(case.tip_clvs[t])[:, None, :]
+                clv[:n, :, :s] = np.asarray(case.tip_clvs[t])[:, None, :]
+                if na > n:
+                    clv[n:, :, :s] = np.eye(s)[:, None, :]
             nd.clv = np.ascontiguousarray(clv)
         nodes[t] = nd
 
@@ -174,13 +186,13 @@ def run_case(case, states_padded=None, pattern_tip=None):
             lch.scaler = _up(scalers[s1]) if s1 >= 0 else None
             rch.scaler = _up(scalers[s2]) if s2 >= 0 else None
             par = _Node()
-            par.clv = np.zeros((n, r, sp))
+            par.clv = np.zeros((na, r, sp))
             mode = 0
             pscal = None
             if psc >= 0:
                 mode = 2 if per_rate else 1
-                pscal = np.zeros(n * (r if per_rate else 1), dtype=np.uint32)
-            d.orc_update_partial(s, sp, r, n, _dp(par.clv), _up(pscal), None, C.byref(lch),
+                pscal = np.zeros(na * (r if per_rate else 1), dtype=np.uint32)
+            d.orc_update_partial(s, sp, r, na, _dp(par.clv), _up(pscal), None, C.byref(lch),
                                  _dp(pm[m1]), C.byref(rch), _dp(pm[m2]), mode)
             nodes[pc] = par
             if psc >= 0:
@@ -193,7 +205,7 @@ def run_case(case, states_padded=None, pattern_tip=None):
         out["clv"][idx] = nodes[idx].clv[:, :, :s].copy()
         psc = parents.get(idx, -1)
         if psc >= 0:
-            out["scaler"][idx] = scalers[psc].reshape(n, -1).copy()
+            out["scaler"][idx] = scalers[psc].reshape(na, -1).copy()
 
     fr = np.zeros((case.rate_matrices, sp))
     # pll_set_frequencies renormalises only when the sum is off by more than 1e-8
@@ -207,6 +219,14 @@ def run_case(case, states_padded=None, pattern_tip=None):
     inv = invariant_sites(case) if (pinv > 0).any() else None
     fi = np.ascontiguousarray(case.freqs_indices, dtype=np.uint32)
     invp = inv.ctypes.data_as(C.POINTER(C.c_int)) if inv is not None else None
+    aw = np.ascontiguousarray(case.asc_weights if case.asc_weights is not None else np.zeros(s), dtype=np.uint32)
+    pw_sum = int(np.asarray(case.pattern_weights, dtype=np.uint64).sum())
+
+    def asc(ach, bch, pmat):
+        if not case.asc_type:
+            return 0.0
+        return d.orc_asc_bias_correction(s, sp, r, n, ach, bch, pmat, fptrs, _dp(rw), _up(aw), pw_sum, _up(fi),
+                                         case.asc_type, int(per_rate))
 
     for (pc, psc, cc, csc, mi) in case.edges:
         a, b = nodes[pc], nodes[cc]
@@ -219,7 +239,7 @@ def run_case(case, states_padded=None, pattern_tip=None):
         v = d.orc_edge_loglikelihood(s, sp, r, n, C.byref(ach), C.byref(bch), _dp(pm[mi]), fptrs,
                                      _dp(rw), _up(pw), _dp(pinv), invp, _up(fi), _dp(ps),
                                      int(per_rate))
-        out["lnl"].append(v)
+        out["lnl"].append(v + asc(C.byref(ach), C.byref(bch), _dp(pm[mi])))
         out["persite"].append(ps)
     for (rc, rsc) in case.roots:
         ch = nodes[rc].child()
@@ -227,6 +247,6 @@ def run_case(case, states_padded=None, pattern_tip=None):
         ps = np.zeros(n)
         v = d.orc_root_loglikelihood(s, sp, r, n, C.byref(ch), fptrs, _dp(rw), _up(pw), _dp(pinv),
                                      invp, _up(fi), _dp(ps), int(per_rate))
-        out["root_lnl"].append(v)
+        out["root_lnl"].append(v + asc(C.byref(ch), None, None))
         out["root_persite"].append(ps)
     return out

@@ -415,3 +415,124 @@ void orc_likelihood_derivatives(unsigned int states, unsigned int sp, unsigned i
   }
   free(diag);
 }
+
+/* ---- ascertainment-bias correction ------------------------------------------------------------
+ * src/likelihood.c:24-48 (formula), :50-120 (root), :191-268 (tip-inner), :342-440 (inner-inner):
+ * the per-state extra entries first + n of both ends, state n's weight asc_weights[n]. The
+ * tip-inner variant multiplies by P[j][n] because the tip's extra entry n is state n (:232); here
+ * that falls out of the tip's code at the extra entry. Per-rate scalers: the reference indexes the
+ * [entry][rate] array per site there; this restatement brings the rates to the smallest count like
+ * the main routine (identical whenever the extra entries were never rescaled). */
+double orc_asc_bias_correction(unsigned int states, unsigned int sp, unsigned int rate_cats,
+                               unsigned int first, const orc_child_t *parent, const orc_child_t *child,
+                               const double *pmatrix, const double *const *frequencies,
+                               const double *rate_weights, const unsigned int *asc_weights,
+                               unsigned int pattern_weight_sum, const unsigned int *freqs_indices,
+                               int asc_type, int per_rate)
+{
+  const unsigned int span = rate_cats * sp;
+  double minlh[ORC_RATE_MAXDIFF];
+  unsigned int *excess = (unsigned int *)calloc(rate_cats ? rate_cats : 1, sizeof(unsigned int));
+  double *tb = (double *)malloc(sizeof(double) * states);
+  double base = 0;
+  unsigned int n, k, i, sum_w_inv = 0;
+  fill_minlh(minlh);
+  for (n = 0; n < states; ++n)
+  {
+    const unsigned int e = first + n;
+    const unsigned int scal = site_scalings(parent, e, child, e, rate_cats, per_rate, excess);
+    double terma = 0, site_lk;
+    for (k = 0; k < rate_cats; ++k)
+    {
+      const double *freqs = frequencies[freqs_indices[k]];
+      const double *xp = parent->clv + (size_t)e * span + (size_t)k * sp;
+      double terma_r = 0;
+      if (child)
+        branch_term(child, e, k, pmatrix + (size_t)k * states * sp, states, sp, span, tb);
+      else
+        for (i = 0; i < states; ++i) tb[i] = 1.0;
+      for (i = 0; i < states; ++i) terma_r += xp[i] * freqs[i] * tb[i];
+      if (per_rate && excess[k] > 0) terma_r *= minlh[excess[k] - 1];
+      terma += terma_r * rate_weights[k];
+    }
+    sum_w_inv += asc_weights[n];
+    if (asc_type == 3)
+    {
+      site_lk = log(terma) * asc_weights[n];
+      if (scal) site_lk += scal * log(ORC_SCALE_THRESHOLD); /* unweighted, as in :98-100 */
+    }
+    else
+      site_lk = terma * pow(ORC_SCALE_THRESHOLD, (double)scal);
+    base += site_lk;
+  }
+  free(excess);
+  free(tb);
+  switch (asc_type)
+  {
+    case 1: return -(pattern_weight_sum * log(1 - base));
+    case 2: return sum_w_inv * log(base);
+    case 3: return base;
+  }
+  return -INFINITY;
+}
+
+/* src/core_derivatives.c:851-924 (Lewis, Felsenstein; Stamatakis is the ordinary loop over
+ * sites + states entries, :733-742): contributions to d_f / dd_f from the extra table entries. */
+void orc_asc_bias_derivatives(unsigned int states, unsigned int sp, unsigned int rate_cats, unsigned int first,
+                              const unsigned int *parent_scaler, const unsigned int *child_scaler,
+                              const double *rate_weights, const unsigned int *asc_weights,
+                              unsigned int pattern_weight_sum, double branch_length, const double *prop_invar,
+                              const double *rates, const double *const *eigenvals, const double *sumtable,
+                              int asc_type, int per_rate, double *d_f, double *dd_f)
+{
+  double asc[3] = {0, 0, 0};
+  unsigned int n, k, j, sum_w_inv = 0;
+  for (n = 0; n < states; ++n)
+  {
+    double lk[3] = {0, 0, 0}, f;
+    unsigned int scal;
+    for (k = 0; k < rate_cats; ++k)
+    {
+      const double *sum = sumtable + ((size_t)(first + n) * rate_cats + k) * sp;
+      const double ki = rates[k] / (1.0 - prop_invar[k]);
+      double c[3] = {0, 0, 0};
+      for (j = 0; j < states; ++j)
+      {
+        const double e = exp(eigenvals[k][j] * ki * branch_length);
+        c[0] += sum[j] * e;
+        c[1] += sum[j] * (eigenvals[k][j] * ki * e);
+        c[2] += sum[j] * (eigenvals[k][j] * ki * eigenvals[k][j] * ki * e);
+      }
+      lk[0] += c[0] * rate_weights[k];
+      lk[1] += c[1] * rate_weights[k];
+      lk[2] += c[2] * rate_weights[k];
+    }
+    if (per_rate)
+    {
+      scal = UINT_MAX;
+      for (k = 0; k < rate_cats; ++k)
+      {
+        unsigned int s = (parent_scaler ? parent_scaler[(size_t)(first + n) * rate_cats + k] : 0) +
+                         (child_scaler ? child_scaler[(size_t)(first + n) * rate_cats + k] : 0);
+        if (s < scal) scal = s;
+      }
+    }
+    else
+      scal = (parent_scaler ? parent_scaler[first + n] : 0) + (child_scaler ? child_scaler[first + n] : 0);
+    f = pow(ORC_SCALE_THRESHOLD, (double)scal);
+    asc[0] += lk[0] * f;
+    asc[1] += lk[1] * f;
+    asc[2] += lk[2] * f;
+    sum_w_inv += asc_weights[n];
+  }
+  if (asc_type == 1)
+  {
+    *d_f += pattern_weight_sum * (asc[1] / (asc[0] - 1.0));
+    *dd_f += pattern_weight_sum * (((asc[0] - 1.0) * asc[2] - asc[1] * asc[1]) / ((asc[0] - 1.0) * (asc[0] - 1.0)));
+  }
+  else if (asc_type == 2)
+  {
+    *d_f -= sum_w_inv * (asc[1] / asc[0]);
+    *dd_f -= sum_w_inv * (((asc[2] * asc[0]) - asc[1] * asc[1]) / (asc[0] * asc[0]));
+  }
+}

@@ -93,6 +93,24 @@ void orc_likelihood_derivatives(unsigned int states, unsigned int states_padded,
                                 const double *rates, const double *const *eigenvals,
                                 const double *sumtable, double *d_f, double *dd_f);
 
+/* Ascertainment-bias correction. asc_type: 1 Lewis, 2 Felsenstein,
+ * 3 Stamatakis (= PLL_ATTRIB_AB_* >> 5). `first` = entry of state 0's extra site in both ends;
+ * child = NULL for a root. Returns the term ADDED to lnL (src/likelihood.c:24-120,191-268,342-440). */
+double orc_asc_bias_correction(unsigned int states, unsigned int states_padded, unsigned int rate_cats,
+                               unsigned int first, const orc_child_t *parent, const orc_child_t *child,
+                               const double *pmatrix, const double *const *frequencies,
+                               const double *rate_weights, const unsigned int *asc_weights,
+                               unsigned int pattern_weight_sum, const unsigned int *freqs_indices,
+                               int asc_type, int per_rate_scaling);
+/* adds the Lewis / Felsenstein terms to d_f, dd_f (src/core_derivatives.c:851-924) */
+void orc_asc_bias_derivatives(unsigned int states, unsigned int states_padded, unsigned int rate_cats,
+                              unsigned int first, const unsigned int *parent_scaler,
+                              const unsigned int *child_scaler, const double *rate_weights,
+                              const unsigned int *asc_weights, unsigned int pattern_weight_sum,
+                              double branch_length, const double *prop_invar, const double *rates,
+                              const double *const *eigenvals, const double *sumtable, int asc_type,
+                              int per_rate_scaling, double *d_f, double *dd_f);
+
 #ifdef __cplusplus
 }
 #endif

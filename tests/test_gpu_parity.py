@@ -24,7 +24,7 @@ def test_golden_avx2_layout(amd_lib, path):
         assert scalers_equal(got, exp), "scaler vectors differ from the reference"
 
 
-@pytest.mark.parametrize("path", [g for g in GOLDEN if any(t in g for t in ("kat_", "s5_", "s7_", "s61_plain", "dna_deep_rate", "aa_tip"))],
+@pytest.mark.parametrize("path", [g for g in GOLDEN if any(t in g for t in ("kat_", "s5_", "s7_", "s61_plain", "dna_deep_rate", "aa_tip", "asc_"))],
                          ids=lambda p: p.split("/")[-1][:-4])
 @pytest.mark.parametrize("arch", [api.ARCH_CPU, api.ARCH_SSE], ids=["cpu-layout", "sse-layout"])
 def test_golden_other_layouts(amd_lib, path, arch):
@@ -247,3 +247,32 @@ def test_large_states_through_fma_kernels(amd_lib, kw, monkeypatch):
     got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
     assert_results_match(got, exp, what=_id(kw))
     assert scalers_equal(got, exp)
+
+
+ASC_CASES = [
+    dict(states=4, tips=16, sites=333, asc_type=1, seed=71),
+    dict(states=4, tips=16, sites=333, asc_type=2, asc_weights=[50, 40, 60, 20], attributes=api.PATTERN_TIP, ambiguity_pct=5, seed=72),
+    dict(states=4, tips=16, sites=333, asc_type=3, asc_weights=[5, 4, 6, 2], attributes=api.RATE_SCALERS, seed=73),
+    dict(states=4, tips=256, sites=70, tree="caterpillar", brlen_scale=4, asc_type=2, asc_weights=[5, 4, 6, 2], seed=74),
+    dict(states=4, tips=256, sites=70, tree="caterpillar", brlen_scale=4, asc_type=1, attributes=api.RATE_SCALERS | api.PATTERN_TIP, seed=75),
+    dict(states=20, tips=16, sites=130, asc_type=2, asc_weights=list(range(1, 21)), seed=76),
+    dict(states=20, tips=128, sites=64, tree="caterpillar", brlen_scale=3, asc_type=3, asc_weights=list(range(1, 21)), attributes=api.PATTERN_TIP, seed=77),
+    dict(states=7, tips=8, sites=100, rate_cats=3, asc_type=1, seed=78),
+    dict(states=61, tips=16, sites=90, asc_type=2, asc_weights=list(range(1, 62)), seed=79),
+    dict(states=61, tips=64, sites=64, tree="caterpillar", brlen_scale=3, asc_type=3, asc_weights=list(range(1, 62)), seed=80),
+    dict(states=4, tips=16, sites=200, asc_type=0, seed=81),
+]
+
+
+@pytest.mark.parametrize("kw", ASC_CASES, ids=lambda k: _id(k) + "-asc%d" % k["asc_type"])
+def test_ascertainment_bias_against_oracle(amd_lib, kw):
+    """edge and root lnL with the Lewis / Felsenstein / Stamatakis corrections; the per-state extra
+    entries ride through every CLV update (CLVs and scalers are compared with them included)"""
+    case = W.make_case("asc", **kw)
+    case.roots = [(case.edges[0][0], case.edges[0][1])]
+    exp = O.run_case(case)
+    got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    assert_results_match(got, exp, what=_id(kw))
+    assert scalers_equal(got, exp)
+    for idx, a in got["clv"].items():
+        assert a.shape[0] == case.sites + case.states

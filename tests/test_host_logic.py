@@ -68,8 +68,49 @@ def test_invalid_attribute_combinations(amd_lib):
     assert amd_lib.errno() == 113
     assert not amd_lib.pll_partition_create(4, 2, 4, 100, 1, 5, 4, 2, api.PATTERN_TIP | api.SITE_REPEATS)
     assert amd_lib.errno() == 113
-    assert not amd_lib.pll_partition_create(4, 2, 4, 100, 1, 5, 4, 2, api.AB_LEWIS | api.AB_FLAG)
+    # the reference's repeats update never computes the per-state extra entries: refused
+    assert not amd_lib.pll_partition_create(4, 2, 4, 100, 1, 5, 4, 2, api.AB_LEWIS | api.AB_FLAG | api.SITE_REPEATS)
     assert amd_lib.errno() == 902
+    assert not amd_lib.pll_partition_create(4, 2, 4, 100, 1, 5, 4, 2, 5 << 5)
+    assert amd_lib.errno() == 121
+
+
+def test_asc_bias_partition_bookkeeping(amd_lib, ref_lib):
+    """extra per-state entries: allocation sizes, weights, tip codes / tip CLVs, setter errors -
+    same observable state as the reference (src/pll.c:525-531, 822-824, 897-905, 935-953,
+    1003-1021, 1145-1200; src/models.c:500-508)"""
+    nt = (C.c_ulonglong * 256)(*[int(v) for v in W.map_nt()])
+    for attr in (api.AB_FLAG, api.AB_FLAG | api.PATTERN_TIP):
+        st = []
+        for lib in (amd_lib, ref_lib):
+            p = lib.pll_partition_create(4, 2, 4, 20, 1, 5, 2, 2, api.ARCH_AVX2 | attr)
+            assert p
+            part = p.contents
+            assert (part.asc_bias_alloc, part.asc_additional_sites) == (1, 4)
+            assert lib.pll_set_tip_states(p, 1, nt, b"ACGTACGTAC-NRYACGTAC")
+            w = api.as_np(part.pattern_weights, 24, np.uint32).copy()
+            assert list(w[20:]) == [0, 0, 0, 0]
+            sw = np.array([5, 4, 6, 2], dtype=np.uint32)
+            lib.pll_set_asc_state_weights(p, api.uptr(sw))
+            assert list(api.as_np(part.pattern_weights, 24, np.uint32)[20:]) == [5, 4, 6, 2]
+            assert part.pattern_weight_sum == 20
+            assert lib.pll_get_sites_number(p, 4) == 24
+            if attr & api.PATTERN_TIP:
+                obs = bytes(api.as_np(part.tipchars[1], 24, np.uint8))
+            else:
+                obs = api.as_np(part.clv[1], 24 * 2 * 4, np.float64).copy().tobytes()
+            assert lib.pll_set_asc_bias_type(p, api.AB_FELSENSTEIN)
+            assert part.attributes & (7 << 5) == api.AB_FELSENSTEIN
+            assert not lib.pll_update_invariant_sites_proportion(p, 0, 0.3) and lib.errno() == 117
+            assert not lib.pll_set_asc_bias_type(p, api.AB_LEWIS | 1) and lib.errno() == 121
+            assert lib.pll_set_asc_bias_type(p, 0) and part.attributes & (7 << 5) == 0
+            st.append(obs)
+            lib.pll_partition_destroy(p)
+        assert st[0] == st[1]
+    for lib in (amd_lib, ref_lib):
+        p = lib.pll_partition_create(4, 2, 4, 20, 1, 5, 2, 2, api.ARCH_AVX2)
+        assert not lib.pll_set_asc_bias_type(p, api.AB_LEWIS) and lib.errno() == 122
+        lib.pll_partition_destroy(p)
 
 
 @pytest.mark.parametrize("states,arch,sp,align", [(4, 0, 4, 8), (5, api.ARCH_SSE, 6, 16), (7, api.ARCH_AVX, 8, 32),
