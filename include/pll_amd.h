@@ -268,6 +268,9 @@ void pll_fill_parent_scaler(unsigned int scaler_size, unsigned int *parent_scale
  * mirror. Callers that read those arrays directly call one of these first. */
 int pll_gpu_sync_clv(pll_partition_t *partition, unsigned int clv_index);     /* D2H one CLV */
 int pll_gpu_sync_scaler(pll_partition_t *partition, unsigned int scaler_index);
+/* transition matrices computed by pll_update_prob_matrices live on the device; this refreshes
+ * partition->pmatrix[index] (index < 0: every matrix that is newer on the device) */
+int pll_gpu_sync_pmatrix(pll_partition_t *partition, int index);
 int pll_gpu_sync_all(pll_partition_t *partition);
 /* Callers that WRITE partition arrays directly (instead of through the setters above) tell the
  * library which device copies are stale. what = bitwise OR of PLL_GPU_DIRTY_*; index = array

@@ -120,6 +120,21 @@ int pllgpu_root_loglikelihood(pllgpu_ctx_t *ctx, unsigned int clv, int scaler, u
                               const unsigned int *freqs_indices, double *persite_host,
                               double *lnl_out);
 
+/* ---- transition matrices on the device ---------------------------- */
+/* eigensystem of rate matrix `index` in the reference's layouts: eigenvecs[j*sp+i],
+ * inv_eigenvecs[i*sp+j] ([states][states_padded] each), eigenvals[states_padded] */
+int pllgpu_eigen_upload(pllgpu_ctx_t *ctx, unsigned int index, const double *eigenvecs,
+                        const double *inv_eigenvecs, const double *eigenvals);
+/* replaces pll_core_update_pmatrix (src/core_pmatrix.c:24-258): P = I + Vinv' diag(expm1(lambda r t /
+ * (1 - pinv))) V per (matrix, rate category), identity for t = 0, written straight into the
+ * device's transposed layout. Needs the eigensystems, category rates (pllgpu_rates_upload) and
+ * prop_invar on the device. Asynchronous. */
+int pllgpu_update_pmatrices(pllgpu_ctx_t *ctx, const unsigned int *params_indices /* [rate_cats] */,
+                            const unsigned int *matrix_indices, const double *branch_lengths,
+                            unsigned int count);
+/* device matrix `index` back in the reference's host layout [rate][row][states_padded]. Synchronises. */
+int pllgpu_pmatrix_download(pllgpu_ctx_t *ctx, unsigned int index, double *host);
+
 /* ascertainment-bias correction (src/likelihood.c:50-120, :191-268,
  * :342-440): for each state n the likelihood of the per-state extra entry `sites + n` of the same
  * edge (is_root = 0; edge->child_is_tip honoured) or root (is_root = 1; only parent_clv /

@@ -315,3 +315,57 @@ __global__ __launch_bounds__(64) void k_asc_deriv_terms(const DevAscDeriv a, con
   a.out[n * 3 + 2] = lk2;
   a.out[3 * g.S + n] = (double)sc;
 }
+
+// ---- transition matrices (src/core_pmatrix.c:186-247) -----------------
+// One workgroup per (matrix, rate category): A[i][m] = Vinv[i][m] * expm1(lambda_m r t / (1-pinv))
+// and B = V staged in LDS, every thread forms entries P[i][j] = delta_ij + sum_m A[i][m] B[m][j] in
+// the reference's summation order and stores them transposed (PT[j][i], the kernels' layout).
+struct DevPmat
+{
+  double *pmat;                 // base of the device matrix block
+  const double *evecs, *ievecs; // [rate_matrices][S][SP]
+  const double *evals;          // [rate_matrices][SP]
+  const double *rates, *prop_invar;
+  const unsigned *mindex;       // [count]
+  const double *brlen;          // [count]
+  size_t pm_stride;
+  unsigned S, SP, SPT;
+  unsigned char fidx[kMaxRates];
+};
+
+__global__ __launch_bounds__(256) void k_pmatrix(const DevPmat d)
+{
+  extern __shared__ double sm[];
+  const unsigned S = d.S, LD = S | 1u; // odd row stride: conflict-free column walks
+  double *A = sm, *B = sm + (size_t)S * LD;
+  const unsigned b = blockIdx.x, n = blockIdx.y;
+  const unsigned fi = d.fidx[n];
+  const double t = d.brlen[b];
+  double *out = d.pmat + (size_t)d.mindex[b] * d.pm_stride + (size_t)n * S * d.SPT;
+  if (t > 0.0)
+  {
+    const double pinv = d.prop_invar[fi];
+    const double scale = pinv > 1e-8 ? d.rates[n] * t / (1.0 - pinv) : d.rates[n] * t; // PLL_MISC_EPSILON
+    const double *ev = d.evecs + (size_t)fi * S * d.SP, *iev = d.ievecs + (size_t)fi * S * d.SP;
+    const double *lam = d.evals + (size_t)fi * d.SP;
+    for (unsigned idx = threadIdx.x; idx < S * S; idx += blockDim.x)
+    {
+      const unsigned i = idx / S, m = idx % S;
+      A[i * LD + m] = iev[(size_t)i * d.SP + m] * expm1(lam[m] * scale);
+      B[i * LD + m] = ev[(size_t)i * d.SP + m];
+    }
+    __syncthreads();
+  }
+  for (unsigned idx = threadIdx.x; idx < S * d.SPT; idx += blockDim.x)
+  {
+    const unsigned j = idx / d.SPT, i = idx % d.SPT;
+    double acc = 0.0;
+    if (i < S)
+    {
+      acc = (i == j) ? 1.0 : 0.0;
+      if (t > 0.0)
+        for (unsigned m = 0; m < S; ++m) acc += A[i * LD + m] * B[m * LD + j];
+    }
+    out[idx] = acc;
+  }
+}

@@ -99,6 +99,8 @@ struct pllgpu_ctx
   DevBuf<unsigned> counter;
   DevBuf<unsigned char> mfma_flags;      // [op in launch][rate][entry] scaling decisions (kernels_mfma.h)
   DevBuf<double> eigenvals, rates, diag; // derivatives: [rate_matrices][SP], [R], [R][S][4]
+  DevBuf<double> evecs, ievecs, brlen;   // device P-matrices: [rate_matrices][S][SP] x 2, staged branch lengths
+  DevBuf<unsigned> mindex;               // staged matrix indices
   DevBuf<double> sumtable[4];            // device-resident sumtables (tiled like a CLV)
   double *result_dev = nullptr;  // device alias of result_host
   DevBuf<unsigned> pattern_weights;
@@ -254,6 +256,10 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->counter.release();
   c->mfma_flags.release();
   c->eigenvals.release();
+  c->evecs.release();
+  c->ievecs.release();
+  c->brlen.release();
+  c->mindex.release();
   c->rates.release();
   c->diag.release();
   for (auto &b : c->sumtable) b.release();
@@ -1140,5 +1146,96 @@ extern "C" int pllgpu_asc_derivative_terms(pllgpu_ctx_t *c, unsigned slot, int p
     lk[3 * n + 2] = c->result_host[kAscOff + 3 * n + 2];
     scalings[n] = (unsigned)c->result_host[kAscOff + 3 * g.states + n];
   }
+  return 0;
+}
+
+// ---- transition matrices on the device -----------------------------------------------------------
+extern "C" int pllgpu_eigen_upload(pllgpu_ctx_t *c, unsigned index, const double *eigenvecs, const double *inv_eigenvecs,
+                                   const double *eigenvals)
+{
+  CHECK_CTX(c);
+  const pllgpu_geometry_t &g = c->geo;
+  if (index >= g.rate_matrices) return fail(PLLGPU_EINVAL, "eigensystem %u out of range", index);
+  const size_t n = (size_t)g.states * g.states_padded;
+  if (int rc = c->evecs.ensure(n * g.rate_matrices)) return rc;
+  if (int rc = c->ievecs.ensure(n * g.rate_matrices)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->evecs.p + index * n, eigenvecs, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->ievecs.p + index * n, inv_eigenvecs, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return pllgpu_eigenvals_upload(c, index, eigenvals);
+}
+
+extern "C" int pllgpu_update_pmatrices(pllgpu_ctx_t *c, const unsigned *params_indices, const unsigned *matrix_indices,
+                                       const double *branch_lengths, unsigned count)
+{
+  CHECK_CTX(c);
+  const pllgpu_geometry_t &g = c->geo;
+  if (!count) return 0;
+  if (!c->evecs.p || !c->ievecs.p || !c->eigenvals.p || !c->rates.p)
+    return fail(PLLGPU_EINVAL, "eigensystem / category rates were not uploaded");
+  DevPmat d;
+  memset(&d, 0, sizeof d);
+  for (unsigned k = 0; k < g.rate_cats; ++k)
+  {
+    if (params_indices[k] >= g.rate_matrices) return fail(PLLGPU_EINVAL, "params_indices[%u] out of range", k);
+    d.fidx[k] = (unsigned char)params_indices[k];
+  }
+  for (unsigned i = 0; i < count; ++i)
+    if (matrix_indices[i] >= g.prob_matrices || !(branch_lengths[i] >= 0))
+      return fail(PLLGPU_EINVAL, "matrix index %u / branch length %g invalid", matrix_indices[i], branch_lengths[i]);
+  // earlier launches may still read the staging buffers: a grown buffer is a fresh allocation
+  // (ensure() frees synchronously), a reused one is overwritten in stream order
+  if (int rc = c->mindex.ensure(count)) return rc;
+  if (int rc = c->brlen.ensure(count)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->mindex.p, matrix_indices, count * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->brlen.p, branch_lengths, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  d.pmat = c->pmat.p;
+  d.evecs = c->evecs.p;
+  d.ievecs = c->ievecs.p;
+  d.evals = c->eigenvals.p;
+  d.rates = c->rates.p;
+  d.prop_invar = c->prop_invar.p;
+  d.mindex = c->mindex.p;
+  d.brlen = c->brlen.p;
+  d.pm_stride = c->pm_stride;
+  d.S = g.states;
+  d.SP = g.states_padded;
+  d.SPT = c->gg.SPT;
+  const size_t lds = (size_t)2 * g.states * (g.states | 1u) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set)
+  {
+    (void)hipFuncSetAttribute((const void *)k_pmatrix, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  for (unsigned first = 0; first < count; first += 65535u) // gridDim.x stays far below its limit; y = rate
+  {
+    const unsigned nb = std::min(count - first, 65535u);
+    DevPmat dd = d;
+    dd.mindex += first;
+    dd.brlen += first;
+    hipLaunchKernelGGL(k_pmatrix, dim3(nb, g.rate_cats), dim3(256), lds, c->stream, dd);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pllgpu_pmatrix_download(pllgpu_ctx_t *c, unsigned index, double *host)
+{
+  CHECK_CTX(c);
+  const pllgpu_geometry_t &g = c->geo;
+  if (index >= g.prob_matrices) return fail(PLLGPU_EINVAL, "matrix %u out of range", index);
+  HIP_TRY(hipStreamSynchronize(c->stream)); // an earlier upload may still read the staging vector
+  c->stage.resize(c->pm_stride);
+  HIP_TRY(hipMemcpyAsync(c->stage.data(), c->pmat.p + (size_t)index * c->pm_stride, c->pm_stride * sizeof(double),
+                         hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const unsigned S = g.states, SP = g.states_padded, SPT = c->gg.SPT;
+  for (unsigned k = 0; k < g.rate_cats; ++k)
+    for (unsigned i = 0; i < S; ++i)
+    {
+      double *row = host + ((size_t)k * S + i) * SP;
+      for (unsigned j = 0; j < S; ++j) row[j] = c->stage[((size_t)k * S + j) * SPT + i];
+      for (unsigned j = S; j < SP; ++j) row[j] = 0.0;
+    }
   return 0;
 }

@@ -45,32 +45,8 @@ static int slot_of(pll_amd_ext_t *x, const double *key, int create)
   return victim;
 }
 
-/* eigenvalues, category rates, prop_invar, frequencies: whatever is stale */
-static int flush_deriv_model(pll_partition_t *p, pll_amd_ext_t *x)
-{
-  unsigned int i;
-  if (!pll_flush_model(p, x)) return PLL_FAILURE;
-  for (i = 0; i < p->rate_matrices; ++i)
-    if (x->eigen_dirty[i] || x->always_upload)
-    {
-      if (pllgpu_eigenvals_upload(x->ctx, i, p->eigenvals[i]) != 0)
-      {
-        pll_set_gpu_error("eigenvalues upload");
-        return PLL_FAILURE;
-      }
-      x->eigen_dirty[i] = 0;
-    }
-  if (x->rates_dirty || x->always_upload)
-  {
-    if (pllgpu_rates_upload(x->ctx, p->rates) != 0)
-    {
-      pll_set_gpu_error("category rates upload");
-      return PLL_FAILURE;
-    }
-    x->rates_dirty = 0;
-  }
-  return PLL_SUCCESS;
-}
+/* eigensystems, category rates, prop_invar, frequencies: whatever is stale */
+static int flush_deriv_model(pll_partition_t *p, pll_amd_ext_t *x) { return pll_flush_eigen(p, x); }
 
 static int flush_aux_matrices(pll_partition_t *p, pll_amd_ext_t *x, const unsigned int *params_indices)
 {

@@ -243,55 +243,45 @@ int pll_update_prob_matrices(pll_partition_t *p, const unsigned int *params_indi
                              const unsigned int *matrix_indices, const double *branch_lengths,
                              unsigned int count)
 {
-  const unsigned int s = p->states, sp = p->states_padded;
-  unsigned int b, n, i, j, m;
-  pll_amd_ext_t *x = pll_ext(p);
-  for (n = 0; n < p->rate_cats; ++n)
-    if (!p->eigen_decomp_valid[params_indices[n]] && !pll_update_eigen(p, params_indices[n])) return PLL_FAILURE;
-  double *expd = (double *)malloc(sizeof(double) * s);
-  double *tmp = (double *)malloc(sizeof(double) * s * s);
-  if (!expd || !tmp)
+  /* the matrices are formed ON THE DEVICE (k_pmatrix,
+   * src/core_pmatrix.c:186-247) and stay there; partition->pmatrix is a host mirror refreshed by
+   * pll_gpu_sync_pmatrix() or after every call under PLL_AMD_EAGER_MIRROR=1. Only the eigensystem
+   * (a few kB per rate matrix) crosses PCIe, and only when it changed. */
+  unsigned int b, n;
+  pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
+  if (!x || !x->ctx)
   {
-    free(expd); free(tmp);
-    pll_set_error(PLL_ERROR_MEM_ALLOC, "Unable to allocate enough memory.");
+    pll_set_error(PLL_ERROR_GPU_UNAVAILABLE, "pll_update_prob_matrices: no MI355X context behind this partition; this library has no CPU path");
+    fprintf(stderr, "libpll_amd: pll_update_prob_matrices: [%d] %s\n", pll_errno, pll_errmsg);
+    return PLL_FAILURE;
+  }
+  for (n = 0; n < p->rate_cats; ++n)
+  {
+    if (params_indices[n] >= p->rate_matrices)
+    {
+      pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_update_prob_matrices: params_indices[%u] out of range", n);
+      return PLL_FAILURE;
+    }
+    if (!p->eigen_decomp_valid[params_indices[n]] && !pll_update_eigen(p, params_indices[n])) return PLL_FAILURE;
+  }
+  for (b = 0; b < count; ++b)
+    if (matrix_indices[b] >= p->prob_matrices || !(branch_lengths[b] >= 0))
+    {
+      pll_set_error(PLL_ERROR_PARAM_INVALID, "invalid matrix index or negative branch length");
+      return PLL_FAILURE;
+    }
+  if (!pll_flush_eigen(p, x)) return PLL_FAILURE;
+  if (pllgpu_update_pmatrices(x->ctx, params_indices, matrix_indices, branch_lengths, count) != 0)
+  {
+    pll_set_gpu_error("pll_update_prob_matrices");
     return PLL_FAILURE;
   }
   for (b = 0; b < count; ++b)
   {
-    if (matrix_indices[b] >= p->prob_matrices || branch_lengths[b] < 0)
-    {
-      free(expd); free(tmp);
-      pll_set_error(PLL_ERROR_PARAM_INVALID, "invalid matrix index or negative branch length");
-      return PLL_FAILURE;
-    }
-    for (n = 0; n < p->rate_cats; ++n)
-    {
-      double *pm = p->pmatrix[matrix_indices[b]] + (size_t)n * s * sp;
-      const unsigned int mi = params_indices[n];
-      const double pinv = p->prop_invar[mi];
-      const double *ev = p->eigenvecs[mi], *iev = p->inv_eigenvecs[mi], *lam = p->eigenvals[mi];
-      if (branch_lengths[b] > 0.0)
-      {
-        const double t = p->rates[n] * branch_lengths[b] / (pinv > 1e-8 ? 1.0 - pinv : 1.0);
-        for (j = 0; j < s; ++j) expd[j] = expm1(lam[j] * t);
-        for (i = 0; i < s; ++i)
-          for (j = 0; j < s; ++j) tmp[i * s + j] = iev[i * sp + j] * expd[j];
-        for (i = 0; i < s; ++i)
-          for (j = 0; j < s; ++j)
-          {
-            double acc = (i == j) ? 1.0 : 0.0;
-            for (m = 0; m < s; ++m) acc += tmp[i * s + m] * ev[m * sp + j];
-            pm[i * sp + j] = acc;
-          }
-      }
-      else
-        for (i = 0; i < s; ++i)
-          for (j = 0; j < s; ++j) pm[i * sp + j] = (i == j) ? 1.0 : 0.0;
-    }
-    if (x) x->pmatrix_dirty[matrix_indices[b]] = 1;
+    x->pmatrix_dirty[matrix_indices[b]] = 0;
+    x->pmatrix_stale[matrix_indices[b]] = 1;
   }
-  free(expd);
-  free(tmp);
+  if (x->eager_mirror) return pll_gpu_sync_pmatrix(p, -1);
   return PLL_SUCCESS;
 }
 

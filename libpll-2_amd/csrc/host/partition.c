@@ -90,6 +90,7 @@ static void free_ext(pll_amd_ext_t *x)
   free(x->pmatrix_dirty);
   free(x->freqs_dirty);
   free(x->eigen_dirty);
+  free(x->pmatrix_stale);
   free(x->aux_params);
   free(x->gops);
   free(x->lvl_clv_w);
@@ -338,6 +339,8 @@ pll_partition_t *pll_partition_create(unsigned int tips, unsigned int clv_buffer
   x->no_tip_codes = env_flag("PLL_AMD_NO_TIP_CODES");
   NEED(x->tip_compact && x->tipcodes && x->ctipmap);
   x->eigen_dirty = (unsigned char *)malloc(rate_matrices ? rate_matrices : 1);
+  x->pmatrix_stale = (unsigned char *)calloc(prob_matrices ? prob_matrices : 1, 1);
+  NEED(x->pmatrix_stale);
   x->aux_params = (unsigned int *)malloc(sizeof(unsigned int) * rate_cats);
   NEED(x->clv_side && x->scaler_side && x->scaler_entries && x->tipchars_dirty && x->repeats_dirty &&
        x->pmatrix_dirty && x->freqs_dirty && x->eigen_dirty && x->aux_params);
@@ -615,16 +618,36 @@ int pll_flush_pmatrix(pll_partition_t *p, pll_amd_ext_t *x, unsigned int first, 
   if (x->always_upload) memset(x->pmatrix_dirty + first, 1, last - first + 1);
   while (i <= last)
   {
-    if (!x->pmatrix_dirty[i])
+    /* a matrix computed on the device is newer than its host mirror: never overwrite it */
+    if (!x->pmatrix_dirty[i] || x->pmatrix_stale[i])
     {
+      x->pmatrix_dirty[i] = 0;
       ++i;
       continue;
     }
     unsigned int j = i;
-    while (j + 1 <= last && x->pmatrix_dirty[j + 1]) ++j;
+    while (j + 1 <= last && x->pmatrix_dirty[j + 1] && !x->pmatrix_stale[j + 1]) ++j;
     GPU_TRY(pllgpu_pmatrix_upload(x->ctx, i, j - i + 1, p->pmatrix[i]), "p-matrix upload");
     memset(x->pmatrix_dirty + i, 0, j - i + 1);
     i = j + 1;
+  }
+  return PLL_SUCCESS;
+}
+
+int pll_flush_eigen(pll_partition_t *p, pll_amd_ext_t *x)
+{
+  unsigned int i;
+  if (!pll_flush_model(p, x)) return PLL_FAILURE;
+  for (i = 0; i < p->rate_matrices; ++i)
+    if (x->eigen_dirty[i] || x->always_upload)
+    {
+      GPU_TRY(pllgpu_eigen_upload(x->ctx, i, p->eigenvecs[i], p->inv_eigenvecs[i], p->eigenvals[i]), "eigensystem upload");
+      x->eigen_dirty[i] = 0;
+    }
+  if (x->rates_dirty || x->always_upload)
+  {
+    GPU_TRY(pllgpu_rates_upload(x->ctx, p->rates), "category rates upload");
+    x->rates_dirty = 0;
   }
   return PLL_SUCCESS;
 }
@@ -688,10 +711,34 @@ int pll_gpu_sync_scaler(pll_partition_t *p, unsigned int idx)
   return PLL_SUCCESS;
 }
 
+int pll_gpu_sync_pmatrix(pll_partition_t *p, int index)
+{
+  pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
+  unsigned int i;
+  if (!x || !x->ctx)
+  {
+    pll_set_error(PLL_ERROR_GPU_UNAVAILABLE, "pll_gpu_sync_pmatrix: no MI355X context behind this partition");
+    return PLL_FAILURE;
+  }
+  if (index >= (int)p->prob_matrices)
+  {
+    pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_gpu_sync_pmatrix: matrix index %d out of range", index);
+    return PLL_FAILURE;
+  }
+  for (i = 0; i < p->prob_matrices; ++i)
+  {
+    if ((index >= 0 && i != (unsigned int)index) || !x->pmatrix_stale[i]) continue;
+    GPU_TRY(pllgpu_pmatrix_download(x->ctx, i, p->pmatrix[i]), "pll_gpu_sync_pmatrix");
+    x->pmatrix_stale[i] = 0;
+  }
+  return PLL_SUCCESS;
+}
+
 int pll_gpu_sync_all(pll_partition_t *p)
 {
   unsigned int i;
   int ok = PLL_SUCCESS;
+  ok &= pll_gpu_sync_pmatrix(p, -1);
   for (i = 0; i < p->nodes; ++i) ok &= pll_gpu_sync_clv(p, i);
   for (i = 0; i < p->scale_buffers; ++i) ok &= pll_gpu_sync_scaler(p, i);
   return ok;
@@ -710,7 +757,11 @@ void pll_gpu_invalidate(pll_partition_t *p, unsigned int what, int index)
     else if ((unsigned)index < (n))                                   \
       x->arr[index] = (val);                                          \
   } while (0)
-  if (what & PLL_GPU_DIRTY_PMATRIX) MARK(pmatrix_dirty, p->prob_matrices, 1);
+  if (what & PLL_GPU_DIRTY_PMATRIX)
+  {
+    MARK(pmatrix_dirty, p->prob_matrices, 1);
+    MARK(pmatrix_stale, p->prob_matrices, 0); /* the caller wrote the host copy: it is the truth now */
+  }
   if (what & PLL_GPU_DIRTY_FREQS) MARK(freqs_dirty, p->rate_matrices, 1);
   if (what & PLL_GPU_DIRTY_RATE_WEIGHTS) x->rate_weights_dirty = x->prop_invar_dirty = 1;
   if (what & PLL_GPU_DIRTY_PATTERN_WEIGHTS) x->pattern_weights_dirty = 1;

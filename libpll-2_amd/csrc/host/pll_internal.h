@@ -49,7 +49,8 @@ typedef struct pll_amd_ext
   /* derivatives: eigenvalues / category rates on the device, the two sumtable contraction
    * matrices (rebuilt when the eigensystem, the frequencies or params_indices change), and which
    * caller-owned host sumtable each device slot stands for */
-  unsigned char *eigen_dirty;   /* [rate_matrices] eigenvalues not yet on the device */
+  unsigned char *eigen_dirty;   /* [rate_matrices] eigensystem (vectors + values) not yet on the device */
+  unsigned char *pmatrix_stale; /* [prob_matrices] computed on the device, host mirror not refreshed */
   int rates_dirty;
   unsigned int eigen_version;   /* bumped whenever an eigensystem or frequency vector changes */
   unsigned int aux_version;     /* eigen_version the device contraction matrices were built from */
@@ -79,6 +80,8 @@ unsigned int pll_sites_alloc(const pll_partition_t *p);
 int pll_flush_model(pll_partition_t *p, pll_amd_ext_t *x);
 int pll_flush_clv(pll_partition_t *p, pll_amd_ext_t *x, unsigned int clv_index);
 int pll_flush_scaler(pll_partition_t *p, pll_amd_ext_t *x, int scaler_index);
+/* model arrays + eigensystems + category rates: what the derivative and P-matrix kernels read */
+int pll_flush_eigen(pll_partition_t *p, pll_amd_ext_t *x);
 int pll_flush_pmatrix(pll_partition_t *p, pll_amd_ext_t *x, unsigned int first, unsigned int last);
 int pll_flush_repeats(pll_partition_t *p, pll_amd_ext_t *x, unsigned int node);
 int pll_is_pattern_tip(const pll_partition_t *p, unsigned int clv_index);

@@ -252,44 +252,64 @@ def model_pmatrices(lib, states, exch, freqs, alpha, cats, brlens, arch, pinv=0.
     return p, part, sp, rates, bl
 
 
+def _p_from_eigen(part, states, sp, rates, brlens, pinv):
+    """P(t) = I + Vinv' diag(expm1(lambda r t / (1 - pinv))) V from the partition's eigen arrays
+    (src/core_pmatrix.c:186-232)"""
+    ev = api.as_np(part.eigenvecs[0], states * sp, np.float64).reshape(states, sp)[:, :states]
+    iev = api.as_np(part.inv_eigenvecs[0], states * sp, np.float64).reshape(states, sp)[:, :states]
+    lam = api.as_np(part.eigenvals[0], states, np.float64)
+    out = np.zeros((len(brlens), len(rates), states, states))
+    for b, t in enumerate(brlens):
+        for k, r in enumerate(rates):
+            out[b, k] = np.eye(states) + (iev * np.expm1(lam * r * t / (1.0 - pinv))[None, :]) @ ev if t > 0 else np.eye(states)
+    return out
+
+
 @pytest.mark.parametrize("states,arch", [(4, api.ARCH_AVX2), (7, api.ARCH_AVX2), (20, api.ARCH_CPU), (61, api.ARCH_AVX2)])
-def test_prob_matrices_match_reference(amd_lib, ref_lib, states, arch):
-    """same category rates on both sides (the reference's own), then P(t) must agree to 1e-12"""
+def test_eigensystem_reproduces_reference_prob_matrices(amd_lib, ref_lib, states, arch):
+    """the eigen decomposition stays on the host (pll_update_eigen); the transition matrices it
+    implies must agree with the reference's pll_update_prob_matrices to 1e-12. (The matrices
+    themselves are formed on the device: tests/test_gpu_models.py.)"""
     exch, freqs = (W.GTR_DNA["exch"], W.GTR_DNA["freqs"]) if states == 4 else W.synthetic_exch(states)
     brlens = [0.0, 1e-6, 0.05, 0.5, 3.0]
-    out = {}
-    ref_rates = None
-    for lib in (ref_lib, amd_lib):
-        p, part, sp, rates, bl = model_pmatrices(lib, states, exch, freqs, 0.7, 4, brlens, arch, pinv=0.1)
-        if ref_rates is None:
-            ref_rates = rates
-        lib.pll_set_category_rates(p, api.dptr(ref_rates))
-        pi = np.zeros(4, dtype=np.uint32)
-        mi = np.arange(len(brlens), dtype=np.uint32)
-        assert lib.pll_update_prob_matrices(p, api.uptr(pi), api.uptr(mi), api.dptr(bl), len(brlens))
-        out[lib.is_amd] = np.stack([api.as_np(part.pmatrix[i], 4 * states * sp, np.float64).reshape(4, states, sp)[:, :, :states].copy()
-                                    for i in range(len(brlens))])
-        assert part.eigen_decomp_valid[0] == 1
-        lib.pll_partition_destroy(p)
-    a, b = out[True], out[False]
-    assert np.allclose(a.sum(-1), 1.0, atol=1e-12)
-    assert np.max(np.abs(a - b)) < 1e-12
-    assert (a[0] == np.eye(states)[None]).all()
+    p, part, sp, rates, bl = model_pmatrices(ref_lib, states, exch, freqs, 0.7, 4, brlens, arch, pinv=0.1)
+    ref_lib.pll_set_category_rates(p, api.dptr(rates))
+    pi = np.zeros(4, dtype=np.uint32)
+    mi = np.arange(len(brlens), dtype=np.uint32)
+    assert ref_lib.pll_update_prob_matrices(p, api.uptr(pi), api.uptr(mi), api.dptr(bl), len(brlens))
+    exp = np.stack([api.as_np(part.pmatrix[i], 4 * states * sp, np.float64).reshape(4, states, sp)[:, :, :states].copy()
+                    for i in range(len(brlens))])
+    ref_lib.pll_partition_destroy(p)
+    p, part, sp, _, bl = model_pmatrices(amd_lib, states, exch, freqs, 0.7, 4, brlens, arch, pinv=0.1)
+    assert amd_lib.pll_update_eigen(p, 0) and part.eigen_decomp_valid[0] == 1
+    got = _p_from_eigen(part, states, sp, rates, brlens, 0.1)
+    amd_lib.pll_partition_destroy(p)
+    assert np.allclose(got.sum(-1), 1.0, atol=1e-12)
+    assert np.max(np.abs(got - exp)) < 1e-12
 
 
 def test_zero_frequency_states_are_dropped(amd_lib, ref_lib):
     """src/models.c:254-291,346-385"""
     freqs = np.array([0.4, 0.0, 0.35, 0.25])
-    out = {}
-    for lib in (ref_lib, amd_lib):
-        p, part, sp, rates, bl = model_pmatrices(lib, 4, [1, 2, 3, 4, 5, 6], freqs, 1.0, 2, [0.3], api.ARCH_AVX2)
-        lib.pll_set_category_rates(p, api.dptr(np.array([0.5, 1.5])))
-        pi = np.zeros(2, dtype=np.uint32)
-        mi = np.zeros(1, dtype=np.uint32)
-        assert lib.pll_update_prob_matrices(p, api.uptr(pi), api.uptr(mi), api.dptr(bl), 1)
-        out[lib.is_amd] = api.as_np(part.pmatrix[0], 2 * 4 * sp, np.float64).copy()
-        lib.pll_partition_destroy(p)
-    assert np.max(np.abs(out[True] - out[False])) < 1e-12
+    p, part, sp, rates, bl = model_pmatrices(ref_lib, 4, [1, 2, 3, 4, 5, 6], freqs, 1.0, 2, [0.3], api.ARCH_AVX2)
+    ref_lib.pll_set_category_rates(p, api.dptr(np.array([0.5, 1.5])))
+    assert ref_lib.pll_update_prob_matrices(p, api.uptr(np.zeros(2, dtype=np.uint32)), api.uptr(np.zeros(1, dtype=np.uint32)), api.dptr(bl), 1)
+    exp = api.as_np(part.pmatrix[0], 2 * 4 * sp, np.float64).reshape(2, 4, sp)[:, :, :4].copy()
+    ref_lib.pll_partition_destroy(p)
+    p, part, sp, _, bl = model_pmatrices(amd_lib, 4, [1, 2, 3, 4, 5, 6], freqs, 1.0, 2, [0.3], api.ARCH_AVX2)
+    assert amd_lib.pll_update_eigen(p, 0)
+    got = _p_from_eigen(part, 4, sp, [0.5, 1.5], [0.3], 0.0)[0]
+    amd_lib.pll_partition_destroy(p)
+    assert np.max(np.abs(got - exp)) < 1e-12
+
+
+def test_prob_matrices_need_the_device(amd_lib):
+    """pll_update_prob_matrices forms the matrices on the MI355X; a host-only shell refuses loudly"""
+    p, part, sp, rates, bl = model_pmatrices(amd_lib, 4, W.GTR_DNA["exch"], W.GTR_DNA["freqs"], 0.7, 4, [0.1], api.ARCH_AVX2)
+    amd_lib.pll_set_category_rates(p, api.dptr(rates))
+    ok = amd_lib.pll_update_prob_matrices(p, api.uptr(np.zeros(4, dtype=np.uint32)), api.uptr(np.zeros(1, dtype=np.uint32)), api.dptr(bl), 1)
+    assert not ok and amd_lib.errno() == 900
+    amd_lib.pll_partition_destroy(p)
 
 
 @pytest.mark.parametrize("alpha", [0.05, 0.5, 1.0, 4.2, 50.0])
