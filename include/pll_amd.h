@@ -271,6 +271,10 @@ int pll_gpu_sync_scaler(pll_partition_t *partition, unsigned int scaler_index);
 /* transition matrices computed by pll_update_prob_matrices live on the device; this refreshes
  * partition->pmatrix[index] (index < 0: every matrix that is newer on the device) */
 int pll_gpu_sync_pmatrix(pll_partition_t *partition, int index);
+/* site-repeats class maps of inner nodes are computed on the device; pll_get_site_id() /
+ * pll_get_id_site() refresh the host arrays they return, this call does it explicitly for callers
+ * that read partition->repeats->pernode_* directly (node < 0: all nodes) */
+int pll_gpu_sync_repeats(pll_partition_t *partition, int node);
 int pll_gpu_sync_all(pll_partition_t *partition);
 /* Callers that WRITE partition arrays directly (instead of through the setters above) tell the
  * library which device copies are stale. what = bitwise OR of PLL_GPU_DIRTY_*; index = array

@@ -107,6 +107,24 @@ int pllgpu_repeats_upload(pllgpu_ctx_t *ctx, unsigned int node, const unsigned i
                           const unsigned int *id_site, unsigned int ids);
 
 /* ---- compute ------------------------------------------------------------------------------ */
+/* class maps computed ON the device (replaces the table walk of
+ * pll_update_repeats, src/repeats.c:299-382): for every op the parent's site -> class map and
+ * class -> first-site map from the children's maps (which must be on the device, nleft/nright their
+ * class counts; nleft * nright cells of direct-address table per op). The ops must be mutually
+ * independent (one dependency level). counts_out[i] = classes of ops[i].parent. Synchronises. */
+typedef struct pllgpu_repop
+{
+  unsigned int parent, left, right;
+  unsigned int nleft, nright;
+} pllgpu_repop_t;
+int pllgpu_repeats_classes(pllgpu_ctx_t *ctx, const pllgpu_repop_t *ops, unsigned int count,
+                           unsigned int *counts_out);
+/* how many classes the kernels shall assume for `node` (0 = one entry per site, maps unused) */
+int pllgpu_repeats_set_ids(pllgpu_ctx_t *ctx, unsigned int node, unsigned int ids);
+/* device maps of `node` back to the host: site_id[sites], id_site[ids]. Synchronises. */
+int pllgpu_repeats_download(pllgpu_ctx_t *ctx, unsigned int node, unsigned int *site_id,
+                            unsigned int *id_site, unsigned int ids);
+
 /* replaces pll_core_update_partial_{ii,ti,tt,repeats} + pll_core_create_lookup
  * (src/core_partials.c:48-1210). Asynchronous on the context's stream. ops must be sorted by
  * level; ops of one level are independent. */

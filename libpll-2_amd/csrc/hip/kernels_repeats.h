@@ -1,0 +1,150 @@
+// kernels_repeats.h - site-repeats class maps on the device (SURVEY.md section 8 row f4;
+// src/repeats.c:299-382, pll_update_repeats).
+//
+// A parent's classes are the distinct pairs (left class, right class) of its sites, numbered in
+// order of first occurrence; id_site[class] is that first site. The reference walks the sites
+// sequentially through a direct-address table (cell = lid + rid * ids_left). The same numbering
+// without the sequential walk:
+//   1. table[cell] = min over the sites that map to the cell            (k_rep_mark, atomicMin)
+//   2. a site is a class representative iff table[cell(site)] == site; the class number of a
+//      representative is the count of representatives before it         (k_rep_count, k_rep_scan,
+//                                                                        k_rep_rank: prefix sum)
+//   3. site_id[site] = class number of table[cell(site)]                (k_rep_assign)
+// Integer work only: the maps are bit-identical to the reference's. All ops of one dependency level
+// go through each kernel together (grid.y = op); every op owns a slice of the table, cleared with
+// one memset before the level instead of the reference's to-clean list.
+#pragma once
+#include <hip/hip_runtime.h>
+
+constexpr int kRepOps = 32;           // ops per launch
+constexpr unsigned kRepBlock = 1024;  // sites per workgroup: 256 threads x 4 consecutive sites
+
+struct RepOp
+{
+  const unsigned *lid;   // site -> class of the left child  [sites]
+  const unsigned *rid;
+  unsigned *psid;        // out: site -> class of the parent   [sites]
+  unsigned *pids;        // out: class -> first site           [<= sites]
+  unsigned *rank;        // scratch [sites]: class number of a representative site
+  unsigned *blocksum;    // scratch [nblk]: representatives per workgroup, then their exclusive scan
+  unsigned nleft;        // classes of the left child
+  unsigned tab_off;      // first cell of this op's table slice
+};
+
+struct RepPack
+{
+  RepOp ops[kRepOps];
+  unsigned *table;
+  unsigned *counts;      // out [nops]: classes per op
+  unsigned sites;
+  unsigned nblk;
+};
+
+__device__ __forceinline__ unsigned rep_cell(const RepOp &o, unsigned s)
+{
+  return o.tab_off + o.lid[s] + o.rid[s] * o.nleft;
+}
+
+__global__ __launch_bounds__(256) void k_rep_mark(const RepPack p)
+{
+  const RepOp &o = p.ops[blockIdx.y];
+  const unsigned base = blockIdx.x * kRepBlock + threadIdx.x * 4u;
+#pragma unroll
+  for (unsigned q = 0; q < 4; ++q)
+  {
+    const unsigned s = base + q;
+    if (s < p.sites) atomicMin(&p.table[rep_cell(o, s)], s);
+  }
+}
+
+// inclusive scan of one value per thread over the 256 threads of a workgroup; returns the
+// exclusive prefix of the calling thread and, in `total`, the workgroup's sum
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned &total)
+{
+  __shared__ unsigned wsum[4];
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  unsigned inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1)
+  {
+    const unsigned t = __shfl_up(inc, off, 64);
+    if ((int)lane >= off) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  unsigned before = 0;
+  for (unsigned w = 0; w < wave; ++w) before += wsum[w];
+  total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads(); // wsum is reused by the next call
+  return before + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_rep_count(const RepPack p)
+{
+  const RepOp &o = p.ops[blockIdx.y];
+  const unsigned base = blockIdx.x * kRepBlock + threadIdx.x * 4u;
+  unsigned n = 0;
+#pragma unroll
+  for (unsigned q = 0; q < 4; ++q)
+  {
+    const unsigned s = base + q;
+    if (s < p.sites && p.table[rep_cell(o, s)] == s) ++n;
+  }
+  unsigned total;
+  (void)block_exclusive_scan(n, total);
+  if (threadIdx.x == 0) o.blocksum[blockIdx.x] = total;
+}
+
+// one workgroup per op: exclusive scan of the per-workgroup counts in place, total -> counts[op]
+__global__ __launch_bounds__(256) void k_rep_scan(const RepPack p)
+{
+  const RepOp &o = p.ops[blockIdx.x];
+  unsigned carry = 0;
+  for (unsigned first = 0; first < p.nblk; first += 256u)
+  {
+    const unsigned i = first + threadIdx.x;
+    const unsigned v = i < p.nblk ? o.blocksum[i] : 0u;
+    unsigned total;
+    const unsigned ex = block_exclusive_scan(v, total);
+    if (i < p.nblk) o.blocksum[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) p.counts[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_rep_rank(const RepPack p)
+{
+  const RepOp &o = p.ops[blockIdx.y];
+  const unsigned base = blockIdx.x * kRepBlock + threadIdx.x * 4u;
+  bool rep[4];
+  unsigned n = 0;
+#pragma unroll
+  for (unsigned q = 0; q < 4; ++q)
+  {
+    const unsigned s = base + q;
+    rep[q] = s < p.sites && p.table[rep_cell(o, s)] == s;
+    n += rep[q] ? 1u : 0u;
+  }
+  unsigned total;
+  unsigned r = o.blocksum[blockIdx.x] + block_exclusive_scan(n, total);
+#pragma unroll
+  for (unsigned q = 0; q < 4; ++q)
+    if (rep[q])
+    {
+      o.rank[base + q] = r;
+      o.pids[r] = base + q;
+      ++r;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rep_assign(const RepPack p)
+{
+  const RepOp &o = p.ops[blockIdx.y];
+  const unsigned base = blockIdx.x * kRepBlock + threadIdx.x * 4u;
+#pragma unroll
+  for (unsigned q = 0; q < 4; ++q)
+  {
+    const unsigned s = base + q;
+    if (s < p.sites) o.psid[s] = o.rank[p.table[rep_cell(o, s)]];
+  }
+}

@@ -18,6 +18,7 @@
 #include "kernels_generic.h"
 #include "kernels_deriv.h"
 #include "kernels_mfma.h"
+#include "kernels_repeats.h"
 
 // ---------------------------------------------------------------------------------------------
 static thread_local char g_err[256] = "";
@@ -101,6 +102,7 @@ struct pllgpu_ctx
   DevBuf<double> eigenvals, rates, diag; // derivatives: [rate_matrices][SP], [R], [R][S][4]
   DevBuf<double> evecs, ievecs, brlen;   // device P-matrices: [rate_matrices][S][SP] x 2, staged branch lengths
   DevBuf<unsigned> mindex;               // staged matrix indices
+  DevBuf<unsigned> rep_table, rep_rank, rep_blocksum, rep_counts; // site-repeats class computation (kernels_repeats.h)
   DevBuf<double> sumtable[4];            // device-resident sumtables (tiled like a CLV)
   double *result_dev = nullptr;  // device alias of result_host
   DevBuf<unsigned> pattern_weights;
@@ -260,6 +262,10 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->ievecs.release();
   c->brlen.release();
   c->mindex.release();
+  c->rep_table.release();
+  c->rep_rank.release();
+  c->rep_blocksum.release();
+  c->rep_counts.release();
   c->rates.release();
   c->diag.release();
   for (auto &b : c->sumtable) b.release();
@@ -1237,5 +1243,93 @@ extern "C" int pllgpu_pmatrix_download(pllgpu_ctx_t *c, unsigned index, double *
       for (unsigned j = 0; j < S; ++j) row[j] = c->stage[((size_t)k * S + j) * SPT + i];
       for (unsigned j = S; j < SP; ++j) row[j] = 0.0;
     }
+  return 0;
+}
+
+// ---- site-repeats class maps on the device -------------------------------------------------------
+extern "C" int pllgpu_repeats_set_ids(pllgpu_ctx_t *c, unsigned node, unsigned ids)
+{
+  CHECK_CTX(c);
+  if (node >= c->geo.nodes) return fail(PLLGPU_EINVAL, "node %u out of range", node);
+  c->ids[node] = ids;
+  return 0;
+}
+
+extern "C" int pllgpu_repeats_download(pllgpu_ctx_t *c, unsigned node, unsigned *site_id, unsigned *id_site, unsigned ids)
+{
+  CHECK_CTX(c);
+  const pllgpu_geometry_t &g = c->geo;
+  if (node >= g.nodes || !c->site_id[node].p || !c->id_site[node].p || ids > g.sites)
+    return fail(PLLGPU_EINVAL, "node %u has no class maps on the device", node);
+  HIP_TRY(hipMemcpyAsync(site_id, c->site_id[node].p, g.sites * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  if (ids) HIP_TRY(hipMemcpyAsync(id_site, c->id_site[node].p, ids * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops, unsigned count, unsigned *counts_out)
+{
+  CHECK_CTX(c);
+  const pllgpu_geometry_t &g = c->geo;
+  const unsigned sites = g.sites;
+  const unsigned nblk = (sites + kRepBlock - 1) / kRepBlock;
+  const size_t table_cap = (size_t)64 << 20; // cells per batch (256 MB); a single larger op still gets its slice
+  unsigned done = 0;
+  while (done < count)
+  {
+    // batch: up to kRepOps ops whose table slices fit
+    unsigned n = 0;
+    size_t cells = 0;
+    while (done + n < count && n < (unsigned)kRepOps)
+    {
+      const pllgpu_repop_t &o = ops[done + n];
+      if (o.parent >= g.nodes || o.left >= g.nodes || o.right >= g.nodes) return fail(PLLGPU_EINVAL, "repeats op references a node out of range");
+      if (!o.nleft || !o.nright || !c->site_id[o.left].p || !c->site_id[o.right].p)
+        return fail(PLLGPU_EINVAL, "repeats op: children %u / %u have no class maps on the device", o.left, o.right);
+      const size_t need = (size_t)o.nleft * o.nright;
+      if (n && cells + need > table_cap) break;
+      cells += need;
+      ++n;
+    }
+    if (cells >= 0xFFFFFFFFull) return fail(PLLGPU_EINVAL, "repeats table of %zu cells exceeds 32-bit addressing", cells);
+    if (int rc = c->rep_table.ensure(cells)) return rc;
+    if (int rc = c->rep_rank.ensure((size_t)kRepOps * sites)) return rc;
+    if (int rc = c->rep_blocksum.ensure((size_t)kRepOps * nblk)) return rc;
+    if (int rc = c->rep_counts.ensure(kRepOps)) return rc;
+    RepPack pk;
+    memset(&pk, 0, sizeof pk);
+    size_t off = 0;
+    for (unsigned i = 0; i < n; ++i)
+    {
+      const pllgpu_repop_t &o = ops[done + i];
+      if (int rc = c->site_id[o.parent].ensure(g.sites_alloc)) return rc;
+      if (int rc = c->id_site[o.parent].ensure(g.sites_alloc)) return rc;
+      RepOp &r = pk.ops[i];
+      r.lid = c->site_id[o.left].p;
+      r.rid = c->site_id[o.right].p;
+      r.psid = c->site_id[o.parent].p;
+      r.pids = c->id_site[o.parent].p;
+      r.rank = c->rep_rank.p + (size_t)i * sites;
+      r.blocksum = c->rep_blocksum.p + (size_t)i * nblk;
+      r.nleft = o.nleft;
+      r.tab_off = (unsigned)off;
+      off += (size_t)o.nleft * o.nright;
+    }
+    pk.table = c->rep_table.p;
+    pk.counts = c->rep_counts.p;
+    pk.sites = sites;
+    pk.nblk = nblk;
+    HIP_TRY(hipMemsetAsync(c->rep_table.p, 0xFF, cells * sizeof(unsigned), c->stream));
+    const dim3 grid(nblk, n), block(256);
+    hipLaunchKernelGGL(k_rep_mark, grid, block, 0, c->stream, pk);
+    hipLaunchKernelGGL(k_rep_count, grid, block, 0, c->stream, pk);
+    hipLaunchKernelGGL(k_rep_scan, dim3(n), block, 0, c->stream, pk);
+    hipLaunchKernelGGL(k_rep_rank, grid, block, 0, c->stream, pk);
+    hipLaunchKernelGGL(k_rep_assign, grid, block, 0, c->stream, pk);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(counts_out + done, c->rep_counts.p, n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    done += n;
+  }
   return 0;
 }

@@ -118,11 +118,13 @@ void pll_update_partials_rep(pll_partition_t *p, const pll_operation_t *ops, uns
     return;
   }
 
-  /* 1. site-repeats class maps, in list order: a parent's classes derive from its children's
-   *    (src/partials.c:256-257) */
+  unsigned int *level = (unsigned int *)(x->gops + count); /* second half of the scratch block */
+  const unsigned int nlevels = assign_levels(p, x, ops, count, level);
+
+  /* 1. site-repeats class maps: a parent's classes derive from its children's
+   *    (src/partials.c:256-257) - on the device, one dependency level at a time */
   const int rep = pll_repeats_enabled(p);
-  if (rep && update_repeats)
-    for (i = 0; i < count; ++i) pll_update_repeats(p, &ops[i]);
+  if (rep && update_repeats && !pll_update_repeats_device(p, x, ops, count, level, nlevels)) BAIL();
 
   /* 2. bring inputs up to date on the device */
   if (!pll_flush_model(p, x)) BAIL();
@@ -136,9 +138,6 @@ void pll_update_partials_rep(pll_partition_t *p, const pll_operation_t *ops, uns
     if (o->child2_matrix_index > hi) hi = o->child2_matrix_index;
   }
   if (!pll_flush_pmatrix(p, x, lo, hi)) BAIL();
-
-  unsigned int *level = (unsigned int *)(x->gops + count); /* second half of the scratch block */
-  const unsigned int nlevels = assign_levels(p, x, ops, count, level);
 
   /* children that are produced inside this list need no upload; everything else must be
    * current on the device (tips, CLVs computed by an earlier call and since edited on the host).

@@ -91,6 +91,8 @@ static void free_ext(pll_amd_ext_t *x)
   free(x->freqs_dirty);
   free(x->eigen_dirty);
   free(x->pmatrix_stale);
+  free(x->repeats_stale);
+  free(x->repeats_count);
   free(x->aux_params);
   free(x->gops);
   free(x->lvl_clv_w);
@@ -341,6 +343,9 @@ pll_partition_t *pll_partition_create(unsigned int tips, unsigned int clv_buffer
   x->eigen_dirty = (unsigned char *)malloc(rate_matrices ? rate_matrices : 1);
   x->pmatrix_stale = (unsigned char *)calloc(prob_matrices ? prob_matrices : 1, 1);
   NEED(x->pmatrix_stale);
+  x->repeats_stale = (unsigned char *)calloc(p->nodes ? p->nodes : 1, 1);
+  x->repeats_count = (unsigned int *)calloc(p->nodes ? p->nodes : 1, sizeof(unsigned int));
+  NEED(x->repeats_stale && x->repeats_count);
   x->aux_params = (unsigned int *)malloc(sizeof(unsigned int) * rate_cats);
   NEED(x->clv_side && x->scaler_side && x->scaler_entries && x->tipchars_dirty && x->repeats_dirty &&
        x->pmatrix_dirty && x->freqs_dirty && x->eigen_dirty && x->aux_params);
@@ -734,11 +739,32 @@ int pll_gpu_sync_pmatrix(pll_partition_t *p, int index)
   return PLL_SUCCESS;
 }
 
+int pll_gpu_sync_repeats(pll_partition_t *p, int node)
+{
+  pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
+  unsigned int i;
+  if (!x || !pll_repeats_enabled(p)) return PLL_SUCCESS;
+  if (node >= (int)p->nodes)
+  {
+    pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_gpu_sync_repeats: node %d out of range", node);
+    return PLL_FAILURE;
+  }
+  for (i = 0; i < p->nodes; ++i)
+  {
+    if ((node >= 0 && i != (unsigned int)node) || !x->repeats_stale[i]) continue;
+    GPU_TRY(pllgpu_repeats_download(x->ctx, i, p->repeats->pernode_site_id[i], p->repeats->pernode_id_site[i], x->repeats_count[i]),
+            "pll_gpu_sync_repeats");
+    x->repeats_stale[i] = 0;
+  }
+  return PLL_SUCCESS;
+}
+
 int pll_gpu_sync_all(pll_partition_t *p)
 {
   unsigned int i;
   int ok = PLL_SUCCESS;
   ok &= pll_gpu_sync_pmatrix(p, -1);
+  ok &= pll_gpu_sync_repeats(p, -1);
   for (i = 0; i < p->nodes; ++i) ok &= pll_gpu_sync_clv(p, i);
   for (i = 0; i < p->scale_buffers; ++i) ok &= pll_gpu_sync_scaler(p, i);
   return ok;

@@ -51,6 +51,8 @@ typedef struct pll_amd_ext
    * caller-owned host sumtable each device slot stands for */
   unsigned char *eigen_dirty;   /* [rate_matrices] eigensystem (vectors + values) not yet on the device */
   unsigned char *pmatrix_stale; /* [prob_matrices] computed on the device, host mirror not refreshed */
+  unsigned char *repeats_stale; /* [nodes] class maps computed on the device, host mirror not refreshed */
+  unsigned int *repeats_count;  /* [nodes] classes the device found (kept even when the node stays uncompressed) */
   int rates_dirty;
   unsigned int eigen_version;   /* bumped whenever an eigensystem or frequency vector changes */
   unsigned int aux_version;     /* eigen_version the device contraction matrices were built from */
@@ -82,6 +84,9 @@ int pll_flush_clv(pll_partition_t *p, pll_amd_ext_t *x, unsigned int clv_index);
 int pll_flush_scaler(pll_partition_t *p, pll_amd_ext_t *x, int scaler_index);
 /* model arrays + eigensystems + category rates: what the derivative and P-matrix kernels read */
 int pll_flush_eigen(pll_partition_t *p, pll_amd_ext_t *x);
+/* class maps of the parents of `ops` on the device, dependency level by level (repeats.c) */
+int pll_update_repeats_device(pll_partition_t *p, pll_amd_ext_t *x, const pll_operation_t *ops,
+                              unsigned int count, const unsigned int *level, unsigned int nlevels);
 int pll_flush_pmatrix(pll_partition_t *p, pll_amd_ext_t *x, unsigned int first, unsigned int last);
 int pll_flush_repeats(pll_partition_t *p, pll_amd_ext_t *x, unsigned int node);
 int pll_is_pattern_tip(const pll_partition_t *p, unsigned int clv_index);

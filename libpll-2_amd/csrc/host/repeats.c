@@ -1,11 +1,18 @@
-/* repeats.c - site-repeats bookkeeping (integer work, stays on the host: SURVEY.md 8 row a8).
+/* repeats.c - site-repeats bookkeeping.
  *
  * Semantics of src/repeats.c: a node's CLV holds one entry per CLASS of sites that are
  * indistinguishable in the subtree below it. pernode_site_id[node][site] is the class of a site,
  * pernode_id_site[node][class] its first site; classes are numbered by first occurrence. A
  * parent's classes are the distinct (left class, right class) pairs, found with a direct-address
- * table that is wiped after use through a to-clean list (src/repeats.c:334-377). The maps are
- * marked for upload; the gfx950 kernels gather through them.
+ * table that is wiped after use through a to-clean list (src/repeats.c:334-377).
+ *
+ * With a device context the class maps of inner nodes are computed ON the device
+ * (pll_update_repeats_device -> kernels_repeats.h), dependency level by level; the host learns the
+ * class counts (one small copy per level: allocation sizes and the enable_repeats callback need
+ * them) and partition->repeats->pernode_site_id / pernode_id_site become a mirror that
+ * pll_get_site_id / pll_get_id_site / pll_gpu_sync_repeats refresh on demand. Tip maps are built on
+ * the host while the sequence is parsed and uploaded. The sequential table walk below
+ * (pll_update_repeats_host) only serves host-only shells (PLL_AMD_HOST_ONLY, CPU tests).
  */
 #include "pll_internal.h"
 
@@ -35,15 +42,30 @@ unsigned int pll_get_clv_size(const pll_partition_t *p, unsigned int clv_index)
   return pll_get_sites_number(p, clv_index) * p->states_padded * p->rate_cats;
 }
 
+/* the accessors hand out host pointers: bring the mirror up to date first */
+static void mirror_maps(const pll_partition_t *p, unsigned int clv_index)
+{
+  const pll_amd_ext_t *x = pll_ext(p);
+  if (x && x->ctx && x->repeats_stale[clv_index]) (void)pll_gpu_sync_repeats((pll_partition_t *)p, (int)clv_index);
+}
+
 unsigned int *pll_get_site_id(const pll_partition_t *p, unsigned int clv_index)
 {
-  if (pll_repeats_enabled(p) && p->repeats->pernode_ids[clv_index]) return p->repeats->pernode_site_id[clv_index];
+  if (pll_repeats_enabled(p) && p->repeats->pernode_ids[clv_index])
+  {
+    mirror_maps(p, clv_index);
+    return p->repeats->pernode_site_id[clv_index];
+  }
   return NULL;
 }
 
 unsigned int *pll_get_id_site(const pll_partition_t *p, unsigned int clv_index)
 {
-  if (pll_repeats_enabled(p) && p->repeats->pernode_ids[clv_index]) return p->repeats->pernode_id_site[clv_index];
+  if (pll_repeats_enabled(p) && p->repeats->pernode_ids[clv_index])
+  {
+    mirror_maps(p, clv_index);
+    return p->repeats->pernode_id_site[clv_index];
+  }
   return NULL;
 }
 
@@ -160,7 +182,12 @@ int pll_update_repeats_tips(pll_partition_t *p, unsigned int tip, const pll_stat
   memset(p->clv[tip], 0, bytes);
   r->pernode_allocated_clvs[tip] = next;
   pll_amd_ext_t *x = pll_ext(p);
-  if (x) x->repeats_dirty[tip] = 1;
+  if (x)
+  {
+    x->repeats_dirty[tip] = 1;
+    x->repeats_stale[tip] = 0;
+    x->repeats_count[tip] = next;
+  }
   return PLL_SUCCESS;
 }
 
@@ -191,7 +218,101 @@ void pll_default_reallocate_repeats(pll_partition_t *p, unsigned int parent, int
   r->pernode_id_site[parent] = (unsigned int *)malloc((sites_to_alloc ? sites_to_alloc : 1) * sizeof(unsigned int));
 }
 
+/* what follows a parent's class count, on either path (src/repeats.c:349-381) */
+static void adopt_classes(pll_partition_t *p, const pll_operation_t *op, unsigned int classes, int enabled)
+{
+  pll_repeats_t *r = p->repeats;
+  const unsigned int parent = op->parent_clv_index;
+  const unsigned int to_alloc = enabled ? classes : p->sites;
+  r->pernode_ids[parent] = enabled ? classes : 0;
+  if (op->parent_scaler_index != PLL_SCALE_BUFFER_NONE) r->perscale_ids[op->parent_scaler_index] = enabled ? classes : 0;
+  r->reallocate_repeats(p, parent, op->parent_scaler_index, to_alloc);
+  /* no compression gained: fall back to one entry per site (:364-370) */
+  if (to_alloc >= p->sites)
+  {
+    r->pernode_ids[parent] = 0;
+    if (op->parent_scaler_index != PLL_SCALE_BUFFER_NONE) r->perscale_ids[op->parent_scaler_index] = 0;
+  }
+}
+
+int pll_update_repeats_device(pll_partition_t *p, pll_amd_ext_t *x, const pll_operation_t *ops,
+                              unsigned int count, const unsigned int *level, unsigned int nlevels)
+{
+  pll_repeats_t *r = p->repeats;
+  unsigned int l, i, k, n;
+  int ok = PLL_FAILURE;
+  if (!r->lookup_buffer) pll_resize_repeats_lookup(p, PLL_REPEATS_LOOKUP_SIZE); /* its SIZE bounds the pair table */
+  pllgpu_repop_t *rop = (pllgpu_repop_t *)malloc(sizeof(pllgpu_repop_t) * count);
+  unsigned int *idx = (unsigned int *)malloc(sizeof(unsigned int) * 2 * count);
+  if (!rop || !idx)
+  {
+    pll_set_error(PLL_ERROR_MEM_ALLOC, "Unable to allocate enough memory for repeats structure.");
+    goto done;
+  }
+  unsigned int *counts = idx + count;
+  for (l = 0; l < nlevels; ++l)
+  {
+    n = 0;
+    for (i = 0; i < count; ++i)
+    {
+      if (level[i] != l) continue;
+      const pll_operation_t *op = &ops[i];
+      const unsigned int left = op->child1_clv_index, right = op->child2_clv_index, parent = op->parent_clv_index;
+      x->repeats_dirty[parent] = 0;
+      if (!r->enable_repeats(p, left, right))
+      {
+        adopt_classes(p, op, 0, 0);
+        x->repeats_stale[parent] = 0;
+        x->repeats_count[parent] = 0;
+        if (pllgpu_repeats_set_ids(x->ctx, parent, 0) != 0) goto gpu_fail;
+        continue;
+      }
+      /* tips: host-built maps go up now; inner children were produced by an earlier level */
+      if (!pll_flush_repeats(p, x, left) || !pll_flush_repeats(p, x, right)) goto done;
+      rop[n].parent = parent;
+      rop[n].left = left;
+      rop[n].right = right;
+      rop[n].nleft = r->pernode_ids[left];
+      rop[n].nright = r->pernode_ids[right];
+      idx[n++] = i;
+    }
+    if (!n) continue;
+    if (pllgpu_repeats_classes(x->ctx, rop, n, counts) != 0) goto gpu_fail;
+    for (k = 0; k < n; ++k)
+    {
+      const pll_operation_t *op = &ops[idx[k]];
+      adopt_classes(p, op, counts[k], 1);
+      x->repeats_stale[op->parent_clv_index] = 1;
+      x->repeats_count[op->parent_clv_index] = counts[k];
+      if (pllgpu_repeats_set_ids(x->ctx, op->parent_clv_index, r->pernode_ids[op->parent_clv_index]) != 0) goto gpu_fail;
+    }
+  }
+  ok = PLL_SUCCESS;
+  if (x->eager_mirror) ok = pll_gpu_sync_repeats(p, -1);
+  goto done;
+gpu_fail:
+  pll_set_gpu_error("pll_update_repeats");
+done:
+  free(rop);
+  free(idx);
+  return ok;
+}
+
+static void pll_update_repeats_host(pll_partition_t *p, const pll_operation_t *op);
+
 void pll_update_repeats(pll_partition_t *p, const pll_operation_t *op)
+{
+  pll_amd_ext_t *x = pll_ext(p);
+  if (x && x->ctx)
+  {
+    const unsigned int level = 0;
+    (void)pll_update_repeats_device(p, x, op, 1, &level, 1);
+    return;
+  }
+  pll_update_repeats_host(p, op);
+}
+
+static void pll_update_repeats_host(pll_partition_t *p, const pll_operation_t *op)
 {
   pll_repeats_t *r = p->repeats;
   const unsigned int left = op->child1_clv_index, right = op->child2_clv_index, parent = op->parent_clv_index;

@@ -1,0 +1,101 @@
+"""GPU: site-repeats class maps computed on the device (SURVEY section 8 row f4,
+kernels_repeats.h) against the reference's sequential table walk (src/repeats.c:299-382).
+Integer work: bit-exact, including the class counts and the fall-back to uncompressed nodes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from pllamd import api, driver, workload as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _maps(lib, s, sites, through_accessors):
+    rep = s.part.repeats.contents
+    rows = []
+    if lib.is_amd and not through_accessors:
+        assert lib.pll_gpu_sync_repeats(s.p, -1)
+    for node in range(s.part.nodes):
+        ids = rep.pernode_ids[node]
+        if through_accessors:
+            sid, ids_ptr = lib.pll_get_site_id(s.p, node), lib.pll_get_id_site(s.p, node)
+            assert bool(sid) == bool(ids) == bool(ids_ptr)
+        else:
+            sid, ids_ptr = rep.pernode_site_id[node], rep.pernode_id_site[node]
+        rows.append((ids, api.as_np(sid, sites, np.uint32).copy() if ids else None,
+                     api.as_np(ids_ptr, ids, np.uint32).copy() if ids else None,
+                     lib.pll_get_sites_number(s.p, node), lib.pll_get_clv_size(s.p, node)))
+    return rows
+
+
+CASES = [
+    dict(states=4, tips=16, sites=300, mutate_pct=2, seed=7),
+    dict(states=4, tips=16, sites=300, mutate_pct=30, seed=8),          # compression stops paying near the root
+    dict(states=4, tips=64, sites=5000, mutate_pct=4, seed=9),
+    dict(states=4, tips=128, sites=1025, mutate_pct=1, seed=10),        # one site past a workgroup boundary
+    dict(states=4, tips=200, sites=700, tree="caterpillar", mutate_pct=2, seed=11),
+    dict(states=20, tips=32, sites=2000, mutate_pct=3, seed=12),
+    dict(states=61, tips=16, sites=999, mutate_pct=2, seed=13),
+    dict(states=4, tips=8, sites=70000, mutate_pct=6, seed=14),         # several scan chunks per op
+]
+
+
+@pytest.mark.parametrize("kw", CASES, ids=lambda k: "s%d-t%d-n%d-m%d" % (k["states"], k["tips"], k["sites"], k["mutate_pct"]))
+@pytest.mark.parametrize("how", ["traversal", "op-by-op"])
+def test_device_class_maps_match_reference(amd_lib, ref_lib, kw, how):
+    case = W.make_case("rep", attributes=api.SITE_REPEATS, **kw)
+    ops = api.make_ops(case.op_batches[0])
+    res = {}
+    for lib in (amd_lib, ref_lib):
+        with driver.Session(lib, case, api.ARCH_AVX2) as s:
+            if how == "traversal":
+                lib.pll_update_partials(s.p, ops, len(case.op_batches[0]))  # levels of independent ops at once
+            else:
+                for i in range(len(case.op_batches[0])):
+                    lib.pll_update_repeats(s.p, C.byref(ops[i]))
+            res[lib.is_amd] = _maps(lib, s, case.sites, through_accessors=(how == "traversal"))
+    for node, (a, b) in enumerate(zip(res[True], res[False])):
+        assert a[0] == b[0] and a[3] == b[3] and a[4] == b[4], (node, a[0], b[0])
+        if a[0]:
+            assert (a[1] == b[1]).all() and (a[2] == b[2]).all(), node
+    assert any(r[0] for r in res[True][case.tips:]), "no inner node was compressed - test is vacuous"
+
+
+def test_lookup_size_bounds_the_pair_table(amd_lib, ref_lib):
+    """pll_resize_repeats_lookup: a parent whose children have ids_left * ids_right >= the table size
+    stays uncompressed on both sides (src/repeats.c:100-110)"""
+    case = W.make_case("rep", 4, 16, 3000, attributes=api.SITE_REPEATS, mutate_pct=8, seed=21)
+    ops = api.make_ops(case.op_batches[0])
+    out = {}
+    for lib in (amd_lib, ref_lib):
+        with driver.Session(lib, case, api.ARCH_AVX2) as s:
+            lib.pll_resize_repeats_lookup(s.p, 200)
+            lib.pll_update_partials(s.p, ops, len(case.op_batches[0]))
+            rep = s.part.repeats.contents
+            out[lib.is_amd] = [rep.pernode_ids[n] for n in range(s.part.nodes)]
+            if lib.is_amd:
+                v, _ = s.edge_lnl(case.edges[0], persite=False)
+                assert np.isfinite(v)
+    assert out[True] == out[False]
+    assert 0 in out[True][16:] and any(out[True][16:])
+
+
+def test_maps_survive_partial_traversals(amd_lib, ref_lib):
+    """update_repeats = 0 reuses the device maps; a later partial update recomputes only its parents"""
+    case = W.make_case("rep", 4, 16, 800, attributes=api.SITE_REPEATS, mutate_pct=3, seed=22)
+    batch = case.op_batches[0]
+    ops = api.make_ops(batch)
+    tail = api.make_ops(batch[-3:])
+    vals = {}
+    for lib in (amd_lib, ref_lib):
+        with driver.Session(lib, case, api.ARCH_AVX2) as s:
+            lib.pll_update_partials(s.p, ops, len(batch))
+            a, _ = s.edge_lnl(case.edges[0], persite=False)
+            lib.pll_update_partials_rep(s.p, ops, len(batch), 0)
+            b, _ = s.edge_lnl(case.edges[0], persite=False)
+            lib.pll_update_partials(s.p, tail, 3)
+            c, _ = s.edge_lnl(case.edges[0], persite=False)
+            vals[lib.is_amd] = (a, b, c)
+    assert vals[True][0] == vals[True][1] == vals[True][2]
+    assert abs(vals[True][0] - vals[False][0]) <= 1e-10 * abs(vals[False][0])
