@@ -53,7 +53,23 @@ __global__ __launch_bounds__(256) void k_rep_mark(const RepPack p)
   for (unsigned q = 0; q < 4; ++q)
   {
     const unsigned s = base + q;
-    if (s < p.sites) atomicMin(&p.table[rep_cell(o, s)], s);
+    // many sites share a cell (that is the point of site repeats): (1) look before the atomic, so
+    // that only sites that could still lower the minimum queue up on the cell's L2 line - a stale
+    // value read here can only cause a redundant atomic, never a wrong minimum; (2) of the lanes of
+    // a wave that want the same cell only the lowest one (= the lowest site) goes out.
+    const unsigned c = s < p.sites ? rep_cell(o, s) : 0u;
+    bool pending = s < p.sites && __hip_atomic_load(&p.table[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > s;
+    unsigned long long m;
+    while ((m = __ballot(pending)) != 0ull)
+    {
+      const int leader = __ffsll((long long)m) - 1;
+      const unsigned lc = __shfl(c, leader, 64);
+      if (pending && c == lc)
+      {
+        if ((int)(threadIdx.x & 63u) == leader) atomicMin(&p.table[c], s);
+        pending = false;
+      }
+    }
   }
 }
 
