@@ -174,9 +174,13 @@ def main():
     os.environ.setdefault("PLL_AMD_DEVICE", "0" if same_device else str(local))
     dist = None
     torch = None
-    if world > 1:
+    if world > 1 or os.environ.get("PLL_BENCH_FORCE_DIST") == "1":  # FORCE_DIST: rehearse the collective path at world 1
         import torch
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -202,7 +206,16 @@ def main():
     lib = api.PllLib()
     sess = driver.Session(lib, case, api.ARCH_AVX2)  # uploads happen on first use (warm-up)
     edge = case.edges[0]
-    red = torch.zeros(1, dtype=torch.float64, device=tdev) if dist else None
+    red = torch.zeros(2, dtype=torch.float64, device=tdev) if dist else None
+    on_device = bool(dist) and args.backend == "nccl"
+    if on_device:
+        # the partition works on torch's stream, the shard's lnL stays in HBM ({lnL, sequence} in `red`)
+        # and RCCL reduces it there: no host round trip before the one exchange of the path
+        tstream = torch.cuda.Stream()
+        torch.cuda.set_stream(tstream)
+        if not lib.pll_gpu_set_stream(sess.p, tstream.cuda_stream):
+            raise SystemExit(f"pll_gpu_set_stream: [{lib.errno()}] {lib.errmsg()}")
+        fi = np.ascontiguousarray(case.freqs_indices, dtype=np.uint32)
 
     # site repeats: class maps are computed once (host, integer) and re-used, as applications do
     # between topology changes: pll_update_partials_rep(..., update_repeats = 0)
@@ -212,11 +225,17 @@ def main():
         sess.update_partials(update_repeats=upd[0])
         if cfg.get("repeats"):
             upd[0] = 0
+        if on_device:
+            if not lib.pll_gpu_edge_loglikelihood_async(sess.p, edge[0], edge[1], edge[2], edge[3], edge[4], api.uptr(fi),
+                                                        red.data_ptr()):
+                raise SystemExit(f"pll_gpu_edge_loglikelihood_async: [{lib.errno()}] {lib.errmsg()}")
+            dist.all_reduce(red[:1])  # the path's one exchange: sum of the shards' log-likelihoods
+            return float(red[0].item())
         v, _ = sess.edge_lnl(edge, persite=False)
         if dist:
             red[0] = v
-            dist.all_reduce(red)  # the path's one exchange: sum of the shards' log-likelihoods
-            v = float(red.item())
+            dist.all_reduce(red[:1])
+            v = float(red[0].item())
         return v
 
     def fence():

@@ -297,6 +297,17 @@ int pll_gpu_sync_sumtable(pll_partition_t *partition, double *sumtable);
 int pll_gpu_set_stream(pll_partition_t *partition, void *hip_stream);
 void *pll_gpu_get_stream(const pll_partition_t *partition);
 int pll_gpu_synchronize(pll_partition_t *partition);
+/* Multi-GPU building block (SURVEY section 8 row e): pll_compute_edge_loglikelihood
+ * (src/pll.h:790-797) without the host round trip. The evaluation is enqueued on the partition's
+ * stream and leaves {lnL of this partition's sites, call sequence number} in the two doubles of
+ * DEVICE memory at device_result; nothing is copied back and the call does not wait. A site-sharded
+ * run hands device_result[0] of every rank to one RCCL all-reduce on the same stream
+ * (pll_gpu_set_stream) and reads the sum once. Returns PLL_SUCCESS when enqueued. Not available
+ * with an ascertainment-bias correction (its formula runs on the host). */
+int pll_gpu_edge_loglikelihood_async(pll_partition_t *partition, unsigned int parent_clv_index,
+                                     int parent_scaler_index, unsigned int child_clv_index,
+                                     int child_scaler_index, unsigned int matrix_index,
+                                     const unsigned int *freqs_indices, double *device_result);
 /* HIP-event stopwatch on the partition's stream (bench.py's roofline leg): start .. stop
  * brackets whatever was enqueued in between; returns elapsed milliseconds from stop(). */
 int pll_gpu_timer_start(pll_partition_t *partition);

@@ -70,6 +70,10 @@ typedef struct pllgpu_edge
   unsigned int gather;                /* either end class-compressed */
   const unsigned int *freqs_indices;  /* host, [rate_cats] */
   int want_persite;
+  double *device_result;              /* NULL: synchronous call. Otherwise 2 doubles of DEVICE memory:
+                                         the kernel leaves {lnL, call sequence number} there and the
+                                         call returns without waiting (multi-GPU: the sum over shards
+                                         is reduced on the device, pll_gpu_edge_loglikelihood_async) */
 } pllgpu_edge_t;
 
 int pllgpu_device_count(void);

@@ -726,7 +726,7 @@ static void launch_edge_generic(pllgpu_ctx *c, const DevEdge &e, unsigned blocks
 }
 
 static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsigned *freqs_indices,
-                   double *persite_host, double *lnl_out)
+                   double *persite_host, double *lnl_out, double *device_result = nullptr)
 {
   const pllgpu_geometry_t &g = c->geo;
   for (unsigned k = 0; k < g.rate_cats; ++k)
@@ -742,7 +742,7 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
   e.persite = persite_host ? c->persite.p : nullptr;
   e.block_sums = c->block_sums.p;
   e.counter = c->counter.p;
-  e.result = c->result_dev;
+  e.result = device_result ? device_result : c->result_dev;
   c->seq += 1.0;
   e.sequence = c->seq;
   unsigned long long seq_bits;
@@ -784,6 +784,7 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
     }
   }
   HIP_TRY(hipGetLastError());
+  if (device_result) return 0; // asynchronous: the value stays on the device
   if (persite_host)
   {
     HIP_TRY(hipMemcpyAsync(persite_host, c->persite.p, g.sites * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -850,7 +851,8 @@ extern "C" int pllgpu_edge_loglikelihood(pllgpu_ctx_t *c, const pllgpu_edge_t *e
     e.csid = c->ids[ed->child_clv] ? c->site_id[ed->child_clv].p : nullptr;
   }
   e.is_root = 0;
-  return run_lnl(c, e, ed->child_is_tip != 0, ed->gather != 0, ed->freqs_indices, persite_host, lnl_out);
+  if (ed->device_result && persite_host) return fail(PLLGPU_EINVAL, "per-site values are not available from an asynchronous evaluation");
+  return run_lnl(c, e, ed->child_is_tip != 0, ed->gather != 0, ed->freqs_indices, persite_host, lnl_out, ed->device_result);
 }
 
 extern "C" int pllgpu_root_loglikelihood(pllgpu_ctx_t *c, unsigned clv, int scaler, unsigned gather,

@@ -70,10 +70,9 @@ static int prepare_end(pll_partition_t *p, pll_amd_ext_t *x, unsigned int clv, i
   return 1;
 }
 
-double pll_compute_edge_loglikelihood(pll_partition_t *p, unsigned int parent_clv_index,
-                                      int parent_scaler_index, unsigned int child_clv_index,
-                                      int child_scaler_index, unsigned int matrix_index,
-                                      const unsigned int *freqs_indices, double *persite_lnl)
+static double edge_lnl(pll_partition_t *p, unsigned int parent_clv_index, int parent_scaler_index,
+                       unsigned int child_clv_index, int child_scaler_index, unsigned int matrix_index,
+                       const unsigned int *freqs_indices, double *persite_lnl, double *device_result)
 {
   pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
   if (!x || !x->ctx)
@@ -117,6 +116,12 @@ double pll_compute_edge_loglikelihood(pll_partition_t *p, unsigned int parent_cl
              (p->repeats->pernode_ids[parent_clv_index] || p->repeats->pernode_ids[child_clv_index]);
   e.freqs_indices = freqs_indices;
   e.want_persite = persite_lnl != NULL;
+  e.device_result = device_result;
+  if (device_result && (p->attributes & PLL_ATTRIB_AB_MASK))
+  {
+    pll_set_error(PLL_ERROR_GPU_UNSUPPORTED, "the ascertainment-bias correction needs the synchronous call");
+    return fail_lnl("pll_gpu_edge_loglikelihood_async");
+  }
   double lnl = 0;
   if (pllgpu_edge_loglikelihood(x->ctx, &e, persite_lnl, &lnl) != 0)
   {
@@ -125,6 +130,30 @@ double pll_compute_edge_loglikelihood(pll_partition_t *p, unsigned int parent_cl
   }
   if (p->attributes & PLL_ATTRIB_AB_MASK) lnl += asc_correction(p, x, &e, 0);
   return lnl;
+}
+
+double pll_compute_edge_loglikelihood(pll_partition_t *p, unsigned int parent_clv_index,
+                                      int parent_scaler_index, unsigned int child_clv_index,
+                                      int child_scaler_index, unsigned int matrix_index,
+                                      const unsigned int *freqs_indices, double *persite_lnl)
+{
+  return edge_lnl(p, parent_clv_index, parent_scaler_index, child_clv_index, child_scaler_index, matrix_index,
+                  freqs_indices, persite_lnl, NULL);
+}
+
+int pll_gpu_edge_loglikelihood_async(pll_partition_t *p, unsigned int parent_clv_index, int parent_scaler_index,
+                                     unsigned int child_clv_index, int child_scaler_index,
+                                     unsigned int matrix_index, const unsigned int *freqs_indices,
+                                     double *device_result)
+{
+  if (!device_result)
+  {
+    pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_gpu_edge_loglikelihood_async: device_result is NULL");
+    return PLL_FAILURE;
+  }
+  const double v = edge_lnl(p, parent_clv_index, parent_scaler_index, child_clv_index, child_scaler_index,
+                            matrix_index, freqs_indices, NULL, device_result);
+  return v == 0.0 ? PLL_SUCCESS : PLL_FAILURE; /* 0 = enqueued; failures come back as -inf */
 }
 
 double pll_compute_root_loglikelihood(pll_partition_t *p, unsigned int clv_index, int scaler_index,

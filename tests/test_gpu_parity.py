@@ -276,3 +276,37 @@ def test_ascertainment_bias_against_oracle(amd_lib, kw):
     assert scalers_equal(got, exp)
     for idx, a in got["clv"].items():
         assert a.shape[0] == case.sites + case.states
+
+
+def test_async_edge_lnl_stays_on_the_device(amd_lib):
+    """pll_gpu_edge_loglikelihood_async: same value as the synchronous call, left in device memory
+    (the multi-GPU path reduces it there); refused with an ascertainment-bias correction"""
+    import ctypes as C
+    hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")  # the runtime the library itself is linked against
+    dev = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dev), C.c_size_t(16)) == 0
+    host = (C.c_double * 2)()
+    try:
+        case = W.make_case("async", 4, 16, 5000, seed=95)
+        with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+            s.update_partials()
+            e = case.edges[0]
+            ref, _ = s.edge_lnl(e, persite=False)
+            fi = np.zeros(4, dtype=np.uint32)
+            for _ in range(3):
+                assert amd_lib.pll_gpu_edge_loglikelihood_async(s.p, e[0], e[1], e[2], e[3], e[4], api.uptr(fi), dev)
+            assert amd_lib.pll_gpu_synchronize(s.p)
+            assert hip.hipMemcpy(host, dev, C.c_size_t(16), 2) == 0  # hipMemcpyDeviceToHost
+            assert host[0] == ref
+            # the synchronous path still works afterwards
+            again, _ = s.edge_lnl(e, persite=False)
+            assert again == ref
+        asc = W.make_case("async_asc", 4, 16, 200, seed=96, asc_type=1)
+        with driver.Session(amd_lib, asc, api.ARCH_AVX2) as s:
+            s.update_partials()
+            e = asc.edges[0]
+            assert not amd_lib.pll_gpu_edge_loglikelihood_async(s.p, e[0], e[1], e[2], e[3], e[4],
+                                                                api.uptr(np.zeros(4, dtype=np.uint32)), dev)
+            assert amd_lib.errno() == 902
+    finally:
+        hip.hipFree(dev)
