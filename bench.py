@@ -272,6 +272,7 @@ def main():
         sess.update_partials(update_repeats=upd[0])
     ms_full = lib.pll_gpu_timer_stop(sess.p)
     launches_full = lib.pll_gpu_last_launch_count(sess.p)
+    bytes_full = lib.pll_gpu_last_algorithmic_bytes(sess.p)
     # ---- roofline leg: the DOMINANT kernel = the inner x inner CLV update. Its launches are timed by
     # re-running the part of the traversal whose children are both inner CLVs (a valid partial
     # traversal: the tip-level parents it reads are already in HBM)
@@ -290,7 +291,10 @@ def main():
     ms = lib.pll_gpu_timer_stop(sess.p)
     launches = lib.pll_gpu_last_launch_count(sess.p)
     entries = {op[0]: sess.entries(op[0]) for op in all_ops} if cfg.get("repeats") else None
-    trav_bytes = op_bytes(case, api, ii_ops, entries)
+    # bytes the launches had to move AS GROUPED (fused producer/consumer groups do not read the
+    # intermediate CLVs back): reported by the library; op_bytes() = the same ops launched one by one
+    unfused_bytes = op_bytes(case, api, ii_ops, entries)
+    trav_bytes = lib.pll_gpu_last_algorithmic_bytes(sess.p) or unfused_bytes
     per_launch_bytes = trav_bytes / launches
     per_launch_ms = ms / reps / launches
     achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
@@ -299,7 +303,8 @@ def main():
     if os.path.exists(tfile) and not args.pattern_tip and not args.sites:  # PMC-derived HBM bytes per launch of the same command (profiles/README.md)
         traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
     mfma = cfg["states"] > 32 and not os.environ.get("PLL_AMD_NO_MFMA", "0").strip("0")
-    kernel = {4: "k_partials_dna<false,false,%s>", 20: "k_partials_tiled<20,false,false,%s>",
+    fused = cfg["states"] == 4 and not cfg.get("repeats") and not os.environ.get("PLL_AMD_NO_FUSE", "0").strip("0")
+    kernel = {4: "k_partials_dna_fused<4,4>%.0s" if fused else "k_partials_dna<false,false,%s>", 20: "k_partials_tiled<20,false,false,%s>",
               61: "k_partials_mfma<false,false,%s>" if mfma else "k_partials_tiled<32,false,false,%s>"
               }[cfg["states"]] % ("true" if cfg.get("repeats") else "false")
     if mfma:
@@ -321,9 +326,12 @@ def main():
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, kernel=kernel,
                         launches=launches, ops_in_those_launches=len(ii_ops), avg_launch_ms=round(per_launch_ms, 5),
                         algorithmic_bytes_per_launch=int(per_launch_bytes))
+    roofline["unfused_equivalent"] = dict(
+        note="the same ops priced at SURVEY 8d's per-update bytes (every op reads both children from HBM)",
+        GBps=round(unfused_bytes / launches / (per_launch_ms * 1e-3) / 1e9, 1), bytes_per_launch=int(unfused_bytes / launches))
     roofline.update(
                     full_traversal=dict(launches=launches_full, ms=round(ms_full / reps, 5),
-                                        algorithmic_GBps=round(op_bytes(case, api, all_ops, entries) / (ms_full / reps * 1e-3) / 1e9, 1),
+                                        algorithmic_GBps=round((bytes_full or op_bytes(case, api, all_ops, entries)) / (ms_full / reps * 1e-3) / 1e9, 1),
                                         update_partials_only_M_per_s=round(sites * nops / (ms_full / reps * 1e-3) / 1e6, 1)))
 
     out = {

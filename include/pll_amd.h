@@ -314,6 +314,10 @@ int pll_gpu_timer_start(pll_partition_t *partition);
 double pll_gpu_timer_stop(pll_partition_t *partition);
 /* number of kernel launches issued by the last pll_update_partials call (bench bookkeeping) */
 unsigned int pll_gpu_last_launch_count(const pll_partition_t *partition);
+/* HBM bytes the kernels of the last pll_update_partials call had to move by construction: child
+ * reads + parent and scaler writes of every launch AS IT WAS GROUPED (an op evaluated together with
+ * the producers of its children does not read those children back) - bench.py's roofline numerator */
+double pll_gpu_last_algorithmic_bytes(const pll_partition_t *partition);
 int pll_gpu_device_count(void);
 /* 1 if a usable gfx950 device is present, 0 otherwise (the analogue of src/hardware.c's probe) */
 int pll_gpu_available(void);

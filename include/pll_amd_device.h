@@ -59,6 +59,9 @@ typedef struct pllgpu_op
   unsigned int parent_entries;                        /* sites, or class count under repeats */
   unsigned int flags;
   unsigned int level;                                 /* dependency level, 0-based */
+  int war_level;                                      /* latest level at which an EARLIER op of the list still
+                                                         reads or writes this op's parent CLV / scaler
+                                                         (-1: none): the op may not run before it */
 } pllgpu_op_t;
 
 typedef struct pllgpu_edge
@@ -205,6 +208,9 @@ int pllgpu_synchronize(pllgpu_ctx_t *ctx);
 int pllgpu_timer_start(pllgpu_ctx_t *ctx);
 double pllgpu_timer_stop(pllgpu_ctx_t *ctx); /* ms, < 0 on error */
 unsigned int pllgpu_last_launch_count(const pllgpu_ctx_t *ctx);
+/* HBM bytes the kernels of the last pllgpu_update_partials call had to move by construction
+ * (child reads + parent and scaler writes of every launch as it was grouped) */
+double pllgpu_last_algorithmic_bytes(const pllgpu_ctx_t *ctx);
 
 #ifdef __cplusplus
 }

@@ -229,3 +229,202 @@ __global__ __launch_bounds__(256) void k_edge_dna(const DevEdge e, unsigned tile
   }
   publish_block_sum(e, wave_sum(acc), 4u);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Fused groups: a CLV update whose child was produced by another op of the same
+// pll_update_partials call does not need to read that child back from HBM. k_partials_dna_fused
+// evaluates, per site and entirely in registers, up to three ops - the parent P and the ops A / B
+// that produce its left / right child - and stores ALL their CLVs and scalers (callers may read any
+// of them later), so the arithmetic and every stored value are those of the unfused launches; only
+// the re-reads disappear. Bytes per site of a (tt, tt -> ii) group: 4 + 3 * 128 = 388 instead of
+// 2 * 130 + 384 = 644; of an (ii, ii -> ii) group: 4 * 128 + 3 * 128 = 896 instead of 3 * 384 = 1152.
+// Grouping is decided per call by plan_fusion() (pllgpu.hip) under the same dependency rules as the
+// level scheduler. No site repeats in fused groups (lane = site = entry for all three ops).
+enum DnaChildKind
+{
+  CK_INNER = 0, // child CLV read from HBM
+  CK_TIP = 1,   // child tip codes read from HBM
+  CK_FTT = 2,   // child computed here from two tips
+  CK_FTI = 3,   // child computed here from a tip (left) and an inner CLV (right)
+  CK_FII = 4    // child computed here from two inner CLVs
+};
+
+struct FOp // one CLV update of a fused group, pointers resolved (80 bytes)
+{
+  double *parent;
+  const double *left, *right;
+  const unsigned char *ltip, *rtip;
+  unsigned *pscaler;
+  const unsigned *lscaler, *rscaler;
+  const double *lmat, *rmat;
+};
+
+struct FGroup
+{
+  FOp p;    // the parent op; for a fused child its left/right/lscaler/rscaler fields are not read
+  FOp a, b; // producer of the left / right child when that child is fused
+};
+
+constexpr int kMaxGroups = 16; // 16 * 240 B = 3840 B of the 4 KiB kernarg segment
+
+struct FusePack
+{
+  FGroup g[kMaxGroups];
+};
+
+// scaling decision + scaler words of one op (src/core_partials.c:729-763): v is rescaled in place,
+// sc receives the op's scaler entry (per site in .x, or the four per-rate counts)
+__device__ __forceinline__ void dna_scale(double (&v)[4][4], const bool (&small)[4], int mode, uint4 lsc, uint4 rsc, uint4 &sc)
+{
+  sc = make_uint4(0, 0, 0, 0);
+  if (mode == 1)
+  {
+    const bool s = small[0] && small[1] && small[2] && small[3];
+    if (s)
+    {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[k][i] *= PLLGPU_SCALE_FACTOR;
+    }
+    sc.x = lsc.x + rsc.x + (s ? 1u : 0u);
+  }
+  else if (mode == 2)
+  {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (small[k])
+      {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[k][i] *= PLLGPU_SCALE_FACTOR;
+      }
+    sc.x = lsc.x + rsc.x + small[0];
+    sc.y = lsc.y + rsc.y + small[1];
+    sc.z = lsc.z + rsc.z + small[2];
+    sc.w = lsc.w + rsc.w + small[3];
+  }
+}
+
+__device__ __forceinline__ uint4 dna_load_scaler(const unsigned *s, unsigned n, int scale_mode)
+{
+  if (!s) return make_uint4(0, 0, 0, 0);
+  if (scale_mode == 2) return reinterpret_cast<const uint4 *>(s)[n];
+  return make_uint4(s[n], 0, 0, 0);
+}
+
+// STREAM: the CLV of a fused child is not read again by this traversal (its consumer took it from
+// registers), so it goes out with non-temporal stores and leaves L2/MALL to the group parents the
+// next level reads. (For unfused launches non-temporal stores LOSE bandwidth, profiles/README.md -
+// there the next level does want the lines.)
+template <bool STREAM>
+__device__ __forceinline__ void dna_store(const FOp &op, size_t off, unsigned n, bool valid, int mode, const double (&v)[4][4], uint4 sc)
+{
+  if (!valid) return;
+  if (mode == 1) op.pscaler[n] = sc.x;
+  if (mode == 2) reinterpret_cast<uint4 *>(op.pscaler)[n] = sc;
+  double *__restrict__ out = op.parent + off;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+      if (STREAM)
+        __builtin_nontemporal_store(v[k][i], out + (k * 4 + i) * 64);
+      else
+        out[(k * 4 + i) * 64] = v[k][i];
+    }
+}
+
+// the 16 values of one child of the parent op and the child's scaler words
+template <int KIND>
+__device__ __forceinline__ void dna_child(const FOp &pop, bool left_side, const FOp &cop, size_t off, unsigned n, bool valid,
+                                          int scale_mode, double (&v)[4][4], uint4 &sc)
+{
+  if (KIND == CK_INNER)
+  {
+    const double *__restrict__ x = (left_side ? pop.left : pop.right) + off;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dna_fetch<false>(v[k], x, k, 0u);
+    sc = dna_load_scaler(left_side ? pop.lscaler : pop.rscaler, n, scale_mode);
+  }
+  else if (KIND == CK_TIP)
+  {
+    const unsigned code = (left_side ? pop.ltip : pop.rtip)[n];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dna_fetch<true>(v[k], nullptr, k, code);
+    sc = make_uint4(0, 0, 0, 0);
+  }
+  else
+  {
+    constexpr bool LT = (KIND == CK_FTT || KIND == CK_FTI), RT = (KIND == CK_FTT);
+    const int mode = cop.pscaler ? scale_mode : 0;
+    const unsigned lcode = LT ? cop.ltip[n] : 0u, rcode = RT ? cop.rtip[n] : 0u;
+    const double *__restrict__ lx = LT ? nullptr : cop.left + off;
+    const double *__restrict__ rx = RT ? nullptr : cop.right + off;
+    cdouble_p lm = as_const(cop.lmat), rm = as_const(cop.rmat);
+    bool small[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      double xl[4], xr[4], a[4], b[4];
+      dna_fetch<LT>(xl, lx, k, lcode);
+      dna_fetch<RT>(xr, rx, k, rcode);
+      dna_matvec(a, lm + k * 16, xl);
+      dna_matvec(b, rm + k * 16, xr);
+      small[k] = true;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+      {
+        v[k][i] = a[i] * b[i];
+        small[k] = small[k] && (v[k][i] < PLLGPU_SCALE_THRESHOLD);
+      }
+    }
+    const uint4 lsc = dna_load_scaler(LT ? nullptr : cop.lscaler, n, scale_mode);
+    const uint4 rsc = dna_load_scaler(RT ? nullptr : cop.rscaler, n, scale_mode);
+    dna_scale(v, small, mode, lsc, rsc, sc);
+    dna_store<true>(cop, off, n, valid, mode, v, sc);
+  }
+}
+
+template <int LK, int RK>
+__global__ __launch_bounds__(256) void k_partials_dna_fused(const FusePack pack, unsigned entries, int scale_mode, unsigned tiles_per_wave)
+{
+  const FGroup &g = pack.g[blockIdx.y];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned ntiles = (entries + 63u) / 64u;
+  const int mode = g.p.pscaler ? scale_mode : 0;
+  cdouble_p lm = as_const(g.p.lmat), rm = as_const(g.p.rmat);
+
+  for (unsigned t = 0; t < tiles_per_wave; ++t)
+  {
+    const unsigned tile = (blockIdx.x * 4u + wave) * tiles_per_wave + t;
+    if (tile >= ntiles) break; // wave-uniform
+    const unsigned n0 = tile * 64u + lane;
+    const bool valid = n0 < entries;
+    const unsigned n = valid ? n0 : entries - 1;
+    const size_t off = (size_t)(n >> 6) * kDnaTile + (n & 63u);
+
+    double va[4][4], vb[4][4], v[4][4];
+    uint4 sca, scb, sc;
+    dna_child<LK>(g.p, true, g.a, off, n, valid, scale_mode, va, sca);
+    dna_child<RK>(g.p, false, g.b, off, n, valid, scale_mode, vb, scb);
+    bool small[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      double a[4], b[4];
+      dna_matvec(a, lm + k * 16, va[k]);
+      dna_matvec(b, rm + k * 16, vb[k]);
+      small[k] = true;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+      {
+        v[k][i] = a[i] * b[i];
+        small[k] = small[k] && (v[k][i] < PLLGPU_SCALE_THRESHOLD);
+      }
+    }
+    dna_scale(v, small, mode, sca, scb, sc);
+    dna_store<false>(g.p, off, n, valid, mode, v, sc);
+  }
+}

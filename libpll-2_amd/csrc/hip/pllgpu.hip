@@ -112,6 +112,8 @@ struct pllgpu_ctx
   double seq = 0.0;
   std::vector<double> stage;     // host staging for the P-matrix re-layout
   unsigned last_launches = 0;
+  double last_bytes = 0.0;       // algorithmic HBM bytes of the last update_partials call
+  bool fuse = false;             // DNA: evaluate producer + consumer ops in one kernel (kernels_dna.h)
 };
 
 static inline int use(pllgpu_ctx *c)
@@ -145,6 +147,9 @@ static void derive_geometry(pllgpu_ctx *c)
   c->dna_fast = (g.states == 4 && g.rate_cats == 4);
   if (const char *v = getenv("PLL_AMD_GENERIC_ONLY")) // experiment switch: route DNA through the generic kernels
     if (*v && *v != '0') c->dna_fast = false;
+  c->fuse = c->dna_fast;
+  if (const char *v = getenv("PLL_AMD_NO_FUSE")) // experiment switch: one kernel per op group, no producer/consumer fusion
+    if (*v && *v != '0') c->fuse = false;
   c->tiled = true; // every shape keeps CLVs in the tiled sites-contiguous layout
   // 33..64 states: CLV updates on the fp64 matrix pipe (kernels_mfma.h); PLL_AMD_NO_MFMA=1 keeps the FMA kernel
   c->use_mfma = (g.states > 32 && g.rate_cats <= 16);
@@ -661,17 +666,144 @@ static int launch_partials(pllgpu_ctx *c, const OpPack &pack, unsigned nops, uns
   return 0;
 }
 
+// ---- producer/consumer fusion (DNA) ---------------------------------------------------------------
+// A group = an op P plus the ops that produce its children in the SAME call, evaluated by one
+// kernel at the producers' level (kernels_dna.h: k_partials_dna_fused). P may move one level up
+// only if nothing it must wait for sits at that level: its non-fused child is older, and no earlier
+// op of the list still reads or writes P's outputs there (war_level, from the host's scheduler).
+struct FusedGroup
+{
+  unsigned p;
+  int a, b;       // producer ops of the left / right child, or -1
+  int lk, rk;     // DnaChildKind of the left / right child
+  unsigned level; // execution level (= level of the producers)
+};
+
+static int child_kind(const pllgpu_op_t &prod)
+{
+  const bool lt = prod.flags & PLLGPU_OP_LEFT_TIP, rt = prod.flags & PLLGPU_OP_RIGHT_TIP;
+  return (lt && rt) ? CK_FTT : lt ? CK_FTI : CK_FII;
+}
+
+static void plan_fusion(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count, std::vector<int> &role,
+                        std::vector<FusedGroup> &groups)
+{
+  // role: 0 plain, 1 parent of a group, 2 fused into a group as a child
+  role.assign(count, 0);
+  groups.clear();
+  if (!c->fuse) return;
+  const unsigned nodes = c->geo.nodes;
+  std::vector<int> producer(nodes, -1), prod_l(count, -1), prod_r(count, -1);
+  std::vector<unsigned> eff(count);
+  // ops arrive sorted by level; same-level ops are independent, so the producer table may be
+  // updated as we go
+  for (unsigned i = 0; i < count; ++i)
+  {
+    eff[i] = ops[i].level;
+    if (!(ops[i].flags & PLLGPU_OP_LEFT_TIP)) prod_l[i] = producer[ops[i].left_clv];
+    if (!(ops[i].flags & PLLGPU_OP_RIGHT_TIP)) prod_r[i] = producer[ops[i].right_clv];
+    producer[ops[i].parent_clv] = (int)i;
+  }
+  for (unsigned i = 0; i < count; ++i)
+  {
+    const pllgpu_op_t &P = ops[i];
+    if (role[i] || (P.flags & PLLGPU_OP_GATHER) || P.level == 0) continue;
+    const unsigned L = P.level - 1;
+    if (P.war_level >= (int)L) continue;
+    auto fusable = [&](int pr, int pscal) {
+      return pr >= 0 && role[pr] == 0 && eff[pr] == L && ops[pr].level == L && !(ops[pr].flags & PLLGPU_OP_GATHER) &&
+             ops[pr].parent_scaler == pscal && ops[pr].parent_entries == P.parent_entries;
+    };
+    auto older = [&](int pr) { return pr < 0 || eff[pr] < L; };
+    const bool fl = fusable(prod_l[i], P.left_scaler), fr = fusable(prod_r[i], P.right_scaler) && prod_r[i] != prod_l[i];
+    if (!fl && !fr) continue;
+    if ((!fl && !older(prod_l[i])) || (!fr && !older(prod_r[i]))) continue;
+    FusedGroup g;
+    g.p = i;
+    g.a = fl ? prod_l[i] : -1;
+    g.b = fr ? prod_r[i] : -1;
+    g.lk = fl ? child_kind(ops[g.a]) : (P.flags & PLLGPU_OP_LEFT_TIP) ? CK_TIP : CK_INNER;
+    g.rk = fr ? child_kind(ops[g.b]) : (P.flags & PLLGPU_OP_RIGHT_TIP) ? CK_TIP : CK_INNER;
+    g.level = L;
+    role[i] = 1;
+    eff[i] = L;
+    if (fl) role[g.a] = 2;
+    if (fr) role[g.b] = 2;
+    groups.push_back(g);
+  }
+}
+
+static void to_fop(const DevOp &d, FOp &f)
+{
+  f.parent = d.parent;
+  f.left = d.left;
+  f.right = d.right;
+  f.ltip = d.ltip;
+  f.rtip = d.rtip;
+  f.pscaler = d.pscaler;
+  f.lscaler = d.lscaler;
+  f.rscaler = d.rscaler;
+  f.lmat = d.lmat;
+  f.rmat = d.rmat;
+}
+
+template <int LK, int RK>
+static void launch_fused_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries)
+{
+  const unsigned tiles = (entries + 63) / 64;
+  const unsigned want_blocks = 4096;
+  unsigned tpw = (unsigned)(((size_t)tiles * ngroups + 4 * want_blocks - 1) / (4 * want_blocks));
+  tpw = std::max(1u, std::min(tpw, 8u));
+  dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), ngroups), block(256);
+  hipLaunchKernelGGL((k_partials_dna_fused<LK, RK>), grid, block, 0, c->stream, pack, entries, c->gg.scale_mode, tpw);
+}
+
+static int launch_fused(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries, int lk, int rk)
+{
+#define FZ(A, B)                                          \
+  if (lk == A && rk == B)                                 \
+  {                                                       \
+    launch_fused_t<A, B>(c, pack, ngroups, entries);      \
+    return 0;                                             \
+  }
+  FZ(CK_INNER, CK_FTT) FZ(CK_INNER, CK_FTI) FZ(CK_INNER, CK_FII)
+  FZ(CK_TIP, CK_FTT) FZ(CK_TIP, CK_FTI) FZ(CK_TIP, CK_FII)
+  FZ(CK_FTT, CK_FTT) FZ(CK_FTT, CK_FTI) FZ(CK_FTT, CK_FII)
+  FZ(CK_FTI, CK_FTI) FZ(CK_FTI, CK_FII) FZ(CK_FII, CK_FII)
+#undef FZ
+  return fail(PLLGPU_EINVAL, "no fused kernel for child kinds (%d, %d)", lk, rk);
+}
+
+// bytes one CLV update has to move: inner children, tip codes, the parent, the scaler vectors
+static double op_traffic(const pllgpu_ctx *c, const pllgpu_op_t &o, bool read_left, bool read_right)
+{
+  const double span = (double)c->gg.S * c->gg.R * 8.0, sc = c->geo.per_rate_scalers ? 4.0 * c->gg.R : 4.0;
+  double b = span + (o.parent_scaler >= 0 ? sc : 0.0);
+  if (read_left) b += (o.flags & PLLGPU_OP_LEFT_TIP) ? 1.0 : span + (o.left_scaler >= 0 ? sc : 0.0);
+  if (read_right) b += (o.flags & PLLGPU_OP_RIGHT_TIP) ? 1.0 : span + (o.right_scaler >= 0 ? sc : 0.0);
+  return b * o.parent_entries;
+}
+
 extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, unsigned count)
 {
   CHECK_CTX(c);
   c->last_launches = 0;
+  c->last_bytes = 0.0;
+  std::vector<int> role;
+  std::vector<FusedGroup> groups;
+  plan_fusion(c, ops, count, role, groups);
+  size_t gi_sorted = 0;
+  if (!groups.empty())
+    std::stable_sort(groups.begin(), groups.end(), [](const FusedGroup &x, const FusedGroup &y) { return x.level < y.level; });
   unsigned i = 0;
-  while (i < count)
+  unsigned level = 0;
+  const unsigned last_level = count ? ops[count - 1].level : 0;
+  for (level = 0; level <= last_level; ++level)
   {
-    // [i, j) = one dependency level
+    // [i, j) = the ops of this dependency level
     unsigned j = i;
-    while (j < count && ops[j].level == ops[i].level) ++j;
-    // within the level: one launch group per (child kinds, gather) in packs of kMaxOpsPerLaunch
+    while (j < count && ops[j].level == level) ++j;
+    // plain ops: one launch group per (child kinds, gather) in packs of kMaxOpsPerLaunch
     for (unsigned kind = 0; kind < 3; ++kind)
       for (unsigned ga = 0; ga < 2; ++ga)
       {
@@ -691,14 +823,72 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
           const unsigned tips = ((f & PLLGPU_OP_LEFT_TIP) ? 1u : 0u) + ((f & PLLGPU_OP_RIGHT_TIP) ? 1u : 0u);
           if ((f & PLLGPU_OP_RIGHT_TIP) && !(f & PLLGPU_OP_LEFT_TIP))
             return fail(PLLGPU_EINVAL, "tip-inner operations must carry the tip as the left child");
-          if (tips != kind || ((f & PLLGPU_OP_GATHER) ? 1u : 0u) != ga) continue;
+          if (role[o] || tips != kind || ((f & PLLGPU_OP_GATHER) ? 1u : 0u) != ga) continue;
           if (ops[o].parent_entries == 0) continue;
           if (int rc = resolve_op(c, ops[o], pack.ops[nops])) return rc;
+          c->last_bytes += op_traffic(c, ops[o], true, true);
           maxent = std::max(maxent, ops[o].parent_entries);
           if (++nops == (unsigned)kMaxOpsPerLaunch) flush();
         }
         flush();
         if (lrc) return lrc;
+      }
+    // fused groups executing at this level, one launch per pair of child kinds
+    const size_t g0 = gi_sorted;
+    while (gi_sorted < groups.size() && groups[gi_sorted].level == level) ++gi_sorted;
+    for (int lk = 0; lk <= CK_FII; ++lk)
+      for (int rk = lk; rk <= CK_FII; ++rk)
+      {
+        FusePack pack;
+        unsigned n = 0, entries = 0;
+        auto flush = [&]() -> int {
+          if (!n) return 0;
+          if (int rc = launch_fused(c, pack, n, entries, lk, rk)) return rc;
+          ++c->last_launches;
+          n = 0;
+          return 0;
+        };
+        for (size_t gi = g0; gi < gi_sorted; ++gi)
+        {
+          FusedGroup g = groups[gi];
+          const bool swap = g.lk > g.rk; // canonical order: the "smaller" kind on the left
+          if ((swap ? g.rk : g.lk) != lk || (swap ? g.lk : g.rk) != rk) continue;
+          const pllgpu_op_t &P = ops[g.p];
+          if (P.parent_entries == 0) continue;
+          if (n && P.parent_entries != entries)
+            if (int rc = flush()) return rc;
+          entries = P.parent_entries;
+          DevOp dp, da, db;
+          FGroup &fg = pack.g[n];
+          memset(&fg, 0, sizeof fg);
+          // producers first: their parent buffers must exist before P's children are resolved
+          if (g.a >= 0)
+          {
+            if (int rc = resolve_op(c, ops[g.a], da)) return rc;
+            c->last_bytes += op_traffic(c, ops[g.a], true, true);
+          }
+          if (g.b >= 0)
+          {
+            if (int rc = resolve_op(c, ops[g.b], db)) return rc;
+            c->last_bytes += op_traffic(c, ops[g.b], true, true);
+          }
+          if (int rc = resolve_op(c, P, dp)) return rc;
+          c->last_bytes += op_traffic(c, P, g.a < 0, g.b < 0);
+          to_fop(dp, fg.p);
+          if (g.a >= 0) to_fop(da, fg.a);
+          if (g.b >= 0) to_fop(db, fg.b);
+          if (swap)
+          {
+            std::swap(fg.p.left, fg.p.right);
+            std::swap(fg.p.ltip, fg.p.rtip);
+            std::swap(fg.p.lscaler, fg.p.rscaler);
+            std::swap(fg.p.lmat, fg.p.rmat);
+            std::swap(fg.a, fg.b);
+          }
+          if (++n == (unsigned)kMaxGroups)
+            if (int rc = flush()) return rc;
+        }
+        if (int rc = flush()) return rc;
       }
     i = j;
   }
@@ -706,6 +896,8 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
   if (e != hipSuccess) return fail(PLLGPU_ERUNTIME, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
 }
+
+extern "C" double pllgpu_last_algorithmic_bytes(const pllgpu_ctx_t *c) { return c ? c->last_bytes : 0.0; }
 
 // ---- log-likelihood ----------------------------------------------------------------------------
 template <int ICH>

@@ -38,7 +38,7 @@ static int imax(int a, int b) { return a > b ? a : b; }
  * traversals legally re-orient (overwrite) a CLV that an earlier op of the same list still reads
  * (SURVEY.md section 3.4). */
 static unsigned int assign_levels(const pll_partition_t *p, pll_amd_ext_t *x, const pll_operation_t *ops,
-                                  unsigned int count, unsigned int *level)
+                                  unsigned int count, unsigned int *level, int *war)
 {
   unsigned int i, nlevels = 0;
   for (i = 0; i < p->nodes; ++i) x->lvl_clv_w[i] = x->lvl_clv_r[i] = -1;
@@ -52,14 +52,16 @@ static unsigned int assign_levels(const pll_partition_t *p, pll_amd_ext_t *x, co
     l = imax(l, x->lvl_clv_w[o->child2_clv_index]);
     if (o->child1_scaler_index >= 0) l = imax(l, x->lvl_sc_w[o->child1_scaler_index]);
     if (o->child2_scaler_index >= 0) l = imax(l, x->lvl_sc_w[o->child2_scaler_index]);
-    /* WAW + WAR on outputs */
-    l = imax(l, x->lvl_clv_w[o->parent_clv_index]);
-    l = imax(l, x->lvl_clv_r[o->parent_clv_index]);
+    /* WAW + WAR on outputs; kept separately too: the device layer may run an op together with the
+     * producers of its children, one level early, if nothing of this kind sits there */
+    int w = imax(x->lvl_clv_w[o->parent_clv_index], x->lvl_clv_r[o->parent_clv_index]);
     if (o->parent_scaler_index >= 0)
     {
-      l = imax(l, x->lvl_sc_w[o->parent_scaler_index]);
-      l = imax(l, x->lvl_sc_r[o->parent_scaler_index]);
+      w = imax(w, x->lvl_sc_w[o->parent_scaler_index]);
+      w = imax(w, x->lvl_sc_r[o->parent_scaler_index]);
     }
+    war[i] = w;
+    l = imax(l, w);
     l += 1;
     level[i] = (unsigned int)l;
     if ((unsigned int)l + 1 > nlevels) nlevels = l + 1;
@@ -119,7 +121,8 @@ void pll_update_partials_rep(pll_partition_t *p, const pll_operation_t *ops, uns
   }
 
   unsigned int *level = (unsigned int *)(x->gops + count); /* second half of the scratch block */
-  const unsigned int nlevels = assign_levels(p, x, ops, count, level);
+  int *war = (int *)(level + count);
+  const unsigned int nlevels = assign_levels(p, x, ops, count, level, war);
 
   /* 1. site-repeats class maps: a parent's classes derive from its children's
    *    (src/partials.c:256-257) - on the device, one dependency level at a time */
@@ -197,6 +200,7 @@ void pll_update_partials_rep(pll_partition_t *p, const pll_operation_t *ops, uns
                 p->repeats->pernode_ids[o->child2_clv_index]))
       g->flags |= PLLGPU_OP_GATHER;
     g->level = level[i];
+    g->war_level = war[i];
   }
   free(start);
 

@@ -154,6 +154,7 @@ _GPU_PROTOS = {
     "pll_gpu_sync_scaler": (C.c_int, [PartitionP, C.c_uint]),
     "pll_gpu_sync_pmatrix": (C.c_int, [PartitionP, C.c_int]),
     "pll_gpu_edge_loglikelihood_async": (C.c_int, [PartitionP, C.c_uint, C.c_int, C.c_uint, C.c_int, C.c_uint, c_uint_p, C.c_void_p]),
+    "pll_gpu_last_algorithmic_bytes": (C.c_double, [PartitionP]),
     "pll_gpu_sync_repeats": (C.c_int, [PartitionP, C.c_int]),
     "pll_gpu_sync_all": (C.c_int, [PartitionP]),
     "pll_gpu_invalidate": (None, [PartitionP, C.c_uint, C.c_int]),

@@ -310,3 +310,40 @@ def test_async_edge_lnl_stays_on_the_device(amd_lib):
             assert amd_lib.errno() == 902
     finally:
         hip.hipFree(dev)
+
+
+@pytest.mark.parametrize("kw", [k for k in ORACLE_CASES + ASC_CASES if k["states"] == 4 and k.get("rate_cats", 4) == 4], ids=_id)
+def test_dna_without_fusion(amd_lib, kw, monkeypatch):
+    """DNA traversals normally evaluate an op together with the producers of its children
+    (k_partials_dna_fused); PLL_AMD_NO_FUSE=1 launches every op group on its own - same numbers,
+    bit for bit, since the arithmetic per op is identical"""
+    case = W.make_case("rnd", **kw)
+    fused = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    monkeypatch.setenv("PLL_AMD_NO_FUSE", "1")
+    plain = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    exp = O.run_case(case)
+    assert_results_match(plain, exp, what=_id(kw))
+    assert fused["lnl"] == plain["lnl"]
+    for k in plain["clv"]:
+        assert (fused["clv"][k] == plain["clv"][k]).all()
+        if k in plain["scaler"]:
+            assert (fused["scaler"][k] == plain["scaler"][k]).all()
+
+
+def test_fusion_plan_on_a_balanced_tree(amd_lib):
+    """64 taxa, full traversal: 16 (tt, tt -> ii) groups, 4 (ii, ii -> ii) groups and the 2 root-side
+    ops = 3 launches instead of 5; a traversal of the inner x inner ops alone = 2 launches"""
+    case = W.make_case("plan", 4, 64, 640, seed=97)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        assert amd_lib.pll_gpu_last_launch_count(s.p) == 3
+        per_site = amd_lib.pll_gpu_last_algorithmic_bytes(s.p) / 640
+        # 16 x (4 B codes + 3 CLVs + 1 scaler vector: tip-tip parents carry none) ...: just bound it
+        assert 10000 < per_site < 11200, per_site
+        ii = [op for op in case.op_batches[0] if op[2] >= 64 and op[5] >= 64]
+        arr = api.make_ops(ii)
+        amd_lib.pll_update_partials(s.p, arr, len(ii))
+        assert amd_lib.pll_gpu_last_launch_count(s.p) == 2  # 16+8 ops as 8 groups, 4+2 ops as 2 groups
+        v, _ = s.edge_lnl(case.edges[0], persite=False)
+        exp = O.run_case(case)
+        assert abs(v - exp["lnl"][0]) <= RTOL * abs(v)
