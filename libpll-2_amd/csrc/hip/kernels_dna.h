@@ -335,42 +335,76 @@ __device__ __forceinline__ void dna_store(const FOp &op, size_t off, unsigned n,
     }
 }
 
-// the 16 values of one child of the parent op and the child's scaler words
-template <int KIND>
-__device__ __forceinline__ void dna_child(const FOp &pop, bool left_side, const FOp &cop, size_t off, unsigned n, bool valid,
-                                          int scale_mode, double (&v)[4][4], uint4 &sc)
+// A child of the group parent in three steps, so that the kernel can put the NEXT loads in front of
+// the PREVIOUS stores in program order (the compiler must assume that a store to one CLV buffer may
+// alias a later load from another and would otherwise serialise store -> load):
+//   load    - issue the HBM reads the child needs (its own children for a fused kind)
+//   compute - the child's 16 values + scaler words, the producer's scaling decision applied
+//   store   - fused kinds only: the producer op's CLV and scaler go out
+struct DnaRaw
 {
+  double xl[4][4], xr[4][4];
+  unsigned lcode, rcode;
+};
+
+template <int KIND>
+__device__ __forceinline__ void dna_child_load(const FOp &pop, bool left_side, const FOp &cop, size_t off, unsigned n, DnaRaw &raw)
+{
+  raw.lcode = raw.rcode = 0u;
   if (KIND == CK_INNER)
   {
     const double *__restrict__ x = (left_side ? pop.left : pop.right) + off;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dna_fetch<false>(v[k], x, k, 0u);
+    for (int k = 0; k < 4; ++k) dna_fetch<false>(raw.xl[k], x, k, 0u);
+  }
+  else if (KIND == CK_TIP)
+    raw.lcode = (left_side ? pop.ltip : pop.rtip)[n];
+  else
+  {
+    constexpr bool LT = (KIND == CK_FTT || KIND == CK_FTI), RT = (KIND == CK_FTT);
+    if (LT) raw.lcode = cop.ltip[n];
+    if (RT) raw.rcode = cop.rtip[n];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      if (!LT) dna_fetch<false>(raw.xl[k], cop.left + off, k, 0u);
+      if (!RT) dna_fetch<false>(raw.xr[k], cop.right + off, k, 0u);
+    }
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ void dna_child_compute(const FOp &pop, bool left_side, const FOp &cop, unsigned n, int scale_mode,
+                                                  const DnaRaw &raw, double (&v)[4][4], uint4 &sc)
+{
+  if (KIND == CK_INNER)
+  {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[k][i] = raw.xl[k][i];
     sc = dna_load_scaler(left_side ? pop.lscaler : pop.rscaler, n, scale_mode);
   }
   else if (KIND == CK_TIP)
   {
-    const unsigned code = (left_side ? pop.ltip : pop.rtip)[n];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dna_fetch<true>(v[k], nullptr, k, code);
+    for (int k = 0; k < 4; ++k) dna_fetch<true>(v[k], nullptr, k, raw.lcode);
     sc = make_uint4(0, 0, 0, 0);
   }
   else
   {
     constexpr bool LT = (KIND == CK_FTT || KIND == CK_FTI), RT = (KIND == CK_FTT);
     const int mode = cop.pscaler ? scale_mode : 0;
-    const unsigned lcode = LT ? cop.ltip[n] : 0u, rcode = RT ? cop.rtip[n] : 0u;
-    const double *__restrict__ lx = LT ? nullptr : cop.left + off;
-    const double *__restrict__ rx = RT ? nullptr : cop.right + off;
     cdouble_p lm = as_const(cop.lmat), rm = as_const(cop.rmat);
     bool small[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
       double xl[4], xr[4], a[4], b[4];
-      dna_fetch<LT>(xl, lx, k, lcode);
-      dna_fetch<RT>(xr, rx, k, rcode);
-      dna_matvec(a, lm + k * 16, xl);
-      dna_matvec(b, rm + k * 16, xr);
+      if (LT) dna_fetch<true>(xl, nullptr, k, raw.lcode);
+      if (RT) dna_fetch<true>(xr, nullptr, k, raw.rcode);
+      dna_matvec(a, lm + k * 16, LT ? xl : raw.xl[k]);
+      dna_matvec(b, rm + k * 16, RT ? xr : raw.xr[k]);
       small[k] = true;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -382,8 +416,14 @@ __device__ __forceinline__ void dna_child(const FOp &pop, bool left_side, const 
     const uint4 lsc = dna_load_scaler(LT ? nullptr : cop.lscaler, n, scale_mode);
     const uint4 rsc = dna_load_scaler(RT ? nullptr : cop.rscaler, n, scale_mode);
     dna_scale(v, small, mode, lsc, rsc, sc);
-    dna_store<true>(cop, off, n, valid, mode, v, sc);
   }
+}
+
+template <int KIND>
+__device__ __forceinline__ void dna_child_store(const FOp &cop, size_t off, unsigned n, bool valid, int scale_mode,
+                                                const double (&v)[4][4], uint4 sc)
+{
+  if (KIND >= CK_FTT) dna_store<true>(cop, off, n, valid, cop.pscaler ? scale_mode : 0, v, sc);
 }
 
 template <int LK, int RK>
@@ -407,8 +447,15 @@ __global__ __launch_bounds__(256) void k_partials_dna_fused(const FusePack pack,
 
     double va[4][4], vb[4][4], v[4][4];
     uint4 sca, scb, sc;
-    dna_child<LK>(g.p, true, g.a, off, n, valid, scale_mode, va, sca);
-    dna_child<RK>(g.p, false, g.b, off, n, valid, scale_mode, vb, scb);
+    {
+      DnaRaw ra, rb;
+      dna_child_load<LK>(g.p, true, g.a, off, n, ra);
+      dna_child_compute<LK>(g.p, true, g.a, n, scale_mode, ra, va, sca);
+      dna_child_load<RK>(g.p, false, g.b, off, n, rb); // in flight while the left producer's CLV is stored
+      dna_child_store<LK>(g.a, off, n, valid, scale_mode, va, sca);
+      dna_child_compute<RK>(g.p, false, g.b, n, scale_mode, rb, vb, scb);
+      dna_child_store<RK>(g.b, off, n, valid, scale_mode, vb, scb);
+    }
     bool small[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
