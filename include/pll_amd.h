@@ -70,6 +70,8 @@ extern "C" {
 #define PLL_ERROR_INVAR_NONEFOUND 120
 #define PLL_ERROR_AB_INVALIDMETHOD 121
 #define PLL_ERROR_AB_NOSUPPORT 122
+#define PLL_ERROR_MSA_EMPTY 131
+#define PLL_ERROR_MSA_MAP_INVALID 132
 /* new, outside the reference's range: device problems are reported through the same
  * pll_errno / pll_errmsg convention */
 #define PLL_ERROR_GPU_UNAVAILABLE 900
@@ -157,6 +159,15 @@ typedef struct pll_operation
   int child2_scaler_index;
 } pll_operation_t;
 
+/* src/pll.h:347-354 */
+typedef struct pll_msa_s
+{
+  int count;
+  int length;
+  char **sequence;
+  char **label;
+} pll_msa_t;
+
 /* ---- thread-local error state (src/pll.h:553-555, src/pll.c:24-25) ------------------------- */
 extern __thread int pll_errno;
 extern __thread char pll_errmsg[200];
@@ -175,6 +186,16 @@ pll_partition_t *pll_partition_create(unsigned int tips, unsigned int clv_buffer
 void pll_partition_destroy(pll_partition_t *partition);
 void *pll_aligned_alloc(size_t size, size_t alignment); /* src/pll.h:778 */
 void pll_aligned_free(void *ptr);                       /* src/pll.h:780 */
+
+/* ---- site-pattern compression (src/pll.h:2499-2510, src/compress.c:171-410) ----------------- */
+/* Merges identical alignment columns: the sequences are rewritten in place with the unique columns
+ * (sorted lexicographically by encoded character, NUL-terminated), *length becomes their number,
+ * the returned vector (malloc'ed, caller frees) holds their multiplicities; the _msa variant also
+ * fills site_pattern_map[original site] = pattern index. The ordering and counting run on the
+ * MI355X (csrc/hip/compress.hip); outputs are identical to the reference's. */
+unsigned int *pll_compress_site_patterns(char **sequence, const pll_state_t *map, int count, int *length);
+unsigned int *pll_compress_site_patterns_msa(pll_msa_t *msa, const pll_state_t *map,
+                                             unsigned int *site_pattern_map);
 
 /* ---- inputs (src/pll.h:650-661,746-758; src/pll.c:1026-1143; src/models.c:445-493) --------- */
 int pll_set_tip_states(pll_partition_t *partition, unsigned int tip_index,

@@ -201,6 +201,17 @@ int pllgpu_asc_derivative_terms(pllgpu_ctx_t *ctx, unsigned int slot, int parent
                                 const unsigned int *params_indices, double *lk /* [states][3] */,
                                 unsigned int *scalings /* [states] */);
 
+/* ---- site-pattern compression (src/compress.c:171-410) ------------- */
+/* encoded: [count][length] bytes, one row per sequence (characters already recoded). Outputs:
+ * compressed [count][*patterns_out] (row stride = *patterns_out) = the unique columns in
+ * lexicographic order of the characters taken as signed char, weights[*patterns_out] their
+ * multiplicities, site_pattern_map[length] (or NULL) the pattern of every original site. No
+ * context: the call owns a stream on `device` (-1: PLL_AMD_DEVICE or 0). Synchronous. */
+int pllgpu_compress_patterns(const unsigned char *encoded, unsigned int count, unsigned int length,
+                             unsigned char *compressed, unsigned int *weights,
+                             unsigned int *site_pattern_map, unsigned int *patterns_out, int device);
+const char *pllgpu_compress_last_error(void);
+
 /* ---- stream / timing ---------------------------------------------------------------------- */
 int pllgpu_set_stream(pllgpu_ctx_t *ctx, void *hip_stream);
 void *pllgpu_get_stream(const pllgpu_ctx_t *ctx);

@@ -101,6 +101,11 @@ class Operation(C.Structure):
     ]
 
 
+class Msa(C.Structure):
+    """pll_msa_t (src/pll.h:347-354)"""
+    _fields_ = [("count", C.c_int), ("length", C.c_int), ("sequence", C.POINTER(C.c_void_p)), ("label", C.POINTER(C.c_void_p))]
+
+
 assert C.sizeof(Partition) == 232 and C.sizeof(Repeats) == 104 and C.sizeof(Operation) == 32
 
 PartitionP = C.POINTER(Partition)
@@ -146,6 +151,8 @@ _PROTOS = {
     "pll_update_repeats": (None, [PartitionP, C.POINTER(Operation)]),
     "pll_disable_bclv": (None, [PartitionP]),
     "pll_resize_repeats_lookup": (None, [PartitionP, C.c_uint]),
+    "pll_compress_site_patterns": (c_uint_p, [C.POINTER(C.c_void_p), c_state_p, C.c_int, C.POINTER(C.c_int)]),
+    "pll_compress_site_patterns_msa": (c_uint_p, [C.c_void_p, c_state_p, c_uint_p]),
 }
 
 # device-residency extension of libpll_amd.so (include/pll_amd.h); absent from other libraries
