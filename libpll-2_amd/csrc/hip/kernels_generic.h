@@ -52,6 +52,41 @@ __device__ __forceinline__ void contract(double (&acc)[ICH], const double *pt, u
   }
 }
 
+// A tip whose mask is a single state or a full gap needs no contraction: (P x)_i is column `state`
+// of P, or the row sum of P (ascending j, the order of the reference's set-bit walk,
+// src/core_partials.c:480-489: bit-identical to the FMA route). The wave stages the transposed
+// matrix of its rate category in LDS ((S + 1) x SPT doubles incl. the row sums) and every lane reads
+// its column from there: 20 LDS reads instead of 400 FMAs per child and (site, rate) for 20 states.
+// (Gathering the columns straight from L2 was slower than the FMA route: 64 separate 8-byte
+// requests per load instruction.) Used when every lane of the wave has such a mask and the staged
+// matrices fit (S * SPT <= 1024, i.e. up to 32 states; larger ones run in kernels_mfma.h).
+template <int ICH>
+__device__ __forceinline__ void tip_columns(double (&acc)[ICH], const double *staged, unsigned c, const GenGeo &g,
+                                            unsigned long long mask, unsigned long long full)
+{
+  const unsigned row = mask == full ? g.S : (unsigned)__ffsll((long long)mask) - 1u; // row S = the row sums
+  const double *p = staged + row * g.SPT + c * ICH;
+#pragma unroll
+  for (int i = 0; i < ICH; ++i) acc[i] = p[i];
+}
+
+// PT[k] (S x SPT, contiguous) and its column sums over j into this wave's LDS slot
+__device__ __forceinline__ void tip_stage(double *staged, const double *pt, unsigned k, const GenGeo &g, unsigned lane)
+{
+  __builtin_amdgcn_wave_barrier(); // earlier readers of this wave's slot are done (LDS ops of a wave stay in order)
+  const double *src = pt + (size_t)k * g.S * g.SPT;
+  const unsigned n = g.S * g.SPT;
+  for (unsigned idx = lane; idx < n; idx += 64u) staged[idx] = src[idx];
+  for (unsigned i = lane; i < g.SPT; i += 64u)
+  {
+    double s = 0.0;
+    for (unsigned j = 0; j < g.S; ++j) s += src[(size_t)j * g.SPT + i];
+    staged[n + i] = s;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // tiled address of element 0 of (entry e, rate 0, state 0)
 __device__ __forceinline__ size_t tiled_base(unsigned e, unsigned tile_sz)
 {
@@ -60,90 +95,124 @@ __device__ __forceinline__ size_t tiled_base(unsigned e, unsigned tile_sz)
 
 template <int ICH, bool LTIP, bool RTIP, bool GATHER>
 __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const GenGeo g,
-                                                        const unsigned long long *__restrict__ tipmap)
+                                                        const unsigned long long *__restrict__ tipmap, unsigned tip_lds,
+                                                        unsigned tiles_per_block)
 {
   __shared__ unsigned char flags[kMaxRates][64];
+  extern __shared__ double tipmat[]; // tip_lds: [child][wave][(S + 1) x SPT] staged tip matrices + row sums
 
   const DevOp &op = pack.ops[blockIdx.y];
-  const unsigned tile = blockIdx.x;
-  if (tile * 64u >= op.entries) return; // whole workgroup
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned nw = blockDim.x >> 6;
   const int mode = op.pscaler ? g.scale_mode : 0;
+  const unsigned ntiles = (op.entries + 63u) / 64u;
+  if (blockIdx.x * tiles_per_block >= ntiles) return; // whole workgroup
 
-  const unsigned n = tile * 64u + lane;
-  const bool valid = n < op.entries;
-  const unsigned nn = valid ? n : op.entries - 1; // tail lanes redo the last entry, store nothing
-  unsigned le = nn, re = nn;
-  if (GATHER)
+  const unsigned long long full = g.S >= 64 ? ~0ull : ((1ull << g.S) - 1ull);
+  const unsigned slot = (g.S + 1u) * g.SPT;
+  double *lstage = tipmat + (size_t)wave * slot, *rstage = tipmat + (size_t)(nw + wave) * slot;
+  // one rate category per wave (R <= 4): the tip matrices are staged once for all tiles of the workgroup
+  const bool stage_once = tip_lds && g.R <= nw && wave < g.R;
+  if (stage_once)
   {
-    const unsigned site = op.id_site ? op.id_site[nn] : nn;
-    le = op.lsid ? op.lsid[site] : site;
-    re = op.rsid ? op.rsid[site] : site;
+    if (LTIP) tip_stage(lstage, op.lmat, wave, g, lane);
+    if (RTIP) tip_stage(rstage, op.rmat, wave, g, lane);
   }
-  unsigned long long lmask = 0, rmask = 0;
-  if (LTIP) lmask = tipmap ? tipmap[op.ltip[le]] : (unsigned long long)op.ltip[le];
-  if (RTIP) rmask = tipmap ? tipmap[op.rtip[re]] : (unsigned long long)op.rtip[re];
-  const double *__restrict__ lx = LTIP ? nullptr : op.left + tiled_base(le, g.tile_sz);
-  const double *__restrict__ rx = RTIP ? nullptr : op.right + tiled_base(re, g.tile_sz);
-  double *__restrict__ out = op.parent + (size_t)tile * g.tile_sz + lane;
 
-  auto rescale_rate = [&](unsigned k) {
-    // this lane's stored column of rate k: same lane wrote it; order the accesses explicitly
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    double *col = out + (size_t)k * g.S * 64;
-    for (unsigned s = 0; s < g.S; ++s)
-    {
-      const double v = __builtin_nontemporal_load(col + (size_t)s * 64);
-      col[(size_t)s * 64] = v * PLLGPU_SCALE_FACTOR;
-    }
-  };
-
-  for (unsigned k = wave; k < g.R; k += nw)
+  for (unsigned t = 0; t < tiles_per_block; ++t)
   {
-    bool small = true;
-    for (unsigned c = 0; c < g.nchunks; ++c)
+    const unsigned tile = blockIdx.x * tiles_per_block + t;
+    if (tile >= ntiles) break; // whole workgroup
+    const unsigned n = tile * 64u + lane;
+    const bool valid = n < op.entries;
+    const unsigned nn = valid ? n : op.entries - 1; // tail lanes redo the last entry, store nothing
+    unsigned le = nn, re = nn;
+    if (GATHER)
     {
-      double A[ICH], B[ICH];
-      contract<ICH, LTIP>(A, op.lmat, k, c, g, LTIP ? nullptr : lx + (size_t)k * g.S * 64, lmask);
-      contract<ICH, RTIP>(B, op.rmat, k, c, g, RTIP ? nullptr : rx + (size_t)k * g.S * 64, rmask);
-      double *dst = out + ((size_t)k * g.S + c * ICH) * 64;
-#pragma unroll
-      for (int i = 0; i < ICH; ++i)
-        if (c * ICH + i < g.S)
-        {
-          const double v = A[i] * B[i];
-          small = small && (v < PLLGPU_SCALE_THRESHOLD);
-          if (valid) dst[(size_t)i * 64] = v;
-        }
+      const unsigned site = op.id_site ? op.id_site[nn] : nn;
+      le = op.lsid ? op.lsid[site] : site;
+      re = op.rsid ? op.rsid[site] : site;
     }
-    if (mode == 2)
+    unsigned long long lmask = 0, rmask = 0;
+    if (LTIP) lmask = tipmap ? tipmap[op.ltip[le]] : (unsigned long long)op.ltip[le];
+    if (RTIP) rmask = tipmap ? tipmap[op.rtip[re]] : (unsigned long long)op.rtip[re];
+    const double *__restrict__ lx = LTIP ? nullptr : op.left + tiled_base(le, g.tile_sz);
+    const double *__restrict__ rx = RTIP ? nullptr : op.right + tiled_base(re, g.tile_sz);
+    double *__restrict__ out = op.parent + (size_t)tile * g.tile_sz + lane;
+
+    auto rescale_rate = [&](unsigned k) {
+      // this lane's stored column of rate k: same lane wrote it; order the accesses explicitly
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      double *col = out + (size_t)k * g.S * 64;
+      for (unsigned s = 0; s < g.S; ++s)
+      {
+        const double v = __builtin_nontemporal_load(col + (size_t)s * 64);
+        col[(size_t)s * 64] = v * PLLGPU_SCALE_FACTOR;
+      }
+    };
+
+    // tips: does every lane of this wave hold a single state or a full gap?
+    const bool lsimple = LTIP && tip_lds && __all(__popcll(lmask) == 1 || lmask == full);
+    const bool rsimple = RTIP && tip_lds && __all(__popcll(rmask) == 1 || rmask == full);
+
+    for (unsigned k = wave; k < g.R; k += nw)
     {
+      bool small = true;
+      if (!stage_once)
+      {
+        if (lsimple) tip_stage(lstage, op.lmat, k, g, lane);
+        if (rsimple) tip_stage(rstage, op.rmat, k, g, lane);
+      }
+      for (unsigned c = 0; c < g.nchunks; ++c)
+      {
+        double A[ICH], B[ICH];
+        if (lsimple)
+          tip_columns<ICH>(A, lstage, c, g, lmask, full);
+        else
+          contract<ICH, LTIP>(A, op.lmat, k, c, g, LTIP ? nullptr : lx + (size_t)k * g.S * 64, lmask);
+        if (rsimple)
+          tip_columns<ICH>(B, rstage, c, g, rmask, full);
+        else
+          contract<ICH, RTIP>(B, op.rmat, k, c, g, RTIP ? nullptr : rx + (size_t)k * g.S * 64, rmask);
+        double *dst = out + ((size_t)k * g.S + c * ICH) * 64;
+#pragma unroll
+        for (int i = 0; i < ICH; ++i)
+          if (c * ICH + i < g.S)
+          {
+            const double v = A[i] * B[i];
+            small = small && (v < PLLGPU_SCALE_THRESHOLD);
+            if (valid) dst[(size_t)i * 64] = v;
+          }
+      }
+      if (mode == 2)
+      {
+        if (valid)
+        {
+          if (small) rescale_rate(k);
+          op.pscaler[(size_t)n * g.R + k] = (op.lscaler ? op.lscaler[(size_t)le * g.R + k] : 0u) +
+                                            (op.rscaler ? op.rscaler[(size_t)re * g.R + k] : 0u) +
+                                            (small ? 1u : 0u);
+        }
+      }
+      else if (mode == 1)
+        flags[k][lane] = small ? 1 : 0;
+    }
+
+    if (mode == 1)
+    {
+      __syncthreads();
+      bool site_small = true;
+      for (unsigned k = 0; k < g.R; ++k) site_small = site_small && flags[k][lane];
       if (valid)
       {
-        if (small) rescale_rate(k);
-        op.pscaler[(size_t)n * g.R + k] = (op.lscaler ? op.lscaler[(size_t)le * g.R + k] : 0u) +
-                                          (op.rscaler ? op.rscaler[(size_t)re * g.R + k] : 0u) +
-                                          (small ? 1u : 0u);
+        if (site_small)
+          for (unsigned k = wave; k < g.R; k += nw) rescale_rate(k);
+        if (wave == 0)
+          op.pscaler[n] = (op.lscaler ? op.lscaler[le] : 0u) + (op.rscaler ? op.rscaler[re] : 0u) +
+                          (site_small ? 1u : 0u);
       }
-    }
-    else if (mode == 1)
-      flags[k][lane] = small ? 1 : 0;
-  }
-
-  if (mode == 1)
-  {
-    __syncthreads();
-    bool site_small = true;
-    for (unsigned k = 0; k < g.R; ++k) site_small = site_small && flags[k][lane];
-    if (valid)
-    {
-      if (site_small)
-        for (unsigned k = wave; k < g.R; k += nw) rescale_rate(k);
-      if (wave == 0)
-        op.pscaler[n] = (op.lscaler ? op.lscaler[le] : 0u) + (op.rscaler ? op.rscaler[re] : 0u) +
-                        (site_small ? 1u : 0u);
+      __syncthreads(); // flags[] is reused by the next tile
     }
   }
 }

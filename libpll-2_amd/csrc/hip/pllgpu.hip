@@ -113,6 +113,7 @@ struct pllgpu_ctx
   std::vector<double> stage;     // host staging for the P-matrix re-layout
   unsigned last_launches = 0;
   double last_bytes = 0.0;       // algorithmic HBM bytes of the last update_partials call
+  bool no_tip_columns = false;   // PLL_AMD_NO_TIP_COLUMNS=1: tips always through the FMA contraction
   bool fuse = false;             // DNA: evaluate producer + consumer ops in one kernel (kernels_dna.h)
 };
 
@@ -150,6 +151,8 @@ static void derive_geometry(pllgpu_ctx *c)
   c->fuse = c->dna_fast;
   if (const char *v = getenv("PLL_AMD_NO_FUSE")) // experiment switch: one kernel per op group, no producer/consumer fusion
     if (*v && *v != '0') c->fuse = false;
+  if (const char *v = getenv("PLL_AMD_NO_TIP_COLUMNS"))
+    if (*v && *v != '0') c->no_tip_columns = true;
   c->tiled = true; // every shape keeps CLVs in the tiled sites-contiguous layout
   // 33..64 states: CLV updates on the fp64 matrix pipe (kernels_mfma.h); PLL_AMD_NO_MFMA=1 keeps the FMA kernel
   c->use_mfma = (g.states > 32 && g.rate_cats <= 16);
@@ -552,10 +555,19 @@ static void launch_generic(pllgpu_ctx *c, const OpPack &pack, unsigned nops, uns
 {
   // one workgroup per 64-entry tile; min(R,4) waves share the tile's rate categories
   const unsigned tiles = (maxent + 63) / 64;
-  dim3 grid(tiles, nops), block(64u * std::min(c->gg.R, 4u));
   const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
+  // tip children: room in LDS for the staged matrices of every wave (kernels_generic.h: tip_stage)
+  const unsigned nw = std::min(c->gg.R, 4u);
+  const bool stage = kind != 0 && c->gg.S * c->gg.SPT <= 1024u && !c->no_tip_columns;
+  const unsigned tip_lds = stage ? 1u : 0u;
+  const size_t lds = stage ? (size_t)2 * nw * (c->gg.S + 1u) * c->gg.SPT * sizeof(double) : 0;
+  // staged tip matrices are shared by the tiles of a workgroup: several tiles each, as long as
+  // ~4096 workgroups remain
+  unsigned tpb = 1;
+  if (stage) tpb = std::max(1u, std::min(8u, (unsigned)(((size_t)tiles * nops) / 4096u)));
+  dim3 grid((tiles + tpb - 1) / tpb, nops), block(64u * nw);
 #define GEN_LAUNCH(LT, RT, GA) \
-  hipLaunchKernelGGL((k_partials_tiled<ICH, LT, RT, GA>), grid, block, 0, c->stream, pack, c->gg, tm)
+  hipLaunchKernelGGL((k_partials_tiled<ICH, LT, RT, GA>), grid, block, lds, c->stream, pack, c->gg, tm, tip_lds, tpb)
   if (kind == 0)
   {
     if (gather) GEN_LAUNCH(false, false, true); else GEN_LAUNCH(false, false, false);
