@@ -338,3 +338,198 @@ __global__ __launch_bounds__(256) void k_mfma_scale_epilogue(const OpPack pack, 
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Edge log-likelihood for 33..64 states on the matrix pipe (src/core_likelihood.c:1388-1490 ii,
+// :812-915 ti, :1077-1183 repeats). Same fragments and lane maps as k_partials_mfma: per rate
+// category the workgroup stages the edge's transition matrix in LDS, every wave forms D = P x
+// (child side) for its items of 32 sites with MFMAs (or reads columns / row sums of P for simple
+// tips), dots it with parent_i * pi_i over the 16 parent states a lane owns, and keeps the
+// rate-weighted partial per (item, site group) in registers; after the last rate the four row
+// groups of a site meet through two shuffles and row group 0 finishes the site (scaling undone,
+// invariant share, log, pattern weight). A wave carries up to 4 items per round (their partials
+// wait in LDS between rate categories: the item loop stays rolled, one item's 128 fragment
+// registers at a time); more work per workgroup = more rounds, each re-staging the R matrices.
+constexpr int kEdgeItems = 4;
+
+template <bool CTIP, bool GATHER>
+__global__ __launch_bounds__(256, 2) void k_edge_mfma(const DevEdge e, const GenGeo g,
+                                                      const unsigned long long *__restrict__ tipmap, unsigned rounds, unsigned ipw)
+{
+  extern __shared__ double lds[];
+  double *PM = lds;           // [16 ig][16 jg][4 k][4 i]
+  double *RS = lds + 4096;    // row sums [64]
+  double *TA = lds + 4096 + 64 + (size_t)(threadIdx.x >> 6) * (kEdgeItems * 2 * 64) + (threadIdx.x & 63u); // [it][sg][lane] of this wave
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned row = lane >> 4, col = lane & 15u;
+  const unsigned S = g.S, R = g.R;
+  const unsigned nitems = (e.sites + 31u) / 32u;
+  const unsigned fragoff = row * 4u + (lane & 3u);
+  const unsigned long long full = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
+  double acc = 0.0;
+
+  for (unsigned rd = 0; rd < rounds; ++rd)
+  {
+    const unsigned item0 = ((blockIdx.x * rounds + rd) * 4u + wave) * ipw; // ipw <= kEdgeItems items per wave and round
+    for (int q = 0; q < kEdgeItems * 2; ++q) TA[q * 64] = 0.0;
+
+    for (unsigned k = 0; k < R; ++k)
+    {
+      __syncthreads(); // the previous matrix is no longer read
+      for (unsigned idx = threadIdx.x; idx < 4096; idx += 256)
+      {
+        const unsigned ii = idx & 3u, kk = (idx >> 2) & 3u, jg = (idx >> 4) & 15u, ig = idx >> 8;
+        const unsigned j = 4 * jg + kk, i = 4 * ig + ii;
+        PM[idx] = (j < S && i < g.SPT) ? e.mat[((size_t)k * S + j) * g.SPT + i] : 0.0;
+      }
+      __syncthreads();
+      if (CTIP)
+      {
+        if (threadIdx.x < 64)
+        {
+          const unsigned i = threadIdx.x;
+          double s = 0.0;
+          for (unsigned j = 0; j < S; ++j) s += PM[((i >> 2) * 16 + (j >> 2)) * 16 + (j & 3u) * 4 + (i & 3u)];
+          RS[i] = s;
+        }
+        __syncthreads();
+      }
+      const unsigned fi = e.fidx[k];
+      const double pinv = e.prop_invar ? e.prop_invar[fi] : 0.0;
+      const double wk = pinv > 0.0 ? e.rate_weights[k] * (1.0 - pinv) : e.rate_weights[k];
+      // pi_i of the 16 parent states this lane owns
+      double pif[16];
+#pragma unroll
+      for (int ig = 0; ig < 16; ++ig) pif[ig] = (4 * ig + row < S) ? e.freqs[(size_t)fi * g.SP + 4 * ig + row] : 0.0;
+
+#pragma unroll 1
+      for (unsigned it = 0; it < ipw; ++it)
+      {
+        const unsigned item = item0 + it;
+        if (item >= nitems) break; // wave-uniform
+        unsigned pe[2], ce[2];
+        unsigned long long cm[2] = {0, 0};
+        double ex[2];
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+        {
+          const unsigned n = item * 32u + sg * 16u + col;
+          const unsigned nn = n < e.sites ? n : e.sites - 1;
+          pe[sg] = ce[sg] = nn;
+          if (GATHER)
+          {
+            pe[sg] = e.psid ? e.psid[nn] : nn;
+            ce[sg] = e.csid ? e.csid[nn] : nn;
+          }
+          if (CTIP) cm[sg] = tipmap ? tipmap[e.ctip[ce[sg]]] : (unsigned long long)e.ctip[ce[sg]];
+          ex[sg] = 1.0;
+          if (e.per_rate)
+          {
+            unsigned mn = 0xFFFFFFFFu, mine = 0;
+            for (unsigned q = 0; q < R; ++q)
+            {
+              const unsigned rs = (e.pscaler ? e.pscaler[(size_t)pe[sg] * R + q] : 0u) + (e.cscaler ? e.cscaler[(size_t)ce[sg] * R + q] : 0u);
+              mn = min(mn, rs);
+              if (q == k) mine = rs;
+            }
+            const unsigned d = min(mine - mn, PLLGPU_RATE_MAXDIFF);
+            if (d) ex[sg] = minlh(d);
+          }
+        }
+        double D[16][2];
+        const bool simple = CTIP && mfma_simple_tips(cm, full);
+        if (simple)
+        {
+#pragma unroll
+          for (int ig = 0; ig < 16; ++ig)
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) D[ig][sg] = mfma_tip_column(PM, RS, cm[sg], full, row, ig);
+        }
+        else
+        {
+          double x[16][2];
+#pragma unroll
+          for (int jg = 0; jg < 16; ++jg)
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg)
+              x[jg][sg] = CTIP ? mfma_x<true>(nullptr, cm[sg], S, 4 * jg + row)
+                               : mfma_x<false>(e.child + tiled_base(ce[sg], g.tile_sz) + (size_t)k * S * 64, 0, S, 4 * jg + row);
+#pragma unroll
+          for (int ig = 0; ig < 16; ++ig) D[ig][0] = D[ig][1] = 0.0;
+#pragma unroll
+          for (int jg = 0; jg < 16; ++jg)
+          {
+#pragma unroll
+            for (int ig = 0; ig < 16; ++ig)
+            {
+              const double a = PM[(ig * 16 + jg) * 16 + fragoff];
+              D[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][0], D[ig][0], 0, 0, 0);
+              D[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][1], D[ig][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+        {
+          const double *pb = e.parent + tiled_base(pe[sg], g.tile_sz) + (size_t)k * S * 64;
+          double tr = 0.0;
+#pragma unroll
+          for (int ig = 0; ig < 16; ++ig)
+          {
+            const unsigned i = 4 * ig + row;
+            const double pv = i < S ? __builtin_nontemporal_load(pb + (size_t)i * 64) : 0.0;
+            tr = fma(pv * pif[ig], D[ig][sg], tr);
+          }
+          TA[(it * 2 + sg) * 64] += wk * (tr * ex[sg]);
+        }
+      }
+    }
+
+    // the four row groups of a site meet; row group 0 finishes the site
+#pragma unroll 1
+    for (unsigned it = 0; it < ipw; ++it)
+    {
+      const unsigned item = item0 + it;
+      if (item >= nitems) break;
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg)
+      {
+        double t = TA[(it * 2 + sg) * 64];
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        const unsigned n = item * 32u + sg * 16u + col;
+        if (row != 0 || n >= e.sites) continue;
+        unsigned pe = n, ce = n;
+        if (GATHER)
+        {
+          pe = e.psid ? e.psid[n] : n;
+          ce = e.csid ? e.csid[n] : n;
+        }
+        unsigned scal;
+        if (e.per_rate)
+        {
+          scal = 0xFFFFFFFFu;
+          for (unsigned q = 0; q < R; ++q)
+            scal = min(scal, (e.pscaler ? e.pscaler[(size_t)pe * R + q] : 0u) + (e.cscaler ? e.cscaler[(size_t)ce * R + q] : 0u));
+        }
+        else
+          scal = (e.pscaler ? e.pscaler[pe] : 0u) + (e.cscaler ? e.cscaler[ce] : 0u);
+        double terminv = 0.0;
+        const int inv = e.invariant ? e.invariant[n] : -1;
+        if (inv >= 0 && e.prop_invar)
+          for (unsigned q = 0; q < R; ++q)
+          {
+            const unsigned fi = e.fidx[q];
+            const double pinv = e.prop_invar[fi];
+            if (pinv > 0.0) terminv += e.rate_weights[q] * e.freqs[(size_t)fi * g.SP + inv] * pinv;
+          }
+        const double site = finish_site(t, terminv, scal, 0) * (double)e.pattern_weights[n];
+        if (e.persite) e.persite[n] = site;
+        acc += site;
+      }
+    }
+  }
+  publish_block_sum(e, wave_sum(acc), 4u);
+}

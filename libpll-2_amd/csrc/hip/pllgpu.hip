@@ -957,7 +957,31 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
   const unsigned tiles = (g.sites + 63) / 64;
   const unsigned max_blocks = 1024;
   unsigned blocks, tpw;
-  if (c->dna_fast)
+  if (c->use_mfma && !e.is_root)
+  {
+    // 33..64 states: P x on the matrix pipe (kernels_mfma.h: k_edge_mfma); 16 items of 32 sites per
+    // workgroup and round
+    const unsigned items = (g.sites + 31) / 32;
+    // small inputs: one item per wave so that every CU gets work; large ones: up to kEdgeItems
+    const unsigned ipw = std::max(1u, std::min((unsigned)kEdgeItems, items / (4u * 512u)));
+    const unsigned per_round = 4u * ipw;
+    unsigned rounds = (items + per_round * 2048u - 1) / (per_round * 2048u);
+    rounds = std::max(1u, rounds);
+    blocks = (items + per_round * rounds - 1) / (per_round * rounds);
+    const size_t lds = (4096 + 64 + 4 * kEdgeItems * 2 * 64) * sizeof(double);
+    const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
+#define EM(CT, GA) hipLaunchKernelGGL((k_edge_mfma<CT, GA>), dim3(blocks), dim3(256), lds, c->stream, e, c->gg, tm, rounds, ipw)
+    if (ctip)
+    {
+      if (gather) EM(true, true); else EM(true, false);
+    }
+    else
+    {
+      if (gather) EM(false, true); else EM(false, false);
+    }
+#undef EM
+  }
+  else if (c->dna_fast)
   {
     // 4 waves = 4 tiles per workgroup, tpw consecutive tiles per wave
     tpw = (tiles + 4 * max_blocks - 1) / (4 * max_blocks);
