@@ -26,6 +26,9 @@ CONFIGS = {
     "C3-lg-64x50k": dict(states=20, tips=64, sites=50000, seed=1000, **lg()),
     "C5-codon61-32x20k": dict(states=61, tips=32, sites=20000, seed=1000),
     "C4shard-dna-128x125k": dict(states=4, tips=128, sites=125000, seed=1000),
+    # BASELINE's largest site count on ONE device: offsets beyond 2^31 bytes inside a traversal
+    "C4sites-dna-16x1M": dict(states=4, tips=16, sites=1000000, seed=1001),
+    "C4sites-dna-16x1M-repeats": dict(states=4, tips=16, sites=1000000, seed=1001, mutate_pct=4),
 }
 
 
@@ -48,7 +51,7 @@ def reference():
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_full_size_against_reference_avx2(amd_lib, reference, name):
     kw = CONFIGS[name]
-    attrs = api.SITE_REPEATS if name.startswith("C4") else 0
+    attrs = api.SITE_REPEATS if (name.startswith("C4shard") or name.endswith("repeats")) else 0
     case = W.make_case(name, attributes=attrs, **kw)
     a, b = case.edges[0][0], case.edges[0][2]
     r_lnl, r_ps, r_clv, r_ids = run(reference, case, clvs=(a, b))
