@@ -38,7 +38,7 @@ struct DevOp
   const unsigned *lsid;        // site -> left entry, or null
   const unsigned *rsid;
   unsigned entries;
-  unsigned pad_;
+  unsigned layout;             // 4x4 kernels: kAosLeft | kAosRight | kAosParent (entry-contiguous CLVs of compressed nodes)
 };
 
 // passed BY VALUE as a kernel argument: descriptors arrive through the kernarg segment (scalar
@@ -81,6 +81,7 @@ struct DevEdge
   unsigned sites;
   int per_rate;
   int is_root;
+  unsigned layout;               // 4x4 kernels: kAosParent | kAosLeft (= child) for entry-contiguous CLVs
   unsigned char fidx[kMaxRates]; // freqs_indices
 };
 

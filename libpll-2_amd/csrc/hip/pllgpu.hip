@@ -90,6 +90,7 @@ struct pllgpu_ctx
   unsigned span = 0;
 
   std::vector<DevBuf<double>> clv;
+  std::vector<unsigned char> clv_aos;   // 4x4: the node's device CLV is entry-contiguous (class-compressed node)
   std::vector<DevBuf<unsigned>> scaler;
   std::vector<DevBuf<unsigned char>> tipchars;
   std::vector<DevBuf<unsigned>> site_id, id_site;
@@ -162,6 +163,13 @@ static void derive_geometry(pllgpu_ctx *c)
   c->span = g.rate_cats * g.states_padded;
 }
 
+// 4 states x 4 rates: a node that holds fewer entries than sites is class-compressed (site repeats);
+// its CLV stays entry-contiguous on the device (kernels_dna.h: gathers read whole entries)
+static inline bool aos_entries(const pllgpu_ctx *c, unsigned entries)
+{
+  return c->dna_fast && entries != c->geo.sites_alloc;
+}
+
 // doubles of device storage for `entries` entries of one CLV
 static inline size_t clv_elems(const pllgpu_ctx *c, unsigned entries)
 {
@@ -226,6 +234,7 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   c->own_stream = true;
   c->result_host[0] = c->result_host[1] = 0.0;
   c->clv.resize(geo->nodes);
+  c->clv_aos.assign(geo->nodes, 0);
   c->scaler.resize(geo->scale_buffers);
   c->tipchars.resize(geo->tips);
   c->site_id.resize(geo->nodes);
@@ -304,7 +313,8 @@ extern "C" int pllgpu_clv_upload(pllgpu_ctx_t *c, unsigned node, const double *h
 {
   if (int rc = pllgpu_clv_reserve(c, node, entries)) return rc;
   const size_t bytes = (size_t)entries * c->span * sizeof(double);
-  if (!c->tiled)
+  c->clv_aos[node] = aos_entries(c, entries) ? 1 : 0;
+  if (!c->tiled || c->clv_aos[node])
   {
     HIP_TRY(hipMemcpyAsync(c->clv[node].p, host, bytes, hipMemcpyHostToDevice, c->stream));
     return 0;
@@ -324,7 +334,7 @@ extern "C" int pllgpu_clv_download(pllgpu_ctx_t *c, unsigned node, double *host,
     return fail(PLLGPU_EINVAL, "clv %u: download of %u entries exceeds the device buffer", node, entries);
   const size_t bytes = (size_t)entries * c->span * sizeof(double);
   const double *src = c->clv[node].p;
-  if (c->tiled)
+  if (c->tiled && !c->clv_aos[node])
   {
     if (int rc = c->scratch.ensure((size_t)entries * c->span)) return rc;
     hipLaunchKernelGGL(k_tiled_to_aos, dim3(1024), dim3(256), 0, c->stream, c->clv[node].p, c->scratch.p, entries,
@@ -501,6 +511,12 @@ static int resolve_op(pllgpu_ctx *c, const pllgpu_op_t &o, DevOp &d)
   if (int rc = c->clv[o.parent_clv].ensure(clv_elems(c, o.parent_entries))) return rc;
   d.parent = c->clv[o.parent_clv].p;
   d.entries = o.parent_entries;
+  // layout of the three CLVs (4x4 only): what the children were written as, what the parent becomes
+  c->clv_aos[o.parent_clv] = aos_entries(c, o.parent_entries) ? 1 : 0;
+  d.layout = c->clv_aos[o.parent_clv] ? kAosParent : 0u;
+  if (!(o.flags & PLLGPU_OP_LEFT_TIP) && c->clv_aos[o.left_clv]) d.layout |= kAosLeft;
+  if (!(o.flags & PLLGPU_OP_RIGHT_TIP) && c->clv_aos[o.right_clv]) d.layout |= kAosRight;
+  if (d.layout && !(o.flags & PLLGPU_OP_GATHER)) return fail(PLLGPU_EINVAL, "a class-compressed CLV met an operation without the gather flag");
   if (o.flags & PLLGPU_OP_LEFT_TIP)
   {
     if (o.left_clv >= g.tips || !c->tipchars[o.left_clv].p) return fail(PLLGPU_EINVAL, "tip %u has no codes on the device", o.left_clv);
@@ -1073,6 +1089,8 @@ extern "C" int pllgpu_edge_loglikelihood(pllgpu_ctx_t *c, const pllgpu_edge_t *e
   if (int rc = scaler_ptr(c, ed->parent_scaler, e.pscaler)) return rc;
   if (int rc = scaler_ptr(c, ed->child_scaler, e.cscaler)) return rc;
   e.mat = c->pmat.p + (size_t)ed->matrix * c->pm_stride;
+  e.layout = (c->clv_aos[ed->parent_clv] ? kAosParent : 0u) | ((!ed->child_is_tip && c->clv_aos[ed->child_clv]) ? kAosLeft : 0u);
+  if (e.layout && !ed->gather) return fail(PLLGPU_EINVAL, "a class-compressed CLV met an evaluation without the gather flag");
   if (ed->gather)
   {
     e.psid = c->ids[ed->parent_clv] ? c->site_id[ed->parent_clv].p : nullptr;
@@ -1093,6 +1111,8 @@ extern "C" int pllgpu_root_loglikelihood(pllgpu_ctx_t *c, unsigned clv, int scal
   e.parent = c->clv[clv].p;
   if (int rc = scaler_ptr(c, scaler, e.pscaler)) return rc;
   if (gather) e.psid = c->ids[clv] ? c->site_id[clv].p : nullptr;
+  e.layout = c->clv_aos[clv] ? kAosParent : 0u;
+  if (e.layout && !gather) return fail(PLLGPU_EINVAL, "a class-compressed CLV met an evaluation without the gather flag");
   e.is_root = 1;
   return run_lnl(c, e, false, gather != 0, freqs_indices, persite_host, lnl_out);
 }
@@ -1189,6 +1209,8 @@ extern "C" int pllgpu_update_sumtable(pllgpu_ctx_t *c, const pllgpu_sumtable_t *
   d.right = c->clv[st->right_clv].p;
   d.lmat = c->pmat.p + (size_t)g.prob_matrices * c->pm_stride;
   d.rmat = c->pmat.p + (size_t)(g.prob_matrices + 1) * c->pm_stride;
+  d.layout = ((!st->left_is_tip && c->clv_aos[st->left_clv]) ? kAosLeft : 0u) | (c->clv_aos[st->right_clv] ? kAosRight : 0u);
+  if (d.layout && !st->gather) return fail(PLLGPU_EINVAL, "a class-compressed CLV met a sumtable without the gather flag");
   if (st->gather)
   {
     d.lsid = c->ids[st->left_clv] ? c->site_id[st->left_clv].p : nullptr;
