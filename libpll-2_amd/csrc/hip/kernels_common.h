@@ -35,11 +35,29 @@ struct DevOp
   const double *lmat;          // PT layout
   const double *rmat;
   const unsigned *id_site;     // parent entry -> representative site, or null
-  const unsigned *lsid;        // site -> left entry, or null
+  const unsigned *lsid;        // site -> left entry, or null; with kDirectMaps: PARENT ENTRY -> left entry
   const unsigned *rsid;
   unsigned entries;
-  unsigned layout;             // 4x4 kernels: kAosLeft | kAosRight | kAosParent (entry-contiguous CLVs of compressed nodes)
+  unsigned layout;             // kDirectMaps; 4x4 kernels also kAosLeft | kAosRight | kAosParent (entry-contiguous CLVs of compressed nodes)
 };
+
+// DevOp::layout bit: lsid / rsid are indexed by the parent's entry (filled by the class kernels,
+// kernels_repeats.h) - two coalesced loads instead of the dependent id_site -> site_id chain
+constexpr unsigned kDirectMaps = 8u;
+
+// child entries of parent entry nn for a gathering op
+__device__ __forceinline__ void gather_entries(const DevOp &op, unsigned nn, unsigned &le, unsigned &re)
+{
+  if (op.layout & kDirectMaps)
+  {
+    le = op.lsid[nn];
+    re = op.rsid[nn];
+    return;
+  }
+  const unsigned site = op.id_site ? op.id_site[nn] : nn;
+  le = op.lsid ? op.lsid[site] : site;
+  re = op.rsid ? op.rsid[site] : site;
+}
 
 // passed BY VALUE as a kernel argument: descriptors arrive through the kernarg segment (scalar
 // loads, no staging copy, graph-capturable). 32 * 112 B = 3584 B < 4 KiB kernarg limit.

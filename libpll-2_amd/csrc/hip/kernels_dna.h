@@ -66,9 +66,17 @@ __device__ __forceinline__ void dna_matvec(double (&r)[4], cdouble_p pt_k, const
     r[i] = fma(pt_k[12 + i], x[3], fma(pt_k[8 + i], x[2], fma(pt_k[4 + i], x[1], pt_k[i] * x[0])));
 }
 
+// row stride (doubles) of a wave's LDS transpose buffer: 18 keeps 16-byte accesses of 16 consecutive
+// lanes on distinct banks both when a lane writes its own entry and when it reads the dense order
+constexpr unsigned kAosRow = 18;
+
 template <bool LTIP, bool RTIP, bool GATHER>
 __global__ __launch_bounds__(256) void k_partials_dna(const OpPack pack, int scale_mode, unsigned tiles_per_wave)
 {
+  // entry-contiguous parents leave through LDS: a lane holds ITS entry's 128 bytes, but 64 lanes
+  // writing 16 bytes each at a 128-byte stride reach only half the store bandwidth of dense 1 KB
+  // rows (tools/store_probe.hip: 3.3 vs 6.6 TB/s)
+  __shared__ double transpose[GATHER ? 4 * 64 * kAosRow : 1];
   const DevOp &op = pack.ops[blockIdx.y];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -86,9 +94,7 @@ __global__ __launch_bounds__(256) void k_partials_dna(const OpPack pack, int sca
     unsigned le = nn, re = nn;
     if (GATHER)
     {
-      const unsigned site = op.id_site ? op.id_site[nn] : nn;
-      le = op.lsid ? op.lsid[site] : site;
-      re = op.rsid ? op.rsid[site] : site;
+      gather_entries(op, nn, le, re);
     }
     const unsigned lcode = LTIP ? op.ltip[le] : 0u;
     const unsigned rcode = RTIP ? op.rtip[re] : 0u;
@@ -160,27 +166,40 @@ __global__ __launch_bounds__(256) void k_partials_dna(const OpPack pack, int sca
     }
     if (valid)
     {
-      if (paos)
-      {
-        dbl2 *o = reinterpret_cast<dbl2 *>(op.parent + (size_t)n * 16);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-        {
-          dbl2 lo, hi;
-          lo.x = v[k][0];
-          lo.y = v[k][1];
-          hi.x = v[k][2];
-          hi.y = v[k][3];
-          o[2 * k] = lo;
-          o[2 * k + 1] = hi;
-        }
-      }
-      else
+      if (!paos)
       {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
           for (int i = 0; i < 4; ++i) out[(k * 4 + i) * 64] = v[k][i];
+      }
+    }
+    if (GATHER && paos) // wave-uniform
+    {
+      double *mine = transpose + (size_t)wave * 64 * kAosRow;
+      __builtin_amdgcn_wave_barrier(); // the previous tile's reads of this buffer are done
+      dbl2 *w = reinterpret_cast<dbl2 *>(mine + lane * kAosRow);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+      {
+        dbl2 lo, hi;
+        lo.x = v[k][0];
+        lo.y = v[k][1];
+        hi.x = v[k][2];
+        hi.y = v[k][3];
+        w[2 * k] = lo;
+        w[2 * k + 1] = hi;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      dbl2 *o = reinterpret_cast<dbl2 *>(op.parent + (size_t)tile * 64 * 16);
+      const unsigned first = tile * 64u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+      {
+        const unsigned t = q * 64u + lane, ent = t >> 3, pair = t & 7u;
+        const dbl2 x = *reinterpret_cast<const dbl2 *>(mine + ent * kAosRow + pair * 2);
+        if (first + ent < op.entries) o[t] = x;
       }
     }
   }

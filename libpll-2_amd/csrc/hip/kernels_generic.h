@@ -130,9 +130,7 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
     unsigned le = nn, re = nn;
     if (GATHER)
     {
-      const unsigned site = op.id_site ? op.id_site[nn] : nn;
-      le = op.lsid ? op.lsid[site] : site;
-      re = op.rsid ? op.rsid[site] : site;
+      gather_entries(op, nn, le, re);
     }
     unsigned long long lmask = 0, rmask = 0;
     if (LTIP) lmask = tipmap ? tipmap[op.ltip[le]] : (unsigned long long)op.ltip[le];

@@ -61,9 +61,7 @@ __device__ __forceinline__ MfmaItem mfma_item(const DevOp &op, const GenGeo &g, 
     unsigned le = nn, re = nn;
     if (GATHER)
     {
-      const unsigned site = op.id_site ? op.id_site[nn] : nn;
-      le = op.lsid ? op.lsid[site] : site;
-      re = op.rsid ? op.rsid[site] : site;
+      gather_entries(op, nn, le, re);
     }
     m.lm[sg] = m.rm[sg] = 0;
     if (LTIP) m.lm[sg] = tipmap ? tipmap[op.ltip[le]] : (unsigned long long)op.ltip[le];
@@ -312,9 +310,7 @@ __global__ __launch_bounds__(256) void k_mfma_scale_epilogue(const OpPack pack, 
   unsigned le = n, re = n;
   if (GATHER)
   {
-    const unsigned site = op.id_site ? op.id_site[n] : n;
-    le = op.lsid ? op.lsid[site] : site;
-    re = op.rsid ? op.rsid[site] : site;
+    gather_entries(op, n, le, re);
   }
   double *base = op.parent + (size_t)(n >> 6) * g.tile_sz + (n & 63u);
   const unsigned char *f = flagbuf + (size_t)blockIdx.y * R * flag_stride + n;

@@ -25,6 +25,7 @@ struct RepOp
   const unsigned *rid;
   unsigned *psid;        // out: site -> class of the parent   [sites]
   unsigned *pids;        // out: class -> first site           [<= sites]
+  unsigned *lent, *rent; // out: class -> entry of the left / right child (what the gather kernels want)
   unsigned *rank;        // scratch [sites]: class number of a representative site
   unsigned *blocksum;    // scratch [nblk]: representatives per workgroup, then their exclusive scan
   unsigned nleft;        // classes of the left child
@@ -149,6 +150,8 @@ __global__ __launch_bounds__(256) void k_rep_rank(const RepPack p)
     {
       o.rank[base + q] = r;
       o.pids[r] = base + q;
+      o.lent[r] = o.lid[base + q];
+      o.rent[r] = o.rid[base + q];
       ++r;
     }
 }

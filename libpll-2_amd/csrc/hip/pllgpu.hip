@@ -94,6 +94,8 @@ struct pllgpu_ctx
   std::vector<DevBuf<unsigned>> scaler;
   std::vector<DevBuf<unsigned char>> tipchars;
   std::vector<DevBuf<unsigned>> site_id, id_site;
+  std::vector<DevBuf<unsigned>> lent, rent; // class -> child entry, per compressed node (kernels_repeats.h)
+  std::vector<int> rep_left, rep_right;     // the children those maps were built for, or -1
   std::vector<unsigned> ids;
   DevBuf<unsigned long long> tipmap;
   bool tipmap_set = false;
@@ -239,6 +241,10 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   c->tipchars.resize(geo->tips);
   c->site_id.resize(geo->nodes);
   c->id_site.resize(geo->nodes);
+  c->lent.resize(geo->nodes);
+  c->rent.resize(geo->nodes);
+  c->rep_left.assign(geo->nodes, -1);
+  c->rep_right.assign(geo->nodes, -1);
   c->ids.assign(geo->nodes, 0);
   if (c->pmat.ensure(c->pm_stride * (geo->prob_matrices + 2)) || c->freqs.ensure((size_t)geo->rate_matrices * geo->states_padded) ||
       c->rate_weights.ensure(geo->rate_cats) || c->prop_invar.ensure(geo->rate_matrices) ||
@@ -264,6 +270,8 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   for (auto &b : c->tipchars) b.release();
   for (auto &b : c->site_id) b.release();
   for (auto &b : c->id_site) b.release();
+  for (auto &b : c->lent) b.release();
+  for (auto &b : c->rent) b.release();
   c->tipmap.release();
   c->scratch.release();
   c->pmat.release();
@@ -490,6 +498,7 @@ extern "C" int pllgpu_repeats_upload(pllgpu_ctx_t *c, unsigned node, const unsig
   CHECK_CTX(c);
   if (node >= c->geo.nodes) return fail(PLLGPU_EINVAL, "node %u out of range", node);
   c->ids[node] = ids;
+  c->rep_left[node] = c->rep_right[node] = -1; // host-built maps: no entry-indexed child maps
   if (!ids) return 0;
   if (int rc = c->site_id[node].ensure(c->geo.sites_alloc)) return rc;
   if (int rc = c->id_site[node].ensure(c->geo.sites_alloc)) return rc;
@@ -559,9 +568,25 @@ static int resolve_op(pllgpu_ctx *c, const pllgpu_op_t &o, DevOp &d)
   d.rmat = c->pmat.p + (size_t)o.right_matrix * c->pm_stride;
   if (o.flags & PLLGPU_OP_GATHER)
   {
-    d.id_site = c->ids[o.parent_clv] ? c->id_site[o.parent_clv].p : nullptr;
-    d.lsid = c->ids[o.left_clv] ? c->site_id[o.left_clv].p : nullptr;
-    d.rsid = c->ids[o.right_clv] ? c->site_id[o.right_clv].p : nullptr;
+    const unsigned p = o.parent_clv;
+    if (c->ids[p] && c->rep_left[p] == (int)o.left_clv && c->rep_right[p] == (int)o.right_clv)
+    {
+      d.lsid = c->lent[p].p; // entry-indexed: two coalesced loads per lane
+      d.rsid = c->rent[p].p;
+      d.layout |= kDirectMaps;
+    }
+    else if (c->ids[p] && c->rep_left[p] == (int)o.right_clv && c->rep_right[p] == (int)o.left_clv)
+    {
+      d.lsid = c->rent[p].p; // the host put the tip on the left
+      d.rsid = c->lent[p].p;
+      d.layout |= kDirectMaps;
+    }
+    else
+    {
+      d.id_site = c->ids[p] ? c->id_site[p].p : nullptr;
+      d.lsid = c->ids[o.left_clv] ? c->site_id[o.left_clv].p : nullptr;
+      d.rsid = c->ids[o.right_clv] ? c->site_id[o.right_clv].p : nullptr;
+    }
   }
   return 0;
 }
@@ -1504,6 +1529,7 @@ extern "C" int pllgpu_repeats_set_ids(pllgpu_ctx_t *c, unsigned node, unsigned i
   CHECK_CTX(c);
   if (node >= c->geo.nodes) return fail(PLLGPU_EINVAL, "node %u out of range", node);
   c->ids[node] = ids;
+  if (!ids) c->rep_left[node] = c->rep_right[node] = -1;
   return 0;
 }
 
@@ -1556,11 +1582,17 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
       const pllgpu_repop_t &o = ops[done + i];
       if (int rc = c->site_id[o.parent].ensure(g.sites_alloc)) return rc;
       if (int rc = c->id_site[o.parent].ensure(g.sites_alloc)) return rc;
+      if (int rc = c->lent[o.parent].ensure(g.sites_alloc)) return rc;
+      if (int rc = c->rent[o.parent].ensure(g.sites_alloc)) return rc;
+      c->rep_left[o.parent] = (int)o.left;
+      c->rep_right[o.parent] = (int)o.right;
       RepOp &r = pk.ops[i];
       r.lid = c->site_id[o.left].p;
       r.rid = c->site_id[o.right].p;
       r.psid = c->site_id[o.parent].p;
       r.pids = c->id_site[o.parent].p;
+      r.lent = c->lent[o.parent].p;
+      r.rent = c->rent[o.parent].p;
       r.rank = c->rep_rank.p + (size_t)i * sites;
       r.blocksum = c->rep_blocksum.p + (size_t)i * nblk;
       r.nleft = o.nleft;
