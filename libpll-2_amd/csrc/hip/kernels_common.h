@@ -1,10 +1,10 @@
 // kernels_common.h - device-side structures shared by the gfx950 kernels.
 //
 // Data layout in HBM (DESIGN.md "Data layout"):
-//   CLV      4 states x 4 rates: [entry][rate][state] doubles - the reference's own site-major
-//            layout (src/pll.c:565-567); a quad of lanes covers one site, a wavefront reads 64
-//            consecutive 32-byte pieces. Every other shape: tiled sites-contiguous
-//            [tile][rate][state][64 lanes] (kernels_generic.h).
+//   CLV      tiled sites-contiguous for every shape: [tile][rate][state][64 lanes], tile =
+//            entry >> 6, lane = entry & 63 (kernels_generic.h); state padding dropped. Exception:
+//            class-compressed nodes of a 4 x 4 partition are entry-contiguous [entry][16]
+//            (kernels_dna.h: scattered entries are read whole).
 //   scaler   [entry] or [entry][rate] unsigned (src/pll.c:838-857)
 //   P matrix per branch, TRANSPOSED relative to the reference: PT[rate][col j][row i padded to
 //            SPT]; a kernel walking the contraction index j then finds the ICH parent-state

@@ -2,8 +2,9 @@
  *
  * Case selection mirrors src/likelihood.c:586-636: site repeats on either end -> gather maps;
  * PATTERN_TIP with a tip end -> the inner node becomes the "parent" and the tip is read as codes;
- * otherwise two CLVs. One kernel evaluates all sites, a second sums the per-workgroup partials in
- * a fixed order, the double comes back over PCIe (8 bytes) and the call returns it.
+ * otherwise two CLVs. One kernel evaluates all sites; the last workgroup to arrive adds the
+ * per-workgroup partials in a fixed order and leaves {lnL, call sequence} in mapped host memory,
+ * which the call polls (or in device memory for pll_gpu_edge_loglikelihood_async).
  */
 #include <math.h>
 
