@@ -65,7 +65,7 @@ __device__ __forceinline__ void tip_columns(double (&acc)[ICH], const double *st
                                             unsigned long long mask, unsigned long long full)
 {
   const unsigned row = mask == full ? g.S : (unsigned)__ffsll((long long)mask) - 1u; // row S = the row sums
-  const double *p = staged + row * g.SPT + c * ICH;
+  const double *p = staged + row * (g.SPT | 1u) + c * ICH; // odd row stride: lanes with different states hit different banks
 #pragma unroll
   for (int i = 0; i < ICH; ++i) acc[i] = p[i];
 }
@@ -75,13 +75,13 @@ __device__ __forceinline__ void tip_stage(double *staged, const double *pt, unsi
 {
   __builtin_amdgcn_wave_barrier(); // earlier readers of this wave's slot are done (LDS ops of a wave stay in order)
   const double *src = pt + (size_t)k * g.S * g.SPT;
-  const unsigned n = g.S * g.SPT;
-  for (unsigned idx = lane; idx < n; idx += 64u) staged[idx] = src[idx];
+  const unsigned n = g.S * g.SPT, ls = g.SPT | 1u;
+  for (unsigned idx = lane; idx < n; idx += 64u) staged[(idx / g.SPT) * ls + idx % g.SPT] = src[idx];
   for (unsigned i = lane; i < g.SPT; i += 64u)
   {
     double s = 0.0;
     for (unsigned j = 0; j < g.S; ++j) s += src[(size_t)j * g.SPT + i];
-    staged[n + i] = s;
+    staged[g.S * ls + i] = s;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
   if (blockIdx.x * tiles_per_block >= ntiles) return; // whole workgroup
 
   const unsigned long long full = g.S >= 64 ? ~0ull : ((1ull << g.S) - 1ull);
-  const unsigned slot = (g.S + 1u) * g.SPT;
+  const unsigned slot = (g.S + 1u) * (g.SPT | 1u);
   double *lstage = tipmat + (size_t)wave * slot, *rstage = tipmat + (size_t)(nw + wave) * slot;
   // one rate category per wave (R <= 4): the tip matrices are staged once for all tiles of the workgroup
   const bool stage_once = tip_lds && g.R <= nw && wave < g.R;

@@ -601,7 +601,7 @@ static void launch_generic(pllgpu_ctx *c, const OpPack &pack, unsigned nops, uns
   const unsigned nw = std::min(c->gg.R, 4u);
   const bool stage = kind != 0 && c->gg.S * c->gg.SPT <= 1024u && !c->no_tip_columns;
   const unsigned tip_lds = stage ? 1u : 0u;
-  const size_t lds = stage ? (size_t)2 * nw * (c->gg.S + 1u) * c->gg.SPT * sizeof(double) : 0;
+  const size_t lds = stage ? (size_t)2 * nw * (c->gg.S + 1u) * (c->gg.SPT | 1u) * sizeof(double) : 0;
   // staged tip matrices are shared by the tiles of a workgroup: several tiles each, as long as
   // ~4096 workgroups remain
   unsigned tpb = 1;
