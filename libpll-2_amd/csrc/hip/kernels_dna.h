@@ -499,7 +499,8 @@ __device__ __forceinline__ void dna_child_store(const FOp &cop, size_t off, unsi
 }
 
 template <int LK, int RK>
-__global__ __launch_bounds__(256) void k_partials_dna_fused(const FusePack pack, unsigned entries, int scale_mode, unsigned tiles_per_wave)
+__global__ __launch_bounds__(256) void k_partials_dna_fused(const FusePack pack, unsigned entries, int scale_mode, unsigned tiles_per_wave,
+                                                              unsigned stream_parent)
 {
   const FGroup &g = pack.g[blockIdx.y];
   const unsigned lane = threadIdx.x & 63u;
@@ -544,6 +545,11 @@ __global__ __launch_bounds__(256) void k_partials_dna_fused(const FusePack pack,
       }
     }
     dna_scale(v, small, mode, sca, scb, sc);
-    dna_store<false>(g.p, off, n, valid, mode, v, sc);
+    // the group parent is read by the next level: keep it cacheable unless the level's output cannot
+    // stay in L2/MALL anyway (stream_parent: decided by the launcher from the bytes written)
+    if (stream_parent)
+      dna_store<true>(g.p, off, n, valid, mode, v, sc);
+    else
+      dna_store<false>(g.p, off, n, valid, mode, v, sc);
   }
 }

@@ -117,6 +117,7 @@ struct pllgpu_ctx
   unsigned last_launches = 0;
   double last_bytes = 0.0;       // algorithmic HBM bytes of the last update_partials call
   bool no_tip_columns = false;   // PLL_AMD_NO_TIP_COLUMNS=1: tips always through the FMA contraction
+  size_t stream_parent_bytes = (size_t)256 << 20; // PLL_AMD_STREAM_PARENT_MB overrides (experiments)
   bool fuse = false;             // DNA: evaluate producer + consumer ops in one kernel (kernels_dna.h)
 };
 
@@ -156,6 +157,7 @@ static void derive_geometry(pllgpu_ctx *c)
     if (*v && *v != '0') c->fuse = false;
   if (const char *v = getenv("PLL_AMD_NO_TIP_COLUMNS"))
     if (*v && *v != '0') c->no_tip_columns = true;
+  if (const char *v = getenv("PLL_AMD_STREAM_PARENT_MB")) c->stream_parent_bytes = (size_t)atol(v) << 20;
   c->tiled = true; // every shape keeps CLVs in the tiled sites-contiguous layout
   // 33..64 states: CLV updates on the fp64 matrix pipe (kernels_mfma.h); PLL_AMD_NO_MFMA=1 keeps the FMA kernel
   c->use_mfma = (g.states > 32 && g.rate_cats <= 16);
@@ -808,7 +810,10 @@ static void launch_fused_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups
   unsigned tpw = (unsigned)(((size_t)tiles * ngroups + 4 * want_blocks - 1) / (4 * want_blocks));
   tpw = std::max(1u, std::min(tpw, 8u));
   dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), ngroups), block(256);
-  hipLaunchKernelGGL((k_partials_dna_fused<LK, RK>), grid, block, 0, c->stream, pack, entries, c->gg.scale_mode, tpw);
+  // parents of this launch: entries x 128 B each. Beyond the 256 MB Infinity Cache nothing of them
+  // survives until the next level reads it: stream them out as well
+  unsigned stream_parent = ((size_t)ngroups * entries * 128u > c->stream_parent_bytes) ? 1u : 0u;
+  hipLaunchKernelGGL((k_partials_dna_fused<LK, RK>), grid, block, 0, c->stream, pack, entries, c->gg.scale_mode, tpw, stream_parent);
 }
 
 static int launch_fused(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries, int lk, int rk)
