@@ -553,3 +553,87 @@ __global__ __launch_bounds__(256) void k_partials_dna_fused(const FusePack pack,
       dna_store<false>(g.p, off, n, valid, mode, v, sc);
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Tail fusion: a traversal's last ops produce the two ends of the edge whose log-likelihood the
+// caller asks for next (the universal call sequence: pll_update_partials, then
+// pll_compute_edge_loglikelihood on the virtual root). The device layer holds those (at most two)
+// ops back for one call; if the next call is the matching edge evaluation, k_edge_dna_tail forms
+// the ends per site in registers (storing their CLVs and scalers like any update), and the site
+// log-likelihood straight from the registers: one launch instead of two and neither end is read
+// back. Any other call launches the held ops as ordinary updates first.
+// KP / KC: DnaChildKind of the parent end (never a tip) and of the child end.
+template <int KP, int KC>
+__global__ __launch_bounds__(256) void k_edge_dna_tail(const DevEdge e, const FGroup g, int scale_mode, unsigned tiles_per_wave)
+{
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned ntiles = (e.sites + 63u) / 64u;
+  cdouble_p pm = as_const(e.mat);
+  double acc = 0.0;
+
+  for (unsigned t = 0; t < tiles_per_wave; ++t)
+  {
+    const unsigned tile = (blockIdx.x * 4u + wave) * tiles_per_wave + t;
+    if (tile >= ntiles) break; // wave-uniform
+    const unsigned n0 = tile * 64u + lane;
+    const bool valid = n0 < e.sites;
+    const unsigned n = valid ? n0 : e.sites - 1;
+    const size_t off = (size_t)(n >> 6) * kDnaTile + (n & 63u);
+
+    double vp[4][4], vc[4][4];
+    uint4 scp, scc;
+    {
+      DnaRaw rp, rc;
+      dna_child_load<KP>(g.p, true, g.a, off, n, rp);
+      dna_child_compute<KP>(g.p, true, g.a, n, scale_mode, rp, vp, scp);
+      dna_child_load<KC>(g.p, false, g.b, off, n, rc);
+      dna_child_store<KP>(g.a, off, n, valid, scale_mode, vp, scp);
+      dna_child_compute<KC>(g.p, false, g.b, n, scale_mode, rc, vc, scc);
+      dna_child_store<KC>(g.b, off, n, valid, scale_mode, vc, scc);
+    }
+    unsigned rs[4] = {0, 0, 0, 0}, scal;
+    if (e.per_rate)
+    {
+      rs[0] = scp.x + scc.x;
+      rs[1] = scp.y + scc.y;
+      rs[2] = scp.z + scc.z;
+      rs[3] = scp.w + scc.w;
+      scal = min(min(rs[0], rs[1]), min(rs[2], rs[3]));
+    }
+    else
+      scal = scp.x + scc.x;
+    const int inv = e.invariant ? e.invariant[n] : -1;
+    double terma = 0.0, terminv = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      double tb[4];
+      dna_matvec(tb, pm + k * 16, vc[k]);
+      const unsigned fi = e.fidx[k];
+      cdouble_p pi = as_const(e.freqs) + (size_t)fi * 4;
+      double tr = fma(vp[k][3] * pi[3], tb[3], fma(vp[k][2] * pi[2], tb[2], fma(vp[k][1] * pi[1], tb[1], (vp[k][0] * pi[0]) * tb[0])));
+      if (e.per_rate)
+      {
+        const unsigned ex = min(rs[k] - scal, PLLGPU_RATE_MAXDIFF);
+        if (ex) tr *= minlh(ex);
+      }
+      const double pinv = e.prop_invar ? e.prop_invar[fi] : 0.0;
+      const double w = e.rate_weights[k];
+      if (pinv > 0.0)
+      {
+        terma += w * tr * (1.0 - pinv);
+        if (inv >= 0) terminv += w * e.freqs[(size_t)fi * 4 + inv] * pinv;
+      }
+      else
+        terma += tr * w;
+    }
+    if (valid)
+    {
+      const double site = finish_site(terma, terminv, scal, 0) * (double)e.pattern_weights[n];
+      if (e.persite) e.persite[n] = site;
+      acc += site;
+    }
+  }
+  publish_block_sum(e, wave_sum(acc), 4u);
+}

@@ -118,6 +118,8 @@ struct pllgpu_ctx
   double last_bytes = 0.0;       // algorithmic HBM bytes of the last update_partials call
   bool no_tip_columns = false;   // PLL_AMD_NO_TIP_COLUMNS=1: tips always through the FMA contraction
   size_t stream_parent_bytes = (size_t)256 << 20; // PLL_AMD_STREAM_PARENT_MB overrides (experiments)
+  bool defer_tail = false;       // DNA: hold the traversal's last ops for one call (k_edge_dna_tail)
+  std::vector<pllgpu_op_t> deferred; // ops accepted by pllgpu_update_partials and not launched yet
   bool fuse = false;             // DNA: evaluate producer + consumer ops in one kernel (kernels_dna.h)
 };
 
@@ -157,6 +159,9 @@ static void derive_geometry(pllgpu_ctx *c)
     if (*v && *v != '0') c->fuse = false;
   if (const char *v = getenv("PLL_AMD_NO_TIP_COLUMNS"))
     if (*v && *v != '0') c->no_tip_columns = true;
+  c->defer_tail = c->dna_fast;
+  if (const char *v = getenv("PLL_AMD_NO_TAIL_FUSION"))
+    if (*v && *v != '0') c->defer_tail = false;
   if (const char *v = getenv("PLL_AMD_STREAM_PARENT_MB")) c->stream_parent_bytes = (size_t)atol(v) << 20;
   c->tiled = true; // every shape keeps CLVs in the tiled sites-contiguous layout
   // 33..64 states: CLV updates on the fp64 matrix pipe (kernels_mfma.h); PLL_AMD_NO_MFMA=1 keeps the FMA kernel
@@ -266,6 +271,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
 {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  c->deferred.clear(); // results nobody will ask for
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto &b : c->clv) b.release();
   for (auto &b : c->scaler) b.release();
@@ -308,9 +314,16 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
 // ---- data movement ---------------------------------------------------------------------------
 // H2D copies from pageable caller memory: hipMemcpyAsync stages pageable sources before it
 // returns, so the caller may reuse its buffer; ordering with kernels is by the stream.
-#define CHECK_CTX(c)                         \
+// every entry point first launches what pllgpu_update_partials is holding back (tail fusion,
+// kernels_dna.h) - except the edge evaluation, which may consume it
+static int flush_deferred(pllgpu_ctx *c);
+#define CHECK_CTX_KEEP(c)                    \
   if (!(c)) return fail(PLLGPU_EINVAL, "null context"); \
   if (int rc_ = use(c)) return rc_
+#define CHECK_CTX(c)                         \
+  CHECK_CTX_KEEP(c);                         \
+  if (!(c)->deferred.empty())                \
+    if (int rc_ = flush_deferred(c)) return rc_
 
 extern "C" int pllgpu_clv_reserve(pllgpu_ctx_t *c, unsigned node, unsigned entries)
 {
@@ -842,6 +855,32 @@ static double op_traffic(const pllgpu_ctx *c, const pllgpu_op_t &o, bool read_le
   return b * o.parent_entries;
 }
 
+// launch the held ops as ordinary updates (they are mutually independent: one level)
+static int flush_deferred(pllgpu_ctx *c)
+{
+  std::vector<pllgpu_op_t> ops;
+  ops.swap(c->deferred);
+  for (unsigned kind = 0; kind < 3; ++kind)
+  {
+    OpPack pack;
+    unsigned nops = 0, maxent = 0;
+    for (const pllgpu_op_t &o : ops)
+    {
+      const unsigned tips = ((o.flags & PLLGPU_OP_LEFT_TIP) ? 1u : 0u) + ((o.flags & PLLGPU_OP_RIGHT_TIP) ? 1u : 0u);
+      if (tips != kind) continue;
+      if (int rc = resolve_op(c, o, pack.ops[nops])) return rc;
+      maxent = std::max(maxent, o.parent_entries);
+      ++nops;
+    }
+    if (!nops) continue;
+    if (int rc = launch_partials(c, pack, nops, maxent, kind, false)) return rc;
+    ++c->last_launches;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PLLGPU_ERUNTIME, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
 extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, unsigned count)
 {
   CHECK_CTX(c);
@@ -850,6 +889,27 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
   std::vector<int> role;
   std::vector<FusedGroup> groups;
   plan_fusion(c, ops, count, role, groups);
+  // tail fusion: the plain ops of the last level (at most two: the ends of the edge a caller evaluates
+  // next) are accepted but not launched yet - role 3
+  if (c->defer_tail && count)
+  {
+    const unsigned top = ops[count - 1].level;
+    unsigned n = 0;
+    bool ok = true;
+    for (unsigned o = 0; o < count && ok; ++o)
+      if (ops[o].level == top)
+      {
+        if (role[o] == 1) continue; // a group parent hoisted away from this level
+        ok = role[o] == 0 && !(ops[o].flags & PLLGPU_OP_GATHER) && ops[o].parent_entries == c->geo.sites_alloc && ++n <= 2;
+      }
+    for (unsigned o = 0; o < count && ok; ++o)
+      if (ops[o].level == top && role[o] == 0)
+      {
+        role[o] = 3;
+        c->deferred.push_back(ops[o]);
+        c->last_bytes += op_traffic(c, ops[o], true, true);
+      }
+  }
   size_t gi_sorted = 0;
   if (!groups.empty())
     std::stable_sort(groups.begin(), groups.end(), [](const FusedGroup &x, const FusedGroup &y) { return x.level < y.level; });
@@ -975,8 +1035,31 @@ static void launch_edge_generic(pllgpu_ctx *c, const DevEdge &e, unsigned blocks
 #undef EG
 }
 
+// the tail-fused evaluation: kinds of the two ends and the descriptors of the held ops
+struct TailCall
+{
+  FGroup g;
+  int kp, kc;
+};
+
+static int launch_edge_tail(pllgpu_ctx *c, const DevEdge &e, const TailCall &t, unsigned blocks, unsigned tpw)
+{
+#define TZ(A, B)                                                                                                      \
+  if (t.kp == A && t.kc == B)                                                                                         \
+  {                                                                                                                   \
+    hipLaunchKernelGGL((k_edge_dna_tail<A, B>), dim3(blocks), dim3(256), 0, c->stream, e, t.g, c->gg.scale_mode, tpw); \
+    return 0;                                                                                                         \
+  }
+  TZ(CK_INNER, CK_FTT) TZ(CK_INNER, CK_FTI) TZ(CK_INNER, CK_FII)
+  TZ(CK_FTT, CK_INNER) TZ(CK_FTT, CK_TIP) TZ(CK_FTT, CK_FTT) TZ(CK_FTT, CK_FTI) TZ(CK_FTT, CK_FII)
+  TZ(CK_FTI, CK_INNER) TZ(CK_FTI, CK_TIP) TZ(CK_FTI, CK_FTT) TZ(CK_FTI, CK_FTI) TZ(CK_FTI, CK_FII)
+  TZ(CK_FII, CK_INNER) TZ(CK_FII, CK_TIP) TZ(CK_FII, CK_FTT) TZ(CK_FII, CK_FTI) TZ(CK_FII, CK_FII)
+#undef TZ
+  return fail(PLLGPU_EINVAL, "no tail kernel for end kinds (%d, %d)", t.kp, t.kc);
+}
+
 static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsigned *freqs_indices,
-                   double *persite_host, double *lnl_out, double *device_result = nullptr)
+                   double *persite_host, double *lnl_out, double *device_result = nullptr, const TailCall *tail = nullptr)
 {
   const pllgpu_geometry_t &g = c->geo;
   for (unsigned k = 0; k < g.rate_cats; ++k)
@@ -1026,6 +1109,13 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
       if (gather) EM(false, true); else EM(false, false);
     }
 #undef EM
+  }
+  else if (c->dna_fast && tail)
+  {
+    tpw = (tiles + 4 * max_blocks - 1) / (4 * max_blocks);
+    blocks = (tiles + 4 * tpw - 1) / (4 * tpw);
+    if (int rc = launch_edge_tail(c, e, *tail, blocks, tpw)) return rc;
+    ++c->last_launches;
   }
   else if (c->dna_fast)
   {
@@ -1098,10 +1188,53 @@ static int scaler_ptr(pllgpu_ctx *c, int idx, const unsigned *&out)
 
 extern "C" int pllgpu_edge_loglikelihood(pllgpu_ctx_t *c, const pllgpu_edge_t *ed, double *persite_host, double *lnl_out)
 {
-  CHECK_CTX(c);
+  CHECK_CTX_KEEP(c);
   const pllgpu_geometry_t &g = c->geo;
   if (ed->parent_clv >= g.nodes || ed->child_clv >= g.nodes || ed->matrix >= g.prob_matrices)
     return fail(PLLGPU_EINVAL, "edge references an index out of range");
+  // held ops (tail fusion): if they produce an end of THIS edge they are evaluated inside the lnL
+  // kernel; whatever else is held goes out as ordinary updates first
+  TailCall tail;
+  bool use_tail = false;
+  if (!c->deferred.empty())
+  {
+    int ia = -1, ib = -1;
+    if (c->dna_fast && !ed->gather)
+      for (size_t i = 0; i < c->deferred.size(); ++i)
+      {
+        const pllgpu_op_t &o = c->deferred[i];
+        if (o.parent_clv == ed->parent_clv && o.parent_scaler == ed->parent_scaler) ia = (int)i;
+        else if (!ed->child_is_tip && o.parent_clv == ed->child_clv && o.parent_scaler == ed->child_scaler) ib = (int)i;
+      }
+    if (ia < 0 && ib < 0)
+    {
+      if (int rc = flush_deferred(c)) return rc;
+    }
+    else
+    {
+      std::vector<pllgpu_op_t> held;
+      held.swap(c->deferred);
+      for (size_t i = 0; i < held.size(); ++i)
+        if ((int)i != ia && (int)i != ib) c->deferred.push_back(held[i]);
+      if (!c->deferred.empty())
+        if (int rc = flush_deferred(c)) return rc;
+      memset(&tail.g, 0, sizeof tail.g);
+      DevOp d;
+      if (ia >= 0)
+      {
+        if (int rc = resolve_op(c, held[ia], d)) return rc;
+        to_fop(d, tail.g.a);
+      }
+      if (ib >= 0)
+      {
+        if (int rc = resolve_op(c, held[ib], d)) return rc;
+        to_fop(d, tail.g.b);
+      }
+      tail.kp = ia >= 0 ? child_kind(held[ia]) : CK_INNER;
+      tail.kc = ib >= 0 ? child_kind(held[ib]) : (ed->child_is_tip ? CK_TIP : CK_INNER);
+      use_tail = true;
+    }
+  }
   DevEdge e;
   memset(&e, 0, sizeof e);
   if (!c->clv[ed->parent_clv].p) return fail(PLLGPU_EINVAL, "CLV %u was never computed or uploaded", ed->parent_clv);
@@ -1128,6 +1261,16 @@ extern "C" int pllgpu_edge_loglikelihood(pllgpu_ctx_t *c, const pllgpu_edge_t *e
   }
   e.is_root = 0;
   if (ed->device_result && persite_host) return fail(PLLGPU_EINVAL, "per-site values are not available from an asynchronous evaluation");
+  if (use_tail)
+  {
+    // memory-side descriptors of the ends that were NOT held
+    tail.g.p.left = e.parent;
+    tail.g.p.lscaler = e.pscaler;
+    tail.g.p.right = e.child;
+    tail.g.p.rtip = e.ctip;
+    tail.g.p.rscaler = e.cscaler;
+    return run_lnl(c, e, ed->child_is_tip != 0, false, ed->freqs_indices, persite_host, lnl_out, ed->device_result, &tail);
+  }
   return run_lnl(c, e, ed->child_is_tip != 0, ed->gather != 0, ed->freqs_indices, persite_host, lnl_out, ed->device_result);
 }
 
@@ -1177,6 +1320,7 @@ extern "C" int pllgpu_timer_start(pllgpu_ctx_t *c)
 extern "C" double pllgpu_timer_stop(pllgpu_ctx_t *c)
 {
   if (!c || use(c)) return -1.0;
+  if (!c->deferred.empty() && flush_deferred(c)) return -1.0;
   float ms = 0;
   if (hipEventRecord(c->ev1, c->stream) != hipSuccess || hipEventSynchronize(c->ev1) != hipSuccess ||
       hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess)

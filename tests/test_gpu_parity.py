@@ -336,7 +336,11 @@ def test_fusion_plan_on_a_balanced_tree(amd_lib):
     case = W.make_case("plan", 4, 64, 640, seed=97)
     with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
         s.update_partials()
-        assert amd_lib.pll_gpu_last_launch_count(s.p) == 3
+        s.edge_lnl(case.edges[0], persite=False)
+        assert amd_lib.pll_gpu_last_launch_count(s.p) == 3  # ... and evaluated inside the lnL kernel
+        s.update_partials()
+        # two launches now; the two root-side ops are held for the edge evaluation (tail fusion)
+        assert amd_lib.pll_gpu_last_launch_count(s.p) == 2
         per_site = amd_lib.pll_gpu_last_algorithmic_bytes(s.p) / 640
         # 16 x (4 B codes + 3 CLVs + 1 scaler vector: tip-tip parents carry none) ...: just bound it
         assert 10000 < per_site < 11200, per_site
@@ -345,5 +349,71 @@ def test_fusion_plan_on_a_balanced_tree(amd_lib):
         amd_lib.pll_update_partials(s.p, arr, len(ii))
         assert amd_lib.pll_gpu_last_launch_count(s.p) == 2  # 16+8 ops as 8 groups, 4+2 ops as 2 groups
         v, _ = s.edge_lnl(case.edges[0], persite=False)
+        assert amd_lib.pll_gpu_last_launch_count(s.p) == 2  # nothing was held: the lnL kernel is not counted
         exp = O.run_case(case)
         assert abs(v - exp["lnl"][0]) <= RTOL * abs(v)
+
+
+def test_tail_fusion_is_transparent(amd_lib, monkeypatch):
+    """The last ops of a traversal are held back for one call so that the edge evaluation can form
+    its two ends in registers (k_edge_dna_tail). Whatever the caller does next must see the same
+    state as without that: lnL on the produced edge (bit-identical), lnL on another edge, a root
+    evaluation, a CLV sync, a second traversal reading or overwriting the held CLVs, derivatives."""
+    case = W.make_case("tail", 4, 16, 3000, seed=98, ambiguity_pct=4)
+    e = case.edges[0]
+    other = (case.op_batches[0][-3][0], case.op_batches[0][-3][1], case.op_batches[0][-4][0], case.op_batches[0][-4][1], e[4])
+    exp = O.run_case(case)
+
+    def observe(lib_env):
+        out = {}
+        with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+            s.update_partials()
+            out["edge"] = s.edge_lnl(e)                        # consumes the held ops
+            s.update_partials()
+            out["edge_nopersite"] = s.edge_lnl(e, persite=False)[0]
+            s.update_partials()
+            out["other_edge"] = s.edge_lnl(other, persite=False)[0]   # held ops go out as plain updates first
+            out["edge_after"] = s.edge_lnl(e, persite=False)[0]
+            s.update_partials()
+            out["clv"] = s.read_clv(e[0])                      # sync of a held CLV
+            out["scaler"] = s.read_scaler(e[1], e[0])
+            s.update_partials()
+            out["root"] = s.root_lnl((e[0], e[1]), persite=False)[0]
+            s.update_partials()
+            s.update_partials()                                # held ops of the first call are flushed by the second
+            out["edge_twice"] = s.edge_lnl(e, persite=False)[0]
+            # one end only: recompute just the last op, the other end comes from memory
+            last = api.make_ops(case.op_batches[0][-1:])
+            amd_lib.pll_update_partials(s.p, last, 1)
+            out["edge_one_end"] = s.edge_lnl(e, persite=False)[0]
+        return out
+
+    fused = observe(None)
+    monkeypatch.setenv("PLL_AMD_NO_TAIL_FUSION", "1")
+    plain = observe(None)
+    for k in fused:
+        if k == "edge":
+            assert fused[k][0] == plain[k][0] and (fused[k][1] == plain[k][1]).all()
+        elif k in ("clv", "scaler"):
+            assert (fused[k] == plain[k]).all()
+        else:
+            assert fused[k] == plain[k], k
+    assert abs(fused["edge"][0] - exp["lnl"][0]) <= RTOL * abs(exp["lnl"][0])
+    assert fused["edge_nopersite"] == fused["edge"][0] == fused["edge_after"] == fused["edge_twice"] == fused["edge_one_end"]
+
+
+@pytest.mark.parametrize("kw", [dict(states=4, tips=16, sites=700, attributes=api.RATE_SCALERS, seed=101),
+                                dict(states=4, tips=4, sites=130, seed=102),                       # tip-tip ends
+                                dict(states=4, tips=64, sites=200, tree="caterpillar", brlen_scale=4, seed=103),  # tip child end, scaling
+                                dict(states=4, tips=16, sites=300, pinv=0.3, mutate_pct=4, seed=104),
+                                dict(states=4, tips=16, sites=300, attributes=api.PATTERN_TIP, ambiguity_pct=6, seed=105)],
+                         ids=_id)
+def test_tail_fusion_shapes(amd_lib, kw, monkeypatch):
+    case = W.make_case("tailshape", **kw)
+    exp = O.run_case(case)
+    fused = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    monkeypatch.setenv("PLL_AMD_NO_TAIL_FUSION", "1")
+    plain = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    assert_results_match(fused, exp, what=_id(kw))
+    assert fused["lnl"] == plain["lnl"]
+    assert all((a == b).all() for a, b in zip(fused["persite"], plain["persite"]))
