@@ -333,6 +333,9 @@ def test_dna_without_fusion(amd_lib, kw, monkeypatch):
 def test_fusion_plan_on_a_balanced_tree(amd_lib):
     """64 taxa, full traversal: 16 (tt, tt -> ii) groups, 4 (ii, ii -> ii) groups and the 2 root-side
     ops = 3 launches instead of 5; a traversal of the inner x inner ops alone = 2 launches"""
+    import os
+    if os.environ.get("PLL_AMD_EAGER_MIRROR", "0") not in ("", "0"):
+        pytest.skip("eager mirroring launches the held ops right away: launch counts differ")
     case = W.make_case("plan", 4, 64, 640, seed=97)
     with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
         s.update_partials()
