@@ -62,14 +62,44 @@ __global__ __launch_bounds__(256) void k_diagtable(const DevDiag d)
   }
 }
 
-__global__ __launch_bounds__(256) void k_derivatives(const DevDeriv d, const GenGeo g, unsigned tiles_per_wave)
+// local_diag: every workgroup forms the (small) diag table itself in LDS instead of waiting for a
+// k_diagtable launch - one launch per derivative evaluation, the call a Newton iteration repeats;
+// workgroup 0 also leaves the table in d.diag_out for k_asc_deriv_terms.
+__global__ __launch_bounds__(256) void k_derivatives(const DevDeriv d, const GenGeo g, unsigned tiles_per_wave, const DevDiag dg,
+                                                     unsigned local_diag)
 {
   __shared__ double ws[2][4];
   __shared__ unsigned last;
+  extern __shared__ double ldiag[]; // [R][S][4] when local_diag
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned ntiles = (d.sites + 63u) / 64u;
-  cdouble_p diag = as_const(d.diag);
+  if (local_diag)
+  {
+    for (unsigned idx = threadIdx.x; idx < dg.R * dg.S; idx += blockDim.x)
+    {
+      const unsigned k = idx / dg.S, j = idx % dg.S;
+      const unsigned fi = dg.fidx[k];
+      const double ki = dg.rates[k] / (1.0 - dg.prop_invar[fi]);
+      const double lam = dg.eigenvals[(size_t)fi * dg.SP + j];
+      const double e = exp(lam * ki * dg.branch_length);
+      double *o = ldiag + (size_t)idx * 4;
+      o[0] = e;
+      o[1] = lam * ki * e;
+      o[2] = lam * ki * lam * ki * e;
+      o[3] = 0.0;
+      if (blockIdx.x == 0)
+      {
+        double *go = dg.diag + (size_t)idx * 4;
+        go[0] = o[0];
+        go[1] = o[1];
+        go[2] = o[2];
+        go[3] = 0.0;
+      }
+    }
+    __syncthreads();
+  }
+  const double *diag = local_diag ? ldiag : d.diag;
   double a1 = 0.0, a2 = 0.0;
 
   for (unsigned t = 0; t < tiles_per_wave; ++t)
@@ -85,7 +115,7 @@ __global__ __launch_bounds__(256) void k_derivatives(const DevDeriv d, const Gen
     for (unsigned k = 0; k < g.R; ++k)
     {
       double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-      cdouble_p dk = diag + (size_t)k * g.S * 4;
+      const double *dk = diag + (size_t)k * g.S * 4; // wave-uniform addresses: LDS broadcast or scalarised loads
       const double *xk = x + (size_t)k * g.S * 64;
 #pragma unroll 4
       for (unsigned j = 0; j < g.S; ++j)

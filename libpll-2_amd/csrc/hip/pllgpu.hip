@@ -1462,7 +1462,10 @@ extern "C" int pllgpu_likelihood_derivatives(pllgpu_ctx_t *c, unsigned slot, dou
   dg.S = g.states;
   dg.SP = g.states_padded;
   dg.R = g.rate_cats;
-  hipLaunchKernelGGL(k_diagtable, dim3(1), dim3(256), 0, c->stream, dg);
+  // small tables are formed inside k_derivatives (one launch per evaluation); large ones keep the pre-kernel
+  const size_t diag_bytes = (size_t)g.rate_cats * g.states * 4 * sizeof(double);
+  const unsigned local_diag = diag_bytes <= 32768 ? 1u : 0u;
+  if (!local_diag) hipLaunchKernelGGL(k_diagtable, dim3(1), dim3(256), 0, c->stream, dg);
 
   dv.table = c->sumtable[slot].p;
   dv.diag = c->diag.p;
@@ -1482,7 +1485,7 @@ extern "C" int pllgpu_likelihood_derivatives(pllgpu_ctx_t *c, unsigned slot, dou
   const unsigned tiles = (eval_sites + 63) / 64;
   const unsigned tpw = (tiles + 4 * 1024 - 1) / (4 * 1024);
   const unsigned blocks = (tiles + 4 * tpw - 1) / (4 * tpw);
-  hipLaunchKernelGGL(k_derivatives, dim3(blocks), dim3(256), 0, c->stream, dv, c->gg, tpw);
+  hipLaunchKernelGGL(k_derivatives, dim3(blocks), dim3(256), local_diag ? diag_bytes : 0, c->stream, dv, c->gg, tpw, dg, local_diag);
   HIP_TRY(hipGetLastError());
   volatile double *res = c->result_host;
   const auto t0 = std::chrono::steady_clock::now();
