@@ -46,3 +46,26 @@ def test_repeat_classes_match_reference(ref_lib):
             assert len(ids) == ids_p
             assert (sid == api.as_np(rep.pernode_site_id[pc], case.sites, np.uint32)).all()
             assert (ids == api.as_np(rep.pernode_id_site[pc], ids_p, np.uint32)).all()
+
+
+@pytest.mark.parametrize("states,attrs,pinv", [(4, 0, (0, 0, 0, 0)), (4, api.PATTERN_TIP | api.RATE_SCALERS, (0.1, 0.0, 0.3, 0.2)),
+                                               (20, 0, (0.0, 0.2, 0.0, 0.1))])
+def test_restatement_matches_reference_on_mixtures(ref_lib, states, attrs, pinv):
+    """per-category model indices (freqs_indices selects frequencies / prop_invar per rate category,
+    src/core_likelihood.c:1421,1442) with non-uniform category weights; asc-bias cases as well"""
+    from test_gpu_mixture import mixture_case
+    case, _, _, _ = mixture_case(states, 16, 200, seed=400 + states, attributes=attrs, pinv=pinv)
+    exp = driver.run_case(ref_lib, case, api.ARCH_AVX2)
+    got = O.run_case(case)
+    assert_results_match(got, exp, rtol=1e-12, what="mixture")
+
+
+@pytest.mark.parametrize("kw", [dict(states=4, tips=16, sites=150, asc_type=1, seed=31),
+                                dict(states=4, tips=64, sites=64, tree="caterpillar", brlen_scale=4, asc_type=2, asc_weights=[3, 1, 4, 1], seed=32),
+                                dict(states=20, tips=8, sites=60, asc_type=3, asc_weights=list(range(2, 22)), attributes=api.PATTERN_TIP, seed=33)],
+                         ids=lambda k: f"s{k['states']}-asc{k['asc_type']}")
+def test_restatement_matches_reference_with_ascertainment_bias(ref_lib, kw):
+    case = W.make_case("asc", **kw)
+    exp = driver.run_case(ref_lib, case, api.ARCH_AVX2)
+    got = O.run_case(case)
+    assert_results_match(got, exp, rtol=1e-12, what=str(kw))
