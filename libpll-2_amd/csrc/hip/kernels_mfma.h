@@ -36,7 +36,12 @@
 #pragma once
 #include "kernels_common.h"
 
-constexpr int kMfmaRowsumOff = 8192; // doubles: after the two fragment arrays come 2 x 64 row sums
+// LDS stride between the 256 fragments of a matrix: 17 doubles instead of 16 spreads the per-lane
+// column reads of the tip route (address ~ state >> 2) over the banks; the MFMA operand reads (16
+// consecutive doubles of one fragment, broadcast to the four blocks) do not care
+constexpr unsigned kFrag = 17;
+constexpr unsigned kFragArray = 256 * kFrag; // doubles per staged matrix
+constexpr int kMfmaRowsumOff = 2 * kFragArray; // doubles: after the two fragment arrays come 2 x 64 row sums
 
 struct MfmaItem
 {
@@ -95,7 +100,7 @@ __device__ __forceinline__ double mfma_tip_column(const double *__restrict__ fra
                                                   unsigned long long m, unsigned long long full, unsigned row, int ig)
 {
   const unsigned code = (unsigned)__ffsll((long long)m) - 1u;
-  const double *p = m == full ? rowsum + 4 * ig + row : frag + ig * 256 + (code >> 2) * 16u + (code & 3u) * 4u + row;
+  const double *p = m == full ? rowsum + 4 * ig + row : frag + (ig * 16 + (code >> 2)) * kFrag + (code & 3u) * 4u + row;
   return *p;
 }
 
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma(const OpPack pack, con
 {
   extern __shared__ double lds[];
   double *PL = lds;                 // [16 ig][16 jg][4 k][4 i]
-  double *PR = lds + 4096;
+  double *PR = lds + kFragArray;
   double *RS = lds + kMfmaRowsumOff; // row sums of P_left [64], P_right [64]
 
   const DevOp &op = pack.ops[blockIdx.y];
@@ -134,8 +139,8 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma(const OpPack pack, con
       l = op.lmat[((size_t)k * S + j) * g.SPT + i];
       r = op.rmat[((size_t)k * S + j) * g.SPT + i];
     }
-    PL[idx] = l;
-    PR[idx] = r;
+    PL[(idx >> 4) * kFrag + (idx & 15u)] = l;
+    PR[(idx >> 4) * kFrag + (idx & 15u)] = r;
   }
   __syncthreads();
   if (LTIP || RTIP)
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma(const OpPack pack, con
       const double *F = threadIdx.x < 64 ? PL : PR;
       const unsigned i = threadIdx.x & 63u;
       double s = 0.0;
-      for (unsigned j = 0; j < S; ++j) s += F[((i >> 2) * 16 + (j >> 2)) * 16 + (j & 3u) * 4 + (i & 3u)];
+      for (unsigned j = 0; j < S; ++j) s += F[((i >> 2) * 16 + (j >> 2)) * kFrag + (j & 3u) * 4 + (i & 3u)];
       RS[threadIdx.x] = s;
     }
     __syncthreads();
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma(const OpPack pack, con
 #pragma unroll
         for (int ig = 0; ig < 16; ++ig)
         {
-          const double a = PL[(ig * 16 + jg) * 16 + fragoff];
+          const double a = PL[(ig * 16 + jg) * kFrag + fragoff];
           DL[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x0, DL[ig][0], 0, 0, 0);
           DL[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x1, DL[ig][1], 0, 0, 0);
         }
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma(const OpPack pack, con
 #pragma unroll
           for (int q = 0; q < 4; ++q)
           {
-            const double a = PR[((c * 4 + q) * 16 + jg) * 16 + fragoff];
+            const double a = PR[((c * 4 + q) * 16 + jg) * kFrag + fragoff];
             DR[q][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x0, DR[q][0], 0, 0, 0);
             DR[q][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x1, DR[q][1], 0, 0, 0);
           }
@@ -354,8 +359,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_mfma(const DevEdge e, const Gen
 {
   extern __shared__ double lds[];
   double *PM = lds;           // [16 ig][16 jg][4 k][4 i]
-  double *RS = lds + 4096;    // row sums [64]
-  double *TA = lds + 4096 + 64 + (size_t)(threadIdx.x >> 6) * (kEdgeItems * 2 * 64) + (threadIdx.x & 63u); // [it][sg][lane] of this wave
+  double *RS = lds + kFragArray;    // row sums [64]
+  double *TA = lds + kFragArray + 64 + (size_t)(threadIdx.x >> 6) * (kEdgeItems * 2 * 64) + (threadIdx.x & 63u); // [it][sg][lane] of this wave
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned row = lane >> 4, col = lane & 15u;
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_mfma(const DevEdge e, const Gen
       {
         const unsigned ii = idx & 3u, kk = (idx >> 2) & 3u, jg = (idx >> 4) & 15u, ig = idx >> 8;
         const unsigned j = 4 * jg + kk, i = 4 * ig + ii;
-        PM[idx] = (j < S && i < g.SPT) ? e.mat[((size_t)k * S + j) * g.SPT + i] : 0.0;
+        PM[(idx >> 4) * kFrag + (idx & 15u)] = (j < S && i < g.SPT) ? e.mat[((size_t)k * S + j) * g.SPT + i] : 0.0;
       }
       __syncthreads();
       if (CTIP)
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_mfma(const DevEdge e, const Gen
         {
           const unsigned i = threadIdx.x;
           double s = 0.0;
-          for (unsigned j = 0; j < S; ++j) s += PM[((i >> 2) * 16 + (j >> 2)) * 16 + (j & 3u) * 4 + (i & 3u)];
+          for (unsigned j = 0; j < S; ++j) s += PM[((i >> 2) * 16 + (j >> 2)) * kFrag + (j & 3u) * 4 + (i & 3u)];
           RS[i] = s;
         }
         __syncthreads();
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_mfma(const DevEdge e, const Gen
 #pragma unroll
             for (int ig = 0; ig < 16; ++ig)
             {
-              const double a = PM[(ig * 16 + jg) * 16 + fragoff];
+              const double a = PM[(ig * 16 + jg) * kFrag + fragoff];
               D[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][0], D[ig][0], 0, 0, 0);
               D[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][1], D[ig][1], 0, 0, 0);
             }

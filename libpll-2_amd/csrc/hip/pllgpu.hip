@@ -1097,7 +1097,7 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
     unsigned rounds = (items + per_round * 2048u - 1) / (per_round * 2048u);
     rounds = std::max(1u, rounds);
     blocks = (items + per_round * rounds - 1) / (per_round * rounds);
-    const size_t lds = (4096 + 64 + 4 * kEdgeItems * 2 * 64) * sizeof(double);
+    const size_t lds = (kFragArray + 64 + 4 * kEdgeItems * 2 * 64) * sizeof(double);
     const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
 #define EM(CT, GA) hipLaunchKernelGGL((k_edge_mfma<CT, GA>), dim3(blocks), dim3(256), lds, c->stream, e, c->gg, tm, rounds, ipw)
     if (ctip)
