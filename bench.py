@@ -328,7 +328,8 @@ def main():
                         algorithmic_bytes_per_launch=int(per_launch_bytes))
     roofline["unfused_equivalent"] = dict(
         note="the same ops priced at SURVEY 8d's per-update bytes (every op reads both children from HBM)",
-        GBps=round(unfused_bytes / launches / (per_launch_ms * 1e-3) / 1e9, 1), bytes_per_launch=int(unfused_bytes / launches))
+        GBps=round(unfused_bytes / launches / (per_launch_ms * 1e-3) / 1e9, 1), bytes_per_launch=int(unfused_bytes / launches),
+        frac_of_hbm_peak=round(unfused_bytes / launches / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
     roofline.update(
                     full_traversal=dict(launches=launches_full, ms=round(ms_full / reps, 5),
                                         algorithmic_GBps=round((bytes_full or op_bytes(case, api, all_ops, entries)) / (ms_full / reps * 1e-3) / 1e9, 1),
