@@ -419,9 +419,33 @@ struct DnaRaw
   unsigned lcode, rcode;
 };
 
+// parts: 1 = what the producer's left child needs (everything for the memory kinds), 2 = its right
+// child's CLV; 3 = both. Splitting lets the kernel keep fewer loads (registers) in flight at a time.
 template <int KIND>
-__device__ __forceinline__ void dna_child_load(const FOp &pop, bool left_side, const FOp &cop, size_t off, unsigned n, DnaRaw &raw)
+__device__ __forceinline__ void dna_child_load(const FOp &pop, bool left_side, const FOp &cop, size_t off, unsigned n, DnaRaw &raw,
+                                               int parts = 3)
 {
+  if (KIND >= CK_FTT)
+  {
+    constexpr bool LT = (KIND == CK_FTT || KIND == CK_FTI), RT = (KIND == CK_FTT);
+    if (parts & 1)
+    {
+      raw.lcode = LT ? cop.ltip[n] : 0u;
+      raw.rcode = RT ? cop.rtip[n] : 0u;
+      if (!LT)
+      {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dna_fetch<false>(raw.xl[k], cop.left + off, k, 0u);
+      }
+    }
+    if ((parts & 2) && !RT)
+    {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dna_fetch<false>(raw.xr[k], cop.right + off, k, 0u);
+    }
+    return;
+  }
+  if (!(parts & 1)) return;
   raw.lcode = raw.rcode = 0u;
   if (KIND == CK_INNER)
   {
@@ -524,8 +548,9 @@ __global__ __launch_bounds__(256) void k_partials_dna_fused(const FusePack pack,
       DnaRaw ra, rb;
       dna_child_load<LK>(g.p, true, g.a, off, n, ra);
       dna_child_compute<LK>(g.p, true, g.a, n, scale_mode, ra, va, sca);
-      dna_child_load<RK>(g.p, false, g.b, off, n, rb); // in flight while the left producer's CLV is stored
+      dna_child_load<RK>(g.p, false, g.b, off, n, rb, 1); // in flight while the left producer's CLV is stored
       dna_child_store<LK>(g.a, off, n, valid, scale_mode, va, sca);
+      dna_child_load<RK>(g.p, false, g.b, off, n, rb, 2);
       dna_child_compute<RK>(g.p, false, g.b, n, scale_mode, rb, vb, scb);
       dna_child_store<RK>(g.b, off, n, valid, scale_mode, vb, scb);
     }
