@@ -420,3 +420,35 @@ def test_tail_fusion_shapes(amd_lib, kw, monkeypatch):
     assert_results_match(fused, exp, what=_id(kw))
     assert fused["lnl"] == plain["lnl"]
     assert all((a == b).all() for a, b in zip(fused["persite"], plain["persite"]))
+
+
+def test_partitions_in_concurrent_threads(amd_lib):
+    """distinct partitions may be driven from distinct threads (no internal threads, no
+    global state): four threads, each with its own partition, stream and shape, interleave freely"""
+    import threading
+    specs = [dict(states=4, tips=16, sites=3000, seed=111), dict(states=4, tips=32, sites=1500, attributes=api.SITE_REPEATS, mutate_pct=5, seed=112),
+             dict(states=20, tips=8, sites=700, seed=113), dict(states=61, tips=8, sites=200, seed=114)]
+    cases = [W.make_case("thr", **kw) for kw in specs]
+    expected = [O.run_case(c)["lnl"][0] for c in cases]
+    results = [None] * len(cases)
+    errors = []
+
+    def work(i):
+        try:
+            vals = []
+            with driver.Session(amd_lib, cases[i], api.ARCH_AVX2) as s:
+                for _ in range(30):
+                    s.update_partials()
+                    vals.append(s.edge_lnl(cases[i].edges[0], persite=False)[0])
+            results[i] = vals
+        except Exception as exc:  # noqa: BLE001
+            errors.append((i, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for vals, exp in zip(results, expected):
+        assert len(set(vals)) == 1 and abs(vals[0] - exp) <= RTOL * abs(exp)
