@@ -23,7 +23,7 @@
 
 namespace
 {
-char g_cerr[256];
+thread_local char g_cerr[256];
 
 int cfail(const char *what, hipError_t e)
 {
