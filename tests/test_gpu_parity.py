@@ -409,17 +409,35 @@ def test_tail_fusion_is_transparent(amd_lib, monkeypatch):
                                 dict(states=4, tips=4, sites=130, seed=102),                       # tip-tip ends
                                 dict(states=4, tips=64, sites=200, tree="caterpillar", brlen_scale=4, seed=103),  # tip child end, scaling
                                 dict(states=4, tips=16, sites=300, pinv=0.3, mutate_pct=4, seed=104),
-                                dict(states=4, tips=16, sites=300, attributes=api.PATTERN_TIP, ambiguity_pct=6, seed=105)],
+                                dict(states=4, tips=16, sites=300, attributes=api.PATTERN_TIP, ambiguity_pct=6, seed=105),
+                                dict(states=4, tips=16, sites=300, asc_type=2, asc_weights=[5, 4, 6, 2], seed=106),
+                                dict(states=4, tips=64, sites=100, tree="caterpillar", brlen_scale=4, attributes=api.RATE_SCALERS | api.PATTERN_TIP, seed=107),
+                                dict(states=4, tips=8, sites=5000, seed=108)],
                          ids=_id)
 def test_tail_fusion_shapes(amd_lib, kw, monkeypatch):
+    """traversal followed DIRECTLY by the edge evaluation (nothing in between that would launch the
+    held ops): every kind of edge end - (tip, tip), (tip, inner), (inner, inner) producers, a tip as
+    the child end - with per-site and per-rate scalers, invariant sites, ascertainment bias"""
     case = W.make_case("tailshape", **kw)
     exp = O.run_case(case)
-    fused = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+
+    def direct():
+        with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+            s.update_partials()
+            v, ps = s.edge_lnl(case.edges[0])
+            clvs = {op[0]: s.read_clv(op[0]) for op in case.op_batches[0][-2:]}
+            return v, ps, clvs
+
+    fused = direct()
     monkeypatch.setenv("PLL_AMD_NO_TAIL_FUSION", "1")
-    plain = driver.run_case(amd_lib, case, api.ARCH_AVX2)
-    assert_results_match(fused, exp, what=_id(kw))
-    assert fused["lnl"] == plain["lnl"]
-    assert all((a == b).all() for a, b in zip(fused["persite"], plain["persite"]))
+    plain = direct()
+    assert abs(fused[0] - exp["lnl"][0]) <= RTOL * abs(exp["lnl"][0])
+    assert np.all(np.abs(fused[1] - exp["persite"][0]) <= RTOL * np.maximum(np.abs(exp["persite"][0]), 1.0))
+    if not kw.get("asc_type"):  # the correction is added on the host in both runs; compare the kernels' part exactly
+        assert fused[0] == plain[0]
+    assert (fused[1] == plain[1]).all()
+    for k in plain[2]:
+        assert (fused[2][k] == plain[2][k]).all()
 
 
 def test_partitions_in_concurrent_threads(amd_lib):
