@@ -97,6 +97,33 @@ def caterpillar_ops(tips, with_scalers=True):
     return ops, (prev, sc(prev), last, -1, last), [[i] for i in range(len(ops))]
 
 
+def random_tree_ops(tips, seed=1, scaler_pct=100):
+    """random unrooted binary tree: join two random subtrees until two remain (the evaluated edge).
+    Ops come out in an order in which producers precede consumers but levels are interleaved; a
+    node keeps a scaler buffer with probability scaler_pct % (children without one pass -1 on)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pool = list(range(tips))
+    has_sc = {}
+    ops = []
+    nxt = tips
+
+    def sc(idx):
+        return (idx - tips) if has_sc.get(idx, False) else -1
+
+    while len(pool) > 2:
+        i, j = sorted(rng.choice(len(pool), size=2, replace=False))
+        b = pool.pop(j)
+        a = pool.pop(i)
+        has_sc[nxt] = bool(rng.integers(0, 100) < scaler_pct)
+        ops.append((nxt, sc(nxt), a, a, sc(a), b, b, sc(b)))
+        pool.append(nxt)
+        nxt += 1
+    a, b = pool
+    if a < tips:  # the inner node plays the parent end
+        a, b = b, a
+    return ops, (a, sc(a), b, sc(b), min(a, b)), None  # the last node is never a child: its own matrix index does not exist
+
+
 def branch_lengths(n, lo=0.05, step=0.01, period=10):
     return lo + step * (np.arange(n) % period)
 
@@ -210,6 +237,8 @@ def make_case(name, states, tips, sites, rate_cats=4, tree="balanced", attribute
     freqs = np.asarray(freqs, dtype=np.float64)
     if tree == "balanced":
         ops, edge, _ = balanced_ops(tips, scalers)
+    elif tree == "random":
+        ops, edge, _ = random_tree_ops(tips, seed=seed + 500, scaler_pct=100 if scalers is True else (int(scalers) if scalers else 0))
     else:
         ops, edge, _ = caterpillar_ops(tips, scalers)
     nmat = 2 * tips - 3

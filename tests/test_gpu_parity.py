@@ -470,3 +470,57 @@ def test_partitions_in_concurrent_threads(amd_lib):
     assert not errors, errors
     for vals, exp in zip(results, expected):
         assert len(set(vals)) == 1 and abs(vals[0] - exp) <= RTOL * abs(exp)
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_random_trees_fused_vs_plain_vs_oracle(amd_lib, seed, monkeypatch):
+    """fuzz for the launch planner: random topologies (levels interleaved in the op list, every mix of
+    child kinds), scaler buffers on ~60 % of the nodes, a second call that recomputes only the tail
+    of the list. The fused / tail-fused schedule must reproduce the one-kernel-per-op-group schedule
+    bit for bit, and both must agree with the restatement."""
+    rng = np.random.default_rng(seed)
+    tips = int(rng.integers(5, 48))
+    attrs = [0, api.PATTERN_TIP, api.RATE_SCALERS, api.PATTERN_TIP | api.RATE_SCALERS][seed % 4]
+    case = W.make_case("fuzz", 4, tips, 130 + seed, tree="random", seed=900 + seed, scalers=60, attributes=attrs,
+                       ambiguity_pct=5, brlen_scale=2.0)
+    k = int(rng.integers(1, len(case.op_batches[0]) + 1))
+    case.op_batches = [case.op_batches[0], case.op_batches[0][-k:]]
+    exp = O.run_case(case)
+
+    def direct():
+        with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+            s.update_partials()
+            v, ps = s.edge_lnl(case.edges[0])
+            clvs = {op[0]: (s.read_clv(op[0]), s.read_scaler(op[1], op[0])) for op in case.op_batches[0]}
+            return v, ps, clvs
+
+    fused = direct()
+    monkeypatch.setenv("PLL_AMD_NO_FUSE", "1")
+    monkeypatch.setenv("PLL_AMD_NO_TAIL_FUSION", "1")
+    plain = direct()
+    assert fused[0] == plain[0] and (fused[1] == plain[1]).all()
+    for node, (clv, sc) in plain[2].items():
+        assert (fused[2][node][0] == clv).all(), node
+        assert sc is None or (fused[2][node][1] == sc).all(), node
+    assert abs(fused[0] - exp["lnl"][0]) <= RTOL * abs(exp["lnl"][0])
+    for node, e in exp["clv"].items():
+        err = driver.rel_err_normalised(fused[2][node][0], fused[2][node][1], e, exp["scaler"].get(node))
+        assert err <= RTOL, (node, err)
+
+
+@pytest.mark.parametrize("kw", [dict(states=4, attributes=api.SITE_REPEATS, mutate_pct=4), dict(states=4, attributes=api.SITE_REPEATS | api.RATE_SCALERS, mutate_pct=10),
+                                dict(states=20), dict(states=20, attributes=api.PATTERN_TIP | api.RATE_SCALERS), dict(states=20, attributes=api.SITE_REPEATS, mutate_pct=5),
+                                dict(states=61), dict(states=7, rate_cats=3), dict(states=4, rate_cats=2)],
+                         ids=lambda k: "s%d-a%d-r%d" % (k["states"], k.get("attributes", 0), k.get("rate_cats", 4)))
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_trees_other_shapes(amd_lib, kw, seed):
+    """random topologies through the gather, any-shape and MFMA kernels (level scheduling with mixed
+    child kinds per level, scalers on ~60 % of the nodes, partial second call)"""
+    tips = 6 + 9 * seed
+    case = W.make_case("fuzz2", tips=tips, sites=150 + seed, tree="random", seed=950 + seed, scalers=60, ambiguity_pct=4,
+                       brlen_scale=2.0, **kw)
+    case.op_batches = [case.op_batches[0], case.op_batches[0][-(1 + seed):]]
+    exp = O.run_case(case)
+    got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    assert_results_match(got, exp, what=str(kw))
+    assert scalers_equal(got, exp)
