@@ -12,6 +12,9 @@
 #include "../../../include/pll_amd.h"
 #include "../../../include/pll_amd_device.h"
 
+/* everything declared below is internal to libpll_amd.so: not part of its exported surface */
+#pragma GCC visibility push(hidden)
+
 #define PLL_AMD_MAGIC 0x504c4c414d443335ull /* "PLLAMD35" */
 
 /* which side holds the current copy of a mirrored buffer */
@@ -94,5 +97,7 @@ int pll_is_pattern_tip(const pll_partition_t *p, unsigned int clv_index);
 int pll_tip_by_codes(const pll_partition_t *p, unsigned int clv_index);
 /* give a compact tip a dense device CLV again (someone needs it as an ordinary CLV) */
 void pll_tip_densify(pll_partition_t *p, unsigned int clv_index);
+
+#pragma GCC visibility pop
 
 #endif
