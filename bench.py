@@ -216,6 +216,11 @@ def main():
         if not lib.pll_gpu_set_stream(sess.p, tstream.cuda_stream):
             raise SystemExit(f"pll_gpu_set_stream: [{lib.errno()}] {lib.errmsg()}")
         fi = np.ascontiguousarray(case.freqs_indices, dtype=np.uint32)
+        # the reduced {lnL, sequence} pair comes back through pinned host memory that the host polls,
+        # like the single-GPU path does (a stream synchronise costs more than the copy)
+        pinned = torch.zeros(2, dtype=torch.float64).pin_memory()
+        pview = pinned.numpy()
+        expected = [None]
 
     # site repeats: class maps are computed once (host, integer) and re-used, as applications do
     # between topology changes: pll_update_partials_rep(..., update_repeats = 0)
@@ -229,8 +234,22 @@ def main():
             if not lib.pll_gpu_edge_loglikelihood_async(sess.p, edge[0], edge[1], edge[2], edge[3], edge[4], api.uptr(fi),
                                                         red.data_ptr()):
                 raise SystemExit(f"pll_gpu_edge_loglikelihood_async: [{lib.errno()}] {lib.errmsg()}")
-            dist.all_reduce(red[:1])  # the path's one exchange: sum of the shards' log-likelihoods
-            return float(red[0].item())
+            # the path's one exchange: sum of the shards' log-likelihoods (word 0); word 1 = every rank's
+            # call sequence number, so its sum tells the host which evaluation the pair belongs to
+            dist.all_reduce(red)
+            pinned[0:1].copy_(red[0:1], non_blocking=True)
+            pinned[1:2].copy_(red[1:2], non_blocking=True)  # stream-ordered behind the value
+            if expected[0] is not None:
+                expected[0] += world
+                t_spin = time.perf_counter()
+                while pview[1] != expected[0]:
+                    if time.perf_counter() - t_spin > 0.02:
+                        expected[0] = None
+                        break
+            if expected[0] is None:
+                torch.cuda.current_stream().synchronize()
+                expected[0] = float(pview[1])
+            return float(pview[0])
         v, _ = sess.edge_lnl(edge, persite=False)
         if dist:
             red[0] = v
