@@ -1301,7 +1301,13 @@ extern "C" int pllgpu_set_stream(pllgpu_ctx_t *c, void *s)
   return 0;
 }
 
-extern "C" void *pllgpu_get_stream(const pllgpu_ctx_t *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" void *pllgpu_get_stream(const pllgpu_ctx_t *cc)
+{
+  // a caller who asks for the stream is about to order its own work against ours: nothing may be held back
+  pllgpu_ctx *c = const_cast<pllgpu_ctx *>(cc);
+  if (c && !c->deferred.empty() && use(c) == 0) (void)flush_deferred(c);
+  return c ? (void *)c->stream : nullptr;
+}
 
 extern "C" int pllgpu_synchronize(pllgpu_ctx_t *c)
 {
