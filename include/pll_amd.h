@@ -314,7 +314,11 @@ void pll_gpu_invalidate(pll_partition_t *partition, unsigned int what, int index
 /* download the device sumtable that stands for this host buffer into it (reference layout) */
 int pll_gpu_sync_sumtable(pll_partition_t *partition, double *sumtable);
 /* stream plumbing: by default each partition owns a stream; a harness may substitute its own
- * (a hipStream_t passed as void*) so that its events see the kernels. */
+ * (a hipStream_t passed as void*) so that its events see the kernels. pll_update_partials is
+ * asynchronous and may hold its last one or two operations back until the next call on the
+ * partition (they are evaluated inside the edge log-likelihood kernel if that is the next call,
+ * DESIGN.md "Tail fusion"); pll_gpu_synchronize(), pll_gpu_get_stream() and the timer calls launch
+ * whatever is held, so a harness that brackets work with its own events calls one of them first. */
 int pll_gpu_set_stream(pll_partition_t *partition, void *hip_stream);
 void *pll_gpu_get_stream(const pll_partition_t *partition);
 int pll_gpu_synchronize(pll_partition_t *partition);
