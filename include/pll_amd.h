@@ -219,6 +219,9 @@ void pll_set_category_weights(pll_partition_t *partition, const double *rate_wei
 int pll_update_invariant_sites_proportion(pll_partition_t *partition, unsigned int params_index,
                                           double prop_invar); /* src/models.c:495-540 */
 int pll_update_invariant_sites(pll_partition_t *partition);  /* src/models.c:651-752 */
+/* src/models.c:546-649: pattern-weighted number of invariant sites; state_inv_count[states] (or
+ * NULL) receives the number of invariant patterns per state */
+unsigned int pll_count_invariant_sites(pll_partition_t *partition, unsigned int *state_inv_count);
 
 /* model side ("next" rows f2 of SURVEY section 8; host code, feeds the path) */
 int pll_update_eigen(pll_partition_t *partition, unsigned int params_index); /* models.c:293 */

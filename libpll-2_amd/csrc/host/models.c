@@ -286,20 +286,14 @@ int pll_update_prob_matrices(pll_partition_t *p, const unsigned int *params_indi
 }
 
 /* ---- invariant sites (src/models.c:495-544, :651-752) ------------------------------------------ */
-int pll_update_invariant_sites(pll_partition_t *p)
+/* per site: index of the single state shared by all tips, or -1 (src/models.c:651-752) */
+static int invariant_states(const pll_partition_t *p, int *out)
 {
   const unsigned int s = p->states, n = p->sites;
   unsigned int i, j, k;
-  pll_amd_ext_t *x = pll_ext(p);
   pll_state_t all = (s >= 64) ? ~0ull : ((1ull << s) - 1ull);
   pll_state_t *acc = (pll_state_t *)malloc(sizeof(pll_state_t) * (n ? n : 1));
-  if (!p->invariant) p->invariant = (int *)malloc(sizeof(int) * (n ? n : 1));
-  if (!acc || !p->invariant)
-  {
-    free(acc);
-    pll_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate charmap for invariant sites array.");
-    return PLL_FAILURE;
-  }
+  if (!acc) return 0;
   for (j = 0; j < n; ++j) acc[j] = all;
   if (p->attributes & PLL_ATTRIB_PATTERN_TIP)
   {
@@ -323,11 +317,54 @@ int pll_update_invariant_sites(pll_partition_t *p)
       }
     }
   }
-  for (j = 0; j < n; ++j)
-    p->invariant[j] = (acc[j] && !(acc[j] & (acc[j] - 1))) ? __builtin_ctzll(acc[j]) : -1;
+  for (j = 0; j < n; ++j) out[j] = (acc[j] && !(acc[j] & (acc[j] - 1))) ? __builtin_ctzll(acc[j]) : -1;
   free(acc);
+  return 1;
+}
+
+int pll_update_invariant_sites(pll_partition_t *p)
+{
+  pll_amd_ext_t *x = pll_ext(p);
+  const unsigned int n = p->sites;
+  if (!p->invariant) p->invariant = (int *)malloc(sizeof(int) * (n ? n : 1));
+  if (!p->invariant || !invariant_states(p, p->invariant))
+  {
+    pll_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate charmap for invariant sites array.");
+    return PLL_FAILURE;
+  }
   if (x) x->invariant_dirty = 1;
   return PLL_SUCCESS;
+}
+
+/* src/models.c:546-649: weighted number of invariant sites, and (unweighted, as in the reference)
+ * how many site patterns are invariant for each state. Host bookkeeping over the tip data. The
+ * reference's PATTERN_TIP branch ANDs the tip CODES (:597), which are masks only for 4 states; here
+ * the masks behind the codes are used for every state count. */
+unsigned int pll_count_invariant_sites(pll_partition_t *p, unsigned int *state_inv_count)
+{
+  unsigned int j, total = 0;
+  const int *inv = p->invariant;
+  int *tmp = NULL;
+  if (state_inv_count) memset(state_inv_count, 0, p->states * sizeof(unsigned int));
+  if (!inv)
+  {
+    tmp = (int *)malloc(sizeof(int) * (p->sites ? p->sites : 1));
+    if (!tmp || !invariant_states(p, tmp))
+    {
+      free(tmp);
+      pll_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate memory for counting invariant sites.");
+      return 0;
+    }
+    inv = tmp;
+  }
+  for (j = 0; j < p->sites; ++j)
+    if (inv[j] > -1)
+    {
+      total += p->pattern_weights[j];
+      if (state_inv_count) state_inv_count[inv[j]]++;
+    }
+  free(tmp);
+  return total;
 }
 
 int pll_update_invariant_sites_proportion(pll_partition_t *p, unsigned int idx, double pinv)

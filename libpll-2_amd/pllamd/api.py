@@ -125,6 +125,7 @@ _PROTOS = {
     "pll_set_category_weights": (None, [PartitionP, c_double_p]),
     "pll_update_invariant_sites_proportion": (C.c_int, [PartitionP, C.c_uint, C.c_double]),
     "pll_update_invariant_sites": (C.c_int, [PartitionP]),
+    "pll_count_invariant_sites": (C.c_uint, [PartitionP, c_uint_p]),
     "pll_update_eigen": (C.c_int, [PartitionP, C.c_uint]),
     "pll_update_prob_matrices": (C.c_int, [PartitionP, c_uint_p, c_uint_p, c_double_p, C.c_uint]),
     "pll_compute_gamma_cats": (C.c_int, [C.c_double, C.c_uint, c_double_p, C.c_int]),

@@ -237,6 +237,23 @@ def test_invariant_sites_match_reference(amd_lib, ref_lib):
         assert (inv[True] == inv[False]).all() and (inv[True] >= 0).any() and (inv[True] < 0).any()
 
 
+def test_count_invariant_sites_matches_reference(amd_lib, ref_lib):
+    """src/models.c:546-649: with and without a stored invariant array, weighted total and per-state
+    pattern counts (4 states with tip codes and tip CLVs, 20 states with tip CLVs)"""
+    rng = np.random.default_rng(3)
+    for states, attr, pinv in ((4, 0, 0.0), (4, api.PATTERN_TIP, 0.0), (4, 0, 0.2), (20, 0, 0.0)):
+        w = rng.integers(1, 9, 200).astype(np.uint32)
+        case = W.make_case("t", states, 8, 200, attributes=attr, mutate_pct=3, ambiguity_pct=10, pinv=pinv, pattern_weights=w)
+        got = {}
+        for lib in (amd_lib, ref_lib):
+            with driver.Session(lib, case, api.ARCH_AVX2) as s:
+                per = np.zeros(states, dtype=np.uint32)
+                total = lib.pll_count_invariant_sites(s.p, api.uptr(per))
+                got[lib.is_amd] = (total, per.copy(), lib.pll_count_invariant_sites(s.p, None))
+        assert got[True][0] == got[False][0] > 0 and got[True][2] == got[False][2]
+        assert (got[True][1] == got[False][1]).all()
+
+
 def model_pmatrices(lib, states, exch, freqs, alpha, cats, brlens, arch, pinv=0.0):
     p = lib.pll_partition_create(2, 1, states, 16, 1, len(brlens), cats, 0, arch)
     part = p.contents
