@@ -524,3 +524,21 @@ def test_random_trees_other_shapes(amd_lib, kw, seed):
     got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
     assert_results_match(got, exp, what=str(kw))
     assert scalers_equal(got, exp)
+
+
+@pytest.mark.parametrize("states,sites,tips,attrs", [(4, 1, 3, 0), (4, 2, 4, api.PATTERN_TIP), (4, 63, 3, api.RATE_SCALERS), (4, 65, 5, 0),
+                                                    (20, 1, 3, 0), (20, 3, 5, api.PATTERN_TIP), (61, 1, 3, 0), (61, 33, 4, 0),
+                                                    (2, 1, 3, 0), (64, 2, 3, api.RATE_SCALERS)])
+def test_tiny_inputs(amd_lib, states, sites, tips, attrs):
+    """one site, three taxa: the smallest things the API accepts (tail lanes of the only tile, ops
+    whose only edge is inner-tip, a single workgroup everywhere)"""
+    case = W.make_case("tiny", states, tips, sites, tree="random", seed=700 + states + sites, attributes=attrs, ambiguity_pct=10)
+    case.roots = [(case.edges[0][0], case.edges[0][1])]
+    exp = O.run_case(case)
+    got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    assert_results_match(got, exp, what="tiny")
+    assert scalers_equal(got, exp)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:  # traversal straight into the evaluation (tail fusion)
+        s.update_partials()
+        v, ps = s.edge_lnl(case.edges[0])
+        assert abs(v - exp["lnl"][0]) <= RTOL * max(abs(exp["lnl"][0]), 1.0) and abs(ps.sum() - v) <= 1e-9 * max(abs(v), 1.0)
