@@ -361,3 +361,19 @@ def test_frequencies_are_normalised_like_reference(amd_lib, ref_lib):
             got.append(api.as_np(p.contents.frequencies[0], 4, np.float64).copy())
             lib.pll_partition_destroy(p)
         assert (got[0] == got[1]).all()
+
+
+def test_caller_built_against_the_reference_header_links(tmp_path):
+    """authoring container only: tests/c_caller/dropin.c compiled against the REFERENCE's pll.h links
+    against libpll_amd.so with no unresolved symbol - the drop-in claim at the C level (it runs on
+    the GPU box built against include/pll_amd.h: tests/test_gpu_c_caller.py)"""
+    import subprocess
+    ref_inc = "/root/reference/src"
+    if not os.path.exists(os.path.join(ref_inc, "pll.h")):
+        pytest.skip("reference header not present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "libpll-2_amd", "csrc")
+    exe = str(tmp_path / "dropin_ref")
+    subprocess.check_call(["gcc", "-O2", "-DUSE_REFERENCE_HEADER", "-I" + ref_inc, os.path.join(root, "tests", "c_caller", "dropin.c"),
+                           "-L" + libdir, "-lpll_amd", "-lm", "-Wl,-rpath," + libdir, "-Wl,--no-undefined", "-o", exe])
+    assert os.path.getsize(exe) > 0
