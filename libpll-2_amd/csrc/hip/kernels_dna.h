@@ -609,10 +609,12 @@ __global__ __launch_bounds__(256) void k_edge_dna_tail(const DevEdge e, const FG
     double vp[4][4], vc[4][4];
     uint4 scp, scc;
     {
+      // few waves per SIMD here (one tile each): registers are plentiful, latency is not - both
+      // ends' loads go out before anything is computed
       DnaRaw rp, rc;
       dna_child_load<KP>(g.p, true, g.a, off, n, rp);
-      dna_child_compute<KP>(g.p, true, g.a, n, scale_mode, rp, vp, scp);
       dna_child_load<KC>(g.p, false, g.b, off, n, rc);
+      dna_child_compute<KP>(g.p, true, g.a, n, scale_mode, rp, vp, scp);
       dna_child_store<KP>(g.a, off, n, valid, scale_mode, vp, scp);
       dna_child_compute<KC>(g.p, false, g.b, n, scale_mode, rc, vc, scc);
       dna_child_store<KC>(g.b, off, n, valid, scale_mode, vc, scc);
