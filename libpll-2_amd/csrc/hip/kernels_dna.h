@@ -580,6 +580,144 @@ __global__ __launch_bounds__(256) void k_partials_dna_fused(const FusePack pack,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Two levels of producers: a child of the group parent P may be an inner x inner op A whose own
+// children are both CHERRIES (tip x tip ops) of the level below - kind CK_FCC. The four tip codes are
+// all such a child needs from HBM; the two cherries and A are formed in registers and stored like
+// every other op. A group with two CK_FCC children is a complete 8-tip subtree: 7 updates for 8 bytes
+// read and 7 CLVs written (per site: 8 + 7 x 132 B instead of 2 x 400 + 396 for the same ops as two
+// (tt, tt -> ii) groups and a plain op). The other child of P may be a CLV or tip codes in HBM.
+constexpr int CK_FCC = 5;
+
+struct TOp // a tip x tip op of a CK_FCC child (48 bytes)
+{
+  double *parent;
+  const unsigned char *ltip, *rtip;
+  unsigned *pscaler;
+  const double *lmat, *rmat;
+};
+
+struct CCGroup
+{
+  FOp p;          // group parent; for a CK_FCC child its memory-side fields are not read
+  FOp a, b;       // the inner x inner producers of the left / right child (CK_FCC sides)
+  TOp aa, ab;     // cherries under a: producers of a's left / right child
+  TOp ba, bb;     // cherries under b
+};
+
+constexpr int kMaxCCGroups = 9; // 9 * 432 B = 3888 B of kernarg
+
+struct CCPack
+{
+  CCGroup g[kMaxCCGroups];
+};
+
+// a cherry from its two tip codes: the arithmetic of dna_child_compute<CK_FTT>, stored streaming
+__device__ __forceinline__ void dna_cherry(const TOp &t, size_t off, unsigned n, bool valid, int scale_mode, double (&v)[4][4], uint4 &sc)
+{
+  const unsigned lcode = t.ltip[n], rcode = t.rtip[n];
+  const int mode = t.pscaler ? scale_mode : 0;
+  cdouble_p lm = as_const(t.lmat), rm = as_const(t.rmat);
+  bool small[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    double xl[4], xr[4], a[4], b[4];
+    dna_fetch<true>(xl, nullptr, k, lcode);
+    dna_fetch<true>(xr, nullptr, k, rcode);
+    dna_matvec(a, lm + k * 16, xl);
+    dna_matvec(b, rm + k * 16, xr);
+    small[k] = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+      v[k][i] = a[i] * b[i];
+      small[k] = small[k] && (v[k][i] < PLLGPU_SCALE_THRESHOLD);
+    }
+  }
+  dna_scale(v, small, mode, make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), sc);
+  FOp st = {};
+  st.parent = t.parent;
+  st.pscaler = t.pscaler;
+  dna_store<true>(st, off, n, valid, mode, v, sc);
+}
+
+// an inner x inner op from two register-resident children (values + scaler words)
+__device__ __forceinline__ void dna_combine(const FOp &op, int scale_mode, const double (&va)[4][4], uint4 sca, const double (&vb)[4][4],
+                                            uint4 scb, double (&v)[4][4], uint4 &sc, int &mode)
+{
+  mode = op.pscaler ? scale_mode : 0;
+  cdouble_p lm = as_const(op.lmat), rm = as_const(op.rmat);
+  bool small[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    double a[4], b[4];
+    dna_matvec(a, lm + k * 16, va[k]);
+    dna_matvec(b, rm + k * 16, vb[k]);
+    small[k] = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+      v[k][i] = a[i] * b[i];
+      small[k] = small[k] && (v[k][i] < PLLGPU_SCALE_THRESHOLD);
+    }
+  }
+  dna_scale(v, small, mode, sca, scb, sc);
+}
+
+// one child of the group parent: CK_INNER / CK_TIP from HBM, or CK_FCC formed here
+template <int KIND>
+__device__ __forceinline__ void dna_cc_child(const FOp &pop, bool left_side, const FOp &cop, const TOp &x, const TOp &y, size_t off,
+                                             unsigned n, bool valid, int scale_mode, double (&v)[4][4], uint4 &sc)
+{
+  if (KIND == CK_FCC)
+  {
+    double vx[4][4], vy[4][4];
+    uint4 scx, scy;
+    int mode;
+    dna_cherry(x, off, n, valid, scale_mode, vx, scx);
+    dna_cherry(y, off, n, valid, scale_mode, vy, scy);
+    dna_combine(cop, scale_mode, vx, scx, vy, scy, v, sc, mode);
+    dna_store<true>(cop, off, n, valid, mode, v, sc);
+  }
+  else
+  {
+    DnaRaw raw;
+    dna_child_load<KIND>(pop, left_side, cop, off, n, raw);
+    dna_child_compute<KIND>(pop, left_side, cop, n, scale_mode, raw, v, sc);
+  }
+}
+
+template <int LK, int RK>
+__global__ __launch_bounds__(256) void k_partials_dna_cc(const CCPack pack, unsigned entries, int scale_mode, unsigned tiles_per_wave,
+                                                          unsigned stream_parent)
+{
+  const CCGroup &g = pack.g[blockIdx.y];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned ntiles = (entries + 63u) / 64u;
+  for (unsigned t = 0; t < tiles_per_wave; ++t)
+  {
+    const unsigned tile = (blockIdx.x * 4u + wave) * tiles_per_wave + t;
+    if (tile >= ntiles) break; // wave-uniform
+    const unsigned n0 = tile * 64u + lane;
+    const bool valid = n0 < entries;
+    const unsigned n = valid ? n0 : entries - 1;
+    const size_t off = (size_t)(n >> 6) * kDnaTile + (n & 63u);
+    double va[4][4], vb[4][4], v[4][4];
+    uint4 sca, scb, sc;
+    int mode;
+    dna_cc_child<LK>(g.p, true, g.a, g.aa, g.ab, off, n, valid, scale_mode, va, sca);
+    dna_cc_child<RK>(g.p, false, g.b, g.ba, g.bb, off, n, valid, scale_mode, vb, scb);
+    dna_combine(g.p, scale_mode, va, sca, vb, scb, v, sc, mode);
+    if (stream_parent)
+      dna_store<true>(g.p, off, n, valid, mode, v, sc);
+    else
+      dna_store<false>(g.p, off, n, valid, mode, v, sc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Tail fusion: a traversal's last ops produce the two ends of the edge whose log-likelihood the
 // caller asks for next (the universal call sequence: pll_update_partials, then
 // pll_compute_edge_loglikelihood on the virtual root). The device layer holds those (at most two)

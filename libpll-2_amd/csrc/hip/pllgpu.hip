@@ -120,6 +120,7 @@ struct pllgpu_ctx
   size_t stream_parent_bytes = (size_t)256 << 20; // PLL_AMD_STREAM_PARENT_MB overrides (experiments)
   bool defer_tail = false;       // DNA: hold the traversal's last ops for one call (k_edge_dna_tail)
   std::vector<pllgpu_op_t> deferred; // ops accepted by pllgpu_update_partials and not launched yet
+  bool fuse_cc = false;          // DNA: also two producer levels under a group parent (cherry-cherry children)
   bool fuse = false;             // DNA: evaluate producer + consumer ops in one kernel (kernels_dna.h)
 };
 
@@ -163,6 +164,9 @@ static void derive_geometry(pllgpu_ctx *c)
   if (const char *v = getenv("PLL_AMD_NO_TAIL_FUSION"))
     if (*v && *v != '0') c->defer_tail = false;
   if (const char *v = getenv("PLL_AMD_STREAM_PARENT_MB")) c->stream_parent_bytes = (size_t)atol(v) << 20;
+  c->fuse_cc = c->fuse;
+  if (const char *v = getenv("PLL_AMD_NO_FUSE_CC"))
+    if (*v && *v != '0') c->fuse_cc = false;
   c->tiled = true; // every shape keeps CLVs in the tiled sites-contiguous layout
   // 33..64 states: CLV updates on the fp64 matrix pipe (kernels_mfma.h); PLL_AMD_NO_MFMA=1 keeps the FMA kernel
   c->use_mfma = (g.states > 32 && g.rate_cats <= 16);
@@ -744,7 +748,8 @@ struct FusedGroup
   unsigned p;
   int a, b;       // producer ops of the left / right child, or -1
   int lk, rk;     // DnaChildKind of the left / right child
-  unsigned level; // execution level (= level of the producers)
+  unsigned level; // execution level (= level of the lowest producers)
+  int aa = -1, ab = -1, ba = -1, bb = -1; // CK_FCC sides: the cherries under a / b
 };
 
 static int child_kind(const pllgpu_op_t &prod)
@@ -772,6 +777,56 @@ static void plan_fusion(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count, s
     if (!(ops[i].flags & PLLGPU_OP_RIGHT_TIP)) prod_r[i] = producer[ops[i].right_clv];
     producer[ops[i].parent_clv] = (int)i;
   }
+  // first pass: parents of complete cherry-cherry subtrees (kind CK_FCC, kernels_dna.h): P two levels
+  // above the cherries, its child A an inner x inner op between them. Everything moves to the
+  // cherries' level, so neither A's nor P's outputs may be touched by an earlier op from there on.
+  if (c->fuse_cc)
+    for (unsigned i = 0; i < count; ++i)
+    {
+      const pllgpu_op_t &P = ops[i];
+      if (role[i] || (P.flags & PLLGPU_OP_GATHER) || P.level < 2) continue;
+      const unsigned L = P.level - 2;
+      if (P.war_level >= (int)L) continue;
+      auto cherry = [&](int pr, int pscal, unsigned entries) {
+        return pr >= 0 && role[pr] == 0 && ops[pr].level == L && !(ops[pr].flags & PLLGPU_OP_GATHER) &&
+               (ops[pr].flags & PLLGPU_OP_LEFT_TIP) && (ops[pr].flags & PLLGPU_OP_RIGHT_TIP) && ops[pr].parent_scaler == pscal &&
+               ops[pr].parent_entries == entries;
+      };
+      auto cc = [&](int pr, int pscal) {
+        if (pr < 0 || role[pr] != 0 || ops[pr].level != L + 1 || (ops[pr].flags & (PLLGPU_OP_GATHER | PLLGPU_OP_LEFT_TIP | PLLGPU_OP_RIGHT_TIP)))
+          return false;
+        const pllgpu_op_t &A = ops[pr];
+        return A.parent_scaler == pscal && A.parent_entries == P.parent_entries && A.war_level < (int)L &&
+               prod_l[pr] != prod_r[pr] && cherry(prod_l[pr], A.left_scaler, P.parent_entries) && cherry(prod_r[pr], A.right_scaler, P.parent_entries);
+      };
+      auto memory_side = [&](int pr, bool tip) { return tip || pr < 0 || eff[pr] < L; };
+      const bool ltip = P.flags & PLLGPU_OP_LEFT_TIP, rtip = P.flags & PLLGPU_OP_RIGHT_TIP;
+      const bool cl = !ltip && cc(prod_l[i], P.left_scaler), cr = !rtip && prod_r[i] != prod_l[i] && cc(prod_r[i], P.right_scaler);
+      if (!cl && !cr) continue;
+      if ((!cl && !memory_side(prod_l[i], ltip)) || (!cr && !memory_side(prod_r[i], rtip))) continue;
+      FusedGroup g;
+      g.p = i;
+      g.a = cl ? prod_l[i] : -1;
+      g.b = cr ? prod_r[i] : -1;
+      g.lk = cl ? CK_FCC : ltip ? CK_TIP : CK_INNER;
+      g.rk = cr ? CK_FCC : rtip ? CK_TIP : CK_INNER;
+      g.level = L;
+      role[i] = 1;
+      eff[i] = L;
+      if (cl)
+      {
+        g.aa = prod_l[g.a];
+        g.ab = prod_r[g.a];
+        role[g.a] = role[g.aa] = role[g.ab] = 2;
+      }
+      if (cr)
+      {
+        g.ba = prod_l[g.b];
+        g.bb = prod_r[g.b];
+        role[g.b] = role[g.ba] = role[g.bb] = 2;
+      }
+      groups.push_back(g);
+    }
   for (unsigned i = 0; i < count; ++i)
   {
     const pllgpu_op_t &P = ops[i];
@@ -827,6 +882,37 @@ static void launch_fused_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups
   // survives until the next level reads it: stream them out as well
   unsigned stream_parent = ((size_t)ngroups * entries * 128u > c->stream_parent_bytes) ? 1u : 0u;
   hipLaunchKernelGGL((k_partials_dna_fused<LK, RK>), grid, block, 0, c->stream, pack, entries, c->gg.scale_mode, tpw, stream_parent);
+}
+
+static void to_top(const DevOp &d, TOp &t)
+{
+  t.parent = d.parent;
+  t.ltip = d.ltip;
+  t.rtip = d.rtip;
+  t.pscaler = d.pscaler;
+  t.lmat = d.lmat;
+  t.rmat = d.rmat;
+}
+
+template <int LK, int RK>
+static void launch_cc_t(pllgpu_ctx *c, const CCPack &pack, unsigned ngroups, unsigned entries)
+{
+  const unsigned tiles = (entries + 63) / 64;
+  const unsigned want_blocks = 4096;
+  unsigned tpw = (unsigned)(((size_t)tiles * ngroups + 4 * want_blocks - 1) / (4 * want_blocks));
+  tpw = std::max(1u, std::min(tpw, 8u));
+  dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), ngroups), block(256);
+  unsigned stream_parent = ((size_t)ngroups * entries * 128u > c->stream_parent_bytes) ? 1u : 0u;
+  hipLaunchKernelGGL((k_partials_dna_cc<LK, RK>), grid, block, 0, c->stream, pack, entries, c->gg.scale_mode, tpw, stream_parent);
+}
+
+static int launch_cc(pllgpu_ctx *c, const CCPack &pack, unsigned ngroups, unsigned entries, int lk, int rk)
+{
+  if (lk == CK_INNER && rk == CK_FCC) launch_cc_t<CK_INNER, CK_FCC>(c, pack, ngroups, entries);
+  else if (lk == CK_TIP && rk == CK_FCC) launch_cc_t<CK_TIP, CK_FCC>(c, pack, ngroups, entries);
+  else if (lk == CK_FCC && rk == CK_FCC) launch_cc_t<CK_FCC, CK_FCC>(c, pack, ngroups, entries);
+  else return fail(PLLGPU_EINVAL, "no cherry-cherry kernel for child kinds (%d, %d)", lk, rk);
+  return 0;
 }
 
 static int launch_fused(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries, int lk, int rk)
@@ -954,6 +1040,68 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
     // fused groups executing at this level, one launch per pair of child kinds
     const size_t g0 = gi_sorted;
     while (gi_sorted < groups.size() && groups[gi_sorted].level == level) ++gi_sorted;
+    // cherry-cherry groups (kind CK_FCC on at least one side) have their own descriptor and kernel
+    for (int lk = 0; lk <= CK_FCC; ++lk)
+    {
+      const int rk = CK_FCC;
+      if (lk != CK_INNER && lk != CK_TIP && lk != CK_FCC) continue;
+      CCPack pack;
+      unsigned n = 0, entries = 0;
+      auto flush = [&]() -> int {
+        if (!n) return 0;
+        if (int rc = launch_cc(c, pack, n, entries, lk, rk)) return rc;
+        ++c->last_launches;
+        n = 0;
+        return 0;
+      };
+      for (size_t gi = g0; gi < gi_sorted; ++gi)
+      {
+        const FusedGroup &g = groups[gi];
+        if (g.lk != CK_FCC && g.rk != CK_FCC) continue;
+        const bool swap = g.lk == CK_FCC && g.rk != CK_FCC; // canonical order: the memory side on the left
+        const int glk = swap ? g.rk : g.lk;
+        if (glk != lk) continue;
+        const pllgpu_op_t &P = ops[g.p];
+        if (P.parent_entries == 0) continue;
+        if (n && P.parent_entries != entries)
+          if (int rc = flush()) return rc;
+        entries = P.parent_entries;
+        CCGroup &cg = pack.g[n];
+        memset(&cg, 0, sizeof cg);
+        DevOp d;
+        auto side = [&](int a, int x, int y, FOp &fa, TOp &tx, TOp &ty) -> int {
+          if (a < 0) return 0;
+          if (int rc = resolve_op(c, ops[x], d)) return rc;
+          to_top(d, tx);
+          c->last_bytes += op_traffic(c, ops[x], true, true);
+          if (int rc = resolve_op(c, ops[y], d)) return rc;
+          to_top(d, ty);
+          c->last_bytes += op_traffic(c, ops[y], true, true);
+          if (int rc = resolve_op(c, ops[a], d)) return rc;
+          to_fop(d, fa);
+          c->last_bytes += op_traffic(c, ops[a], false, false);
+          return 0;
+        };
+        if (int rc = side(g.a, g.aa, g.ab, cg.a, cg.aa, cg.ab)) return rc;
+        if (int rc = side(g.b, g.ba, g.bb, cg.b, cg.ba, cg.bb)) return rc;
+        if (int rc = resolve_op(c, P, d)) return rc;
+        c->last_bytes += op_traffic(c, P, g.a < 0, g.b < 0);
+        to_fop(d, cg.p);
+        if (swap)
+        {
+          std::swap(cg.p.left, cg.p.right);
+          std::swap(cg.p.ltip, cg.p.rtip);
+          std::swap(cg.p.lscaler, cg.p.rscaler);
+          std::swap(cg.p.lmat, cg.p.rmat);
+          std::swap(cg.a, cg.b);
+          std::swap(cg.aa, cg.ba);
+          std::swap(cg.ab, cg.bb);
+        }
+        if (++n == (unsigned)kMaxCCGroups)
+          if (int rc = flush()) return rc;
+      }
+      if (int rc = flush()) return rc;
+    }
     for (int lk = 0; lk <= CK_FII; ++lk)
       for (int rk = lk; rk <= CK_FII; ++rk)
       {
@@ -969,6 +1117,7 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
         for (size_t gi = g0; gi < gi_sorted; ++gi)
         {
           FusedGroup g = groups[gi];
+          if (g.lk == CK_FCC || g.rk == CK_FCC) continue; // launched above
           const bool swap = g.lk > g.rk; // canonical order: the "smaller" kind on the left
           if ((swap ? g.rk : g.lk) != lk || (swap ? g.lk : g.rk) != rk) continue;
           const pllgpu_op_t &P = ops[g.p];

@@ -330,30 +330,37 @@ def test_dna_without_fusion(amd_lib, kw, monkeypatch):
             assert (fused["scaler"][k] == plain["scaler"][k]).all()
 
 
-def test_fusion_plan_on_a_balanced_tree(amd_lib):
-    """64 taxa, full traversal: 16 (tt, tt -> ii) groups, 4 (ii, ii -> ii) groups and the 2 root-side
-    ops = 3 launches instead of 5; a traversal of the inner x inner ops alone = 2 launches"""
+def test_fusion_plan_on_a_balanced_tree(amd_lib, monkeypatch):
+    """64 taxa, full traversal: 8 groups of seven ops (complete 8-tip subtrees: four cherries, two ops
+    above them, one above those) and 2 groups (ii, ii -> ii) at the top = 2 launches instead of 5;
+    without the two-level groups 16 (tt, tt -> ii) groups, 4 (ii, ii -> ii) groups and the two
+    root-side ops, which are held for the edge evaluation (tail fusion)."""
     import os
     if os.environ.get("PLL_AMD_EAGER_MIRROR", "0") not in ("", "0"):
         pytest.skip("eager mirroring launches the held ops right away: launch counts differ")
     case = W.make_case("plan", 4, 64, 640, seed=97)
+    exp = O.run_case(case)
     with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
         s.update_partials()
-        s.edge_lnl(case.edges[0], persite=False)
-        assert amd_lib.pll_gpu_last_launch_count(s.p) == 3  # ... and evaluated inside the lnL kernel
-        s.update_partials()
-        # two launches now; the two root-side ops are held for the edge evaluation (tail fusion)
         assert amd_lib.pll_gpu_last_launch_count(s.p) == 2
         per_site = amd_lib.pll_gpu_last_algorithmic_bytes(s.p) / 640
-        # 16 x (4 B codes + 3 CLVs + 1 scaler vector: tip-tip parents carry none) ...: just bound it
-        assert 10000 < per_site < 11200, per_site
+        assert 8800 < per_site < 9900, per_site  # 8 x (8 B + 7 CLVs + scalers) + 2 x (4 CLVs in, 3 out)
+        v, _ = s.edge_lnl(case.edges[0], persite=False)
+        assert abs(v - exp["lnl"][0]) <= RTOL * abs(v)
         ii = [op for op in case.op_batches[0] if op[2] >= 64 and op[5] >= 64]
         arr = api.make_ops(ii)
         amd_lib.pll_update_partials(s.p, arr, len(ii))
         assert amd_lib.pll_gpu_last_launch_count(s.p) == 2  # 16+8 ops as 8 groups, 4+2 ops as 2 groups
         v, _ = s.edge_lnl(case.edges[0], persite=False)
-        assert amd_lib.pll_gpu_last_launch_count(s.p) == 2  # nothing was held: the lnL kernel is not counted
-        exp = O.run_case(case)
+        assert abs(v - exp["lnl"][0]) <= RTOL * abs(v)
+    monkeypatch.setenv("PLL_AMD_NO_FUSE_CC", "1")
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        assert amd_lib.pll_gpu_last_launch_count(s.p) == 2  # the two root-side ops are held
+        per_site = amd_lib.pll_gpu_last_algorithmic_bytes(s.p) / 640
+        assert 10000 < per_site < 11200, per_site
+        v, _ = s.edge_lnl(case.edges[0], persite=False)
+        assert amd_lib.pll_gpu_last_launch_count(s.p) == 3  # ... and evaluated inside the lnL kernel
         assert abs(v - exp["lnl"][0]) <= RTOL * abs(v)
 
 
