@@ -300,6 +300,20 @@ def main():
     ii_ops = [op for op in all_ops if op[2] >= case.tips and op[5] >= case.tips] if codes else list(all_ops)
     if not ii_ops:
         ii_ops = list(all_ops)
+    fused = cfg["states"] == 4 and not cfg.get("repeats") and not os.environ.get("PLL_AMD_NO_FUSE", "0").strip("0")
+    cc = fused and codes and not os.environ.get("PLL_AMD_NO_FUSE_CC", "0").strip("0")
+    if cc:
+        # 4x4 with tips as codes: most of the step is ONE launch, the groups of seven ops over complete
+        # 8-tip subtrees (k_partials_dna_cc<5,5>). The leg re-runs exactly those ops: everything within
+        # three levels of the tips.
+        depth = {t: 0 for t in range(case.tips)}
+        for op in all_ops:
+            depth[op[0]] = 1 + max(depth[op[2]], depth[op[5]])
+        low = [op for op in all_ops if depth[op[0]] <= 3]
+        if len(low) == 7 * (case.tips // 8):
+            ii_ops = low
+        else:
+            cc = False
     ii_arr = api.make_ops(ii_ops)
     for _ in range(3):
         lib.pll_update_partials_rep(sess.p, ii_arr, len(ii_ops), 0)
@@ -322,8 +336,7 @@ def main():
     if os.path.exists(tfile) and not args.pattern_tip and not args.sites:  # PMC-derived HBM bytes per launch of the same command (profiles/README.md)
         traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
     mfma = cfg["states"] > 32 and not os.environ.get("PLL_AMD_NO_MFMA", "0").strip("0")
-    fused = cfg["states"] == 4 and not cfg.get("repeats") and not os.environ.get("PLL_AMD_NO_FUSE", "0").strip("0")
-    kernel = {4: "k_partials_dna_fused<4,4>%.0s" if fused else "k_partials_dna<false,false,%s>", 20: "k_partials_tiled<20,false,false,%s>",
+    kernel = {4: "k_partials_dna_cc<5,5>%.0s" if cc else "k_partials_dna_fused<4,4>%.0s" if fused else "k_partials_dna<false,false,%s>", 20: "k_partials_tiled<20,false,false,%s>",
               61: "k_partials_mfma<false,false,%s>" if mfma else "k_partials_tiled<32,false,false,%s>"
               }[cfg["states"]] % ("true" if cfg.get("repeats") else "false")
     if mfma:

@@ -10,6 +10,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu > $O/prof_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu > $O/prof_write.log 2>&1
 find $O/prof_stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
-python3 tools/pmc_traffic.py --fetch $O/prof_fetch --write $O/prof_write --kernel 'k_partials_dna_fused<4, 4>' \
-  --grid 800768 200192 --algorithmic 462000000 --out $O/traffic_c2.json --trim $O/pmc
+python3 tools/pmc_traffic.py --fetch $O/prof_fetch --write $O/prof_write --kernel 'k_partials_dna_cc<5, 5>' \
+  --algorithmic 745600000 --out $O/traffic_c2.json --trim $O/pmc
 tail -c 400 $O/prof_stats.log
