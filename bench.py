@@ -49,14 +49,14 @@ CONFIGS = {
 }
 
 
-def build_case(cfg, sites, seed, attributes):
+def build_case(cfg, sites, seed, attributes, tree="balanced"):
     import numpy as np
     from pllamd import workload as W
     kw = {}
     if cfg["states"] == 20:
         lg = np.load(os.path.join(ROOT, "tests", "golden", "model_lg.npz"))
         kw.update(exch=lg["rates"], freqs=lg["freqs"])
-    return W.make_case("bench", cfg["states"], cfg["tips"], sites, attributes=attributes, seed=seed, **kw)
+    return W.make_case("bench", cfg["states"], cfg["tips"], sites, attributes=attributes, seed=seed, tree=tree, **kw)
 
 
 def tips_are_codes(case, api):
@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--sites", type=int, default=0, help="override sites per GPU")
     ap.add_argument("--pattern-tip", action="store_true", help="PLL_ATTRIB_PATTERN_TIP variant (tip codes instead of tip CLVs)")
+    ap.add_argument("--tree", default="balanced", choices=["balanced", "random", "caterpillar"],
+                    help="topology (BASELINE's configs are balanced; the others show what irregular level structures cost)")
+    ap.add_argument("--taxa", type=int, default=0, help="override the number of taxa")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + PLL_BENCH_SAME_DEVICE=1 rehearses the N>1 flow on a one-GPU box")
@@ -196,12 +199,17 @@ def main():
     import numpy as np
     from pllamd import api, driver
 
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.taxa:
+        cfg["tips"] = args.taxa
+        cfg["desc"] += f" [{args.taxa} taxa]"
+    if args.tree != "balanced":
+        cfg["desc"] = cfg["desc"].replace("balanced tree", "") + f" [{args.tree} tree]"
     sites = args.sites or cfg["sites"]
     attributes = api.PATTERN_TIP if args.pattern_tip else 0
     if cfg.get("repeats"):
         attributes |= api.SITE_REPEATS
-    case = build_case(cfg, sites, seed=1000 + rank, attributes=attributes)
+    case = build_case(cfg, sites, seed=1000 + rank, attributes=attributes, tree=args.tree)
     nops = len(case.op_batches[0])
     lib = api.PllLib()
     sess = driver.Session(lib, case, api.ARCH_AVX2)  # uploads happen on first use (warm-up)
@@ -314,6 +322,8 @@ def main():
             ii_ops = low
         else:
             cc = False
+    if args.tree != "balanced":  # irregular levels: no single dominant launch shape - the leg is the whole traversal
+        ii_ops, cc = list(all_ops), False
     ii_arr = api.make_ops(ii_ops)
     for _ in range(3):
         lib.pll_update_partials_rep(sess.p, ii_arr, len(ii_ops), 0)
@@ -333,12 +343,14 @@ def main():
     achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
-    if os.path.exists(tfile) and not args.pattern_tip and not args.sites:  # PMC-derived HBM bytes per launch of the same command (profiles/README.md)
+    if os.path.exists(tfile) and not args.pattern_tip and not args.sites and not args.taxa and args.tree == "balanced":  # PMC-derived HBM bytes per launch of the same command (profiles/README.md)
         traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
     mfma = cfg["states"] > 32 and not os.environ.get("PLL_AMD_NO_MFMA", "0").strip("0")
     kernel = {4: "k_partials_dna_cc<5,5>%.0s" if cc else "k_partials_dna_fused<4,4>%.0s" if fused else "k_partials_dna<false,false,%s>", 20: "k_partials_tiled<20,false,false,%s>",
               61: "k_partials_mfma<false,false,%s>" if mfma else "k_partials_tiled<32,false,false,%s>"
               }[cfg["states"]] % ("true" if cfg.get("repeats") else "false")
+    if args.tree != "balanced":
+        kernel = "all update launches of the traversal"
     if mfma:
         # 33..64 states sit past the fp64 ridge: the bounding line is the fp64 matrix pipe.
         # Algorithmic flop per update = the two 64-padded matrix-vector products the MFMA tiles

@@ -718,6 +718,394 @@ __global__ __launch_bounds__(256) void k_partials_dna_cc(const CCPack pack, unsi
 }
 
 // ------------------------------------------------------------------------------------------------
+// Chains: a path of ops towards the root, each taking the previous op's CLV as one child, evaluated by
+// one wave per 64 sites with that CLV held in registers from step to step. The other child of a step
+// (the "sibling") is a LEAF - tip codes or a CLV that is in HBM before the launch starts - or an op
+// over two leaves formed on the fly (and stored, like every op). On irregular trees this is what
+// removes the one-launch-per-level cost: the level scheduler needs as many launches as the tree is
+// deep (a 64-taxon ladder: 62), a chain plan as many as chains are nested (ladder: 1; random
+// 64-taxon trees: 3-4), and no CLV on a chain is read back. plan_chains() (pllgpu.hip) decides.
+// The arithmetic per op is that of the other 4x4 kernels; the two factors of a parent entry commute,
+// so which child rides in registers does not change a bit of the result.
+struct ChainLeaf
+{
+  const void *data;       // const double* (tiled CLV) or const unsigned char* (tip codes)
+  const unsigned *scaler; // CLV leaves only; may be null
+};
+
+// what a step's sibling is, i.e. what has to be fetched for it (low bits of ChainStepLoad::flags)
+enum ChainSiblingKind
+{
+  CS_T = 0,   // tip codes s0
+  CS_C = 1,   // CLV s0
+  CS_OTT = 2, // op over two tips s0, s1
+  CS_OTC = 3, // op over the tip s0 and the CLV s1
+  CS_OCC = 4, // op over two CLVs
+  CS_END = 5  // the terminal pseudo-step of a chain: nothing
+};
+constexpr unsigned kChKindMask = 7u;
+constexpr unsigned kChStream = 8u; // nothing reads the step's CLV back in this traversal: streaming stores
+
+// Buffer sizes as the kernel's buffer descriptors want them (see chain_rsrc below), filled by the
+// host: `clv` = bytes of the tiled CLV (0 for tip codes); `aux` = bytes behind the leaf's 4-byte side
+// load - the codes themselves for a tip (size rounded up to 4), the scaler vector for a CLV (0: none).
+struct ChainLeafBytes
+{
+  unsigned clv, aux, pad;
+};
+
+struct ChainStepLoad // what has to be known one step ahead (64 bytes)
+{
+  ChainLeaf s0, s1;
+  ChainLeafBytes b0, b1;
+  unsigned flags, pad;
+};
+
+struct ChainStepOp // 80 bytes
+{
+  double *parent;
+  unsigned *pscaler;
+  const double *mat_acc, *mat_sib; // matrices of the child in registers / of the sibling
+  double *bparent;                 // sibling op (kChSibOp): its CLV, scaler, matrices of s0 / s1
+  unsigned *bpscaler;
+  const double *bmat0, *bmat1;
+  unsigned p_bytes, psc_bytes, b_bytes, bsc_bytes;
+};
+
+struct ChainHead // 48 bytes
+{
+  ChainLeaf acc0; // the first step's child that rides in registers
+  ChainLeafBytes bacc;
+  unsigned first, nsteps; // nsteps real steps, followed by one all-disabled step (the last prefetch)
+  unsigned acc_tip, pad0, pad1;
+};
+
+typedef const ChainStepLoad __attribute__((address_space(4))) *cstepload_p;
+typedef const ChainStepOp __attribute__((address_space(4))) *cstepop_p;
+typedef const ChainHead __attribute__((address_space(4))) *chead_p;
+
+// descriptors come through the scalar path (constant address space), field by field
+__device__ __forceinline__ ChainStepLoad chain_get(cstepload_p p)
+{
+  ChainStepLoad r;
+  r.s0.data = p->s0.data;
+  r.s0.scaler = p->s0.scaler;
+  r.s1.data = p->s1.data;
+  r.s1.scaler = p->s1.scaler;
+  r.b0.clv = p->b0.clv;
+  r.b0.aux = p->b0.aux;
+  r.b1.clv = p->b1.clv;
+  r.b1.aux = p->b1.aux;
+  r.b0.pad = r.b1.pad = 0u;
+  r.flags = p->flags;
+  r.pad = 0u;
+  return r;
+}
+
+__device__ __forceinline__ ChainStepOp chain_get(cstepop_p p)
+{
+  ChainStepOp r;
+  r.parent = p->parent;
+  r.pscaler = p->pscaler;
+  r.mat_acc = p->mat_acc;
+  r.mat_sib = p->mat_sib;
+  r.bparent = p->bparent;
+  r.bpscaler = p->bpscaler;
+  r.bmat0 = p->bmat0;
+  r.bmat1 = p->bmat1;
+  r.p_bytes = p->p_bytes;
+  r.psc_bytes = p->psc_bytes;
+  r.b_bytes = p->b_bytes;
+  r.bsc_bytes = p->bsc_bytes;
+  return r;
+}
+
+// The kinds of a step are only known at run time, but the kernel must not BRANCH around memory
+// instructions: at a join the compiler's wait-count bookkeeping assumes the shortest path - the fewest
+// instructions issued since the load it waits for - and a step would sit out the latency of the
+// loads just issued for the NEXT one (tried: a switch over the kinds, lane masks, separate fetch
+// registers per kind - every variant ended with waits on the fresh fetch). So every step issues the
+// same memory instructions, through buffer descriptors whose size is 0 for the ones it does not need:
+// an out-of-range buffer load returns 0 and an out-of-range store is dropped, neither touches
+// memory. Measured (tools/chain_probe2.hip): such stores cost nothing; such LOADS still cost their
+// slot on the return path (0.12 us per instruction and step over the whole chip), which is why the
+// kernel is compiled in variants that leave out the fetch groups no step of a launch needs
+// (template flags C0 / S1 / C1). Run-time branches only ever enclose arithmetic.
+typedef unsigned chain_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned chain_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t chain_rsrc(const void *p, unsigned bytes)
+{
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+
+// Work split: a workgroup of four waves owns 64 sites, wave k the rate category k (four values per
+// lane). A chain is sequential per site, so its parallelism is sites x rates and nothing else; with
+// one wave per (tile, rate) a 100 000-site chain keeps 6252 waves busy instead of 1563, each small
+// enough (registers) for six to share a SIMD - the latency of one wave's loads and stores is covered
+// by the others. The only thing the rates of a site share is the per-site scaling decision ("all 16
+// values small", SM = 1): the waves exchange their 64-lane ballots through LDS, one barrier per
+// decision.
+struct ChainGeo
+{
+  unsigned clv_bytes, entries; // bytes of a tiled CLV buffer, entries per CLV
+  unsigned voff;               // this lane's byte offset into a tiled CLV: value (rate, 0) of its site
+  unsigned n;                  // its site; stores of lanes past the end go to offsets that are dropped
+  unsigned voff_store, n_store;
+  unsigned rate;               // wave-uniform
+};
+
+struct ChainRaw // what one step fetches
+{
+  double x0[4], x1[4];
+  unsigned side0, side1; // tip: 4 codes (this lane's = byte n & 3); CLV: the site's scaler count (SM 1) or this rate's (SM 2)
+};
+
+// SM: the partition's scaling mode (1 = one count per site, 2 = one per site and rate)
+// `side` = a leaf's 4-byte side load: four tip codes (this lane's among them) or the CLV's scaler
+// entry; CLV = false leaves the four value loads out (no step of the launch has a CLV in this place)
+template <int SM, bool CLV>
+__device__ __forceinline__ void chain_leaf_issue(const ChainLeaf &leaf, const ChainLeafBytes &bytes, bool tip, const ChainGeo &g, double (&x)[4],
+                                                 unsigned &side)
+{
+  const __amdgpu_buffer_rsrc_t ra = chain_rsrc(tip ? leaf.data : (const void *)leaf.scaler, bytes.aux);
+  side = __builtin_amdgcn_raw_buffer_load_b32(ra, tip ? (g.n & ~3u) : (SM == 2 ? g.n * 16u + g.rate * 4u : g.n * 4u), 0, 0);
+  if (CLV)
+  {
+    const __amdgpu_buffer_rsrc_t rc = chain_rsrc(leaf.data, bytes.clv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      x[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, g.voff + (unsigned)i * 512u, 0, 2)); // nt
+  }
+  else
+  {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = 0.0;
+  }
+}
+
+__device__ __forceinline__ bool chain_s0tip(unsigned kind) { return kind == CS_T || kind == CS_OTT || kind == CS_OTC; }
+
+template <int SM, bool C0, bool S1, bool C1>
+__device__ __forceinline__ void chain_issue(const ChainStepLoad &ld, const ChainGeo &g, ChainRaw &raw)
+{
+  const unsigned kind = ld.flags & kChKindMask;
+  chain_leaf_issue<SM, C0>(ld.s0, ld.b0, chain_s0tip(kind), g, raw.x0, raw.side0);
+  if (S1)
+    chain_leaf_issue<SM, C1>(ld.s1, ld.b1, kind == CS_OTT, g, raw.x1, raw.side1);
+  else
+  {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) raw.x1[i] = 0.0;
+    raw.side1 = 0u;
+  }
+}
+
+// what the side load brought: a tip's code -> its 0/1 vector (scaler count 0), a CLV's scaler count
+__device__ __forceinline__ unsigned chain_leaf_finish(bool tip, unsigned side, unsigned n, double (&x)[4])
+{
+  if (!tip) return side;
+  const unsigned code = (side >> ((n & 3u) * 8u)) & 0xffu;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x[j] = (code >> j) & 1u ? 1.0 : 0.0;
+  return 0u;
+}
+
+// CLV values of this rate + the scaler entry of one op; sizes of 0 turn the instructions into no-ops
+template <int SM, bool STREAM>
+__device__ __forceinline__ void chain_store(double *parent, unsigned *pscaler, unsigned clv_bytes, unsigned sc_bytes, const ChainGeo &g,
+                                            const double (&v)[4], unsigned sc)
+{
+  const __amdgpu_buffer_rsrc_t rc = chain_rsrc(parent, clv_bytes);
+  // SM 1: the four waves hold the same count; the wave of rate 0 writes it
+  const __amdgpu_buffer_rsrc_t rs = chain_rsrc(pscaler, (SM == 2 || g.rate == 0u) ? sc_bytes : 0u);
+  __builtin_amdgcn_raw_buffer_store_b32(sc, rs, SM == 2 ? g.n_store * 16u + g.rate * 4u : g.n_store * 4u, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(chain_u2, v[i]), rc, g.voff_store + (unsigned)i * 512u, 0, STREAM ? 2 : 0);
+}
+
+// one CLV update for this wave's rate: v = (ma . xa) * (mb . xb), scaled like src/core_partials.c:729-763
+template <int SM>
+__device__ __forceinline__ void chain_combine(const double *ma, const double *mb, const unsigned *pscaler, const ChainGeo &g,
+                                              const double (&xa)[4], unsigned sca, const double (&xb)[4], unsigned scb, double (&v)[4],
+                                              unsigned &sc, unsigned long long (*ballots)[4], unsigned slot)
+{
+  double a[4], b[4];
+  dna_matvec(a, as_const(ma) + g.rate * 16u, xa);
+  dna_matvec(b, as_const(mb) + g.rate * 16u, xb);
+  bool small = true;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+  {
+    v[i] = a[i] * b[i];
+    small = small && (v[i] < PLLGPU_SCALE_THRESHOLD);
+  }
+  sc = 0u;
+  if (!pscaler) return; // no scaler on this op: nothing is rescaled (workgroup-uniform)
+  if (SM == 1)
+  {
+    const unsigned long long mine = __ballot(small);
+    if ((threadIdx.x & 63u) == 0u) ballots[slot][g.rate] = mine;
+    __syncthreads();
+    const unsigned long long all = ballots[slot][0] & ballots[slot][1] & ballots[slot][2] & ballots[slot][3];
+    small = (all >> (threadIdx.x & 63u)) & 1ull;
+  }
+  if (small)
+  {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] *= PLLGPU_SCALE_FACTOR;
+  }
+  sc = sca + scb + (small ? 1u : 0u);
+}
+
+// one step: sibling from `cur` (fetched one step earlier), parent from (acc, sibling); acc <- parent
+template <int SM>
+__device__ __forceinline__ void chain_step(const ChainStepOp &op, unsigned flags, const ChainGeo &g, ChainRaw &cur, double (&acc)[4], unsigned &sca,
+                                           unsigned long long (*ballots)[4], unsigned step)
+{
+  const unsigned kind = flags & kChKindMask;
+  const bool s0tip = chain_s0tip(kind), s1tip = kind == CS_OTT, sibop = kind >= CS_OTT && kind != CS_END;
+  const unsigned sc0 = chain_leaf_finish(s0tip, cur.side0, g.n, cur.x0);
+  unsigned scb = sc0;
+  if (sibop) // arithmetic (and the barrier of the scaling decision) only
+  {
+    const unsigned sc1 = chain_leaf_finish(s1tip, cur.side1, g.n, cur.x1);
+    double vb[4];
+    chain_combine<SM>(op.bmat0, op.bmat1, op.bpscaler, g, cur.x0, sc0, cur.x1, sc1, vb, scb, ballots, (step & 1u) * 2u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cur.x0[i] = vb[i];
+  }
+  chain_store<SM, true>(op.bparent, op.bpscaler, op.b_bytes, op.bsc_bytes, g, cur.x0, scb);
+  double v[4];
+  unsigned sc;
+  chain_combine<SM>(op.mat_acc, op.mat_sib, op.pscaler, g, acc, sca, cur.x0, scb, v, sc, ballots, (step & 1u) * 2u + 1u);
+  if (flags & kChStream) // both sides issue the same instructions
+    chain_store<SM, true>(op.parent, op.pscaler, op.p_bytes, op.psc_bytes, g, v, sc);
+  else
+    chain_store<SM, false>(op.parent, op.pscaler, op.p_bytes, op.psc_bytes, g, v, sc);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = v[i];
+  sca = sc;
+}
+
+constexpr int kChainPackHeads = 4, kChainPackSteps = 26; // a ChainPack: 4 * 48 + 26 * (64 + 80) = 3936 B of kernarg
+
+// where the descriptors come from: device memory (any size) ...
+struct ChainSrcMem
+{
+  chead_p heads;
+  cstepload_p loads;
+  cstepop_p ops;
+  __device__ __forceinline__ ChainHead head(unsigned c) const
+  {
+    ChainHead h;
+    h.acc0.data = heads[c].acc0.data;
+    h.acc0.scaler = heads[c].acc0.scaler;
+    h.bacc.clv = heads[c].bacc.clv;
+    h.bacc.aux = heads[c].bacc.aux;
+    h.bacc.pad = 0u;
+    h.first = heads[c].first;
+    h.nsteps = heads[c].nsteps;
+    h.acc_tip = heads[c].acc_tip;
+    h.pad0 = h.pad1 = 0u;
+    return h;
+  }
+  __device__ __forceinline__ ChainStepLoad load(unsigned s) const { return chain_get(loads + s); }
+  __device__ __forceinline__ ChainStepOp op(unsigned s) const { return chain_get(ops + s); }
+};
+
+// ... or the kernarg segment (small plans: no descriptor upload)
+struct ChainPack
+{
+  ChainHead heads[kChainPackHeads];
+  ChainStepLoad loads[kChainPackSteps];
+  ChainStepOp ops[kChainPackSteps];
+};
+
+struct ChainSrcPack
+{
+  const ChainPack &pack;
+  __device__ __forceinline__ ChainHead head(unsigned c) const { return pack.heads[c]; }
+  __device__ __forceinline__ ChainStepLoad load(unsigned s) const { return pack.loads[s]; }
+  __device__ __forceinline__ ChainStepOp op(unsigned s) const { return pack.ops[s]; }
+};
+
+template <int SM, bool C0, bool S1, bool C1, class SRC>
+__device__ __forceinline__ void chain_body(const SRC src, unsigned entries)
+{
+  __shared__ unsigned long long ballots[4][4]; // [step parity x decision][rate]
+  const ChainHead h = src.head(blockIdx.y);
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned ntiles = (entries + 63u) / 64u;
+  const unsigned tile = blockIdx.x;
+  const unsigned n0 = tile * 64u + lane;
+  const bool valid = n0 < entries;
+  ChainGeo g;
+  g.rate = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  g.entries = entries;
+  g.clv_bytes = ntiles * (kDnaTile * 8u);
+  g.n = valid ? n0 : entries - 1;
+  g.voff = ((g.n >> 6) * kDnaTile + g.rate * 256u + (g.n & 63u)) * 8u;
+  g.n_store = valid ? g.n : 0x0fffffffu; // past every scaler buffer: dropped
+  g.voff_store = valid ? g.voff : 0xf0000000u;
+
+  double acc[4];
+  unsigned sca;
+  ChainRaw ra, rb;
+  unsigned fa, fb = 0u;
+  {
+    unsigned side;
+    chain_leaf_issue<SM, true>(h.acc0, h.bacc, h.acc_tip != 0u, g, acc, side);
+    const ChainStepLoad l0 = src.load(h.first);
+    fa = l0.flags;
+    chain_issue<SM, C0, S1, C1>(l0, g, ra);
+    sca = chain_leaf_finish(h.acc_tip != 0u, side, g.n, acc);
+  }
+  // two steps per trip: the fetch buffers swap roles instead of being copied; the next step's loads are
+  // in flight while the current one is computed and stored. The descriptor list of a chain ends with
+  // a CS_END step whose sizes are all 0: the last trip's fetch.
+  for (unsigned s = 0; s < h.nsteps; s += 2)
+  {
+    {
+      const ChainStepLoad l1 = src.load(h.first + s + 1);
+      fb = l1.flags;
+      chain_issue<SM, C0, S1, C1>(l1, g, rb);
+    }
+    {
+      const ChainStepOp o = src.op(h.first + s);
+      chain_step<SM>(o, fa, g, ra, acc, sca, ballots, s);
+    }
+    if (s + 1 >= h.nsteps) break;
+    {
+      const ChainStepLoad l2 = src.load(h.first + s + 2);
+      fa = l2.flags;
+      chain_issue<SM, C0, S1, C1>(l2, g, ra);
+    }
+    {
+      const ChainStepOp o = src.op(h.first + s + 1);
+      chain_step<SM>(o, fb, g, rb, acc, sca, ballots, s + 1);
+    }
+  }
+}
+
+template <int SM, bool C0, bool S1, bool C1>
+__global__ __launch_bounds__(256) void k_partials_dna_chain_pack(const ChainPack pack, unsigned entries)
+{
+  chain_body<SM, C0, S1, C1>(ChainSrcPack{pack}, entries);
+}
+
+template <int SM, bool C0, bool S1, bool C1>
+__global__ __launch_bounds__(256) void k_partials_dna_chain(const ChainHead *heads, const ChainStepLoad *loads, const ChainStepOp *ops, unsigned entries)
+{
+  ChainSrcMem src;
+  src.heads = (chead_p)(uintptr_t)heads;
+  src.loads = (cstepload_p)(uintptr_t)loads;
+  src.ops = (cstepop_p)(uintptr_t)ops;
+  chain_body<SM, C0, S1, C1>(src, entries);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Tail fusion: a traversal's last ops produce the two ends of the edge whose log-likelihood the
 // caller asks for next (the universal call sequence: pll_update_partials, then
 // pll_compute_edge_loglikelihood on the virtual root). The device layer holds those (at most two)

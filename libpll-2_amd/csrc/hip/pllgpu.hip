@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -41,6 +42,9 @@ static int fail(int code, const char *fmt, ...)
                   #call, hipGetErrorString(e_));                                                 \
   } while (0)
 
+// bumped whenever a device block is (re)allocated or freed: cached launch plans hold raw pointers
+static std::atomic<unsigned long long> g_alloc_epoch{1};
+
 template <typename T>
 struct DevBuf
 {
@@ -49,6 +53,7 @@ struct DevBuf
   int ensure(size_t n)
   {
     if (n <= cap) return 0;
+    g_alloc_epoch.fetch_add(1, std::memory_order_relaxed);
     if (p)
     {
       HIP_TRY(hipFree(p)); // hipFree synchronises: no kernel still uses the old block
@@ -62,6 +67,7 @@ struct DevBuf
   void release()
   {
     if (p) (void)hipFree(p);
+    if (p) g_alloc_epoch.fetch_add(1, std::memory_order_relaxed);
     p = nullptr;
     cap = 0;
   }
@@ -122,6 +128,10 @@ struct pllgpu_ctx
   std::vector<pllgpu_op_t> deferred; // ops accepted by pllgpu_update_partials and not launched yet
   bool fuse_cc = false;          // DNA: also two producer levels under a group parent (cherry-cherry children)
   bool fuse = false;             // DNA: evaluate producer + consumer ops in one kernel (kernels_dna.h)
+  bool chains = false;           // DNA: chain plans (k_partials_dna_chain) for dependency-only op lists
+  bool any_aos = false;          // a class-compressed CLV exists (site repeats): no chain plans
+  struct ChainPlan *plan = nullptr; // the last chain plan, re-launched as is when the same list comes again
+  DevBuf<unsigned char> chain_dev;  // its descriptors
 };
 
 static inline int use(pllgpu_ctx *c)
@@ -167,6 +177,9 @@ static void derive_geometry(pllgpu_ctx *c)
   c->fuse_cc = c->fuse;
   if (const char *v = getenv("PLL_AMD_NO_FUSE_CC"))
     if (*v && *v != '0') c->fuse_cc = false;
+  c->chains = c->fuse;
+  if (const char *v = getenv("PLL_AMD_NO_CHAINS"))
+    if (*v && *v != '0') c->chains = false;
   c->tiled = true; // every shape keeps CLVs in the tiled sites-contiguous layout
   // 33..64 states: CLV updates on the fp64 matrix pipe (kernels_mfma.h); PLL_AMD_NO_MFMA=1 keeps the FMA kernel
   c->use_mfma = (g.states > 32 && g.rate_cats <= 16);
@@ -271,12 +284,16 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   return c;
 }
 
+static void drop_chain_plan(pllgpu_ctx *c);
+
 extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
 {
   if (!c) return;
   (void)hipSetDevice(c->device);
   c->deferred.clear(); // results nobody will ask for
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  drop_chain_plan(c);
+  c->chain_dev.release();
   for (auto &b : c->clv) b.release();
   for (auto &b : c->scaler) b.release();
   for (auto &b : c->tipchars) b.release();
@@ -541,6 +558,7 @@ static int resolve_op(pllgpu_ctx *c, const pllgpu_op_t &o, DevOp &d)
   d.entries = o.parent_entries;
   // layout of the three CLVs (4x4 only): what the children were written as, what the parent becomes
   c->clv_aos[o.parent_clv] = aos_entries(c, o.parent_entries) ? 1 : 0;
+  if (c->clv_aos[o.parent_clv]) c->any_aos = true;
   d.layout = c->clv_aos[o.parent_clv] ? kAosParent : 0u;
   if (!(o.flags & PLLGPU_OP_LEFT_TIP) && c->clv_aos[o.left_clv]) d.layout |= kAosLeft;
   if (!(o.flags & PLLGPU_OP_RIGHT_TIP) && c->clv_aos[o.right_clv]) d.layout |= kAosRight;
@@ -759,7 +777,7 @@ static int child_kind(const pllgpu_op_t &prod)
 }
 
 static void plan_fusion(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count, std::vector<int> &role,
-                        std::vector<FusedGroup> &groups)
+                        std::vector<FusedGroup> &groups, bool cc_only = false)
 {
   // role: 0 plain, 1 parent of a group, 2 fused into a group as a child
   role.assign(count, 0);
@@ -827,6 +845,7 @@ static void plan_fusion(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count, s
       }
       groups.push_back(g);
     }
+  if (cc_only) return;
   for (unsigned i = 0; i < count; ++i)
   {
     const pllgpu_op_t &P = ops[i];
@@ -941,6 +960,514 @@ static double op_traffic(const pllgpu_ctx *c, const pllgpu_op_t &o, bool read_le
   return b * o.parent_entries;
 }
 
+// descriptor packs of the cherry-cherry groups [g0, g1) of one level, one per (memory-side kind, entries)
+struct CCLaunch
+{
+  CCPack pack;
+  unsigned n, entries;
+  int lk;
+};
+
+static int build_cc_launches(pllgpu_ctx *c, const pllgpu_op_t *ops, const std::vector<FusedGroup> &groups, size_t g0, size_t g1,
+                             std::vector<CCLaunch> &out)
+{
+  for (int lk = 0; lk <= CK_FCC; ++lk)
+  {
+    if (lk != CK_INNER && lk != CK_TIP && lk != CK_FCC) continue;
+    CCLaunch cur;
+    cur.n = 0;
+    cur.entries = 0;
+    cur.lk = lk;
+    auto flush = [&]() {
+      if (cur.n) out.push_back(cur);
+      cur.n = 0;
+    };
+    for (size_t gi = g0; gi < g1; ++gi)
+    {
+      const FusedGroup &g = groups[gi];
+      if (g.lk != CK_FCC && g.rk != CK_FCC) continue;
+      const bool swap = g.lk == CK_FCC && g.rk != CK_FCC; // canonical order: the memory side on the left
+      const int glk = swap ? g.rk : g.lk;
+      if (glk != lk) continue;
+      const pllgpu_op_t &P = ops[g.p];
+      if (P.parent_entries == 0) continue;
+      if (cur.n && P.parent_entries != cur.entries) flush();
+      cur.entries = P.parent_entries;
+      CCGroup &cg = cur.pack.g[cur.n];
+      memset(&cg, 0, sizeof cg);
+      DevOp d;
+      auto side = [&](int a, int x, int y, FOp &fa, TOp &tx, TOp &ty) -> int {
+        if (a < 0) return 0;
+        if (int rc = resolve_op(c, ops[x], d)) return rc;
+        to_top(d, tx);
+        c->last_bytes += op_traffic(c, ops[x], true, true);
+        if (int rc = resolve_op(c, ops[y], d)) return rc;
+        to_top(d, ty);
+        c->last_bytes += op_traffic(c, ops[y], true, true);
+        if (int rc = resolve_op(c, ops[a], d)) return rc;
+        to_fop(d, fa);
+        c->last_bytes += op_traffic(c, ops[a], false, false);
+        return 0;
+      };
+      if (int rc = side(g.a, g.aa, g.ab, cg.a, cg.aa, cg.ab)) return rc;
+      if (int rc = side(g.b, g.ba, g.bb, cg.b, cg.ba, cg.bb)) return rc;
+      if (int rc = resolve_op(c, P, d)) return rc;
+      c->last_bytes += op_traffic(c, P, g.a < 0, g.b < 0);
+      to_fop(d, cg.p);
+      if (swap)
+      {
+        std::swap(cg.p.left, cg.p.right);
+        std::swap(cg.p.ltip, cg.p.rtip);
+        std::swap(cg.p.lscaler, cg.p.rscaler);
+        std::swap(cg.p.lmat, cg.p.rmat);
+        std::swap(cg.a, cg.b);
+        std::swap(cg.aa, cg.ba);
+        std::swap(cg.ab, cg.bb);
+      }
+      if (++cur.n == (unsigned)kMaxCCGroups) flush();
+    }
+    flush();
+  }
+  return 0;
+}
+
+// ---- chain plans (DNA) ------------------------------------------------------------------------------
+// For op lists whose only ordering constraints are producer -> consumer (every CLV and scaler written
+// once, read by one later op at most, nothing overwritten that an earlier op touches): instead of one
+// launch per dependency level, the ops are partitioned into CHAINS (kernels_dna.h:
+// k_partials_dna_chain) - a path towards the root whose running CLV stays in registers - and the
+// chains into STAGES: a chain runs in the first launch in which every CLV it reads from HBM exists.
+//   S[i] = stage of op i = min over (a = child in registers, b = sibling) of
+//          max( S[a]  (a leaf: 1),  b a leaf or the top of another chain: S[b] + 1,
+//                                   b formed on the fly from two stored CLVs / tips: A[b] )
+//   A[b] = 1 + max(S[children of b])
+// computed bottom-up; the partition follows top-down from the ops nobody consumes. Complete 8-tip
+// subtrees keep their own kernel (cherry-cherry groups, stage 1); their CLVs are leaves here.
+struct ChainLaunchRec
+{
+  unsigned first_head, nchains; // one launch over heads [first_head, first_head + nchains)
+  unsigned variant;             // which fetch groups the kernel issues: 0 tips only, 1 + a second tip (cherry siblings),
+                                // 2 tips or a CLV, 3 everything
+};
+
+struct ChainPlan
+{
+  std::vector<pllgpu_op_t> key;
+  unsigned long long epoch = 0;
+  unsigned entries = 0;
+  std::vector<CCLaunch> cc;            // stage 1, before the chains
+  std::vector<ChainLaunchRec> stages;
+  std::vector<ChainHead> heads;
+  std::vector<ChainStepLoad> loads;
+  std::vector<ChainStepOp> sops;
+  bool in_kernarg = false;             // every stage fits a ChainPack
+  unsigned launches = 0;
+  double bytes = 0.0;
+};
+
+static void drop_chain_plan(pllgpu_ctx *c)
+{
+  delete c->plan;
+  c->plan = nullptr;
+}
+
+static int launch_chain_plan(pllgpu_ctx *c, const ChainPlan &pl)
+{
+  for (const CCLaunch &l : pl.cc)
+    if (int rc = launch_cc(c, l.pack, l.n, l.entries, l.lk, CK_FCC)) return rc;
+  const unsigned tiles = (pl.entries + 63) / 64;
+  const unsigned char *base = c->chain_dev.p;
+  const size_t heads_bytes = pl.heads.size() * sizeof(ChainHead), loads_bytes = pl.loads.size() * sizeof(ChainStepLoad);
+  for (const ChainLaunchRec &st : pl.stages)
+  {
+    dim3 grid(tiles, st.nchains), block(256); // a workgroup = one 64-site tile, wave k = rate category k
+    if (pl.in_kernarg)
+    {
+      ChainPack pack;
+      memset(&pack, 0, sizeof pack);
+      unsigned ns = 0;
+      for (unsigned h = 0; h < st.nchains; ++h)
+      {
+        ChainHead hd = pl.heads[st.first_head + h];
+        memcpy(&pack.loads[ns], &pl.loads[hd.first], (hd.nsteps + 1) * sizeof(ChainStepLoad)); // + the disabled terminal step
+        memcpy(&pack.ops[ns], &pl.sops[hd.first], (hd.nsteps + 1) * sizeof(ChainStepOp));
+        hd.first = ns;
+        ns += hd.nsteps + 1;
+        pack.heads[h] = hd;
+      }
+#define CHAIN_PACK(SMV, C0, S1, C1) hipLaunchKernelGGL((k_partials_dna_chain_pack<SMV, C0, S1, C1>), grid, block, 0, c->stream, pack, pl.entries)
+#define CHAIN_PACK_V(SMV)                         \
+  switch (st.variant)                             \
+  {                                               \
+  case 0: CHAIN_PACK(SMV, false, false, false); break; \
+  case 1: CHAIN_PACK(SMV, false, true, false); break;  \
+  case 2: CHAIN_PACK(SMV, true, false, false); break;  \
+  default: CHAIN_PACK(SMV, true, true, true); break;   \
+  }
+      if (c->gg.scale_mode == 2)
+      {
+        CHAIN_PACK_V(2)
+      }
+      else
+      {
+        CHAIN_PACK_V(1)
+      }
+#undef CHAIN_PACK_V
+#undef CHAIN_PACK
+    }
+    else
+    {
+      const ChainHead *hp = reinterpret_cast<const ChainHead *>(base) + st.first_head;
+      const ChainStepLoad *lp = reinterpret_cast<const ChainStepLoad *>(base + heads_bytes);
+      const ChainStepOp *op = reinterpret_cast<const ChainStepOp *>(base + heads_bytes + loads_bytes);
+#define CHAIN_MEM(SMV, C0, S1, C1) hipLaunchKernelGGL((k_partials_dna_chain<SMV, C0, S1, C1>), grid, block, 0, c->stream, hp, lp, op, pl.entries)
+#define CHAIN_MEM_V(SMV)                         \
+  switch (st.variant)                            \
+  {                                              \
+  case 0: CHAIN_MEM(SMV, false, false, false); break; \
+  case 1: CHAIN_MEM(SMV, false, true, false); break;  \
+  case 2: CHAIN_MEM(SMV, true, false, false); break;  \
+  default: CHAIN_MEM(SMV, true, true, true); break;   \
+  }
+      if (c->gg.scale_mode == 2)
+      {
+        CHAIN_MEM_V(2)
+      }
+      else
+      {
+        CHAIN_MEM_V(1)
+      }
+#undef CHAIN_MEM_V
+#undef CHAIN_MEM
+    }
+  }
+  c->last_launches = pl.launches;
+  c->last_bytes = pl.bytes;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PLLGPU_ERUNTIME, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+// returns 0 and sets used = true when the list was planned and launched as chains
+static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count, bool &used)
+{
+  used = false;
+  if (!c->chains || !c->fuse || count < 3 || c->any_aos) return 0;
+  if (c->plan && c->plan->epoch == g_alloc_epoch.load(std::memory_order_relaxed) && c->plan->key.size() == count &&
+      memcmp(c->plan->key.data(), ops, count * sizeof(pllgpu_op_t)) == 0)
+  {
+    used = true;
+    return launch_chain_plan(c, *c->plan);
+  }
+  const unsigned entries = ops[0].parent_entries;
+  if (entries == 0 || aos_entries(c, entries) || (size_t)entries * 128u >= ((size_t)1 << 31)) return 0; // 32-bit buffer offsets
+  const unsigned nodes = c->geo.nodes, nsb = c->geo.scale_buffers;
+  // ---- is the list dependency-only?
+  std::vector<int> producer(nodes, -1), sc_writer(nsb, -1), consumers(count, 0), pr_of[2];
+  pr_of[0].assign(count, -1);
+  pr_of[1].assign(count, -1);
+  for (unsigned i = 0; i < count; ++i)
+  {
+    const pllgpu_op_t &o = ops[i];
+    if ((o.flags & PLLGPU_OP_GATHER) || o.parent_entries != entries || o.war_level >= 0 || o.left_clv == o.right_clv) return 0;
+    if ((o.flags & PLLGPU_OP_RIGHT_TIP) && !(o.flags & PLLGPU_OP_LEFT_TIP)) return 0; // the level path reports it
+    if (o.parent_clv >= nodes || o.left_clv >= nodes || o.right_clv >= nodes || producer[o.parent_clv] >= 0) return 0;
+    if (o.parent_scaler >= (int)nsb || o.left_scaler >= (int)nsb || o.right_scaler >= (int)nsb) return 0;
+    const unsigned kid[2] = {o.left_clv, o.right_clv};
+    const int ksc[2] = {o.left_scaler, o.right_scaler};
+    const bool tip[2] = {(o.flags & PLLGPU_OP_LEFT_TIP) != 0, (o.flags & PLLGPU_OP_RIGHT_TIP) != 0};
+    for (int sd = 0; sd < 2; ++sd)
+    {
+      if (tip[sd]) continue;
+      const int pr = producer[kid[sd]];
+      if (pr >= 0)
+      {
+        if (++consumers[pr] > 1 || ops[pr].parent_scaler != ksc[sd]) return 0;
+        pr_of[sd][i] = pr;
+      }
+      else if (ksc[sd] >= 0 && sc_writer[ksc[sd]] >= 0)
+        return 0; // a stored CLV paired with a scaler this list rewrites
+    }
+    producer[o.parent_clv] = (int)i;
+    if (o.parent_scaler >= 0)
+    {
+      if (sc_writer[o.parent_scaler] >= 0) return 0;
+      sc_writer[o.parent_scaler] = (int)i;
+    }
+  }
+  // a tip child whose codes were replaced by a dense CLV arrives as an inner child: nothing to do here
+  ChainPlan *pl = new ChainPlan();
+  std::vector<int> role;
+  std::vector<FusedGroup> groups;
+  plan_fusion(c, ops, count, role, groups, true); // cherry-cherry groups only
+  // ---- stages, bottom-up
+  std::vector<unsigned> S(count, 0);
+  std::vector<unsigned char> acc_side(count, 0), absorb(count, 0);
+  auto leaf_ready = [&](unsigned i, int sd) -> unsigned { // stage after which a non-chain child exists in HBM
+    const int pr = pr_of[sd][i];
+    return (pr >= 0 && role[pr] != 0) ? 1u : 0u; // cherry-cherry groups run in stage 1
+  };
+  auto is_chain_op = [&](unsigned i, int sd) { return pr_of[sd][i] >= 0 && role[pr_of[sd][i]] == 0; };
+  auto ready_in_hbm = [&](unsigned i, int sd) -> unsigned { return is_chain_op(i, sd) ? S[pr_of[sd][i]] : leaf_ready(i, sd); };
+  for (unsigned i = 0; i < count; ++i)
+  {
+    if (role[i]) continue;
+    unsigned best = ~0u, best_cost = ~0u;
+    for (int a = 0; a < 2; ++a)
+    {
+      const int b = 1 - a;
+      const bool tip_a = ops[i].flags & (a ? PLLGPU_OP_RIGHT_TIP : PLLGPU_OP_LEFT_TIP);
+      const bool tip_b = ops[i].flags & (b ? PLLGPU_OP_RIGHT_TIP : PLLGPU_OP_LEFT_TIP);
+      unsigned req_a, cost = 0;
+      if (is_chain_op(i, a))
+        req_a = S[pr_of[a][i]];
+      else
+      {
+        req_a = leaf_ready(i, a) + 1;
+        cost += tip_a ? 1u : 132u;
+      }
+      unsigned req_b;
+      bool ab = false;
+      if (is_chain_op(i, b))
+      {
+        const unsigned q = (unsigned)pr_of[b][i];
+        const unsigned A = 1 + std::max(ready_in_hbm(q, 0), ready_in_hbm(q, 1));
+        if (A <= S[q])
+        {
+          ab = true;
+          req_b = A;
+        }
+        else
+        {
+          req_b = S[q] + 1;
+          cost += 132u;
+        }
+      }
+      else
+      {
+        req_b = leaf_ready(i, b) + 1;
+        cost += tip_b ? 1u : 132u;
+      }
+      const unsigned st = std::max(req_a, req_b);
+      if (st < best || (st == best && cost < best_cost))
+      {
+        best = st;
+        best_cost = cost;
+        acc_side[i] = (unsigned char)a;
+        absorb[i] = ab ? 1 : 0;
+      }
+    }
+    S[i] = best;
+  }
+  // ---- partition, top-down: form 0 = top of a chain (default), 1 = step below the next op of its chain, 2 = formed
+  // on the fly as a sibling
+  std::vector<unsigned char> form(count, 0);
+  std::vector<int> chain_of(count, -1);
+  struct PChain
+  {
+    std::vector<unsigned> ops; // top first
+    unsigned stage;
+  };
+  std::vector<PChain> chains;
+  for (unsigned ii = count; ii-- > 0;)
+  {
+    const unsigned i = ii;
+    if (role[i] || form[i] == 2) continue;
+    if (form[i] == 0)
+    {
+      chain_of[i] = (int)chains.size();
+      chains.push_back(PChain{{}, S[i]});
+    }
+    chains[chain_of[i]].ops.push_back(i);
+    const int a = acc_side[i], b = 1 - a;
+    if (is_chain_op(i, a))
+    {
+      form[pr_of[a][i]] = 1;
+      chain_of[pr_of[a][i]] = chain_of[i];
+    }
+    if (is_chain_op(i, b) && absorb[i]) form[pr_of[b][i]] = 2;
+  }
+  // ---- descriptors: resolve every op once, in list order (a producer's buffers exist before its consumer looks)
+  std::vector<DevOp> dev(count);
+  c->last_bytes = 0.0;
+  for (unsigned i = 0; i < count; ++i)
+    if (role[i] == 0)
+      if (int rc = resolve_op(c, ops[i], dev[i]))
+      {
+        delete pl;
+        return rc;
+      }
+  {
+    std::stable_sort(groups.begin(), groups.end(), [](const FusedGroup &x, const FusedGroup &y) { return x.level < y.level; });
+    if (int rc = build_cc_launches(c, ops, groups, 0, groups.size(), pl->cc))
+    {
+      delete pl;
+      return rc;
+    }
+  }
+  const unsigned clv_bytes = (unsigned)(clv_elems(c, entries) * sizeof(double));
+  const unsigned sc_bytes = entries * (c->gg.scale_mode == 2 ? 16u : 4u);
+  auto leaf_of = [&](unsigned i, int sd, bool &tip, ChainLeafBytes &lb) -> ChainLeaf {
+    ChainLeaf l;
+    tip = ops[i].flags & (sd ? PLLGPU_OP_RIGHT_TIP : PLLGPU_OP_LEFT_TIP);
+    lb.clv = lb.aux = lb.pad = 0u;
+    if (tip)
+    {
+      l.data = sd ? dev[i].rtip : dev[i].ltip;
+      l.scaler = nullptr;
+      lb.aux = (entries + 3u) & ~3u; // the codes are read four at a time (hipMalloc blocks are padded well beyond that)
+    }
+    else
+    {
+      l.data = sd ? dev[i].right : dev[i].left;
+      l.scaler = sd ? dev[i].rscaler : dev[i].lscaler;
+      lb.clv = clv_bytes;
+      lb.aux = l.scaler ? sc_bytes : 0u;
+    }
+    return l;
+  };
+  unsigned max_stage = 0;
+  for (const PChain &ch : chains) max_stage = std::max(max_stage, ch.stage);
+  pl->entries = entries;
+  pl->in_kernarg = true;
+  // what a chain's steps have to fetch decides the kernel variant it runs under (kernels_dna.h)
+  auto variant_of = [&](const PChain &ch) -> unsigned {
+    bool c0 = false, s1 = false, c1 = false;
+    for (unsigned i : ch.ops)
+    {
+      const int b = 1 - acc_side[i];
+      if (is_chain_op(i, b) && absorb[i])
+      {
+        const unsigned q = (unsigned)pr_of[b][i];
+        const bool t0 = ops[q].flags & PLLGPU_OP_LEFT_TIP, t1 = ops[q].flags & PLLGPU_OP_RIGHT_TIP;
+        s1 = true;
+        if (!t0) c0 = true;
+        if (!t1) c1 = true;
+      }
+      else if (!(ops[i].flags & (b ? PLLGPU_OP_RIGHT_TIP : PLLGPU_OP_LEFT_TIP)))
+        c0 = true;
+    }
+    if (c1 || (c0 && s1)) return 3u;
+    return c0 ? 2u : s1 ? 1u : 0u;
+  };
+  for (unsigned st = 1; st <= max_stage; ++st)
+   for (unsigned variant = 0; variant < 4; ++variant)
+  {
+    std::vector<unsigned> ids;
+    for (unsigned k = 0; k < chains.size(); ++k)
+      if (chains[k].stage == st && variant_of(chains[k]) == variant) ids.push_back(k);
+    if (ids.empty()) continue;
+    // the longest chains first: their workgroups are dispatched first
+    std::stable_sort(ids.begin(), ids.end(), [&](unsigned x, unsigned y) { return chains[x].ops.size() > chains[y].ops.size(); });
+    ChainLaunchRec rec;
+    rec.first_head = (unsigned)pl->heads.size();
+    rec.nchains = (unsigned)ids.size();
+    rec.variant = variant;
+    const bool stream_tops = (size_t)ids.size() * entries * 128u > c->stream_parent_bytes;
+    unsigned stage_steps = 0;
+    for (unsigned k : ids)
+    {
+      const PChain &ch = chains[k];
+      ChainHead hd;
+      memset(&hd, 0, sizeof hd);
+      hd.first = (unsigned)pl->loads.size();
+      hd.nsteps = (unsigned)ch.ops.size();
+      stage_steps += hd.nsteps;
+      for (size_t t = ch.ops.size(); t-- > 0;) // bottom first
+      {
+        const unsigned i = ch.ops[t];
+        const int a = acc_side[i], b = 1 - a;
+        const bool bottom = t + 1 == ch.ops.size(), top = t == 0;
+        if (bottom)
+        {
+          bool tip;
+          hd.acc0 = leaf_of(i, a, tip, hd.bacc);
+          hd.acc_tip = tip ? 1u : 0u;
+        }
+        ChainStepLoad ld;
+        ChainStepOp so;
+        memset(&ld, 0, sizeof ld);
+        memset(&so, 0, sizeof so);
+        so.parent = dev[i].parent;
+        so.pscaler = dev[i].pscaler;
+        so.mat_acc = a ? dev[i].rmat : dev[i].lmat;
+        so.mat_sib = b ? dev[i].rmat : dev[i].lmat;
+        so.p_bytes = clv_bytes;
+        so.psc_bytes = so.pscaler ? sc_bytes : 0u;
+        if ((!top || stream_tops) && !getenv("PLL_AMD_CHAIN_PLAIN")) ld.flags |= kChStream;
+        bool read_sib = true;
+        if (is_chain_op(i, b) && absorb[i])
+        {
+          const unsigned q = (unsigned)pr_of[b][i];
+          bool t0, t1;
+          ld.s0 = leaf_of(q, 0, t0, ld.b0); // a tip-inner op carries its tip on the left
+          ld.s1 = leaf_of(q, 1, t1, ld.b1);
+          ld.flags |= (t0 && t1) ? CS_OTT : t0 ? CS_OTC : CS_OCC;
+          so.bparent = dev[q].parent;
+          so.bpscaler = dev[q].pscaler;
+          so.bmat0 = dev[q].lmat;
+          so.bmat1 = dev[q].rmat;
+          so.b_bytes = clv_bytes;
+          so.bsc_bytes = so.bpscaler ? sc_bytes : 0u;
+          pl->bytes += op_traffic(c, ops[q], true, true);
+          read_sib = false;
+        }
+        else
+        {
+          bool t0;
+          ld.s0 = leaf_of(i, b, t0, ld.b0);
+          ld.flags |= t0 ? CS_T : CS_C;
+        }
+        pl->bytes += op_traffic(c, ops[i], a == 0 ? bottom : read_sib, a == 0 ? read_sib : bottom);
+        pl->loads.push_back(ld);
+        pl->sops.push_back(so);
+      }
+      {
+        // the terminal step: what the last trip "prefetches" - every size 0
+        ChainStepLoad ld;
+        ChainStepOp so;
+        memset(&ld, 0, sizeof ld);
+        memset(&so, 0, sizeof so);
+        ld.flags = CS_END;
+        pl->loads.push_back(ld);
+        pl->sops.push_back(so);
+        ++stage_steps;
+      }
+      pl->heads.push_back(hd);
+    }
+    if (rec.nchains > (unsigned)kChainPackHeads || stage_steps > (unsigned)kChainPackSteps) pl->in_kernarg = false;
+    pl->stages.push_back(rec);
+  }
+  pl->bytes += c->last_bytes; // the cherry-cherry groups (build_cc_launches counted them)
+  pl->launches = (unsigned)(pl->cc.size() + pl->stages.size());
+  if (!pl->in_kernarg)
+  {
+    const size_t hb = pl->heads.size() * sizeof(ChainHead), lb = pl->loads.size() * sizeof(ChainStepLoad),
+                 ob = pl->sops.size() * sizeof(ChainStepOp);
+    if (int rc = c->chain_dev.ensure(hb + lb + ob))
+    {
+      delete pl;
+      return rc;
+    }
+    // pageable sources are staged before hipMemcpyAsync returns; the stream orders the copies behind the
+    // kernels of the previous plan that still read the old descriptors
+    hipError_t e = hipMemcpyAsync(c->chain_dev.p, pl->heads.data(), hb, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->chain_dev.p + hb, pl->loads.data(), lb, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->chain_dev.p + hb + lb, pl->sops.data(), ob, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess)
+    {
+      delete pl;
+      return fail(PLLGPU_ERUNTIME, "descriptor upload failed: %s", hipGetErrorString(e));
+    }
+  }
+  pl->key.assign(ops, ops + count);
+  pl->epoch = g_alloc_epoch.load(std::memory_order_relaxed);
+  drop_chain_plan(c);
+  c->plan = pl;
+  used = true;
+  return launch_chain_plan(c, *pl);
+}
+
 // launch the held ops as ordinary updates (they are mutually independent: one level)
 static int flush_deferred(pllgpu_ctx *c)
 {
@@ -972,6 +1499,12 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
   CHECK_CTX(c);
   c->last_launches = 0;
   c->last_bytes = 0.0;
+  {
+    bool used = false;
+    if (int rc = try_chain_plan(c, ops, count, used)) return rc;
+    if (used) return 0;
+    c->last_bytes = 0.0;
+  }
   std::vector<int> role;
   std::vector<FusedGroup> groups;
   plan_fusion(c, ops, count, role, groups);
@@ -1041,66 +1574,14 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
     const size_t g0 = gi_sorted;
     while (gi_sorted < groups.size() && groups[gi_sorted].level == level) ++gi_sorted;
     // cherry-cherry groups (kind CK_FCC on at least one side) have their own descriptor and kernel
-    for (int lk = 0; lk <= CK_FCC; ++lk)
     {
-      const int rk = CK_FCC;
-      if (lk != CK_INNER && lk != CK_TIP && lk != CK_FCC) continue;
-      CCPack pack;
-      unsigned n = 0, entries = 0;
-      auto flush = [&]() -> int {
-        if (!n) return 0;
-        if (int rc = launch_cc(c, pack, n, entries, lk, rk)) return rc;
-        ++c->last_launches;
-        n = 0;
-        return 0;
-      };
-      for (size_t gi = g0; gi < gi_sorted; ++gi)
+      std::vector<CCLaunch> ccl;
+      if (int rc = build_cc_launches(c, ops, groups, g0, gi_sorted, ccl)) return rc;
+      for (const CCLaunch &l : ccl)
       {
-        const FusedGroup &g = groups[gi];
-        if (g.lk != CK_FCC && g.rk != CK_FCC) continue;
-        const bool swap = g.lk == CK_FCC && g.rk != CK_FCC; // canonical order: the memory side on the left
-        const int glk = swap ? g.rk : g.lk;
-        if (glk != lk) continue;
-        const pllgpu_op_t &P = ops[g.p];
-        if (P.parent_entries == 0) continue;
-        if (n && P.parent_entries != entries)
-          if (int rc = flush()) return rc;
-        entries = P.parent_entries;
-        CCGroup &cg = pack.g[n];
-        memset(&cg, 0, sizeof cg);
-        DevOp d;
-        auto side = [&](int a, int x, int y, FOp &fa, TOp &tx, TOp &ty) -> int {
-          if (a < 0) return 0;
-          if (int rc = resolve_op(c, ops[x], d)) return rc;
-          to_top(d, tx);
-          c->last_bytes += op_traffic(c, ops[x], true, true);
-          if (int rc = resolve_op(c, ops[y], d)) return rc;
-          to_top(d, ty);
-          c->last_bytes += op_traffic(c, ops[y], true, true);
-          if (int rc = resolve_op(c, ops[a], d)) return rc;
-          to_fop(d, fa);
-          c->last_bytes += op_traffic(c, ops[a], false, false);
-          return 0;
-        };
-        if (int rc = side(g.a, g.aa, g.ab, cg.a, cg.aa, cg.ab)) return rc;
-        if (int rc = side(g.b, g.ba, g.bb, cg.b, cg.ba, cg.bb)) return rc;
-        if (int rc = resolve_op(c, P, d)) return rc;
-        c->last_bytes += op_traffic(c, P, g.a < 0, g.b < 0);
-        to_fop(d, cg.p);
-        if (swap)
-        {
-          std::swap(cg.p.left, cg.p.right);
-          std::swap(cg.p.ltip, cg.p.rtip);
-          std::swap(cg.p.lscaler, cg.p.rscaler);
-          std::swap(cg.p.lmat, cg.p.rmat);
-          std::swap(cg.a, cg.b);
-          std::swap(cg.aa, cg.ba);
-          std::swap(cg.ab, cg.bb);
-        }
-        if (++n == (unsigned)kMaxCCGroups)
-          if (int rc = flush()) return rc;
+        if (int rc = launch_cc(c, l.pack, l.n, l.entries, l.lk, CK_FCC)) return rc;
+        ++c->last_launches;
       }
-      if (int rc = flush()) return rc;
     }
     for (int lk = 0; lk <= CK_FII; ++lk)
       for (int rk = lk; rk <= CK_FII; ++rk)

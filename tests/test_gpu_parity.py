@@ -332,36 +332,83 @@ def test_dna_without_fusion(amd_lib, kw, monkeypatch):
 
 def test_fusion_plan_on_a_balanced_tree(amd_lib, monkeypatch):
     """64 taxa, full traversal: 8 groups of seven ops (complete 8-tip subtrees: four cherries, two ops
-    above them, one above those) and 2 groups (ii, ii -> ii) at the top = 2 launches instead of 5;
-    without the two-level groups 16 (tt, tt -> ii) groups, 4 (ii, ii -> ii) groups and the two
-    root-side ops, which are held for the edge evaluation (tail fusion)."""
+    above them, one above those) and the top six ops as two chains = 2 launches instead of 5; without
+    the two-level groups a chain plan needs 3 stages. PLL_AMD_NO_CHAINS=1 brings back the level
+    scheduler with its groups: 16 (tt, tt -> ii) groups, 4 (ii, ii -> ii) groups and the two root-side
+    ops, which are held for the edge evaluation (tail fusion)."""
     import os
     if os.environ.get("PLL_AMD_EAGER_MIRROR", "0") not in ("", "0"):
         pytest.skip("eager mirroring launches the held ops right away: launch counts differ")
     case = W.make_case("plan", 4, 64, 640, seed=97)
     exp = O.run_case(case)
-    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
-        s.update_partials()
-        assert amd_lib.pll_gpu_last_launch_count(s.p) == 2
-        per_site = amd_lib.pll_gpu_last_algorithmic_bytes(s.p) / 640
-        assert 8800 < per_site < 9900, per_site  # 8 x (8 B + 7 CLVs + scalers) + 2 x (4 CLVs in, 3 out)
-        v, _ = s.edge_lnl(case.edges[0], persite=False)
-        assert abs(v - exp["lnl"][0]) <= RTOL * abs(v)
-        ii = [op for op in case.op_batches[0] if op[2] >= 64 and op[5] >= 64]
-        arr = api.make_ops(ii)
-        amd_lib.pll_update_partials(s.p, arr, len(ii))
-        assert amd_lib.pll_gpu_last_launch_count(s.p) == 2  # 16+8 ops as 8 groups, 4+2 ops as 2 groups
-        v, _ = s.edge_lnl(case.edges[0], persite=False)
-        assert abs(v - exp["lnl"][0]) <= RTOL * abs(v)
+
+    def full_and_partial(first, per_site_range, partial):
+        with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+            s.update_partials()
+            assert amd_lib.pll_gpu_last_launch_count(s.p) == first
+            per_site = amd_lib.pll_gpu_last_algorithmic_bytes(s.p) / 640
+            assert per_site_range[0] < per_site < per_site_range[1], per_site
+            v, _ = s.edge_lnl(case.edges[0], persite=False)
+            assert abs(v - exp["lnl"][0]) <= RTOL * abs(v)
+            ii = [op for op in case.op_batches[0] if op[2] >= 64 and op[5] >= 64]
+            arr = api.make_ops(ii)
+            amd_lib.pll_update_partials(s.p, arr, len(ii))
+            assert amd_lib.pll_gpu_last_launch_count(s.p) == partial
+            again, _ = s.edge_lnl(case.edges[0], persite=False)
+            assert again == v
+            # the same list once more: the cached plan is launched as it is
+            amd_lib.pll_update_partials(s.p, arr, len(ii))
+            assert amd_lib.pll_gpu_last_launch_count(s.p) == partial
+            again, _ = s.edge_lnl(case.edges[0], persite=False)
+            assert again == v
+            return v
+
+    # 8 x (8 B + 7 CLVs + scalers) + 2 x (4 CLVs in, 3 out); the 30 inner x inner ops: two stages
+    v0 = full_and_partial(2, (8800, 9900), 2)
     monkeypatch.setenv("PLL_AMD_NO_FUSE_CC", "1")
+    v1 = full_and_partial(3, (9000, 12000), 2)
+    monkeypatch.setenv("PLL_AMD_NO_CHAINS", "1")
     with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
         s.update_partials()
         assert amd_lib.pll_gpu_last_launch_count(s.p) == 2  # the two root-side ops are held
         per_site = amd_lib.pll_gpu_last_algorithmic_bytes(s.p) / 640
         assert 10000 < per_site < 11200, per_site
-        v, _ = s.edge_lnl(case.edges[0], persite=False)
+        v2, _ = s.edge_lnl(case.edges[0], persite=False)
         assert amd_lib.pll_gpu_last_launch_count(s.p) == 3  # ... and evaluated inside the lnL kernel
-        assert abs(v - exp["lnl"][0]) <= RTOL * abs(v)
+    monkeypatch.delenv("PLL_AMD_NO_FUSE_CC")
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        assert amd_lib.pll_gpu_last_launch_count(s.p) == 2  # 8 groups of seven, 2 groups of three
+        v3, _ = s.edge_lnl(case.edges[0], persite=False)
+    assert v0 == v1 == v2 == v3
+
+
+@pytest.mark.parametrize("tree,taxa,sites,launches", [("caterpillar", 64, 1000, 1), ("caterpillar", 600, 130, 1), ("random", 64, 1000, 4),
+                                                       ("random", 300, 257, 8), ("balanced", 512, 70, 12)])
+@pytest.mark.parametrize("per_rate", [False, True], ids=["site-scalers", "rate-scalers"])
+def test_chain_plans(amd_lib, monkeypatch, tree, taxa, sites, launches, per_rate):
+    """Irregular trees: the ops are partitioned into chains (k_partials_dna_chain), a ladder of any
+    length is one launch. Every CLV and scaler equals, bit for bit, what one kernel per op group
+    produces; the 600-taxon ladder and the 512-taxon tree drive CLVs below 2^-256, so the per-site
+    scaling decision that the four rate waves of a tile take together (and the per-rate one they take
+    alone) is exercised; the result is checked against the oracle as well."""
+    attrs = api.RATE_SCALERS if per_rate else 0
+    case = W.make_case("chain", 4, taxa, sites, tree=tree, seed=131 + taxa, attributes=attrs, ambiguity_pct=3, partial_pct=2)
+    chained = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        assert amd_lib.pll_gpu_last_launch_count(s.p) <= launches
+    monkeypatch.setenv("PLL_AMD_NO_FUSE", "1")
+    plain = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    exp = O.run_case(case)
+    assert_results_match(plain, exp, what=f"{tree}-{taxa}")
+    assert chained["lnl"] == plain["lnl"]
+    if taxa >= 512:
+        assert sum(int(v.sum()) for v in plain["scaler"].values()) > 0  # the tree is deep enough to scale
+    for k in plain["clv"]:
+        assert (chained["clv"][k] == plain["clv"][k]).all(), k
+        if k in plain["scaler"]:
+            assert (chained["scaler"][k] == plain["scaler"][k]).all(), k
 
 
 def test_tail_fusion_is_transparent(amd_lib, monkeypatch):
