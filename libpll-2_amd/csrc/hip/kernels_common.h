@@ -160,10 +160,24 @@ __device__ __forceinline__ double minlh(unsigned d)
 
 // Every workgroup leaves its partial sum; the workgroup that arrives last adds all partials in
 // index order (fixed tree: the result does not depend on arrival order) and writes the total to
-// host-mapped memory. One launch, no separate reduction kernel, no D2H copy. Hand-off follows the
-// agent-scope release/acquire recipe (cdna_hip_programming.md guideline 16): release fence before the
-// ticket, one acquire fence in the last workgroup before it reads the other workgroups' partials.
-// nsum_waves: how many of the calling workgroup's waves contribute a value (wave index < nsum_waves).
+// host-mapped memory. One launch, no separate reduction kernel, no D2H copy.
+// Hand-off WITHOUT release/acquire fences: on this part a release fence at agent scope is a write-back
+// of every dirty line of the XCD's L2 (the eight XCDs do not share one), and a log-likelihood kernel
+// usually runs right after - or, with the tail kernels, while - hundreds of MB of CLVs are written:
+// one such write-back per workgroup cost more than the kernel's own work. Instead the partial itself
+// is stored with an agent-scope atomic (performed at the coherent level, nothing else is flushed), the
+// wave waits for that store, then takes its ticket; the last workgroup reads the partials with
+// agent-scope atomic loads. nsum_waves: how many of the calling workgroup's waves contribute a value.
+__device__ __forceinline__ void partial_store(double *p, double v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ double partial_load(const double *p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ void publish_block_sum(const DevEdge &e, double wave_value, unsigned nsum_waves)
 {
   __shared__ double ws[4];
@@ -175,21 +189,15 @@ __device__ __forceinline__ void publish_block_sum(const DevEdge &e, double wave_
   {
     double s = ws[0];
     for (unsigned w = 1; w < nw; ++w) s += ws[w];
-    e.block_sums[blockIdx.x] = s;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    partial_store(&e.block_sums[blockIdx.x], s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the partial has been performed before the ticket is taken
     const unsigned ticket = __hip_atomic_fetch_add(e.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last = (ticket == gridDim.x - 1) ? 1u : 0u;
-    if (last)
-    {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
   }
   __syncthreads();
   if (!last) return;
   double a = 0.0;
-  for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) a += e.block_sums[i];
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) a += partial_load(&e.block_sums[i]);
   a = wave_sum(a);
   __syncthreads();
   if (lane == 0) ws[wave] = a;
@@ -202,6 +210,7 @@ __device__ __forceinline__ void publish_block_sum(const DevEdge &e, double wave_
     // result[0] = value, then result[1] = this call's sequence number with system-scope release:
     // the host polls the sequence word in mapped memory instead of paying a stream synchronise
     __hip_atomic_store(e.result, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(e.result + 1, e.sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the value is in host memory before the sequence word follows
+    __hip_atomic_store(e.result + 1, e.sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }

@@ -158,25 +158,20 @@ __global__ __launch_bounds__(256) void k_derivatives(const DevDeriv d, const Gen
   __syncthreads();
   if (threadIdx.x == 0)
   {
-    d.block_sums[blockIdx.x] = (ws[0][0] + ws[0][1]) + (ws[0][2] + ws[0][3]);
-    d.block_sums[1024 + blockIdx.x] = (ws[1][0] + ws[1][1]) + (ws[1][2] + ws[1][3]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // hand-off without fences (kernels_common.h: partial_store)
+    partial_store(&d.block_sums[blockIdx.x], (ws[0][0] + ws[0][1]) + (ws[0][2] + ws[0][3]));
+    partial_store(&d.block_sums[1024 + blockIdx.x], (ws[1][0] + ws[1][1]) + (ws[1][2] + ws[1][3]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned ticket = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last = (ticket == gridDim.x - 1) ? 1u : 0u;
-    if (last)
-    {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
   }
   __syncthreads();
   if (!last) return;
   double b1 = 0.0, b2 = 0.0;
   for (unsigned i = threadIdx.x; i < gridDim.x; i += 256)
   {
-    b1 += d.block_sums[i];
-    b2 += d.block_sums[1024 + i];
+    b1 += partial_load(&d.block_sums[i]);
+    b2 += partial_load(&d.block_sums[1024 + i]);
   }
   b1 = wave_sum(b1);
   b2 = wave_sum(b2);
@@ -192,7 +187,8 @@ __global__ __launch_bounds__(256) void k_derivatives(const DevDeriv d, const Gen
     __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(d.result, (ws[0][0] + ws[0][1]) + (ws[0][2] + ws[0][3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(d.result + 2, (ws[1][0] + ws[1][1]) + (ws[1][2] + ws[1][3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(d.result + 1, d.sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the values are in host memory before the sequence word follows
+    __hip_atomic_store(d.result + 1, d.sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

@@ -989,7 +989,7 @@ __device__ __forceinline__ void chain_step(const ChainStepOp &op, unsigned flags
   sca = sc;
 }
 
-constexpr int kChainPackHeads = 4, kChainPackSteps = 26; // a ChainPack: 4 * 48 + 26 * (64 + 80) = 3936 B of kernarg
+constexpr int kChainPackHeads = 4, kChainPackSteps = 24; // a ChainPack: 4 * 48 + 24 * (64 + 80) = 3648 B of kernarg (+ a DevEdge in the tail kernel)
 
 // where the descriptors come from: device memory (any size) ...
 struct ChainSrcMem
@@ -1031,27 +1031,11 @@ struct ChainSrcPack
   __device__ __forceinline__ ChainStepOp op(unsigned s) const { return pack.ops[s]; }
 };
 
+// one chain for this wave's (tile, rate): its top CLV values and scaler count are left in acc / sca
 template <int SM, bool C0, bool S1, bool C1, class SRC>
-__device__ __forceinline__ void chain_body(const SRC src, unsigned entries)
+__device__ __forceinline__ void chain_run(const SRC &src, const ChainHead &h, const ChainGeo &g, double (&acc)[4], unsigned &sca,
+                                          unsigned long long (*ballots)[4])
 {
-  __shared__ unsigned long long ballots[4][4]; // [step parity x decision][rate]
-  const ChainHead h = src.head(blockIdx.y);
-  const unsigned lane = threadIdx.x & 63u;
-  const unsigned ntiles = (entries + 63u) / 64u;
-  const unsigned tile = blockIdx.x;
-  const unsigned n0 = tile * 64u + lane;
-  const bool valid = n0 < entries;
-  ChainGeo g;
-  g.rate = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  g.entries = entries;
-  g.clv_bytes = ntiles * (kDnaTile * 8u);
-  g.n = valid ? n0 : entries - 1;
-  g.voff = ((g.n >> 6) * kDnaTile + g.rate * 256u + (g.n & 63u)) * 8u;
-  g.n_store = valid ? g.n : 0x0fffffffu; // past every scaler buffer: dropped
-  g.voff_store = valid ? g.voff : 0xf0000000u;
-
-  double acc[4];
-  unsigned sca;
   ChainRaw ra, rb;
   unsigned fa, fb = 0u;
   {
@@ -1089,6 +1073,34 @@ __device__ __forceinline__ void chain_body(const SRC src, unsigned entries)
   }
 }
 
+__device__ __forceinline__ ChainGeo chain_geo(unsigned entries)
+{
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned ntiles = (entries + 63u) / 64u;
+  const unsigned n0 = blockIdx.x * 64u + lane;
+  const bool valid = n0 < entries;
+  ChainGeo g;
+  g.rate = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  g.entries = entries;
+  g.clv_bytes = ntiles * (kDnaTile * 8u);
+  g.n = valid ? n0 : entries - 1;
+  g.voff = ((g.n >> 6) * kDnaTile + g.rate * 256u + (g.n & 63u)) * 8u;
+  g.n_store = valid ? g.n : 0x0fffffffu; // past every scaler buffer: dropped
+  g.voff_store = valid ? g.voff : 0xf0000000u;
+  return g;
+}
+
+template <int SM, bool C0, bool S1, bool C1, class SRC>
+__device__ __forceinline__ void chain_body(const SRC src, unsigned entries)
+{
+  __shared__ unsigned long long ballots[4][4]; // [step parity x decision][rate]
+  const ChainHead h = src.head(blockIdx.y);
+  const ChainGeo g = chain_geo(entries);
+  double acc[4];
+  unsigned sca;
+  chain_run<SM, C0, S1, C1>(src, h, g, acc, sca, ballots);
+}
+
 template <int SM, bool C0, bool S1, bool C1>
 __global__ __launch_bounds__(256) void k_partials_dna_chain_pack(const ChainPack pack, unsigned entries)
 {
@@ -1103,6 +1115,134 @@ __global__ __launch_bounds__(256) void k_partials_dna_chain(const ChainHead *hea
   src.loads = (cstepload_p)(uintptr_t)loads;
   src.ops = (cstepop_p)(uintptr_t)ops;
   chain_body<SM, C0, S1, C1>(src, entries);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Chain tail: the chains that end in the two ends of the evaluated edge (the last stage of a
+// traversal, held back for one call like the ops of k_edge_dna_tail below) run inside the
+// log-likelihood kernel: a workgroup takes its tile through the parent end's chain, then the child
+// end's, and forms the site log-likelihoods from the registers. An end that is not produced by a held
+// chain is a chain of no steps (its `acc0` leaf is the end). The rate terms of a site live in four
+// waves: they meet in LDS and the wave of rate 0 finishes the site exactly like k_edge_dna does; the
+// tile sums are added up by the last workgroup in k_edge_dna's order (four tiles to a partial, then
+// the partials), so the value is bit-identical to evaluating the edge from HBM.
+template <int SM, bool C0, bool S1, bool C1, class SRC>
+__device__ __forceinline__ void chain_edge_body(const DevEdge &e, const SRC src, const ChainHead &hp, const ChainHead &hc, unsigned entries)
+{
+  __shared__ unsigned long long ballots[4][4];
+  __shared__ double xtr[4][64];
+  __shared__ unsigned xrs[4][64];
+  __shared__ unsigned last;
+  __shared__ double ws[4];
+  const ChainGeo g = chain_geo(entries);
+  const unsigned lane = threadIdx.x & 63u;
+  double vp[4], vc[4];
+  unsigned scp, scc;
+  chain_run<SM, C0, S1, C1>(src, hp, g, vp, scp, ballots);
+  chain_run<SM, C0, S1, C1>(src, hc, g, vc, scc, ballots);
+  {
+    double tb[4];
+    dna_matvec(tb, as_const(e.mat) + g.rate * 16u, vc);
+    const unsigned fi = e.fidx[g.rate];
+    cdouble_p pi = as_const(e.freqs) + (size_t)fi * 4;
+    xtr[g.rate][lane] = fma(vp[3] * pi[3], tb[3], fma(vp[2] * pi[2], tb[2], fma(vp[1] * pi[1], tb[1], (vp[0] * pi[0]) * tb[0])));
+    xrs[g.rate][lane] = scp + scc;
+  }
+  __syncthreads();
+  if (g.rate == 0u)
+  {
+    const unsigned n0 = blockIdx.x * 64u + lane;
+    const bool valid = n0 < e.sites;
+    const unsigned n = valid ? n0 : e.sites - 1;
+    unsigned rs[4] = {0, 0, 0, 0}, scal;
+    if (e.per_rate)
+    {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rs[k] = xrs[k][lane];
+      scal = min(min(rs[0], rs[1]), min(rs[2], rs[3]));
+    }
+    else
+      scal = xrs[0][lane];
+    const int inv = e.invariant ? e.invariant[n] : -1;
+    double terma = 0.0, terminv = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      double tr = xtr[k][lane];
+      const unsigned fi = e.fidx[k];
+      if (e.per_rate)
+      {
+        const unsigned ex = min(rs[k] - scal, PLLGPU_RATE_MAXDIFF);
+        if (ex) tr *= minlh(ex);
+      }
+      const double pinv = e.prop_invar ? e.prop_invar[fi] : 0.0;
+      const double w = e.rate_weights[k];
+      if (pinv > 0.0)
+      {
+        terma += w * tr * (1.0 - pinv);
+        if (inv >= 0) terminv += w * e.freqs[(size_t)fi * 4 + inv] * pinv;
+      }
+      else
+        terma += tr * w;
+    }
+    double site = 0.0;
+    if (valid)
+    {
+      site = finish_site(terma, terminv, scal, 0) * (double)e.pattern_weights[n];
+      if (e.persite) e.persite[n] = site;
+    }
+    const double tile_sum = wave_sum(site);
+    if (lane == 0)
+    {
+      partial_store(&e.block_sums[blockIdx.x], tile_sum); // kernels_common.h: no fences in the hand-off
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned ticket = __hip_atomic_fetch_add(e.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = (ticket == gridDim.x - 1) ? 1u : 0u;
+    }
+  }
+  __syncthreads();
+  if (!last) return;
+  // k_edge_dna's summation tree: workgroups of four tiles (wave sums added in wave order), then the
+  // partials strided over 256 threads (publish_block_sum)
+  const unsigned wave = threadIdx.x >> 6;
+  const unsigned site_tiles = (e.sites + 63u) / 64u, nblocks = (site_tiles + 3u) / 4u;
+  double a = 0.0;
+  for (unsigned i = threadIdx.x; i < nblocks; i += blockDim.x)
+  {
+    double sblk = partial_load(&e.block_sums[4u * i]);
+#pragma unroll
+    for (unsigned w = 1; w < 4u; ++w) sblk += (4u * i + w < site_tiles) ? partial_load(&e.block_sums[4u * i + w]) : 0.0;
+    a += sblk;
+  }
+  a = wave_sum(a);
+  if (lane == 0) ws[wave] = a;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    double t = ws[0];
+    for (unsigned w = 1; w < 4u; ++w) t += ws[w];
+    __hip_atomic_store(e.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(e.result, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the value is in host memory before the sequence word follows
+    __hip_atomic_store(e.result + 1, e.sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+template <int SM, bool C0, bool S1, bool C1>
+__global__ __launch_bounds__(256) void k_edge_dna_chain_pack(const DevEdge e, const ChainPack pack, unsigned entries)
+{
+  chain_edge_body<SM, C0, S1, C1>(e, ChainSrcPack{pack}, pack.heads[0], pack.heads[1], entries);
+}
+
+template <int SM, bool C0, bool S1, bool C1>
+__global__ __launch_bounds__(256) void k_edge_dna_chain(const DevEdge e, const ChainHead hp, const ChainHead hc, const ChainStepLoad *loads,
+                                                        const ChainStepOp *ops, unsigned entries)
+{
+  ChainSrcMem src;
+  src.heads = nullptr;
+  src.loads = (cstepload_p)(uintptr_t)loads;
+  src.ops = (cstepop_p)(uintptr_t)ops;
+  chain_edge_body<SM, C0, S1, C1>(e, src, hp, hc, entries);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -131,6 +131,7 @@ struct pllgpu_ctx
   bool chains = false;           // DNA: chain plans (k_partials_dna_chain) for dependency-only op lists
   bool any_aos = false;          // a class-compressed CLV exists (site repeats): no chain plans
   struct ChainPlan *plan = nullptr; // the last chain plan, re-launched as is when the same list comes again
+  bool chain_held = false;          // the plan's last stage has not been launched yet (chain tail, kernels_dna.h)
   DevBuf<unsigned char> chain_dev;  // its descriptors
 };
 
@@ -291,6 +292,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   c->deferred.clear(); // results nobody will ask for
+  c->chain_held = false;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   drop_chain_plan(c);
   c->chain_dev.release();
@@ -341,9 +343,9 @@ static int flush_deferred(pllgpu_ctx *c);
 #define CHECK_CTX_KEEP(c)                    \
   if (!(c)) return fail(PLLGPU_EINVAL, "null context"); \
   if (int rc_ = use(c)) return rc_
-#define CHECK_CTX(c)                         \
-  CHECK_CTX_KEEP(c);                         \
-  if (!(c)->deferred.empty())                \
+#define CHECK_CTX(c)                                   \
+  CHECK_CTX_KEEP(c);                                   \
+  if (!(c)->deferred.empty() || (c)->chain_held)       \
     if (int rc_ = flush_deferred(c)) return rc_
 
 extern "C" int pllgpu_clv_reserve(pllgpu_ctx_t *c, unsigned node, unsigned entries)
@@ -1060,7 +1062,11 @@ struct ChainPlan
   std::vector<ChainHead> heads;
   std::vector<ChainStepLoad> loads;
   std::vector<ChainStepOp> sops;
+  std::vector<unsigned> head_top_clv;  // per head: what its last step produces
+  std::vector<int> head_top_scaler;
+  std::vector<unsigned char> head_variant;
   bool in_kernarg = false;             // every stage fits a ChainPack
+  size_t held_from = 0;                // stages[held_from ..) = the last stage when it may be held for the edge evaluation
   unsigned launches = 0;
   double bytes = 0.0;
 };
@@ -1071,78 +1077,100 @@ static void drop_chain_plan(pllgpu_ctx *c)
   c->plan = nullptr;
 }
 
-static int launch_chain_plan(pllgpu_ctx *c, const ChainPlan &pl)
+// one launch over the heads [first_head, first_head + nchains) of a plan
+static void launch_chain_heads(pllgpu_ctx *c, const ChainPlan &pl, unsigned first_head, unsigned nchains, unsigned variant)
 {
-  for (const CCLaunch &l : pl.cc)
-    if (int rc = launch_cc(c, l.pack, l.n, l.entries, l.lk, CK_FCC)) return rc;
   const unsigned tiles = (pl.entries + 63) / 64;
-  const unsigned char *base = c->chain_dev.p;
-  const size_t heads_bytes = pl.heads.size() * sizeof(ChainHead), loads_bytes = pl.loads.size() * sizeof(ChainStepLoad);
-  for (const ChainLaunchRec &st : pl.stages)
+  dim3 grid(tiles, nchains), block(256); // a workgroup = one 64-site tile, wave k = rate category k
+  if (pl.in_kernarg)
   {
-    dim3 grid(tiles, st.nchains), block(256); // a workgroup = one 64-site tile, wave k = rate category k
-    if (pl.in_kernarg)
+    ChainPack pack;
+    memset(&pack, 0, sizeof pack);
+    unsigned ns = 0;
+    for (unsigned h = 0; h < nchains; ++h)
     {
-      ChainPack pack;
-      memset(&pack, 0, sizeof pack);
-      unsigned ns = 0;
-      for (unsigned h = 0; h < st.nchains; ++h)
-      {
-        ChainHead hd = pl.heads[st.first_head + h];
-        memcpy(&pack.loads[ns], &pl.loads[hd.first], (hd.nsteps + 1) * sizeof(ChainStepLoad)); // + the disabled terminal step
-        memcpy(&pack.ops[ns], &pl.sops[hd.first], (hd.nsteps + 1) * sizeof(ChainStepOp));
-        hd.first = ns;
-        ns += hd.nsteps + 1;
-        pack.heads[h] = hd;
-      }
+      ChainHead hd = pl.heads[first_head + h];
+      memcpy(&pack.loads[ns], &pl.loads[hd.first], (hd.nsteps + 1) * sizeof(ChainStepLoad)); // + the terminal step
+      memcpy(&pack.ops[ns], &pl.sops[hd.first], (hd.nsteps + 1) * sizeof(ChainStepOp));
+      hd.first = ns;
+      ns += hd.nsteps + 1;
+      pack.heads[h] = hd;
+    }
 #define CHAIN_PACK(SMV, C0, S1, C1) hipLaunchKernelGGL((k_partials_dna_chain_pack<SMV, C0, S1, C1>), grid, block, 0, c->stream, pack, pl.entries)
-#define CHAIN_PACK_V(SMV)                         \
-  switch (st.variant)                             \
-  {                                               \
+#define CHAIN_PACK_V(SMV)                              \
+  switch (variant)                                     \
+  {                                                    \
   case 0: CHAIN_PACK(SMV, false, false, false); break; \
   case 1: CHAIN_PACK(SMV, false, true, false); break;  \
   case 2: CHAIN_PACK(SMV, true, false, false); break;  \
   default: CHAIN_PACK(SMV, true, true, true); break;   \
   }
-      if (c->gg.scale_mode == 2)
-      {
-        CHAIN_PACK_V(2)
-      }
-      else
-      {
-        CHAIN_PACK_V(1)
-      }
-#undef CHAIN_PACK_V
-#undef CHAIN_PACK
+    if (c->gg.scale_mode == 2)
+    {
+      CHAIN_PACK_V(2)
     }
     else
     {
-      const ChainHead *hp = reinterpret_cast<const ChainHead *>(base) + st.first_head;
-      const ChainStepLoad *lp = reinterpret_cast<const ChainStepLoad *>(base + heads_bytes);
-      const ChainStepOp *op = reinterpret_cast<const ChainStepOp *>(base + heads_bytes + loads_bytes);
+      CHAIN_PACK_V(1)
+    }
+#undef CHAIN_PACK_V
+#undef CHAIN_PACK
+  }
+  else
+  {
+    const unsigned char *base = c->chain_dev.p;
+    const size_t heads_bytes = pl.heads.size() * sizeof(ChainHead), loads_bytes = pl.loads.size() * sizeof(ChainStepLoad);
+    const ChainHead *hp = reinterpret_cast<const ChainHead *>(base) + first_head;
+    const ChainStepLoad *lp = reinterpret_cast<const ChainStepLoad *>(base + heads_bytes);
+    const ChainStepOp *op = reinterpret_cast<const ChainStepOp *>(base + heads_bytes + loads_bytes);
 #define CHAIN_MEM(SMV, C0, S1, C1) hipLaunchKernelGGL((k_partials_dna_chain<SMV, C0, S1, C1>), grid, block, 0, c->stream, hp, lp, op, pl.entries)
-#define CHAIN_MEM_V(SMV)                         \
-  switch (st.variant)                            \
-  {                                              \
+#define CHAIN_MEM_V(SMV)                              \
+  switch (variant)                                    \
+  {                                                   \
   case 0: CHAIN_MEM(SMV, false, false, false); break; \
   case 1: CHAIN_MEM(SMV, false, true, false); break;  \
   case 2: CHAIN_MEM(SMV, true, false, false); break;  \
   default: CHAIN_MEM(SMV, true, true, true); break;   \
   }
-      if (c->gg.scale_mode == 2)
-      {
-        CHAIN_MEM_V(2)
-      }
-      else
-      {
-        CHAIN_MEM_V(1)
-      }
+    if (c->gg.scale_mode == 2)
+    {
+      CHAIN_MEM_V(2)
+    }
+    else
+    {
+      CHAIN_MEM_V(1)
+    }
 #undef CHAIN_MEM_V
 #undef CHAIN_MEM
-    }
   }
-  c->last_launches = pl.launches;
+}
+
+// the whole plan, or - hold = true - everything but its last stage, which stays with the context until
+// the next call shows whether it is the evaluation of the edge those chains end in
+static int launch_chain_plan(pllgpu_ctx *c, const ChainPlan &pl, bool hold)
+{
+  for (const CCLaunch &l : pl.cc)
+    if (int rc = launch_cc(c, l.pack, l.n, l.entries, l.lk, CK_FCC)) return rc;
+  const size_t upto = hold ? pl.held_from : pl.stages.size();
+  for (size_t i = 0; i < upto; ++i) launch_chain_heads(c, pl, pl.stages[i].first_head, pl.stages[i].nchains, pl.stages[i].variant);
+  c->chain_held = hold && upto < pl.stages.size();
+  c->last_launches = pl.launches - (unsigned)(pl.stages.size() - upto);
   c->last_bytes = pl.bytes;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PLLGPU_ERUNTIME, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+static int launch_held_chains(pllgpu_ctx *c)
+{
+  if (!c->chain_held || !c->plan) return 0;
+  c->chain_held = false;
+  const ChainPlan &pl = *c->plan;
+  for (size_t i = pl.held_from; i < pl.stages.size(); ++i)
+  {
+    launch_chain_heads(c, pl, pl.stages[i].first_head, pl.stages[i].nchains, pl.stages[i].variant);
+    ++c->last_launches;
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PLLGPU_ERUNTIME, "kernel launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -1152,12 +1180,12 @@ static int launch_chain_plan(pllgpu_ctx *c, const ChainPlan &pl)
 static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count, bool &used)
 {
   used = false;
-  if (!c->chains || !c->fuse || count < 3 || c->any_aos) return 0;
+  if (!c->chains || !c->fuse || count < 4 || c->any_aos) return 0; // up to three ops the level scheduler + tail kernel is as fast (tools/path_latency.py)
   if (c->plan && c->plan->epoch == g_alloc_epoch.load(std::memory_order_relaxed) && c->plan->key.size() == count &&
       memcmp(c->plan->key.data(), ops, count * sizeof(pllgpu_op_t)) == 0)
   {
     used = true;
-    return launch_chain_plan(c, *c->plan);
+    return launch_chain_plan(c, *c->plan, c->defer_tail);
   }
   const unsigned entries = ops[0].parent_entries;
   if (entries == 0 || aos_entries(c, entries) || (size_t)entries * 128u >= ((size_t)1 << 31)) return 0; // 32-bit buffer offsets
@@ -1330,6 +1358,7 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
   for (const PChain &ch : chains) max_stage = std::max(max_stage, ch.stage);
   pl->entries = entries;
   pl->in_kernarg = true;
+  pl->held_from = (size_t)-1;
   // what a chain's steps have to fetch decides the kernel variant it runs under (kernels_dna.h)
   auto variant_of = [&](const PChain &ch) -> unsigned {
     bool c0 = false, s1 = false, c1 = false;
@@ -1394,7 +1423,9 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
         so.mat_sib = b ? dev[i].rmat : dev[i].lmat;
         so.p_bytes = clv_bytes;
         so.psc_bytes = so.pscaler ? sc_bytes : 0u;
-        if ((!top || stream_tops) && !getenv("PLL_AMD_CHAIN_PLAIN")) ld.flags |= kChStream;
+        // the tops of the last stage are the ends of the edge evaluated next (from registers, chain tail):
+        // nobody reads them back soon either
+        if (!top || stream_tops || (c->defer_tail && st == max_stage && !getenv("PLL_AMD_CHAIN_PLAIN_TOPS"))) ld.flags |= kChStream;
         bool read_sib = true;
         if (is_chain_op(i, b) && absorb[i])
         {
@@ -1434,9 +1465,21 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
         ++stage_steps;
       }
       pl->heads.push_back(hd);
+      pl->head_top_clv.push_back(ops[ch.ops[0]].parent_clv);
+      pl->head_top_scaler.push_back(ops[ch.ops[0]].parent_scaler);
+      pl->head_variant.push_back((unsigned char)variant);
     }
-    if (rec.nchains > (unsigned)kChainPackHeads || stage_steps > (unsigned)kChainPackSteps) pl->in_kernarg = false;
+    if (st == max_stage && pl->held_from == (size_t)-1) pl->held_from = pl->stages.size();
+    if (rec.nchains > (unsigned)kChainPackHeads || stage_steps + 1 > (unsigned)kChainPackSteps) pl->in_kernarg = false; // + 1: a chain of no steps in the tail
     pl->stages.push_back(rec);
+  }
+  {
+    // the last stage may wait for the edge evaluation if it is at most the two ends of an edge and the
+    // tail kernel can reproduce k_edge_dna's summation order (one tile per wave there: <= 4096 tiles)
+    if (pl->held_from == (size_t)-1) pl->held_from = pl->stages.size();
+    unsigned held_chains = 0;
+    for (size_t i = pl->held_from; i < pl->stages.size(); ++i) held_chains += pl->stages[i].nchains;
+    if (held_chains > 2 || (c->geo.sites + 63) / 64 > 4096u) pl->held_from = pl->stages.size();
   }
   pl->bytes += c->last_bytes; // the cherry-cherry groups (build_cc_launches counted them)
   pl->launches = (unsigned)(pl->cc.size() + pl->stages.size());
@@ -1465,12 +1508,13 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
   drop_chain_plan(c);
   c->plan = pl;
   used = true;
-  return launch_chain_plan(c, *pl);
+  return launch_chain_plan(c, *pl, c->defer_tail);
 }
 
 // launch the held ops as ordinary updates (they are mutually independent: one level)
 static int flush_deferred(pllgpu_ctx *c)
 {
+  if (int rc = launch_held_chains(c)) return rc;
   std::vector<pllgpu_op_t> ops;
   ops.swap(c->deferred);
   for (unsigned kind = 0; kind < 3; ++kind)
@@ -1688,8 +1732,73 @@ static int launch_edge_tail(pllgpu_ctx *c, const DevEdge &e, const TailCall &t, 
   return fail(PLLGPU_EINVAL, "no tail kernel for end kinds (%d, %d)", t.kp, t.kc);
 }
 
+// chain tail (kernels_dna.h: k_edge_dna_chain): the two ends of the edge as chains - held ones, or chains of
+// no steps around a CLV / tip that is in HBM
+struct ChainTailCall
+{
+  ChainHead hp, hc;
+  unsigned variant;
+  bool in_kernarg;
+  ChainPack pack; // in_kernarg: heads[0] = hp, heads[1] = hc and their steps
+};
+
+static void launch_edge_chain(pllgpu_ctx *c, const DevEdge &e, const ChainTailCall &t)
+{
+  const ChainPlan &pl = *c->plan;
+  dim3 grid((pl.entries + 63) / 64), block(256);
+  if (t.in_kernarg)
+  {
+#define EC(SMV, C0, S1, C1) hipLaunchKernelGGL((k_edge_dna_chain_pack<SMV, C0, S1, C1>), grid, block, 0, c->stream, e, t.pack, pl.entries)
+#define EC_V(SMV)                              \
+  switch (t.variant)                           \
+  {                                            \
+  case 0: EC(SMV, false, false, false); break; \
+  case 1: EC(SMV, false, true, false); break;  \
+  case 2: EC(SMV, true, false, false); break;  \
+  default: EC(SMV, true, true, true); break;   \
+  }
+    if (c->gg.scale_mode == 2)
+    {
+      EC_V(2)
+    }
+    else
+    {
+      EC_V(1)
+    }
+#undef EC_V
+#undef EC
+  }
+  else
+  {
+    const unsigned char *base = c->chain_dev.p;
+    const size_t heads_bytes = pl.heads.size() * sizeof(ChainHead), loads_bytes = pl.loads.size() * sizeof(ChainStepLoad);
+    const ChainStepLoad *lp = reinterpret_cast<const ChainStepLoad *>(base + heads_bytes);
+    const ChainStepOp *op = reinterpret_cast<const ChainStepOp *>(base + heads_bytes + loads_bytes);
+#define EC(SMV, C0, S1, C1) hipLaunchKernelGGL((k_edge_dna_chain<SMV, C0, S1, C1>), grid, block, 0, c->stream, e, t.hp, t.hc, lp, op, pl.entries)
+#define EC_V(SMV)                              \
+  switch (t.variant)                           \
+  {                                            \
+  case 0: EC(SMV, false, false, false); break; \
+  case 1: EC(SMV, false, true, false); break;  \
+  case 2: EC(SMV, true, false, false); break;  \
+  default: EC(SMV, true, true, true); break;   \
+  }
+    if (c->gg.scale_mode == 2)
+    {
+      EC_V(2)
+    }
+    else
+    {
+      EC_V(1)
+    }
+#undef EC_V
+#undef EC
+  }
+}
+
 static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsigned *freqs_indices,
-                   double *persite_host, double *lnl_out, double *device_result = nullptr, const TailCall *tail = nullptr)
+                   double *persite_host, double *lnl_out, double *device_result = nullptr, const TailCall *tail = nullptr,
+                   const ChainTailCall *ctail = nullptr)
 {
   const pllgpu_geometry_t &g = c->geo;
   for (unsigned k = 0; k < g.rate_cats; ++k)
@@ -1739,6 +1848,11 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
       if (gather) EM(false, true); else EM(false, false);
     }
 #undef EM
+  }
+  else if (c->dna_fast && ctail)
+  {
+    launch_edge_chain(c, e, *ctail);
+    ++c->last_launches;
   }
   else if (c->dna_fast && tail)
   {
@@ -1826,6 +1940,35 @@ extern "C" int pllgpu_edge_loglikelihood(pllgpu_ctx_t *c, const pllgpu_edge_t *e
   // kernel; whatever else is held goes out as ordinary updates first
   TailCall tail;
   bool use_tail = false;
+  int held_p = -1, held_c = -1; // heads of the held chains that end in this edge's parent / child end
+  if (c->chain_held)
+  {
+    const ChainPlan &pl = *c->plan;
+    if (c->dna_fast && !ed->gather)
+      for (size_t i = pl.held_from; i < pl.stages.size(); ++i)
+        for (unsigned h = pl.stages[i].first_head; h < pl.stages[i].first_head + pl.stages[i].nchains; ++h)
+        {
+          if (pl.head_top_clv[h] == ed->parent_clv && pl.head_top_scaler[h] == ed->parent_scaler) held_p = (int)h;
+          else if (!ed->child_is_tip && pl.head_top_clv[h] == ed->child_clv && pl.head_top_scaler[h] == ed->child_scaler) held_c = (int)h;
+        }
+    if (held_p < 0 && held_c < 0)
+    {
+      if (int rc = launch_held_chains(c)) return rc;
+    }
+    else
+    {
+      // whatever else is held goes out as an ordinary chain launch
+      c->chain_held = false;
+      for (size_t i = pl.held_from; i < pl.stages.size(); ++i)
+        for (unsigned h = pl.stages[i].first_head; h < pl.stages[i].first_head + pl.stages[i].nchains; ++h)
+          if ((int)h != held_p && (int)h != held_c)
+          {
+            launch_chain_heads(c, pl, h, 1, pl.stages[i].variant);
+            ++c->last_launches;
+          }
+      if (int rc = c->block_sums.ensure((pl.entries + 63) / 64)) return rc;
+    }
+  }
   if (!c->deferred.empty())
   {
     int ia = -1, ib = -1;
@@ -1891,6 +2034,69 @@ extern "C" int pllgpu_edge_loglikelihood(pllgpu_ctx_t *c, const pllgpu_edge_t *e
   }
   e.is_root = 0;
   if (ed->device_result && persite_host) return fail(PLLGPU_EINVAL, "per-site values are not available from an asynchronous evaluation");
+  if (held_p >= 0 || held_c >= 0)
+  {
+    const ChainPlan &pl = *c->plan;
+    ChainTailCall ct;
+    memset(&ct.hp, 0, sizeof ct.hp);
+    memset(&ct.hc, 0, sizeof ct.hc);
+    const unsigned clv_bytes = (unsigned)(clv_elems(c, pl.entries) * sizeof(double));
+    const unsigned sc_bytes = pl.entries * (c->gg.scale_mode == 2 ? 16u : 4u);
+    const unsigned any_end = pl.heads[0].first + pl.heads[0].nsteps; // a CS_END step: what a chain of no steps "fetches"
+    if (held_p >= 0)
+      ct.hp = pl.heads[held_p];
+    else
+    {
+      ct.hp.acc0.data = e.parent;
+      ct.hp.acc0.scaler = e.pscaler;
+      ct.hp.bacc.clv = clv_bytes;
+      ct.hp.bacc.aux = e.pscaler ? sc_bytes : 0u;
+      ct.hp.first = any_end;
+    }
+    if (held_c >= 0)
+      ct.hc = pl.heads[held_c];
+    else if (ed->child_is_tip)
+    {
+      ct.hc.acc0.data = e.ctip;
+      ct.hc.bacc.aux = (pl.entries + 3u) & ~3u;
+      ct.hc.acc_tip = 1u;
+      ct.hc.first = any_end;
+    }
+    else
+    {
+      ct.hc.acc0.data = e.child;
+      ct.hc.acc0.scaler = e.cscaler;
+      ct.hc.bacc.clv = clv_bytes;
+      ct.hc.bacc.aux = e.cscaler ? sc_bytes : 0u;
+      ct.hc.first = any_end;
+    }
+    const int vp = held_p >= 0 ? (int)pl.head_variant[held_p] : -1, vc = held_c >= 0 ? (int)pl.head_variant[held_c] : -1;
+    ct.variant = (unsigned)((vp < 0) ? vc : (vc < 0) ? vp : (vp == vc ? vp : 3));
+    ct.in_kernarg = pl.in_kernarg;
+    if (ct.in_kernarg)
+    {
+      memset(&ct.pack, 0, sizeof ct.pack);
+      unsigned ns = 0;
+      ChainHead *hh[2] = {&ct.hp, &ct.hc};
+      const int held[2] = {held_p, held_c};
+      for (int k = 0; k < 2; ++k)
+      {
+        const unsigned nst = held[k] >= 0 ? hh[k]->nsteps : 0u;
+        if (ns + nst + 1 > (unsigned)kChainPackSteps) return fail(PLLGPU_ERUNTIME, "chain tail does not fit its descriptor pack");
+        if (held[k] >= 0)
+        {
+          memcpy(&ct.pack.loads[ns], &pl.loads[hh[k]->first], (nst + 1) * sizeof(ChainStepLoad));
+          memcpy(&ct.pack.ops[ns], &pl.sops[hh[k]->first], (nst + 1) * sizeof(ChainStepOp));
+        }
+        else
+          ct.pack.loads[ns].flags = CS_END;
+        hh[k]->first = ns;
+        ns += nst + 1;
+        ct.pack.heads[k] = *hh[k];
+      }
+    }
+    return run_lnl(c, e, ed->child_is_tip != 0, false, ed->freqs_indices, persite_host, lnl_out, ed->device_result, nullptr, &ct);
+  }
   if (use_tail)
   {
     // memory-side descriptors of the ends that were NOT held
@@ -1935,7 +2141,7 @@ extern "C" void *pllgpu_get_stream(const pllgpu_ctx_t *cc)
 {
   // a caller who asks for the stream is about to order its own work against ours: nothing may be held back
   pllgpu_ctx *c = const_cast<pllgpu_ctx *>(cc);
-  if (c && !c->deferred.empty() && use(c) == 0) (void)flush_deferred(c);
+  if (c && (!c->deferred.empty() || c->chain_held) && use(c) == 0) (void)flush_deferred(c);
   return c ? (void *)c->stream : nullptr;
 }
 
@@ -1956,7 +2162,7 @@ extern "C" int pllgpu_timer_start(pllgpu_ctx_t *c)
 extern "C" double pllgpu_timer_stop(pllgpu_ctx_t *c)
 {
   if (!c || use(c)) return -1.0;
-  if (!c->deferred.empty() && flush_deferred(c)) return -1.0;
+  if ((!c->deferred.empty() || c->chain_held) && flush_deferred(c)) return -1.0;
   float ms = 0;
   if (hipEventRecord(c->ev1, c->stream) != hipSuccess || hipEventSynchronize(c->ev1) != hipSuccess ||
       hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess)

@@ -332,10 +332,11 @@ def test_dna_without_fusion(amd_lib, kw, monkeypatch):
 
 def test_fusion_plan_on_a_balanced_tree(amd_lib, monkeypatch):
     """64 taxa, full traversal: 8 groups of seven ops (complete 8-tip subtrees: four cherries, two ops
-    above them, one above those) and the top six ops as two chains = 2 launches instead of 5; without
-    the two-level groups a chain plan needs 3 stages. PLL_AMD_NO_CHAINS=1 brings back the level
-    scheduler with its groups: 16 (tt, tt -> ii) groups, 4 (ii, ii -> ii) groups and the two root-side
-    ops, which are held for the edge evaluation (tail fusion)."""
+    above them, one above those) in one launch; the top six ops are two chains that end in the two
+    ends of the root edge - they are held for the edge evaluation and run inside it (chain tail): 2
+    launches for traversal + log-likelihood. Without the two-level groups a chain plan needs 3 stages.
+    PLL_AMD_NO_CHAINS=1 brings back the level scheduler with its groups: 16 (tt, tt -> ii) groups,
+    4 (ii, ii -> ii) groups and the two root-side ops, which are held for the edge evaluation."""
     import os
     if os.environ.get("PLL_AMD_EAGER_MIRROR", "0") not in ("", "0"):
         pytest.skip("eager mirroring launches the held ops right away: launch counts differ")
@@ -345,10 +346,11 @@ def test_fusion_plan_on_a_balanced_tree(amd_lib, monkeypatch):
     def full_and_partial(first, per_site_range, partial):
         with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
             s.update_partials()
-            assert amd_lib.pll_gpu_last_launch_count(s.p) == first
+            assert amd_lib.pll_gpu_last_launch_count(s.p) == first  # the last stage is held
             per_site = amd_lib.pll_gpu_last_algorithmic_bytes(s.p) / 640
             assert per_site_range[0] < per_site < per_site_range[1], per_site
             v, _ = s.edge_lnl(case.edges[0], persite=False)
+            assert amd_lib.pll_gpu_last_launch_count(s.p) == first + 1  # ... and runs inside the lnL kernel
             assert abs(v - exp["lnl"][0]) <= RTOL * abs(v)
             ii = [op for op in case.op_batches[0] if op[2] >= 64 and op[5] >= 64]
             arr = api.make_ops(ii)
@@ -356,17 +358,19 @@ def test_fusion_plan_on_a_balanced_tree(amd_lib, monkeypatch):
             assert amd_lib.pll_gpu_last_launch_count(s.p) == partial
             again, _ = s.edge_lnl(case.edges[0], persite=False)
             assert again == v
-            # the same list once more: the cached plan is launched as it is
+            # the same list once more: the cached plan is launched as it is; a root evaluation instead of
+            # the edge makes the held chains run as ordinary launches
             amd_lib.pll_update_partials(s.p, arr, len(ii))
             assert amd_lib.pll_gpu_last_launch_count(s.p) == partial
+            r = s.root_lnl((case.edges[0][0], case.edges[0][1]))[0]
             again, _ = s.edge_lnl(case.edges[0], persite=False)
             assert again == v
-            return v
+            return v, r
 
     # 8 x (8 B + 7 CLVs + scalers) + 2 x (4 CLVs in, 3 out); the 30 inner x inner ops: two stages
-    v0 = full_and_partial(2, (8800, 9900), 2)
+    v0, r0 = full_and_partial(1, (8800, 9900), 1)
     monkeypatch.setenv("PLL_AMD_NO_FUSE_CC", "1")
-    v1 = full_and_partial(3, (9000, 12000), 2)
+    v1, r1 = full_and_partial(2, (9000, 12000), 1)
     monkeypatch.setenv("PLL_AMD_NO_CHAINS", "1")
     with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
         s.update_partials()
@@ -375,12 +379,14 @@ def test_fusion_plan_on_a_balanced_tree(amd_lib, monkeypatch):
         assert 10000 < per_site < 11200, per_site
         v2, _ = s.edge_lnl(case.edges[0], persite=False)
         assert amd_lib.pll_gpu_last_launch_count(s.p) == 3  # ... and evaluated inside the lnL kernel
+        r2 = s.root_lnl((case.edges[0][0], case.edges[0][1]))[0]
     monkeypatch.delenv("PLL_AMD_NO_FUSE_CC")
     with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
         s.update_partials()
         assert amd_lib.pll_gpu_last_launch_count(s.p) == 2  # 8 groups of seven, 2 groups of three
         v3, _ = s.edge_lnl(case.edges[0], persite=False)
     assert v0 == v1 == v2 == v3
+    assert r0 == r1 == r2
 
 
 @pytest.mark.parametrize("tree,taxa,sites,launches", [("caterpillar", 64, 1000, 1), ("caterpillar", 600, 130, 1), ("random", 64, 1000, 4),
