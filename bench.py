@@ -177,9 +177,14 @@ def main():
     os.environ.setdefault("PLL_AMD_DEVICE", "0" if same_device else str(local))
     dist = None
     torch = None
-    if world > 1 or os.environ.get("PLL_BENCH_FORCE_DIST") == "1":  # FORCE_DIST: rehearse the collective path at world 1
+    dist_mode = world > 1 or os.environ.get("PLL_BENCH_FORCE_DIST") == "1"
+    if dist_mode:  # FORCE_DIST: rehearse the collective path at world 1
         import torch
         import torch.distributed as dist
+        # RCCL prints a version banner on stdout when it initialises: keep stdout for the one JSON line
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
@@ -401,6 +406,9 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    if dist_mode:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
     if rank == 0:
         print(json.dumps(out))
 
