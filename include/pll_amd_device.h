@@ -223,6 +223,16 @@ unsigned int pllgpu_last_launch_count(const pllgpu_ctx_t *ctx);
  * (child reads + parent and scaler writes of every launch as it was grouped) */
 double pllgpu_last_algorithmic_bytes(const pllgpu_ctx_t *ctx);
 
+/* Test hook, host logic only (no device is touched): how pllgpu_update_partials partitions a
+ * 4-state x 4-rate op list - classified and level-sorted like the ones the host layer hands over -
+ * into chains. Returns the number of launch stages, or 0 when the list does not
+ * qualify (anything but producer -> consumer dependencies: it goes through the level scheduler).
+ * Per op (arrays of `count`, any may be NULL): stage = the launch it runs in (1-based);
+ * chain = its chain's number, -1 for a member of a seven-op group, -2 for an op formed on the fly as
+ * another chain's sibling; form = 0 top of a chain, 1 lower step, 2 formed on the fly, 3 group member. */
+int pllgpu_debug_chain_plan(const pllgpu_op_t *ops, unsigned int count, unsigned int nodes, unsigned int scale_buffers, int fuse_cc,
+                            unsigned int *stage, int *chain, unsigned char *form);
+
 #ifdef __cplusplus
 }
 #endif

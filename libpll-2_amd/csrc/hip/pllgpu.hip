@@ -778,14 +778,13 @@ static int child_kind(const pllgpu_op_t &prod)
   return (lt && rt) ? CK_FTT : lt ? CK_FTI : CK_FII;
 }
 
-static void plan_fusion(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count, std::vector<int> &role,
+static void plan_fusion(bool fuse, bool fuse_cc, unsigned nodes, const pllgpu_op_t *ops, unsigned count, std::vector<int> &role,
                         std::vector<FusedGroup> &groups, bool cc_only = false)
 {
   // role: 0 plain, 1 parent of a group, 2 fused into a group as a child
   role.assign(count, 0);
   groups.clear();
-  if (!c->fuse) return;
-  const unsigned nodes = c->geo.nodes;
+  if (!fuse) return;
   std::vector<int> producer(nodes, -1), prod_l(count, -1), prod_r(count, -1);
   std::vector<unsigned> eff(count);
   // ops arrive sorted by level; same-level ops are independent, so the producer table may be
@@ -800,7 +799,7 @@ static void plan_fusion(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count, s
   // first pass: parents of complete cherry-cherry subtrees (kind CK_FCC, kernels_dna.h): P two levels
   // above the cherries, its child A an inner x inner op between them. Everything moves to the
   // cherries' level, so neither A's nor P's outputs may be touched by an earlier op from there on.
-  if (c->fuse_cc)
+  if (fuse_cc)
     for (unsigned i = 0; i < count; ++i)
     {
       const pllgpu_op_t &P = ops[i];
@@ -1176,31 +1175,38 @@ static int launch_held_chains(pllgpu_ctx *c)
   return 0;
 }
 
-// returns 0 and sets used = true when the list was planned and launched as chains
-static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count, bool &used)
+struct PChain
 {
-  used = false;
-  if (!c->chains || !c->fuse || count < 4 || c->any_aos) return 0; // up to three ops the level scheduler + tail kernel is as fast (tools/path_latency.py)
-  if (c->plan && c->plan->epoch == g_alloc_epoch.load(std::memory_order_relaxed) && c->plan->key.size() == count &&
-      memcmp(c->plan->key.data(), ops, count * sizeof(pllgpu_op_t)) == 0)
-  {
-    used = true;
-    return launch_chain_plan(c, *c->plan, c->defer_tail);
-  }
-  const unsigned entries = ops[0].parent_entries;
-  if (entries == 0 || aos_entries(c, entries) || (size_t)entries * 128u >= ((size_t)1 << 31)) return 0; // 32-bit buffer offsets
-  const unsigned nodes = c->geo.nodes, nsb = c->geo.scale_buffers;
+  std::vector<unsigned> ops; // top first
+  unsigned stage;
+};
+
+struct ChainPartition
+{
+  std::vector<int> pr_of[2];  // producer op of the left / right child, or -1
+  std::vector<int> role;      // != 0: member of a cherry-cherry group (plan_fusion)
+  std::vector<FusedGroup> groups;
+  std::vector<unsigned> S;    // launch stage of every chain op
+  std::vector<unsigned char> acc_side, absorb, form; // form: 0 top of a chain, 1 step below the next op of its chain, 2 formed on the fly as a sibling
+  std::vector<int> chain_of;
+  std::vector<PChain> chains;
+};
+
+// host logic only (no device state): does the list qualify, and how is it partitioned
+static bool partition_chains(const pllgpu_op_t *ops, unsigned count, unsigned nodes, unsigned nsb, unsigned entries, bool fuse_cc, ChainPartition &P)
+{
   // ---- is the list dependency-only?
-  std::vector<int> producer(nodes, -1), sc_writer(nsb, -1), consumers(count, 0), pr_of[2];
+  std::vector<int> producer(nodes, -1), sc_writer(nsb, -1), consumers(count, 0);
+  std::vector<int> (&pr_of)[2] = P.pr_of;
   pr_of[0].assign(count, -1);
   pr_of[1].assign(count, -1);
   for (unsigned i = 0; i < count; ++i)
   {
     const pllgpu_op_t &o = ops[i];
-    if ((o.flags & PLLGPU_OP_GATHER) || o.parent_entries != entries || o.war_level >= 0 || o.left_clv == o.right_clv) return 0;
-    if ((o.flags & PLLGPU_OP_RIGHT_TIP) && !(o.flags & PLLGPU_OP_LEFT_TIP)) return 0; // the level path reports it
-    if (o.parent_clv >= nodes || o.left_clv >= nodes || o.right_clv >= nodes || producer[o.parent_clv] >= 0) return 0;
-    if (o.parent_scaler >= (int)nsb || o.left_scaler >= (int)nsb || o.right_scaler >= (int)nsb) return 0;
+    if ((o.flags & PLLGPU_OP_GATHER) || o.parent_entries != entries || o.war_level >= 0 || o.left_clv == o.right_clv) return false;
+    if ((o.flags & PLLGPU_OP_RIGHT_TIP) && !(o.flags & PLLGPU_OP_LEFT_TIP)) return false; // the level path reports it
+    if (o.parent_clv >= nodes || o.left_clv >= nodes || o.right_clv >= nodes || producer[o.parent_clv] >= 0) return false;
+    if (o.parent_scaler >= (int)nsb || o.left_scaler >= (int)nsb || o.right_scaler >= (int)nsb) return false;
     const unsigned kid[2] = {o.left_clv, o.right_clv};
     const int ksc[2] = {o.left_scaler, o.right_scaler};
     const bool tip[2] = {(o.flags & PLLGPU_OP_LEFT_TIP) != 0, (o.flags & PLLGPU_OP_RIGHT_TIP) != 0};
@@ -1210,27 +1216,29 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
       const int pr = producer[kid[sd]];
       if (pr >= 0)
       {
-        if (++consumers[pr] > 1 || ops[pr].parent_scaler != ksc[sd]) return 0;
+        if (++consumers[pr] > 1 || ops[pr].parent_scaler != ksc[sd]) return false;
         pr_of[sd][i] = pr;
       }
       else if (ksc[sd] >= 0 && sc_writer[ksc[sd]] >= 0)
-        return 0; // a stored CLV paired with a scaler this list rewrites
+        return false; // a stored CLV paired with a scaler this list rewrites
     }
     producer[o.parent_clv] = (int)i;
     if (o.parent_scaler >= 0)
     {
-      if (sc_writer[o.parent_scaler] >= 0) return 0;
+      if (sc_writer[o.parent_scaler] >= 0) return false;
       sc_writer[o.parent_scaler] = (int)i;
     }
   }
   // a tip child whose codes were replaced by a dense CLV arrives as an inner child: nothing to do here
-  ChainPlan *pl = new ChainPlan();
-  std::vector<int> role;
-  std::vector<FusedGroup> groups;
-  plan_fusion(c, ops, count, role, groups, true); // cherry-cherry groups only
+  std::vector<int> &role = P.role;
+  std::vector<FusedGroup> &groups = P.groups;
+  plan_fusion(true, fuse_cc, nodes, ops, count, role, groups, true); // cherry-cherry groups only
   // ---- stages, bottom-up
-  std::vector<unsigned> S(count, 0);
-  std::vector<unsigned char> acc_side(count, 0), absorb(count, 0);
+  std::vector<unsigned> &S = P.S;
+  std::vector<unsigned char> &acc_side = P.acc_side, &absorb = P.absorb;
+  S.assign(count, 0);
+  acc_side.assign(count, 0);
+  absorb.assign(count, 0);
   auto leaf_ready = [&](unsigned i, int sd) -> unsigned { // stage after which a non-chain child exists in HBM
     const int pr = pr_of[sd][i];
     return (pr >= 0 && role[pr] != 0) ? 1u : 0u; // cherry-cherry groups run in stage 1
@@ -1264,6 +1272,7 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
         {
           ab = true;
           req_b = A;
+          cost += 2u; // all else equal, a chain is continued rather than started next to an op formed on the fly
         }
         else
         {
@@ -1289,14 +1298,12 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
   }
   // ---- partition, top-down: form 0 = top of a chain (default), 1 = step below the next op of its chain, 2 = formed
   // on the fly as a sibling
-  std::vector<unsigned char> form(count, 0);
-  std::vector<int> chain_of(count, -1);
-  struct PChain
-  {
-    std::vector<unsigned> ops; // top first
-    unsigned stage;
-  };
-  std::vector<PChain> chains;
+  std::vector<unsigned char> &form = P.form;
+  std::vector<int> &chain_of = P.chain_of;
+  std::vector<PChain> &chains = P.chains;
+  form.assign(count, 0);
+  chain_of.assign(count, -1);
+  chains.clear();
   for (unsigned ii = count; ii-- > 0;)
   {
     const unsigned i = ii;
@@ -1315,6 +1322,57 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
     }
     if (is_chain_op(i, b) && absorb[i]) form[pr_of[b][i]] = 2;
   }
+  return true;
+}
+
+extern "C" int pllgpu_debug_chain_plan(const pllgpu_op_t *ops, unsigned count, unsigned nodes, unsigned scale_buffers, int fuse_cc,
+                                       unsigned *stage, int *chain, unsigned char *form)
+{
+  if (!ops || count == 0) return 0;
+  ChainPartition P;
+  if (!partition_chains(ops, count, nodes, scale_buffers, ops[0].parent_entries, fuse_cc != 0, P)) return 0;
+  unsigned stages = 0;
+  for (unsigned i = 0; i < count; ++i)
+  {
+    const bool member = P.role[i] != 0;
+    unsigned st = member ? 1u : P.S[i];
+    if (!member && P.chain_of[i] >= 0) st = P.chains[P.chain_of[i]].stage; // a chain runs where its top runs
+    if (!member && P.form[i] == 2)
+      for (unsigned j = i + 1; j < count; ++j) // the step that forms it on the fly
+        if (P.role[j] == 0 && P.absorb[j] && P.pr_of[1 - P.acc_side[j]][j] == (int)i) st = P.chains[P.chain_of[j]].stage;
+    if (stage) stage[i] = st;
+    if (chain) chain[i] = member ? -1 : (P.form[i] == 2 ? -2 : P.chain_of[i]);
+    if (form) form[i] = member ? 3 : P.form[i];
+    stages = std::max(stages, st);
+  }
+  return (int)stages;
+}
+
+// returns 0 and sets used = true when the list was planned and launched as chains
+static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count, bool &used)
+{
+  used = false;
+  if (!c->chains || !c->fuse || count < 4 || c->any_aos) return 0; // up to three ops the level scheduler + tail kernel is as fast (tools/path_latency.py)
+  if (c->plan && c->plan->epoch == g_alloc_epoch.load(std::memory_order_relaxed) && c->plan->key.size() == count &&
+      memcmp(c->plan->key.data(), ops, count * sizeof(pllgpu_op_t)) == 0)
+  {
+    used = true;
+    return launch_chain_plan(c, *c->plan, c->defer_tail);
+  }
+  const unsigned entries = ops[0].parent_entries;
+  if (entries == 0 || aos_entries(c, entries) || (size_t)entries * 128u >= ((size_t)1 << 31)) return 0; // 32-bit buffer offsets
+  const unsigned nodes = c->geo.nodes, nsb = c->geo.scale_buffers;
+  ChainPartition part;
+  if (!partition_chains(ops, count, nodes, nsb, entries, c->fuse_cc, part)) return 0;
+  ChainPlan *pl = new ChainPlan();
+  std::vector<int> (&pr_of)[2] = part.pr_of;
+  std::vector<int> &role = part.role;
+  std::vector<FusedGroup> &groups = part.groups;
+  std::vector<unsigned> &S = part.S;
+  std::vector<unsigned char> &acc_side = part.acc_side, &absorb = part.absorb;
+  std::vector<PChain> &chains = part.chains;
+  auto is_chain_op = [&](unsigned i, int sd) { return pr_of[sd][i] >= 0 && role[pr_of[sd][i]] == 0; };
+  (void)S;
   // ---- descriptors: resolve every op once, in list order (a producer's buffers exist before its consumer looks)
   std::vector<DevOp> dev(count);
   c->last_bytes = 0.0;
@@ -1551,7 +1609,7 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
   }
   std::vector<int> role;
   std::vector<FusedGroup> groups;
-  plan_fusion(c, ops, count, role, groups);
+  plan_fusion(c->fuse, c->fuse_cc, c->geo.nodes, ops, count, role, groups);
   // tail fusion: the plain ops of the last level (at most two: the ends of the edge a caller evaluates
   // next) are accepted but not launched yet - role 3
   if (c->defer_tail && count)
