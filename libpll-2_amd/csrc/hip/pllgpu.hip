@@ -1483,7 +1483,7 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
         so.psc_bytes = so.pscaler ? sc_bytes : 0u;
         // the tops of the last stage are the ends of the edge evaluated next (from registers, chain tail):
         // nobody reads them back soon either
-        if (!top || stream_tops || (c->defer_tail && st == max_stage && !getenv("PLL_AMD_CHAIN_PLAIN_TOPS"))) ld.flags |= kChStream;
+        if (!top || stream_tops || (c->defer_tail && st == max_stage)) ld.flags |= kChStream;
         bool read_sib = true;
         if (is_chain_op(i, b) && absorb[i])
         {
