@@ -338,8 +338,8 @@ def test_fusion_plan_on_a_balanced_tree(amd_lib, monkeypatch):
     PLL_AMD_NO_CHAINS=1 brings back the level scheduler with its groups: 16 (tt, tt -> ii) groups,
     4 (ii, ii -> ii) groups and the two root-side ops, which are held for the edge evaluation."""
     import os
-    if os.environ.get("PLL_AMD_EAGER_MIRROR", "0") not in ("", "0"):
-        pytest.skip("eager mirroring launches the held ops right away: launch counts differ")
+    if os.environ.get("PLL_AMD_EAGER_MIRROR", "0") not in ("", "0") or os.environ.get("PLL_AMD_NO_TIP_CODES", "0") not in ("", "0"):
+        pytest.skip("eager mirroring launches the held ops right away, dense tips have no seven-op groups: launch counts differ")
     case = W.make_case("plan", 4, 64, 640, seed=97)
     exp = O.run_case(case)
 
@@ -403,7 +403,9 @@ def test_chain_plans(amd_lib, monkeypatch, tree, taxa, sites, launches, per_rate
     chained = driver.run_case(amd_lib, case, api.ARCH_AVX2)
     with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
         s.update_partials()
-        assert amd_lib.pll_gpu_last_launch_count(s.p) <= launches
+        import os
+        if all(os.environ.get(v, "0") in ("", "0") for v in ("PLL_AMD_EAGER_MIRROR", "PLL_AMD_NO_TIP_CODES")):
+            assert amd_lib.pll_gpu_last_launch_count(s.p) <= launches
     monkeypatch.setenv("PLL_AMD_NO_FUSE", "1")
     plain = driver.run_case(amd_lib, case, api.ARCH_AVX2)
     exp = O.run_case(case)
