@@ -242,7 +242,6 @@ static bool partition_chains(const pllgpu_op_t *ops, unsigned count, unsigned no
         {
           ab = true;
           req_b = A;
-          cost += 2u; // all else equal, a chain is continued rather than started next to an op formed on the fly
         }
         else
         {
@@ -407,12 +406,14 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
     if (c1 || (c0 && s1)) return 3u;
     return c0 ? 2u : s1 ? 1u : 0u;
   };
+  std::vector<unsigned> chain_variant(chains.size());
+  for (unsigned k = 0; k < chains.size(); ++k) chain_variant[k] = variant_of(chains[k]);
   for (unsigned st = 1; st <= max_stage; ++st)
    for (unsigned variant = 0; variant < 4; ++variant)
   {
     std::vector<unsigned> ids;
     for (unsigned k = 0; k < chains.size(); ++k)
-      if (chains[k].stage == st && variant_of(chains[k]) == variant) ids.push_back(k);
+      if (chains[k].stage == st && chain_variant[k] == variant) ids.push_back(k);
     if (ids.empty()) continue;
     // the longest chains first: their workgroups are dispatched first
     std::stable_sort(ids.begin(), ids.end(), [&](unsigned x, unsigned y) { return chains[x].ops.size() > chains[y].ops.size(); });

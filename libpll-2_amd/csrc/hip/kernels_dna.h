@@ -1031,21 +1031,33 @@ struct ChainSrcPack
   __device__ __forceinline__ ChainStepOp op(unsigned s) const { return pack.ops[s]; }
 };
 
-// one chain for this wave's (tile, rate): its top CLV values and scaler count are left in acc / sca
-template <int SM, bool C0, bool S1, bool C1, class SRC>
-__device__ __forceinline__ void chain_run(const SRC &src, const ChainHead &h, const ChainGeo &g, double (&acc)[4], unsigned &sca,
-                                          unsigned long long (*ballots)[4])
+// A chain for this wave's (tile, rate) in two parts, so that a kernel that walks two chains can have
+// the second one's first loads in flight while it walks the first:
+//   chain_begin - issue the loads of the child that rides in registers and the first step's fetch
+//   chain_steps - walk the steps; the top CLV values and scaler count are left in acc / sca
+struct ChainStart
 {
-  ChainRaw ra, rb;
-  unsigned fa, fb = 0u;
-  {
-    unsigned side;
-    chain_leaf_issue<SM, true>(h.acc0, h.bacc, h.acc_tip != 0u, g, acc, side);
-    const ChainStepLoad l0 = src.load(h.first);
-    fa = l0.flags;
-    chain_issue<SM, C0, S1, C1>(l0, g, ra);
-    sca = chain_leaf_finish(h.acc_tip != 0u, side, g.n, acc);
-  }
+  ChainRaw ra;
+  unsigned fa, side;
+};
+
+template <int SM, bool C0, bool S1, bool C1, class SRC>
+__device__ __forceinline__ void chain_begin(const SRC &src, const ChainHead &h, const ChainGeo &g, double (&acc)[4], ChainStart &st)
+{
+  chain_leaf_issue<SM, true>(h.acc0, h.bacc, h.acc_tip != 0u, g, acc, st.side);
+  const ChainStepLoad l0 = src.load(h.first);
+  st.fa = l0.flags;
+  chain_issue<SM, C0, S1, C1>(l0, g, st.ra);
+}
+
+template <int SM, bool C0, bool S1, bool C1, class SRC>
+__device__ __forceinline__ void chain_steps(const SRC &src, const ChainHead &h, const ChainGeo &g, double (&acc)[4], unsigned &sca, ChainStart &st,
+                                            unsigned long long (*ballots)[4])
+{
+  ChainRaw &ra = st.ra;
+  ChainRaw rb;
+  unsigned fa = st.fa, fb = 0u;
+  sca = chain_leaf_finish(h.acc_tip != 0u, st.side, g.n, acc);
   // two steps per trip: the fetch buffers swap roles instead of being copied; the next step's loads are
   // in flight while the current one is computed and stored. The descriptor list of a chain ends with
   // a CS_END step whose sizes are all 0: the last trip's fetch.
@@ -1071,6 +1083,15 @@ __device__ __forceinline__ void chain_run(const SRC &src, const ChainHead &h, co
       chain_step<SM>(o, fb, g, rb, acc, sca, ballots, s + 1);
     }
   }
+}
+
+template <int SM, bool C0, bool S1, bool C1, class SRC>
+__device__ __forceinline__ void chain_run(const SRC &src, const ChainHead &h, const ChainGeo &g, double (&acc)[4], unsigned &sca,
+                                          unsigned long long (*ballots)[4])
+{
+  ChainStart st;
+  chain_begin<SM, C0, S1, C1>(src, h, g, acc, st);
+  chain_steps<SM, C0, S1, C1>(src, h, g, acc, sca, st, ballots);
 }
 
 __device__ __forceinline__ ChainGeo chain_geo(unsigned entries)
@@ -1138,8 +1159,15 @@ __device__ __forceinline__ void chain_edge_body(const DevEdge &e, const SRC src,
   const unsigned lane = threadIdx.x & 63u;
   double vp[4], vc[4];
   unsigned scp, scc;
-  chain_run<SM, C0, S1, C1>(src, hp, g, vp, scp, ballots);
-  chain_run<SM, C0, S1, C1>(src, hc, g, vc, scc, ballots);
+  {
+    // both ends' first loads go out before either chain is walked: the child end's would otherwise queue up
+    // behind the parent end's last stores
+    ChainStart sp, sc;
+    chain_begin<SM, C0, S1, C1>(src, hp, g, vp, sp);
+    chain_begin<SM, C0, S1, C1>(src, hc, g, vc, sc);
+    chain_steps<SM, C0, S1, C1>(src, hp, g, vp, scp, sp, ballots);
+    chain_steps<SM, C0, S1, C1>(src, hc, g, vc, scc, sc, ballots);
+  }
   {
     double tb[4];
     dna_matvec(tb, as_const(e.mat) + g.rate * 16u, vc);

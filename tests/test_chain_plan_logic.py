@@ -103,7 +103,8 @@ def test_ladder_is_one_chain(hook, tips):
     arr = classify(ops, tips)
     stages, stage, chain, form = plan(hook, arr, tips)
     assert stages == 1
-    assert len(set(chain)) == 1 and form.count(0) == 1
+    # one chain; its first cherry may be the op that the second step forms on the fly (equal cost)
+    assert len(set(c for c in chain if c >= 0)) == 1 and form.count(0) == 1 and form.count(2) <= 1
     check_invariants(arr, tips, stages, stage, chain, form)
 
 
