@@ -390,7 +390,7 @@ def test_fusion_plan_on_a_balanced_tree(amd_lib, monkeypatch):
 
 
 @pytest.mark.parametrize("tree,taxa,sites,launches", [("caterpillar", 64, 1000, 1), ("caterpillar", 600, 130, 1), ("random", 64, 1000, 4),
-                                                       ("random", 300, 257, 8), ("balanced", 512, 70, 12)])
+                                                       ("random", 300, 257, 8), ("balanced", 512, 70, 12), ("random", 1500, 64, 12)])
 @pytest.mark.parametrize("per_rate", [False, True], ids=["site-scalers", "rate-scalers"])
 def test_chain_plans(amd_lib, monkeypatch, tree, taxa, sites, launches, per_rate):
     """Irregular trees: the ops are partitioned into chains (k_partials_dna_chain), a ladder of any
