@@ -47,15 +47,46 @@ __device__ __forceinline__ void dna_fetch(double (&x)[4], const double *__restri
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 constexpr unsigned kAosLeft = 1u, kAosRight = 2u, kAosParent = 4u;
 
-// x[j] of (entry, rate k) from an entry-contiguous CLV: `entry` points at the entry's 16 doubles
-__device__ __forceinline__ void dna_fetch_aos(double (&x)[4], const double *__restrict__ entry, unsigned k)
+// The 64 entries a wave needs from an entry-contiguous CLV, fetched COOPERATIVELY: eight lanes share
+// an entry (16 bytes each), so one load instruction covers eight whole 128-byte entries and every
+// line is requested once. (With each lane walking its own entry, the eight instructions of a child
+// touch the same 64 lines again and again and lean on the 16 KB vector cache, which two children of
+// four or five waves overrun.) issue: the loads; finish: through the wave's LDS buffer ([entry][kAosRow])
+// to x[rate][state] of the lane's own entry.
+struct DnaCoop
 {
-  const dbl2 *p = reinterpret_cast<const dbl2 *>(entry + k * 4);
-  const dbl2 a = __builtin_nontemporal_load(p), b = __builtin_nontemporal_load(p + 1);
-  x[0] = a.x;
-  x[1] = a.y;
-  x[2] = b.x;
-  x[3] = b.y;
+  dbl2 piece[8];
+};
+
+__device__ __forceinline__ void dna_coop_issue(DnaCoop &c, const double *__restrict__ clv, unsigned entry, unsigned lane)
+{
+  const unsigned sub = lane & 7u, grp = lane >> 3;
+#pragma unroll
+  for (unsigned q = 0; q < 8; ++q)
+  {
+    const unsigned e = __shfl(entry, q * 8u + grp, 64);
+    c.piece[q] = __builtin_nontemporal_load(reinterpret_cast<const dbl2 *>(clv + (size_t)e * 16) + sub);
+  }
+}
+
+__device__ __forceinline__ void dna_coop_finish(const DnaCoop &c, double *mine /* this wave's LDS buffer */, unsigned lane, unsigned row, double (&x)[4][4])
+{
+  const unsigned sub = lane & 7u, grp = lane >> 3;
+  __builtin_amdgcn_wave_barrier(); // earlier readers of the buffer are done (LDS ops of a wave stay in order)
+#pragma unroll
+  for (unsigned q = 0; q < 8; ++q) *reinterpret_cast<dbl2 *>(mine + (q * 8u + grp) * row + sub * 2u) = c.piece[q];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const dbl2 *r = reinterpret_cast<const dbl2 *>(mine + lane * row);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    const dbl2 a = r[2 * k], b = r[2 * k + 1];
+    x[k][0] = a.x;
+    x[k][1] = a.y;
+    x[k][2] = b.x;
+    x[k][3] = b.y;
+  }
 }
 
 // r[i] = sum_j PT[k][j][i] * x[j], coefficients through the scalar path
@@ -106,16 +137,32 @@ __global__ __launch_bounds__(256) void k_partials_dna(const OpPack pack, int sca
 
     double v[4][4];
     bool small[4];
+    double cl[4][4], cr[4][4]; // entry-contiguous children (GATHER): all 16 values through the cooperative fetch
+    if (GATHER)
+    {
+      DnaCoop pl, pr;
+      double *mine = transpose + (size_t)wave * 64 * kAosRow;
+      if (!LTIP && laos) dna_coop_issue(pl, op.left, le, lane);
+      if (!RTIP && raos) dna_coop_issue(pr, op.right, re, lane);
+      if (!LTIP && laos) dna_coop_finish(pl, mine, lane, kAosRow, cl);
+      if (!RTIP && raos) dna_coop_finish(pr, mine, lane, kAosRow, cr);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
       double xl[4], xr[4], a[4], b[4];
-      if (!LTIP && laos)
-        dna_fetch_aos(xl, lx, k);
+      if (GATHER && !LTIP && laos)
+      {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xl[j] = cl[k][j];
+      }
       else
         dna_fetch<LTIP>(xl, lx, k, lcode);
-      if (!RTIP && raos)
-        dna_fetch_aos(xr, rx, k);
+      if (GATHER && !RTIP && raos)
+      {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xr[j] = cr[k][j];
+      }
       else
         dna_fetch<RTIP>(xr, rx, k, rcode);
       dna_matvec(a, lm + k * 16, xl);
@@ -215,6 +262,7 @@ __global__ __launch_bounds__(256) void k_partials_dna(const OpPack pack, int sca
 template <bool CTIP, bool GATHER>
 __global__ __launch_bounds__(256) void k_edge_dna(const DevEdge e, unsigned tiles_per_wave)
 {
+  __shared__ double transpose[GATHER ? 4 * 64 * kAosRow : 1]; // entry-contiguous ends: cooperative fetch (dna_coop_issue)
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned ntiles = (e.sites + 63u) / 64u;
@@ -252,13 +300,27 @@ __global__ __launch_bounds__(256) void k_edge_dna(const DevEdge e, unsigned tile
       scal = (e.pscaler ? e.pscaler[pe] : 0u) + (e.cscaler ? e.cscaler[ce] : 0u);
     const int inv = e.invariant ? e.invariant[nn] : -1;
 
+    double cp[4][4], cc[4][4];
+    if (GATHER)
+    {
+      DnaCoop qp, qc;
+      double *mine = transpose + (size_t)wave * 64 * kAosRow;
+      const bool cfetch = !CTIP && !e.is_root && caos;
+      if (paos) dna_coop_issue(qp, e.parent, pe, lane);
+      if (cfetch) dna_coop_issue(qc, e.child, ce, lane);
+      if (paos) dna_coop_finish(qp, mine, lane, kAosRow, cp);
+      if (cfetch) dna_coop_finish(qc, mine, lane, kAosRow, cc);
+    }
     double terma = 0.0, terminv = 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
       double xp[4], xc[4], tb[4];
-      if (paos)
-        dna_fetch_aos(xp, px, k);
+      if (GATHER && paos)
+      {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xp[j] = cp[k][j];
+      }
       else
         dna_fetch<false>(xp, px, k, 0u);
       if (e.is_root)
@@ -268,8 +330,11 @@ __global__ __launch_bounds__(256) void k_edge_dna(const DevEdge e, unsigned tile
       }
       else
       {
-        if (!CTIP && caos)
-          dna_fetch_aos(xc, cx, k);
+        if (GATHER && !CTIP && caos)
+        {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xc[j] = cc[k][j];
+        }
         else
           dna_fetch<CTIP>(xc, cx, k, ccode);
         dna_matvec(tb, pm + k * 16, xc);
