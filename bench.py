@@ -44,6 +44,8 @@ CONFIGS = {
     "c3": dict(states=20, tips=64, sites=50000, desc="20-state protein (LG)+G4, 64 taxa, 50k sites"),
     "c5": dict(states=61, tips=32, sites=20000, desc="61-state codon stand-in +G4, 32 taxa, 20k sites"),
     # configs[3]: 1M sites over 8 GPUs = 125k sites per GPU, PLL_ATTRIB_SITE_REPEATS
+    # not a BASELINE configuration: C3's shape with PLL_ATTRIB_SITE_REPEATS (what the any-state gather path costs)
+    "c3r": dict(states=20, tips=64, sites=50000, repeats=True, desc="20-state protein (LG)+G4, 64 taxa, 50k sites, SITE_REPEATS"),
     "c4": dict(states=4, tips=128, sites=125000, repeats=True,
                desc="4-state DNA GTR+G4, 128 taxa, 125k-site shard of the 1M-site alignment, SITE_REPEATS"),
 }
