@@ -642,9 +642,11 @@ static void launch_generic(pllgpu_ctx *c, const OpPack &pack, unsigned nops, uns
   const unsigned tip_lds = stage ? 1u : 0u;
   const size_t lds = stage ? (size_t)2 * nw * (c->gg.S + 1u) * (c->gg.SPT | 1u) * sizeof(double) : 0;
   // staged tip matrices are shared by the tiles of a workgroup: several tiles each, as long as
-  // ~4096 workgroups remain
+  // ~2048 workgroups remain
   unsigned tpb = 1;
-  if (stage) tpb = std::max(1u, std::min(8u, (unsigned)(((size_t)tiles * nops) / 4096u)));
+  // (staging costs a workgroup about as much as four tiles of work: C3's 32-op launch 259 us with up to 8
+  // tiles per workgroup and >= 4096 workgroups, 247 us with up to 16 and >= 2048, 268 us with 32 / 1024)
+  if (stage) tpb = std::max(1u, std::min(16u, (unsigned)(((size_t)tiles * nops) / 2048u)));
   dim3 grid((tiles + tpb - 1) / tpb, nops), block(64u * nw);
 #define GEN_LAUNCH(LT, RT, GA) \
   hipLaunchKernelGGL((k_partials_tiled<ICH, LT, RT, GA>), grid, block, lds, c->stream, pack, c->gg, tm, tip_lds, tpb)
