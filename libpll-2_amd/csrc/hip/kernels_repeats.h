@@ -7,8 +7,9 @@
 // without the sequential walk:
 //   1. table[cell] = min over the sites that map to the cell            (k_rep_mark, atomicMin)
 //   2. a site is a class representative iff table[cell(site)] == site; the class number of a
-//      representative is the count of representatives before it         (k_rep_count, k_rep_scan,
-//                                                                        k_rep_rank: prefix sum)
+//      representative is the count of representatives before it         (k_rep_count: per workgroup;
+//                                                                        k_rep_rank: prefix over the
+//                                                                        workgroups before it + own)
 //   3. site_id[site] = class number of table[cell(site)]                (k_rep_assign)
 // Integer work only: the maps are bit-identical to the reference's. All ops of one dependency level
 // go through each kernel together (grid.y = op); every op owns a slice of the table, cleared with
@@ -27,7 +28,7 @@ struct RepOp
   unsigned *pids;        // out: class -> first site           [<= sites]
   unsigned *lent, *rent; // out: class -> entry of the left / right child (what the gather kernels want)
   unsigned *rank;        // scratch [sites]: class number of a representative site
-  unsigned *blocksum;    // scratch [nblk]: representatives per workgroup, then their exclusive scan
+  unsigned *blocksum;    // scratch [nblk]: representatives per workgroup
   unsigned nleft;        // classes of the left child
   unsigned tab_off;      // first cell of this op's table slice
 };
@@ -37,6 +38,10 @@ struct RepPack
   RepOp ops[kRepOps];
   unsigned *table;
   unsigned *counts;      // out [nops]: classes per op
+  unsigned *host_counts; // the same in host-mapped memory, followed by ...
+  unsigned *host_seq;    // ... the sequence word the host polls (written last)
+  unsigned *ticket;      // arrival counter of the ops' last workgroups (0 between calls)
+  unsigned sequence;
   unsigned sites;
   unsigned nblk;
 };
@@ -112,23 +117,6 @@ __global__ __launch_bounds__(256) void k_rep_count(const RepPack p)
   if (threadIdx.x == 0) o.blocksum[blockIdx.x] = total;
 }
 
-// one workgroup per op: exclusive scan of the per-workgroup counts in place, total -> counts[op]
-__global__ __launch_bounds__(256) void k_rep_scan(const RepPack p)
-{
-  const RepOp &o = p.ops[blockIdx.x];
-  unsigned carry = 0;
-  for (unsigned first = 0; first < p.nblk; first += 256u)
-  {
-    const unsigned i = first + threadIdx.x;
-    const unsigned v = i < p.nblk ? o.blocksum[i] : 0u;
-    unsigned total;
-    const unsigned ex = block_exclusive_scan(v, total);
-    if (i < p.nblk) o.blocksum[i] = carry + ex;
-    carry += total;
-  }
-  if (threadIdx.x == 0) p.counts[blockIdx.x] = carry;
-}
-
 __global__ __launch_bounds__(256) void k_rep_rank(const RepPack p)
 {
   const RepOp &o = p.ops[blockIdx.y];
@@ -142,8 +130,32 @@ __global__ __launch_bounds__(256) void k_rep_rank(const RepPack p)
     rep[q] = s < p.sites && p.table[rep_cell(o, s)] == s;
     n += rep[q] ? 1u : 0u;
   }
+  // representatives in the workgroups before this one (nblk is a few hundred: every workgroup adds them up itself)
+  __shared__ unsigned before_ws[4];
+  unsigned before = 0;
+  for (unsigned b = threadIdx.x; b < blockIdx.x; b += 256u) before += o.blocksum[b];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+  if ((threadIdx.x & 63u) == 0u) before_ws[threadIdx.x >> 6] = before;
+  __syncthreads();
+  before = before_ws[0] + before_ws[1] + before_ws[2] + before_ws[3];
   unsigned total;
-  unsigned r = o.blocksum[blockIdx.x] + block_exclusive_scan(n, total);
+  unsigned r = before + block_exclusive_scan(n, total);
+  if (blockIdx.x == p.nblk - 1u && threadIdx.x == 0u)
+  {
+    // the op's class count goes to the device array and straight to the host (mapped memory); the op
+    // that arrives last publishes the sequence word (hand-off without fences: kernels_common.h)
+    const unsigned cnt = before + total;
+    p.counts[blockIdx.y] = cnt;
+    __hip_atomic_store(&p.host_counts[blockIdx.y], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.y - 1u)
+    {
+      __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.host_seq, p.sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 #pragma unroll
   for (unsigned q = 0; q < 4; ++q)
     if (rep[q])

@@ -117,6 +117,9 @@ struct pllgpu_ctx
   DevBuf<unsigned> pattern_weights;
   DevBuf<int> invariant;
   bool invariant_set = false;
+  unsigned *rep_host = nullptr;  // pinned + mapped: class counts of a repeats batch [kRepOps], then the sequence word
+  unsigned *rep_host_dev = nullptr;
+  unsigned rep_seq = 0;
   double *result_host = nullptr; // pinned + mapped: [0] lnL, [1] sequence of the call that wrote it
   double seq = 0.0;
   std::vector<double> stage;     // host staging for the P-matrix re-layout
@@ -251,7 +254,9 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
             hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipHostMalloc((void **)&c->result_host, kResultBytes, hipHostMallocMapped) == hipSuccess &&
-            hipHostGetDevicePointer((void **)&c->result_dev, c->result_host, 0) == hipSuccess;
+            hipHostGetDevicePointer((void **)&c->result_dev, c->result_host, 0) == hipSuccess &&
+            hipHostMalloc((void **)&c->rep_host, (kRepOps + 2) * sizeof(unsigned), hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer((void **)&c->rep_host_dev, c->rep_host, 0) == hipSuccess;
   if (!ok)
   {
     fail(PLLGPU_ERUNTIME, "stream/event creation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -260,6 +265,7 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   }
   c->own_stream = true;
   c->result_host[0] = c->result_host[1] = 0.0;
+  memset(c->rep_host, 0, (kRepOps + 2) * sizeof(unsigned));
   c->clv.resize(geo->nodes);
   c->clv_aos.assign(geo->nodes, 0);
   c->scaler.resize(geo->scale_buffers);
@@ -328,6 +334,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->pattern_weights.release();
   c->invariant.release();
   if (c->result_host) (void)hipHostFree(c->result_host);
+  if (c->rep_host) (void)hipHostFree(c->rep_host);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1847,18 +1854,34 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     }
     pk.table = c->rep_table.p;
     pk.counts = c->rep_counts.p;
+    pk.host_counts = c->rep_host_dev;
+    pk.host_seq = c->rep_host_dev + kRepOps;
+    pk.ticket = c->counter.p + 2; // [0]: log-likelihood / derivative reductions
+    pk.sequence = ++c->rep_seq;
     pk.sites = sites;
     pk.nblk = nblk;
     HIP_TRY(hipMemsetAsync(c->rep_table.p, 0xFF, cells * sizeof(unsigned), c->stream));
     const dim3 grid(nblk, n), block(256);
     hipLaunchKernelGGL(k_rep_mark, grid, block, 0, c->stream, pk);
     hipLaunchKernelGGL(k_rep_count, grid, block, 0, c->stream, pk);
-    hipLaunchKernelGGL(k_rep_scan, dim3(n), block, 0, c->stream, pk);
     hipLaunchKernelGGL(k_rep_rank, grid, block, 0, c->stream, pk);
     hipLaunchKernelGGL(k_rep_assign, grid, block, 0, c->stream, pk);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(counts_out + done, c->rep_counts.p, n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // the class counts arrive in mapped host memory as soon as k_rep_rank knows them (k_rep_assign still runs;
+    // whatever uses the maps is ordered behind it by the stream): poll the sequence word for a bounded time
+    {
+      volatile unsigned *seq = c->rep_host + kRepOps;
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != pk.sequence)
+        if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50))
+        {
+          HIP_TRY(hipStreamSynchronize(c->stream));
+          break;
+        }
+      if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != pk.sequence) return fail(PLLGPU_ERUNTIME, "class counts did not arrive");
+      for (unsigned i = 0; i < n; ++i) counts_out[done + i] = c->rep_host[i];
+    }
     done += n;
   }
   return 0;
