@@ -249,6 +249,95 @@ double pll_compute_root_loglikelihood(pll_partition_t *partition, unsigned int c
                                       int scaler_index, const unsigned int *freqs_indices,
                                       double *persite_lnl);
 
+/* ---- the flat core seam of the hot path (src/pll.h:1049-1177 and :1295-1414; bodies in
+ * src/core_partials.c:48-1210, src/core_likelihood.c:24-1496) ----------------------------------
+ * Same signatures as the reference: raw HOST arrays in the layout `attrib` describes (PLL_ATTRIB_ARCH_*
+ * -> states_padded; PLL_ATTRIB_RATE_SCALERS -> [entry][rate] scalers). Every call wraps its arrays in a
+ * throw-away partition and runs the device path (csrc/host/core_seam.c): complete, but priced at an
+ * allocation and a PCIe round trip per call - use the partition-level functions above for speed.
+ * The lookup table of pll_core_create_lookup is private to its pair with pll_core_update_partial_tt,
+ * as in the reference (there: products per pair of tip states; here: the two matrices). */
+void pll_core_create_lookup(unsigned int states, unsigned int rate_cats, double *lookup, const double *left_matrix,
+                            const double *right_matrix, const pll_state_t *tipmap, unsigned int tipmap_size, unsigned int attrib);
+void pll_core_create_lookup_4x4(unsigned int rate_cats, double *lookup, const double *left_matrix, const double *right_matrix);
+void pll_core_update_partial_tt(unsigned int states, unsigned int sites, unsigned int rate_cats, double *parent_clv,
+                                unsigned int *parent_scaler, const unsigned char *left_tipchars, const unsigned char *right_tipchars,
+                                const pll_state_t *tipmap, unsigned int tipmap_size, const double *lookup, unsigned int attrib);
+void pll_core_update_partial_tt_4x4(unsigned int sites, unsigned int rate_cats, double *parent_clv, unsigned int *parent_scaler,
+                                    const unsigned char *left_tipchars, const unsigned char *right_tipchars, const double *lookup,
+                                    unsigned int attrib);
+void pll_core_update_partial_ti(unsigned int states, unsigned int sites, unsigned int rate_cats, double *parent_clv,
+                                unsigned int *parent_scaler, const unsigned char *left_tipchars, const double *right_clv,
+                                const double *left_matrix, const double *right_matrix, const unsigned int *right_scaler,
+                                const pll_state_t *tipmap, unsigned int tipmap_size, unsigned int attrib);
+void pll_core_update_partial_ti_4x4(unsigned int sites, unsigned int rate_cats, double *parent_clv, unsigned int *parent_scaler,
+                                    const unsigned char *left_tipchars, const double *right_clv, const double *left_matrix,
+                                    const double *right_matrix, const unsigned int *right_scaler, unsigned int attrib);
+void pll_core_update_partial_ii(unsigned int states, unsigned int sites, unsigned int rate_cats, double *parent_clv,
+                                unsigned int *parent_scaler, const double *left_clv, const double *right_clv,
+                                const double *left_matrix, const double *right_matrix, const unsigned int *left_scaler,
+                                const unsigned int *right_scaler, unsigned int attrib);
+void pll_core_update_partial_repeats(unsigned int states, unsigned int parent_sites, unsigned int left_sites, unsigned int right_sites,
+                                     unsigned int rate_cats, double *parent_clv, unsigned int *parent_scaler, const double *left_clv,
+                                     const double *right_clv, const double *left_matrix, const double *right_matrix,
+                                     const unsigned int *left_scaler, const unsigned int *right_scaler,
+                                     const unsigned int *parent_id_site, const unsigned int *left_site_id,
+                                     const unsigned int *right_site_id, double *bclv_buffer, unsigned int attrib);
+void pll_core_update_partial_repeats_generic(unsigned int states, unsigned int parent_sites, unsigned int left_sites,
+                                             unsigned int right_sites, unsigned int rate_cats, double *parent_clv,
+                                             unsigned int *parent_scaler, const double *left_clv, const double *right_clv,
+                                             const double *left_matrix, const double *right_matrix, const unsigned int *left_scaler,
+                                             const unsigned int *right_scaler, const unsigned int *parent_id_site,
+                                             const unsigned int *left_site_id, const unsigned int *right_site_id,
+                                             double *bclv_buffer, unsigned int attrib);
+void pll_core_update_partial_repeatsbclv_generic(unsigned int states, unsigned int parent_sites, unsigned int left_sites,
+                                                 unsigned int right_sites, unsigned int rate_cats, double *parent_clv,
+                                                 unsigned int *parent_scaler, const double *left_clv, const double *right_clv,
+                                                 const double *left_matrix, const double *right_matrix,
+                                                 const unsigned int *left_scaler, const unsigned int *right_scaler,
+                                                 const unsigned int *parent_id_site, const unsigned int *left_site_id,
+                                                 const unsigned int *right_site_id, double *bclv_buffer, unsigned int attrib);
+double pll_core_edge_loglikelihood_ii(unsigned int states, unsigned int sites, unsigned int rate_cats, const double *parent_clv,
+                                      const unsigned int *parent_scaler, const double *child_clv, const unsigned int *child_scaler,
+                                      const double *pmatrix, double *const *frequencies, const double *rate_weights,
+                                      const unsigned int *pattern_weights, const double *invar_proportion, const int *invar_indices,
+                                      const unsigned int *freqs_indices, double *persite_lnl, unsigned int attrib);
+double pll_core_edge_loglikelihood_ti(unsigned int states, unsigned int sites, unsigned int rate_cats, const double *parent_clv,
+                                      const unsigned int *parent_scaler, const unsigned char *tipchars, const pll_state_t *tipmap,
+                                      unsigned int tipmap_size, const double *pmatrix, double *const *frequencies,
+                                      const double *rate_weights, const unsigned int *pattern_weights, const double *invar_proportion,
+                                      const int *invar_indices, const unsigned int *freqs_indices, double *persite_lnl,
+                                      unsigned int attrib);
+double pll_core_edge_loglikelihood_ti_4x4(unsigned int sites, unsigned int rate_cats, const double *parent_clv,
+                                          const unsigned int *parent_scaler, const unsigned char *tipchars, const double *pmatrix,
+                                          double *const *frequencies, const double *rate_weights, const unsigned int *pattern_weights,
+                                          const double *invar_proportion, const int *invar_indices, const unsigned int *freqs_indices,
+                                          double *persite_lnl, unsigned int attrib);
+double pll_core_edge_loglikelihood_repeats(unsigned int states, unsigned int sites, const unsigned int child_sites, unsigned int rate_cats,
+                                           const double *parent_clv, const unsigned int *parent_scaler, const double *child_clv,
+                                           const unsigned int *child_scaler, const double *pmatrix, double **frequencies,
+                                           const double *rate_weights, const unsigned int *pattern_weights, const double *invar_proportion,
+                                           const int *invar_indices, const unsigned int *freqs_indices, double *persite_lnl,
+                                           const unsigned int *parent_site_id, const unsigned int *child_site_id, double *bclv,
+                                           unsigned int attrib);
+double pll_core_edge_loglikelihood_repeats_generic(unsigned int states, unsigned int sites, const unsigned int child_sites,
+                                                   unsigned int rate_cats, const double *parent_clv, const unsigned int *parent_scaler,
+                                                   const double *child_clv, const unsigned int *child_scaler, const double *pmatrix,
+                                                   double **frequencies, const double *rate_weights, const unsigned int *pattern_weights,
+                                                   const double *invar_proportion, const int *invar_indices,
+                                                   const unsigned int *freqs_indices, double *persite_lnl,
+                                                   const unsigned int *parent_site_id, const unsigned int *child_site_id, double *bclv,
+                                                   unsigned int attrib);
+double pll_core_root_loglikelihood(unsigned int states, unsigned int sites, unsigned int rate_cats, const double *clv,
+                                   const unsigned int *scaler, double *const *frequencies, const double *rate_weights,
+                                   const unsigned int *pattern_weights, const double *invar_proportion, const int *invar_indices,
+                                   const unsigned int *freqs_indices, double *persite_lnl, unsigned int attrib);
+double pll_core_root_loglikelihood_repeats(unsigned int states, unsigned int sites, unsigned int rate_cats, const double *clv,
+                                           const unsigned int *site_id, const unsigned int *scaler, double *const *frequencies,
+                                           const double *rate_weights, const unsigned int *pattern_weights,
+                                           const double *invar_proportion, const int *invar_indices, const unsigned int *freqs_indices,
+                                           double *persite_lnl, unsigned int attrib);
+
 /* ---- branch-length derivatives (src/pll.h:834-852, src/derivatives.c:239-418; SURVEY section 8
  * row f1). `sumtable` is the caller's buffer of sites*rate_cats*states_padded doubles, as in the
  * reference, but it is used as a HANDLE: pll_update_sumtable computes the table into HBM and

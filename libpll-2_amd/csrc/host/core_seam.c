@@ -1,0 +1,396 @@
+/* core_seam.c - the flat pll_core_* entry points of the hot path (reference: src/pll.h:1049-1177 CLV
+ * updates, :1295-1414 log-likelihoods; bodies in src/core_partials.c and src/core_likelihood.c).
+ *
+ * The reference's partition-level functions call these with pointers into the partition; a caller
+ * that uses them directly hands over raw HOST arrays. Each call here wraps the arrays in a throw-away
+ * partition (layout from the PLL_ATTRIB_ARCH_* bits of `attrib`, scaler mode from
+ * PLL_ATTRIB_RATE_SCALERS), runs the same device path as the partition-level API and copies the result
+ * back. Functionally complete; priced at an allocation and a PCIe round trip per call - the
+ * partition-level entry points are the ones to use for speed.
+ *
+ * Tip children (the `ti` / `tt` forms) arrive as encoded characters: their 0/1 indicator vectors are
+ * formed on the host and the update runs as inner x inner - the same arithmetic (a tip's vector is what
+ * the tip kernels multiply with too). The lookup table of the `tt` form is private to the pair
+ * pll_core_create_lookup / pll_core_update_partial_tt in the reference as well: here it carries the two
+ * matrices. Class-compressed operands (the `repeats` forms) are expanded through their id maps on
+ * the host. No CPU arithmetic on CLVs happens here: without a device every call fails loudly. */
+#include "pll_internal.h"
+#include <math.h>
+
+typedef struct
+{
+  pll_partition_t *p;
+  unsigned int span; /* doubles per entry in the caller's layout */
+} seam_t;
+
+static int seam_open(seam_t *s, unsigned int states, unsigned int entries, unsigned int rate_cats, unsigned int clvs,
+                     unsigned int matrices, unsigned int freq_sets, unsigned int attrib)
+{
+  const unsigned int attrs = (attrib & PLL_ATTRIB_ARCH_MASK) | (attrib & PLL_ATTRIB_RATE_SCALERS);
+  /* one (unused) tip: CLV k of the seam is clv[k + 1] of the partition, scale buffer k is scale_buffer[k] */
+  s->p = pll_partition_create(1, clvs, states, entries, freq_sets ? freq_sets : 1, matrices, rate_cats, clvs, attrs);
+  if (!s->p)
+  {
+    fprintf(stderr, "libpll_amd: pll_core_*: [%d] %s\n", pll_errno, pll_errmsg);
+    return 0;
+  }
+  s->span = s->p->states_padded * rate_cats;
+  return 1;
+}
+
+static void seam_close(seam_t *s)
+{
+  if (s->p) pll_partition_destroy(s->p);
+  s->p = NULL;
+}
+
+static size_t scaler_words(const pll_partition_t *p) { return (p->attributes & PLL_ATTRIB_RATE_SCALERS) ? p->rate_cats : 1u; }
+
+/* entry e of CLV `idx` <- entry src_entry of `clv` (or the whole vector when map == NULL) */
+static void seam_put_clv(seam_t *s, unsigned int idx, const double *clv, const unsigned int *scaler, unsigned int entries,
+                         const unsigned int *outer /* entry -> site or NULL */, const unsigned int *inner /* site -> source entry or NULL */)
+{
+  pll_partition_t *p = s->p;
+  const size_t sw = scaler_words(p);
+  for (unsigned int e = 0; e < entries; ++e)
+  {
+    unsigned int src = outer ? outer[e] : e;
+    if (inner) src = inner[src];
+    memcpy(p->clv[idx + 1] + (size_t)e * s->span, clv + (size_t)src * s->span, s->span * sizeof(double));
+    if (scaler) memcpy(p->scale_buffer[idx] + (size_t)e * sw, scaler + (size_t)src * sw, sw * sizeof(unsigned int));
+  }
+  pll_gpu_invalidate(p, PLL_GPU_DIRTY_CLV, (int)idx + 1);
+  if (scaler) pll_gpu_invalidate(p, PLL_GPU_DIRTY_SCALER, (int)idx);
+}
+
+/* CLV `idx` <- the indicator vectors of encoded tip characters */
+static void seam_put_tip(seam_t *s, unsigned int idx, const unsigned char *chars, const pll_state_t *tipmap, unsigned int entries)
+{
+  pll_partition_t *p = s->p;
+  const unsigned int sp = p->states_padded;
+  memset(p->clv[idx + 1], 0, (size_t)entries * s->span * sizeof(double));
+  for (unsigned int e = 0; e < entries; ++e)
+  {
+    const pll_state_t mask = tipmap ? tipmap[chars[e]] : (pll_state_t)chars[e];
+    for (unsigned int k = 0; k < p->rate_cats; ++k)
+      for (unsigned int j = 0; j < p->states; ++j)
+        if ((mask >> j) & 1) p->clv[idx + 1][(size_t)e * s->span + (size_t)k * sp + j] = 1.0;
+  }
+  pll_gpu_invalidate(p, PLL_GPU_DIRTY_CLV, (int)idx + 1);
+}
+
+static void seam_put_matrix(seam_t *s, unsigned int idx, const double *m)
+{
+  pll_partition_t *p = s->p;
+  memcpy(p->pmatrix[idx], m, (size_t)p->rate_cats * p->states * p->states_padded * sizeof(double));
+  pll_gpu_invalidate(p, PLL_GPU_DIRTY_PMATRIX, (int)idx);
+}
+
+/* clv[0] <- op(clv[1], clv[2]) and back to the caller */
+static void seam_update(seam_t *s, double *parent_clv, unsigned int *parent_scaler, int lscal, int rscal, unsigned int entries)
+{
+  pll_partition_t *p = s->p;
+  pll_operation_t op;
+  op.parent_clv_index = 1;
+  op.parent_scaler_index = parent_scaler ? 0 : PLL_SCALE_BUFFER_NONE;
+  op.child1_clv_index = 2;
+  op.child1_matrix_index = 0;
+  op.child1_scaler_index = lscal ? 1 : PLL_SCALE_BUFFER_NONE;
+  op.child2_clv_index = 3;
+  op.child2_matrix_index = 1;
+  op.child2_scaler_index = rscal ? 2 : PLL_SCALE_BUFFER_NONE;
+  pll_errno = 0;
+  pll_update_partials(p, &op, 1);
+  if (pll_errno || !pll_gpu_sync_clv(p, 1) || (parent_scaler && !pll_gpu_sync_scaler(p, 0)))
+  {
+    fprintf(stderr, "libpll_amd: pll_core_update_partial_*: [%d] %s\n", pll_errno, pll_errmsg);
+    return;
+  }
+  memcpy(parent_clv, p->clv[1], (size_t)entries * s->span * sizeof(double));
+  if (parent_scaler) memcpy(parent_scaler, p->scale_buffer[0], (size_t)entries * scaler_words(p) * sizeof(unsigned int));
+}
+
+void pll_core_update_partial_ii(unsigned int states, unsigned int sites, unsigned int rate_cats, double *parent_clv,
+                                unsigned int *parent_scaler, const double *left_clv, const double *right_clv,
+                                const double *left_matrix, const double *right_matrix, const unsigned int *left_scaler,
+                                const unsigned int *right_scaler, unsigned int attrib)
+{
+  seam_t s;
+  if (!seam_open(&s, states, sites, rate_cats, 3, 2, 1, attrib)) return;
+  seam_put_clv(&s, 1, left_clv, left_scaler, sites, NULL, NULL);
+  seam_put_clv(&s, 2, right_clv, right_scaler, sites, NULL, NULL);
+  seam_put_matrix(&s, 0, left_matrix);
+  seam_put_matrix(&s, 1, right_matrix);
+  seam_update(&s, parent_clv, parent_scaler, left_scaler != NULL, right_scaler != NULL, sites);
+  seam_close(&s);
+}
+
+void pll_core_update_partial_ti(unsigned int states, unsigned int sites, unsigned int rate_cats, double *parent_clv,
+                                unsigned int *parent_scaler, const unsigned char *left_tipchars, const double *right_clv,
+                                const double *left_matrix, const double *right_matrix, const unsigned int *right_scaler,
+                                const pll_state_t *tipmap, unsigned int tipmap_size, unsigned int attrib)
+{
+  (void)tipmap_size;
+  seam_t s;
+  if (!seam_open(&s, states, sites, rate_cats, 3, 2, 1, attrib)) return;
+  seam_put_tip(&s, 1, left_tipchars, tipmap, sites);
+  seam_put_clv(&s, 2, right_clv, right_scaler, sites, NULL, NULL);
+  seam_put_matrix(&s, 0, left_matrix);
+  seam_put_matrix(&s, 1, right_matrix);
+  seam_update(&s, parent_clv, parent_scaler, 0, right_scaler != NULL, sites);
+  seam_close(&s);
+}
+
+void pll_core_update_partial_ti_4x4(unsigned int sites, unsigned int rate_cats, double *parent_clv, unsigned int *parent_scaler,
+                                    const unsigned char *left_tipchars, const double *right_clv, const double *left_matrix,
+                                    const double *right_matrix, const unsigned int *right_scaler, unsigned int attrib)
+{
+  pll_core_update_partial_ti(4, sites, rate_cats, parent_clv, parent_scaler, left_tipchars, right_clv, left_matrix, right_matrix,
+                             right_scaler, NULL, 16, attrib);
+}
+
+/* doubles of one matrix in the caller's layout */
+static size_t matrix_doubles(unsigned int states, unsigned int rate_cats, unsigned int attrib)
+{
+  unsigned int sp = states;
+  const unsigned int arch = attrib & PLL_ATTRIB_ARCH_MASK;
+  if (arch == PLL_ATTRIB_ARCH_SSE) sp = (states + 1) & ~1u;
+  if (arch == PLL_ATTRIB_ARCH_AVX || arch == PLL_ATTRIB_ARCH_AVX2 || arch == PLL_ATTRIB_ARCH_AVX512) sp = (states + 3) & ~3u;
+  return (size_t)rate_cats * states * sp;
+}
+
+void pll_core_create_lookup(unsigned int states, unsigned int rate_cats, double *lookup, const double *left_matrix,
+                            const double *right_matrix, const pll_state_t *tipmap, unsigned int tipmap_size, unsigned int attrib)
+{
+  (void)tipmap;
+  (void)tipmap_size;
+  /* the table belongs to the pair create_lookup / update_partial_tt; the caller sized it for
+   * maxstates^2 entries of rate_cats x states_padded doubles (src/pll.c:369-383), the two matrices fit */
+  const size_t n = matrix_doubles(states, rate_cats, attrib);
+  memcpy(lookup, left_matrix, n * sizeof(double));
+  memcpy(lookup + n, right_matrix, n * sizeof(double));
+}
+
+void pll_core_create_lookup_4x4(unsigned int rate_cats, double *lookup, const double *left_matrix, const double *right_matrix)
+{
+  /* the 4x4 form has no attrib argument: the reference's table holds 4-double rows whatever the
+   * architecture (src/core_partials.c:1015-1071); so do the matrices of a 4-state partition */
+  pll_core_create_lookup(4, rate_cats, lookup, left_matrix, right_matrix, NULL, 16, PLL_ATTRIB_ARCH_CPU);
+}
+
+void pll_core_update_partial_tt(unsigned int states, unsigned int sites, unsigned int rate_cats, double *parent_clv,
+                                unsigned int *parent_scaler, const unsigned char *left_tipchars,
+                                const unsigned char *right_tipchars, const pll_state_t *tipmap, unsigned int tipmap_size,
+                                const double *lookup, unsigned int attrib)
+{
+  (void)tipmap_size;
+  seam_t s;
+  if (!seam_open(&s, states, sites, rate_cats, 3, 2, 1, attrib)) return;
+  const size_t n = matrix_doubles(states, rate_cats, attrib);
+  seam_put_tip(&s, 1, left_tipchars, tipmap, sites);
+  seam_put_tip(&s, 2, right_tipchars, tipmap, sites);
+  seam_put_matrix(&s, 0, lookup);
+  seam_put_matrix(&s, 1, lookup + n);
+  seam_update(&s, parent_clv, parent_scaler, 0, 0, sites);
+  seam_close(&s);
+}
+
+void pll_core_update_partial_tt_4x4(unsigned int sites, unsigned int rate_cats, double *parent_clv, unsigned int *parent_scaler,
+                                    const unsigned char *left_tipchars, const unsigned char *right_tipchars, const double *lookup,
+                                    unsigned int attrib)
+{
+  pll_core_update_partial_tt(4, sites, rate_cats, parent_clv, parent_scaler, left_tipchars, right_tipchars, NULL, 16, lookup, attrib);
+}
+
+void pll_core_update_partial_repeats_generic(unsigned int states, unsigned int parent_sites, unsigned int left_sites,
+                                             unsigned int right_sites, unsigned int rate_cats, double *parent_clv,
+                                             unsigned int *parent_scaler, const double *left_clv, const double *right_clv,
+                                             const double *left_matrix, const double *right_matrix, const unsigned int *left_scaler,
+                                             const unsigned int *right_scaler, const unsigned int *parent_id_site,
+                                             const unsigned int *left_site_id, const unsigned int *right_site_id,
+                                             double *bclv_buffer, unsigned int attrib)
+{
+  (void)left_sites;
+  (void)right_sites;
+  (void)bclv_buffer;
+  seam_t s;
+  if (!seam_open(&s, states, parent_sites, rate_cats, 3, 2, 1, attrib)) return;
+  /* parent entry n stands for site id_site[n]; its children's entries are site_id[site] (PLL_GET_SITE / PLL_GET_ID, src/pll.h:682-683) */
+  seam_put_clv(&s, 1, left_clv, left_scaler, parent_sites, parent_id_site, left_site_id);
+  seam_put_clv(&s, 2, right_clv, right_scaler, parent_sites, parent_id_site, right_site_id);
+  seam_put_matrix(&s, 0, left_matrix);
+  seam_put_matrix(&s, 1, right_matrix);
+  seam_update(&s, parent_clv, parent_scaler, left_scaler != NULL, right_scaler != NULL, parent_sites);
+  seam_close(&s);
+}
+
+void pll_core_update_partial_repeats(unsigned int states, unsigned int parent_sites, unsigned int left_sites, unsigned int right_sites,
+                                     unsigned int rate_cats, double *parent_clv, unsigned int *parent_scaler, const double *left_clv,
+                                     const double *right_clv, const double *left_matrix, const double *right_matrix,
+                                     const unsigned int *left_scaler, const unsigned int *right_scaler,
+                                     const unsigned int *parent_id_site, const unsigned int *left_site_id,
+                                     const unsigned int *right_site_id, double *bclv_buffer, unsigned int attrib)
+{
+  pll_core_update_partial_repeats_generic(states, parent_sites, left_sites, right_sites, rate_cats, parent_clv, parent_scaler, left_clv,
+                                          right_clv, left_matrix, right_matrix, left_scaler, right_scaler, parent_id_site, left_site_id,
+                                          right_site_id, bclv_buffer, attrib);
+}
+
+void pll_core_update_partial_repeatsbclv_generic(unsigned int states, unsigned int parent_sites, unsigned int left_sites,
+                                                 unsigned int right_sites, unsigned int rate_cats, double *parent_clv,
+                                                 unsigned int *parent_scaler, const double *left_clv, const double *right_clv,
+                                                 const double *left_matrix, const double *right_matrix,
+                                                 const unsigned int *left_scaler, const unsigned int *right_scaler,
+                                                 const unsigned int *parent_id_site, const unsigned int *left_site_id,
+                                                 const unsigned int *right_site_id, double *bclv_buffer, unsigned int attrib)
+{
+  pll_core_update_partial_repeats_generic(states, parent_sites, left_sites, right_sites, rate_cats, parent_clv, parent_scaler, left_clv,
+                                          right_clv, left_matrix, right_matrix, left_scaler, right_scaler, parent_id_site, left_site_id,
+                                          right_site_id, bclv_buffer, attrib);
+}
+
+/* ---- log-likelihoods --------------------------------------------------------------------------- */
+
+static unsigned int freq_sets(const unsigned int *freqs_indices, unsigned int rate_cats)
+{
+  unsigned int n = 0;
+  for (unsigned int k = 0; k < rate_cats; ++k)
+    if (freqs_indices[k] + 1 > n) n = freqs_indices[k] + 1;
+  return n;
+}
+
+static int seam_model(seam_t *s, double *const *frequencies, const double *rate_weights, const unsigned int *pattern_weights,
+                      const double *invar_proportion, const int *invar_indices, const unsigned int *freqs_indices, unsigned int sites)
+{
+  pll_partition_t *p = s->p;
+  const unsigned int sets = freq_sets(freqs_indices, p->rate_cats);
+  for (unsigned int f = 0; f < sets; ++f)
+  {
+    pll_set_frequencies(p, f, frequencies[f]);
+    if (invar_proportion) p->prop_invar[f] = invar_proportion[f];
+  }
+  pll_gpu_invalidate(p, PLL_GPU_DIRTY_FREQS, -1);
+  pll_set_category_weights(p, rate_weights);
+  pll_set_pattern_weights(p, pattern_weights);
+  if (invar_indices)
+  {
+    if (!p->invariant) p->invariant = (int *)malloc((size_t)sites * sizeof(int));
+    if (!p->invariant)
+    {
+      pll_set_error(PLL_ERROR_MEM_ALLOC, "pll_core_*_loglikelihood: out of memory");
+      return 0;
+    }
+    memcpy(p->invariant, invar_indices, (size_t)sites * sizeof(int));
+    pll_gpu_invalidate(p, PLL_GPU_DIRTY_INVARIANT, -1);
+  }
+  return 1;
+}
+
+static double seam_edge(unsigned int states, unsigned int sites, unsigned int rate_cats, const double *parent_clv,
+                        const unsigned int *parent_scaler, const unsigned int *parent_site_id, const double *child_clv,
+                        const unsigned int *child_scaler, const unsigned int *child_site_id, const unsigned char *tipchars,
+                        const pll_state_t *tipmap, const double *pmatrix, double *const *frequencies, const double *rate_weights,
+                        const unsigned int *pattern_weights, const double *invar_proportion, const int *invar_indices,
+                        const unsigned int *freqs_indices, double *persite_lnl, unsigned int attrib, int root)
+{
+  seam_t s;
+  double lnl = -INFINITY;
+  if (!seam_open(&s, states, sites, rate_cats, 2, 1, freq_sets(freqs_indices, rate_cats), attrib)) return lnl;
+  if (seam_model(&s, frequencies, rate_weights, pattern_weights, invar_proportion, invar_indices, freqs_indices, sites))
+  {
+    seam_put_clv(&s, 0, parent_clv, parent_scaler, sites, NULL, parent_site_id);
+    if (root)
+      lnl = pll_compute_root_loglikelihood(s.p, 1, parent_scaler ? 0 : PLL_SCALE_BUFFER_NONE, freqs_indices, persite_lnl);
+    else
+    {
+      if (tipchars)
+        seam_put_tip(&s, 1, tipchars, tipmap, sites);
+      else
+        seam_put_clv(&s, 1, child_clv, child_scaler, sites, NULL, child_site_id);
+      seam_put_matrix(&s, 0, pmatrix);
+      lnl = pll_compute_edge_loglikelihood(s.p, 1, parent_scaler ? 0 : PLL_SCALE_BUFFER_NONE, 2,
+                                           (!tipchars && child_scaler) ? 1 : PLL_SCALE_BUFFER_NONE, 0, freqs_indices, persite_lnl);
+    }
+  }
+  seam_close(&s);
+  return lnl;
+}
+
+double pll_core_edge_loglikelihood_ii(unsigned int states, unsigned int sites, unsigned int rate_cats, const double *parent_clv,
+                                      const unsigned int *parent_scaler, const double *child_clv, const unsigned int *child_scaler,
+                                      const double *pmatrix, double *const *frequencies, const double *rate_weights,
+                                      const unsigned int *pattern_weights, const double *invar_proportion, const int *invar_indices,
+                                      const unsigned int *freqs_indices, double *persite_lnl, unsigned int attrib)
+{
+  return seam_edge(states, sites, rate_cats, parent_clv, parent_scaler, NULL, child_clv, child_scaler, NULL, NULL, NULL, pmatrix,
+                   frequencies, rate_weights, pattern_weights, invar_proportion, invar_indices, freqs_indices, persite_lnl, attrib, 0);
+}
+
+double pll_core_edge_loglikelihood_ti(unsigned int states, unsigned int sites, unsigned int rate_cats, const double *parent_clv,
+                                      const unsigned int *parent_scaler, const unsigned char *tipchars, const pll_state_t *tipmap,
+                                      unsigned int tipmap_size, const double *pmatrix, double *const *frequencies,
+                                      const double *rate_weights, const unsigned int *pattern_weights, const double *invar_proportion,
+                                      const int *invar_indices, const unsigned int *freqs_indices, double *persite_lnl,
+                                      unsigned int attrib)
+{
+  (void)tipmap_size;
+  return seam_edge(states, sites, rate_cats, parent_clv, parent_scaler, NULL, NULL, NULL, NULL, tipchars, tipmap, pmatrix, frequencies,
+                   rate_weights, pattern_weights, invar_proportion, invar_indices, freqs_indices, persite_lnl, attrib, 0);
+}
+
+double pll_core_edge_loglikelihood_ti_4x4(unsigned int sites, unsigned int rate_cats, const double *parent_clv,
+                                          const unsigned int *parent_scaler, const unsigned char *tipchars, const double *pmatrix,
+                                          double *const *frequencies, const double *rate_weights, const unsigned int *pattern_weights,
+                                          const double *invar_proportion, const int *invar_indices, const unsigned int *freqs_indices,
+                                          double *persite_lnl, unsigned int attrib)
+{
+  return seam_edge(4, sites, rate_cats, parent_clv, parent_scaler, NULL, NULL, NULL, NULL, tipchars, NULL, pmatrix, frequencies,
+                   rate_weights, pattern_weights, invar_proportion, invar_indices, freqs_indices, persite_lnl, attrib, 0);
+}
+
+double pll_core_edge_loglikelihood_repeats_generic(unsigned int states, unsigned int sites, const unsigned int child_sites,
+                                                   unsigned int rate_cats, const double *parent_clv, const unsigned int *parent_scaler,
+                                                   const double *child_clv, const unsigned int *child_scaler, const double *pmatrix,
+                                                   double **frequencies, const double *rate_weights, const unsigned int *pattern_weights,
+                                                   const double *invar_proportion, const int *invar_indices,
+                                                   const unsigned int *freqs_indices, double *persite_lnl,
+                                                   const unsigned int *parent_site_id, const unsigned int *child_site_id, double *bclv,
+                                                   unsigned int attrib)
+{
+  (void)child_sites;
+  (void)bclv;
+  return seam_edge(states, sites, rate_cats, parent_clv, parent_scaler, parent_site_id, child_clv, child_scaler, child_site_id, NULL, NULL,
+                   pmatrix, frequencies, rate_weights, pattern_weights, invar_proportion, invar_indices, freqs_indices, persite_lnl, attrib, 0);
+}
+
+double pll_core_edge_loglikelihood_repeats(unsigned int states, unsigned int sites, const unsigned int child_sites, unsigned int rate_cats,
+                                           const double *parent_clv, const unsigned int *parent_scaler, const double *child_clv,
+                                           const unsigned int *child_scaler, const double *pmatrix, double **frequencies,
+                                           const double *rate_weights, const unsigned int *pattern_weights, const double *invar_proportion,
+                                           const int *invar_indices, const unsigned int *freqs_indices, double *persite_lnl,
+                                           const unsigned int *parent_site_id, const unsigned int *child_site_id, double *bclv,
+                                           unsigned int attrib)
+{
+  return pll_core_edge_loglikelihood_repeats_generic(states, sites, child_sites, rate_cats, parent_clv, parent_scaler, child_clv,
+                                                     child_scaler, pmatrix, frequencies, rate_weights, pattern_weights, invar_proportion,
+                                                     invar_indices, freqs_indices, persite_lnl, parent_site_id, child_site_id, bclv, attrib);
+}
+
+double pll_core_root_loglikelihood(unsigned int states, unsigned int sites, unsigned int rate_cats, const double *clv,
+                                   const unsigned int *scaler, double *const *frequencies, const double *rate_weights,
+                                   const unsigned int *pattern_weights, const double *invar_proportion, const int *invar_indices,
+                                   const unsigned int *freqs_indices, double *persite_lnl, unsigned int attrib)
+{
+  return seam_edge(states, sites, rate_cats, clv, scaler, NULL, NULL, NULL, NULL, NULL, NULL, NULL, frequencies, rate_weights,
+                   pattern_weights, invar_proportion, invar_indices, freqs_indices, persite_lnl, attrib, 1);
+}
+
+double pll_core_root_loglikelihood_repeats(unsigned int states, unsigned int sites, unsigned int rate_cats, const double *clv,
+                                           const unsigned int *site_id, const unsigned int *scaler, double *const *frequencies,
+                                           const double *rate_weights, const unsigned int *pattern_weights,
+                                           const double *invar_proportion, const int *invar_indices, const unsigned int *freqs_indices,
+                                           double *persite_lnl, unsigned int attrib)
+{
+  return seam_edge(states, sites, rate_cats, clv, scaler, site_id, NULL, NULL, NULL, NULL, NULL, NULL, frequencies, rate_weights,
+                   pattern_weights, invar_proportion, invar_indices, freqs_indices, persite_lnl, attrib, 1);
+}

@@ -601,6 +601,8 @@ int pll_flush_scaler(pll_partition_t *p, pll_amd_ext_t *x, int idx)
   if (idx == PLL_SCALE_BUFFER_NONE) return PLL_SUCCESS;
   if (x->scaler_side[idx] == SIDE_HOST)
   {
+    /* a buffer the caller filled before the device ever saw it holds one entry per site */
+    if (!x->scaler_entries[idx]) x->scaler_entries[idx] = x->sites_alloc;
     GPU_TRY(pllgpu_scaler_upload(x->ctx, (unsigned)idx, p->scale_buffer[idx], x->scaler_entries[idx]), "scaler upload");
     x->scaler_side[idx] = SIDE_BOTH;
   }

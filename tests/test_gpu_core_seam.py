@@ -1,0 +1,262 @@
+"""GPU: the flat pll_core_* seam (include/pll_amd.h; reference src/pll.h:1049-1177, :1295-1414) against
+the same functions of the reference library (oracle/_ref, built from the reference's sources in the
+authoring container and shipped as a binary) on seeded raw arrays: CLVs within 1e-10 relative, scaler
+vectors exact, log-likelihoods within 1e-10 relative. Skipped where the reference binary is absent."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from pllamd import api, workload as W
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+D = C.POINTER(C.c_double)
+U = C.POINTER(C.c_uint)
+B = C.POINTER(C.c_ubyte)
+I = C.POINTER(C.c_int)
+S64 = C.POINTER(C.c_ulonglong)
+DP = C.POINTER(D)
+
+
+def aligned(a):
+    """a copy of `a` on a 64-byte boundary (the reference's AVX kernels use aligned loads)"""
+    a = np.ascontiguousarray(a)
+    raw = np.zeros(a.nbytes + 64, dtype=np.uint8)
+    off = (-raw.ctypes.data) % 64
+    out = raw[off:off + a.nbytes].view(a.dtype).reshape(a.shape)
+    out[...] = a
+    return out
+
+
+def dp(a):
+    return None if a is None else a.ctypes.data_as(D)
+
+
+def up(a):
+    return None if a is None else a.ctypes.data_as(U)
+
+
+def bp(a):
+    return a.ctypes.data_as(B)
+
+
+def sp_of(states, arch):
+    return {api.ARCH_CPU: states, api.ARCH_SSE: (states + 1) & ~1, api.ARCH_AVX: (states + 3) & ~3, api.ARCH_AVX2: (states + 3) & ~3}[arch]
+
+
+def rand_clv(rng, entries, rates, states, sp, scale=1.0):
+    a = np.zeros((entries, rates, sp))
+    a[:, :, :states] = rng.random((entries, rates, states)) * scale + 1e-3 * scale
+    return aligned(a)
+
+
+def pmat(states, rates, sp, t, seed):
+    exch, freqs = (W.GTR_DNA["exch"], W.GTR_DNA["freqs"]) if states == 4 else W.synthetic_exch(states)
+    r = W.gamma_rates_mean(0.7, rates)
+    pm = W.pmatrices(exch, np.asarray(freqs, dtype=np.float64), r, np.array([t]), 0.0)  # [1][rate][state][state]
+    out = np.zeros((rates, states, sp))
+    out[:, :, :states] = pm[0]
+    return aligned(out), np.asarray(freqs, dtype=np.float64)
+
+
+def freq_ptrs(freqs, sp, sets):
+    rows = [aligned(np.concatenate([freqs, np.zeros(sp - len(freqs))])) for _ in range(sets)]
+    arr = (D * sets)(*[r.ctypes.data_as(D) for r in rows])
+    return arr, rows
+
+
+def both(amd_lib, ref_lib, name):
+    return getattr(amd_lib.dll, name), getattr(ref_lib.dll, name)
+
+
+@pytest.mark.parametrize("states,rates,arch,per_rate", [(4, 4, api.ARCH_AVX2, False), (4, 4, api.ARCH_CPU, True), (20, 4, api.ARCH_AVX2, False),
+                                                        (5, 2, api.ARCH_SSE, False), (7, 3, api.ARCH_AVX, True)])
+def test_update_partial_ii_and_edge(amd_lib, ref_lib, states, rates, arch, per_rate):
+    rng = np.random.default_rng(states * 100 + rates)
+    n = 333
+    sp = sp_of(states, arch)
+    attrib = arch | (api.RATE_SCALERS if per_rate else 0)
+    sw = rates if per_rate else 1
+    # small values so that some sites rescale
+    l = rand_clv(rng, n, rates, states, sp, 1e-40)
+    r = rand_clv(rng, n, rates, states, sp, 1e-40)
+    l[::7] *= 1e-30
+    r[::7] *= 1e-30
+    lm, freqs = pmat(states, rates, sp, 0.1, 1)
+    rm, _ = pmat(states, rates, sp, 0.23, 2)
+    ls = np.ascontiguousarray(rng.integers(0, 3, size=(n, sw)).astype(np.uint32))
+    rs = np.ascontiguousarray(rng.integers(0, 3, size=(n, sw)).astype(np.uint32))
+    res = {}
+    for tag, lib in (("amd", amd_lib), ("ref", ref_lib)):
+        f = lib.dll.pll_core_update_partial_ii
+        f.restype = None
+        f.argtypes = [C.c_uint] * 3 + [D, U, D, D, D, D, U, U, C.c_uint]
+        pc = aligned(np.zeros((n, rates, sp)))
+        ps = np.zeros((n, sw), dtype=np.uint32)
+        f(states, n, rates, dp(pc), up(ps), dp(l), dp(r), dp(lm), dp(rm), up(ls), up(rs), attrib)
+        res[tag] = (pc, ps)
+    assert (res["amd"][1] == res["ref"][1]).all()
+    assert res["ref"][1].sum() > ls.sum() + rs.sum()  # something was rescaled
+    np.testing.assert_allclose(res["amd"][0][..., :states], res["ref"][0][..., :states], rtol=RTOL, atol=0)  # padding entries: anything
+    # edge log-likelihood between the parent just formed and a fresh child
+    pc, ps = res["ref"]
+    child = rand_clv(rng, n, rates, states, sp)
+    cs = np.ascontiguousarray(rng.integers(0, 2, size=(n, sw)).astype(np.uint32))
+    fp, keep = freq_ptrs(freqs, sp, 2)
+    rw = rng.random(rates) + 0.1
+    rw = aligned(rw / rw.sum())
+    pw = np.ascontiguousarray(rng.integers(1, 5, size=n).astype(np.uint32))
+    pinv = np.ascontiguousarray(np.array([0.0, 0.0]))
+    fi = np.ascontiguousarray((np.arange(rates) % 2).astype(np.uint32))
+    out = {}
+    for tag, lib in (("amd", amd_lib), ("ref", ref_lib)):
+        f = lib.dll.pll_core_edge_loglikelihood_ii
+        f.restype = C.c_double
+        f.argtypes = [C.c_uint] * 3 + [D, U, D, U, D, DP, D, U, D, I, U, D, C.c_uint]
+        per = aligned(np.zeros(n))
+        v = f(states, n, rates, dp(pc), up(ps), dp(child), up(cs), dp(lm), fp, dp(rw), up(pw), dp(pinv), None, up(fi), dp(per), attrib)
+        out[tag] = (v, per)
+    assert abs(out["amd"][0] - out["ref"][0]) <= RTOL * abs(out["ref"][0])
+    np.testing.assert_allclose(out["amd"][1], out["ref"][1], rtol=RTOL, atol=0)
+    # root: against the reference and against the formula itself (src/core_likelihood.c:163-207). The
+    # reference's SSE root kernel is not a usable yardstick for every shape: with an odd number of states or
+    # with rate categories that use different frequency sets it returns NaN or values that disagree with its
+    # own generic kernel (5 states: NaN; 6 states, two sets: -37.36 against -35.11 on a 50-site check) - there
+    # the formula alone decides.
+    scal = None if per_rate else cs
+    for tag, lib in (("amd", amd_lib), ("ref", ref_lib)):
+        f = lib.dll.pll_core_root_loglikelihood
+        f.restype = C.c_double
+        f.argtypes = [C.c_uint] * 3 + [D, U, DP, D, U, D, I, U, D, C.c_uint]
+        out[tag] = f(states, n, rates, dp(child), up(scal), fp, dp(rw), up(pw), dp(pinv), None, up(fi), None, attrib)
+    site = np.log(((child[:, :, :states] * freqs[None, None, :]).sum(axis=2) * rw[None, :]).sum(axis=1))
+    if scal is not None:
+        site = site + scal.ravel() * np.log(2.0 ** -256)
+    manual = float((site * pw).sum())
+    assert abs(out["amd"] - manual) <= 1e-12 * abs(manual)
+    if arch != api.ARCH_SSE:
+        assert abs(out["amd"] - out["ref"]) <= RTOL * abs(out["ref"])
+
+
+@pytest.mark.parametrize("states,arch", [(4, api.ARCH_AVX2), (20, api.ARCH_AVX2), (7, api.ARCH_CPU)])
+def test_tip_forms(amd_lib, ref_lib, states, arch):
+    """ti / tt / edge ti with encoded tip characters and a tipmap (4 states: the 4x4 forms, code = mask)"""
+    rng = np.random.default_rng(states)
+    n, rates = 257, 4
+    sp = sp_of(states, arch)
+    attrib = arch
+    nchar = 16 if states == 4 else states + 3
+    tipmap = np.zeros(256, dtype=np.uint64)
+    if states == 4:
+        tipmap[:16] = np.arange(16)
+        codes = rng.integers(1, 16, size=(2, n)).astype(np.uint8)
+    else:
+        for c in range(states):
+            tipmap[c] = 1 << c
+        tipmap[states] = (1 << states) - 1
+        tipmap[states + 1] = 0b101
+        tipmap[states + 2] = 0b11000
+        codes = rng.integers(0, nchar, size=(2, n)).astype(np.uint8)
+    codes = np.ascontiguousarray(codes)
+    lm, freqs = pmat(states, rates, sp, 0.15, 3)
+    rm, _ = pmat(states, rates, sp, 0.3, 4)
+    inner = rand_clv(rng, n, rates, states, sp)
+    isc = np.ascontiguousarray(rng.integers(0, 2, size=n).astype(np.uint32))
+    tm = tipmap.ctypes.data_as(S64)
+    res = {}
+    for tag, lib in (("amd", amd_lib), ("ref", ref_lib)):
+        d = lib.dll
+        # ti
+        pc = aligned(np.zeros((n, rates, sp)))
+        ps = np.zeros(n, dtype=np.uint32)
+        if states == 4:
+            d.pll_core_update_partial_ti_4x4.restype = None
+            d.pll_core_update_partial_ti_4x4.argtypes = [C.c_uint] * 2 + [D, U, B, D, D, D, U, C.c_uint]
+            d.pll_core_update_partial_ti_4x4(n, rates, dp(pc), up(ps), bp(codes[0]), dp(inner), dp(lm), dp(rm), up(isc), attrib)
+        else:
+            d.pll_core_update_partial_ti.restype = None
+            d.pll_core_update_partial_ti.argtypes = [C.c_uint] * 3 + [D, U, B, D, D, D, U, S64, C.c_uint, C.c_uint]
+            d.pll_core_update_partial_ti(states, n, rates, dp(pc), up(ps), bp(codes[0]), dp(inner), dp(lm), dp(rm), up(isc), tm, nchar, attrib)
+        # tt through the lookup pair
+        pow2 = 1 << int(np.ceil(np.log2(nchar)))  # the reference addresses its table with shifts (src/core_partials.c:1149-1209)
+        look = aligned(np.zeros(max(1024 * rates, pow2 * pow2 * rates * sp)))
+        tc = aligned(np.zeros((n, rates, sp)))
+        ts = np.zeros(n, dtype=np.uint32)
+        if states == 4:
+            d.pll_core_create_lookup_4x4.restype = None
+            d.pll_core_create_lookup_4x4.argtypes = [C.c_uint, D, D, D]
+            d.pll_core_create_lookup_4x4(rates, dp(look), dp(lm), dp(rm))
+            d.pll_core_update_partial_tt_4x4.restype = None
+            d.pll_core_update_partial_tt_4x4.argtypes = [C.c_uint] * 2 + [D, U, B, B, D, C.c_uint]
+            d.pll_core_update_partial_tt_4x4(n, rates, dp(tc), up(ts), bp(codes[0]), bp(codes[1]), dp(look), attrib)
+        else:
+            d.pll_core_create_lookup.restype = None
+            d.pll_core_create_lookup.argtypes = [C.c_uint, C.c_uint, D, D, D, S64, C.c_uint, C.c_uint]
+            d.pll_core_create_lookup(states, rates, dp(look), dp(lm), dp(rm), tm, nchar, attrib)
+            d.pll_core_update_partial_tt.restype = None
+            d.pll_core_update_partial_tt.argtypes = [C.c_uint] * 3 + [D, U, B, B, S64, C.c_uint, D, C.c_uint]
+            d.pll_core_update_partial_tt(states, n, rates, dp(tc), up(ts), bp(codes[0]), bp(codes[1]), tm, nchar, dp(look), attrib)
+        # edge ti
+        fp, keep = freq_ptrs(freqs, sp, 1)
+        rw = aligned(np.full(rates, 1.0 / rates))
+        pw = np.ones(n, dtype=np.uint32)
+        pinv = np.zeros(1)
+        fi = np.zeros(rates, dtype=np.uint32)
+        if states == 4:
+            d.pll_core_edge_loglikelihood_ti_4x4.restype = C.c_double
+            d.pll_core_edge_loglikelihood_ti_4x4.argtypes = [C.c_uint] * 2 + [D, U, B, D, DP, D, U, D, I, U, D, C.c_uint]
+            v = d.pll_core_edge_loglikelihood_ti_4x4(n, rates, dp(inner), up(isc), bp(codes[1]), dp(lm), fp, dp(rw), up(pw), dp(pinv), None, up(fi), None, attrib)
+        else:
+            d.pll_core_edge_loglikelihood_ti.restype = C.c_double
+            d.pll_core_edge_loglikelihood_ti.argtypes = [C.c_uint] * 3 + [D, U, B, S64, C.c_uint, D, DP, D, U, D, I, U, D, C.c_uint]
+            v = d.pll_core_edge_loglikelihood_ti(states, n, rates, dp(inner), up(isc), bp(codes[1]), tm, nchar, dp(lm), fp, dp(rw), up(pw), dp(pinv), None, up(fi), None, attrib)
+        res[tag] = (pc, ps, tc, ts, v)
+    a, r = res["amd"], res["ref"]
+    np.testing.assert_allclose(a[0][..., :states], r[0][..., :states], rtol=RTOL, atol=0)
+    assert (a[1] == r[1]).all()
+    np.testing.assert_allclose(a[2][..., :states], r[2][..., :states], rtol=RTOL, atol=0)
+    assert (a[3] == r[3]).all()
+    assert abs(a[4] - r[4]) <= RTOL * abs(r[4])
+
+
+def test_repeats_forms(amd_lib, ref_lib):
+    """class-compressed operands addressed through id_site / site_id maps"""
+    rng = np.random.default_rng(9)
+    states, rates, arch = 4, 4, api.ARCH_AVX2
+    sp = 4
+    n, nl, nr, npar = 300, 40, 55, 120
+    lsid = np.ascontiguousarray(rng.integers(0, nl, size=n).astype(np.uint32))
+    rsid = np.ascontiguousarray(rng.integers(0, nr, size=n).astype(np.uint32))
+    pids = np.ascontiguousarray(np.sort(rng.choice(n, size=npar, replace=False)).astype(np.uint32))
+    psid = np.ascontiguousarray(rng.integers(0, npar, size=n).astype(np.uint32))
+    l = rand_clv(rng, nl, rates, states, sp)
+    r = rand_clv(rng, nr, rates, states, sp)
+    ls = np.ascontiguousarray(rng.integers(0, 2, size=nl).astype(np.uint32))
+    rs = np.ascontiguousarray(rng.integers(0, 2, size=nr).astype(np.uint32))
+    lm, freqs = pmat(states, rates, sp, 0.1, 5)
+    rm, _ = pmat(states, rates, sp, 0.2, 6)
+    res = {}
+    for tag, lib in (("amd", amd_lib), ("ref", ref_lib)):
+        d = lib.dll
+        f = d.pll_core_update_partial_repeats
+        f.restype = None
+        f.argtypes = [C.c_uint] * 5 + [D, U, D, D, D, D, U, U, U, U, U, D, C.c_uint]
+        pc = aligned(np.zeros((npar, rates, sp)))
+        ps = np.zeros(npar, dtype=np.uint32)
+        bclv = aligned(np.zeros((nl, rates, sp)))
+        f(states, npar, nl, nr, rates, dp(pc), up(ps), dp(l), dp(r), dp(lm), dp(rm), up(ls), up(rs), up(pids), up(lsid), up(rsid), dp(bclv), arch)
+        g = d.pll_core_edge_loglikelihood_repeats
+        g.restype = C.c_double
+        g.argtypes = [C.c_uint] * 4 + [D, U, D, U, D, DP, D, U, D, I, U, D, U, U, D, C.c_uint]
+        fp, keep = freq_ptrs(freqs, sp, 1)
+        rw = aligned(np.full(rates, 0.25))
+        pw = np.ascontiguousarray(rng.integers(1, 3, size=n).astype(np.uint32)) if tag == "amd" else res["pw"]
+        res["pw"] = pw
+        pinv = np.zeros(1)
+        fi = np.zeros(rates, dtype=np.uint32)
+        v = g(states, n, nl, rates, dp(pc), up(ps), dp(l), up(ls), dp(lm), fp, dp(rw), up(pw), dp(pinv), None, up(fi), None, up(psid), up(lsid), dp(bclv), arch)
+        res[tag] = (pc, ps, v)
+    np.testing.assert_allclose(res["amd"][0], res["ref"][0], rtol=RTOL, atol=0)
+    assert (res["amd"][1] == res["ref"][1]).all()
+    assert abs(res["amd"][2] - res["ref"][2]) <= RTOL * abs(res["ref"][2])
