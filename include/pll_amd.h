@@ -168,6 +168,21 @@ typedef struct pll_msa_s
   char **label;
 } pll_msa_t;
 
+/* ---- host feature record (src/pll.h:220-237, :555, :2694-2698; src/hardware.c) -------------- */
+/* Callers test it (PLL_STAT(avx2_present), src/pll.h:77-78) before they ask for a PLL_ATTRIB_ARCH_* layout.
+ * Here the bits describe the host CPU as the reference's probe does; they only ever select a host
+ * LAYOUT (states_padded), the arithmetic runs on the device whatever they say. */
+typedef struct pll_hardware_s
+{
+  int init;
+  int altivec_present, mmx_present, sse_present, sse2_present, sse3_present, ssse3_present, sse41_present,
+      sse42_present, popcnt_present, avx_present, avx2_present;
+} pll_hardware_t;
+extern __thread pll_hardware_t pll_hardware;
+int pll_hardware_probe(void);   /* fills pll_hardware; returns PLL_SUCCESS */
+void pll_hardware_dump(void);   /* prints the record */
+void pll_hardware_ignore(void); /* marks every feature present */
+
 /* ---- thread-local error state (src/pll.h:553-555, src/pll.c:24-25) ------------------------- */
 extern __thread int pll_errno;
 extern __thread char pll_errmsg[200];
@@ -354,6 +369,16 @@ int pll_compute_likelihood_derivatives(pll_partition_t *partition, int parent_sc
                                        double *d_f, double *dd_f);
 
 /* ---- site repeats bookkeeping (src/pll.h:682-742, src/repeats.c) --------------------------- */
+/* scaler vector of a parent whose children are class-compressed (src/pll.h:727-742,
+ * src/repeats.c:392-540): parent[i] = left[lids[site]] + right[rids[site]] with site = psites[i]; a NULL
+ * map is the identity, a NULL scaler contributes 0. Integer utilities on host arrays, like
+ * pll_fill_parent_scaler; the kernels fold this step into the update. */
+void pll_fill_parent_scaler_repeats(unsigned int sites, unsigned int *parent_scaler, const unsigned int *psites,
+                                    const unsigned int *left_scaler, const unsigned int *lids, const unsigned int *right_scaler,
+                                    const unsigned int *rids);
+void pll_fill_parent_scaler_repeats_per_rate(unsigned int sites, unsigned int rates, unsigned int *parent_scaler,
+                                             const unsigned int *psites, const unsigned int *left_scaler, const unsigned int *lids,
+                                             const unsigned int *right_scaler, const unsigned int *rids);
 #define PLL_GET_ID(site_id, site) ((site_id) ? ((site_id)[(site)]) : (site))
 #define PLL_GET_SITE(id_site, site) ((id_site) ? ((id_site)[(site)]) : (site))
 int pll_repeats_enabled(const pll_partition_t *partition);

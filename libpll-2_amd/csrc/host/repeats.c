@@ -365,3 +365,27 @@ static void pll_update_repeats_host(pll_partition_t *p, const pll_operation_t *o
   pll_amd_ext_t *x = pll_ext(p);
   if (x) x->repeats_dirty[parent] = 1;
 }
+
+/* ---- scaler utilities for class-compressed operands (src/repeats.c:392-540) ----------------------
+ * parent entry i stands for site psites[i] (identity without the map), whose children's entries are
+ * lids[site] / rids[site] (identity without a map); a missing scaler contributes nothing. */
+void pll_fill_parent_scaler_repeats_per_rate(unsigned int sites, unsigned int rates, unsigned int *parent_scaler,
+                                             const unsigned int *psites, const unsigned int *left_scaler, const unsigned int *lids,
+                                             const unsigned int *right_scaler, const unsigned int *rids)
+{
+  for (unsigned int i = 0; i < sites; ++i)
+  {
+    const unsigned int site = psites ? psites[i] : i;
+    const unsigned int l = lids ? lids[site] : site, r = rids ? rids[site] : site;
+    for (unsigned int k = 0; k < rates; ++k)
+      parent_scaler[(size_t)i * rates + k] = (left_scaler ? left_scaler[(size_t)l * rates + k] : 0u) +
+                                             (right_scaler ? right_scaler[(size_t)r * rates + k] : 0u);
+  }
+}
+
+void pll_fill_parent_scaler_repeats(unsigned int sites, unsigned int *parent_scaler, const unsigned int *psites,
+                                    const unsigned int *left_scaler, const unsigned int *lids, const unsigned int *right_scaler,
+                                    const unsigned int *rids)
+{
+  pll_fill_parent_scaler_repeats_per_rate(sites, 1, parent_scaler, psites, left_scaler, lids, right_scaler, rids);
+}

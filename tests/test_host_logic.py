@@ -377,3 +377,58 @@ def test_caller_built_against_the_reference_header_links(tmp_path):
     subprocess.check_call(["gcc", "-O2", "-DUSE_REFERENCE_HEADER", "-I" + ref_inc, os.path.join(root, "tests", "c_caller", "dropin.c"),
                            "-L" + libdir, "-lpll_amd", "-lm", "-Wl,-rpath," + libdir, "-Wl,--no-undefined", "-o", exe])
     assert os.path.getsize(exe) > 0
+
+
+def test_repeats_scaler_utilities(amd_lib):
+    """pll_fill_parent_scaler_repeats[_per_rate] (src/repeats.c:392-540): integer gather-adds on host
+    arrays, against the definition - and against the reference binary where it is present"""
+    import ctypes as C
+    import os
+    rng = np.random.default_rng(4)
+    n, nl, nr, npar, rates = 200, 30, 45, 80, 4
+    U = C.POINTER(C.c_uint)
+    up = lambda a: None if a is None else a.ctypes.data_as(U)  # noqa: E731
+    lids = np.ascontiguousarray(rng.integers(0, nl, size=n).astype(np.uint32))
+    rids = np.ascontiguousarray(rng.integers(0, nr, size=n).astype(np.uint32))
+    psites = np.ascontiguousarray(rng.integers(0, n, size=npar).astype(np.uint32))
+    libs = [amd_lib]
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libpll_ref.so")
+    if os.path.exists(ref):
+        libs.append(api.PllLib(ref))
+    for per_rate in (1, rates):
+        ls = np.ascontiguousarray(rng.integers(0, 5, size=(nl, per_rate)).astype(np.uint32))
+        rs = np.ascontiguousarray(rng.integers(0, 5, size=(nr, per_rate)).astype(np.uint32))
+        for use_ps, use_l, use_r in ((True, True, True), (True, True, False), (True, False, True), (False, True, True)):
+            ps = psites if use_ps else None
+            m = npar if use_ps else n
+            site = psites if use_ps else np.arange(n)
+            want = (ls[lids[site]] if use_l else 0) + (rs[rids[site]] if use_r else 0)
+            for lib in libs:
+                out = np.full((m, per_rate), 77, dtype=np.uint32)
+                if per_rate == 1:
+                    f = lib.dll.pll_fill_parent_scaler_repeats
+                    f.restype = None
+                    f.argtypes = [C.c_uint, U, U, U, U, U, U]
+                    f(m, up(out), up(ps), up(ls if use_l else None), up(lids), up(rs if use_r else None), up(rids))
+                else:
+                    f = lib.dll.pll_fill_parent_scaler_repeats_per_rate
+                    f.restype = None
+                    f.argtypes = [C.c_uint, C.c_uint, U, U, U, U, U, U]
+                    f(m, per_rate, up(out), up(ps), up(ls if use_l else None), up(lids), up(rs if use_r else None), up(rids))
+                assert (out == want).all(), (per_rate, use_ps, use_l, use_r)
+
+
+def test_hardware_record(amd_lib):
+    """pll_hardware (src/pll.h:220-237,555): 48 bytes, probe / ignore behave like the reference's"""
+    import ctypes as C
+
+    class HW(C.Structure):
+        _fields_ = [(k, C.c_int) for k in ("init", "altivec", "mmx", "sse", "sse2", "sse3", "ssse3", "sse41", "sse42", "popcnt", "avx", "avx2")]
+
+    assert C.sizeof(HW) == 48
+    amd_lib.dll.pll_hardware_probe.restype = C.c_int
+    assert amd_lib.dll.pll_hardware_probe() == 1
+    hw = HW.in_dll(amd_lib.dll, "pll_hardware")
+    assert hw.init == 1 and hw.sse2 == 1  # every x86-64 host has SSE2
+    amd_lib.dll.pll_hardware_ignore()
+    assert all(getattr(hw, k) == 1 for k, _ in HW._fields_)
