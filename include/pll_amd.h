@@ -190,6 +190,8 @@ extern __thread char pll_errmsg[200];
 /* ---- character maps callers hand to pll_set_tip_states (src/pll.h:557-560, src/maps.c) ----- */
 extern const pll_state_t pll_map_bin[256];
 extern const pll_state_t pll_map_nt[256];
+extern const pll_state_t pll_map_gt10[256]; /* diploid genotypes, 10 unordered / 16 ordered states */
+extern const pll_state_t pll_map_gt16[256];
 extern const pll_state_t pll_map_aa[256];
 
 /* ---- lifecycle (src/pll.h:638-648, src/pll.c:424-873) -------------------------------------- */

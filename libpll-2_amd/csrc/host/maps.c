@@ -36,3 +36,21 @@ const pll_state_t pll_map_aa[256] = {
     BOTH('S', AA(15)), BOTH('T', AA(16)), BOTH('W', AA(17)), BOTH('Y', AA(18)), BOTH('V', AA(19)),
     BOTH('B', AA(2) | AA(3)), BOTH('Z', AA(5) | AA(6)), BOTH('J', AA(9) | AA(10)),
     BOTH('X', AA_ALL), ['*'] = AA_ALL, ['-'] = AA_ALL, ['.'] = AA_ALL, ['?'] = AA_ALL};
+
+/* Diploid genotypes (src/pll.h:560-561): the IUPAC letter of an unphased call names the genotype.
+ * 10 states: the homozygotes AA CC GG TT (bits 0-3, letters A C G T/U), then the heterozygotes in the
+ * order AC AG AT CG CT GT (bits 4-9, letters M R W S Y K); N, O, X, '-' and '?' are fully ambiguous.
+ * 16 states: ordered (phased) pairs - a heterozygote letter stands for both orders, bit b and bit b + 6. */
+#define GT10_ALL ((1ull << 10) - 1)
+const pll_state_t pll_map_gt10[256] = {
+    BOTH('A', 1ull << 0), BOTH('C', 1ull << 1), BOTH('G', 1ull << 2), BOTH('T', 1ull << 3), BOTH('U', 1ull << 3),
+    BOTH('M', 1ull << 4), BOTH('R', 1ull << 5), BOTH('W', 1ull << 6), BOTH('S', 1ull << 7), BOTH('Y', 1ull << 8), BOTH('K', 1ull << 9),
+    BOTH('N', GT10_ALL), BOTH('O', GT10_ALL), BOTH('X', GT10_ALL), ['-'] = GT10_ALL, ['?'] = GT10_ALL};
+
+#define GT16_HET(b) ((1ull << (b)) | (1ull << ((b) + 6)))
+#define GT16_ALL ((1ull << 16) - 1)
+const pll_state_t pll_map_gt16[256] = {
+    BOTH('A', 1ull << 0), BOTH('C', 1ull << 1), BOTH('G', 1ull << 2), BOTH('T', 1ull << 3), BOTH('U', 1ull << 3),
+    BOTH('M', GT16_HET(4)), BOTH('R', GT16_HET(5)), BOTH('W', GT16_HET(6)), BOTH('S', GT16_HET(7)), BOTH('Y', GT16_HET(8)),
+    BOTH('K', GT16_HET(9)),
+    BOTH('N', GT16_ALL), BOTH('O', GT16_ALL), BOTH('X', GT16_ALL), ['-'] = GT16_ALL, ['?'] = GT16_ALL};

@@ -185,7 +185,7 @@ def test_illegal_state_is_reported(amd_lib):
     amd_lib.pll_partition_destroy(p)
 
 
-@pytest.mark.parametrize("name", ["pll_map_nt", "pll_map_aa", "pll_map_bin"])
+@pytest.mark.parametrize("name", ["pll_map_nt", "pll_map_aa", "pll_map_bin", "pll_map_gt10", "pll_map_gt16"])
 def test_state_maps_equal_reference(amd_lib, ref_lib, name):
     assert list(amd_lib.state_map(name)) == list(ref_lib.state_map(name))
 
