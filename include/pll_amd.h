@@ -168,6 +168,10 @@ typedef struct pll_msa_s
   char **label;
 } pll_msa_t;
 
+/* ---- printers used by the reference's examples and tests (src/pll.h:2590-2600, src/output.c) -- */
+void pll_show_pmatrix(const pll_partition_t *partition, unsigned int index, unsigned int float_precision);
+void pll_show_clv(const pll_partition_t *partition, unsigned int clv_index, int scaler_index, unsigned int float_precision);
+
 /* ---- host feature record (src/pll.h:220-237, :555, :2694-2698; src/hardware.c) -------------- */
 /* Callers test it (PLL_STAT(avx2_present), src/pll.h:77-78) before they ask for a PLL_ATTRIB_ARCH_* layout.
  * Here the bits describe the host CPU as the reference's probe does; they only ever select a host

@@ -18,3 +18,50 @@ def test_c_caller_reproduces_the_reference_kat(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
     assert abs(float(lines["lnl"].split()[0]) - (-58.887310)) < 5.1e-7
+
+
+def _captured(fn):
+    """what a C-level printf writes to stdout while fn() runs"""
+    import ctypes as C
+    import os
+    import tempfile
+    libc = C.CDLL(None)
+    libc.fflush(None)
+    with tempfile.TemporaryFile() as tmp:
+        saved = os.dup(1)
+        os.dup2(tmp.fileno(), 1)
+        try:
+            fn()
+            libc.fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        tmp.seek(0)
+        return tmp.read().decode()
+
+
+@pytest.mark.parametrize("attrs", [0, "repeats"], ids=["plain", "site-repeats"])
+def test_show_functions_print_what_the_reference_prints(amd_lib, ref_lib, attrs):
+    """pll_show_pmatrix / pll_show_clv (src/output.c): the examples and tests of the reference call
+    them; same text for the same partition (6 decimals: far above the 1e-10 the numbers agree to)"""
+    import ctypes as C
+    from pllamd import api, driver, workload as W
+    a = api.SITE_REPEATS if attrs == "repeats" else 0
+    case = W.make_case("show", 4, 8, 30, seed=12, attributes=a, mutate_pct=5)
+    text = {}
+    for lib in (amd_lib, ref_lib):
+        lib.dll.pll_show_pmatrix.restype = None
+        lib.dll.pll_show_pmatrix.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
+        lib.dll.pll_show_clv.restype = None
+        lib.dll.pll_show_clv.argtypes = [C.c_void_p, C.c_uint, C.c_int, C.c_uint]
+        with driver.Session(lib, case, api.ARCH_AVX2) as s:
+            s.update_partials()
+            op = case.op_batches[0][-1]
+
+            def show():
+                lib.dll.pll_show_pmatrix(s.p, 3, 6)
+                lib.dll.pll_show_clv(s.p, op[0], op[1], 6)
+                lib.dll.pll_show_clv(s.p, case.op_batches[0][0][0], -1, 6)
+            text[lib.is_amd] = _captured(show)
+    assert len(text[True]) > 1000
+    assert text[True] == text[False]
