@@ -34,6 +34,9 @@ PROGRAMS = ["00010_NMDU_lkcalc", "00011_NMAU_lkcalc", "00012_NMOU_lkcalc", "0002
             # no expected output in the reference's test/out: recorded from the reference build
             # itself by `make -C oracle reftests-golden` (same text for every attribute set)
             "protein-models"]
+# the self-contained programs of the reference's examples/ (inline data, no arguments, attributes
+# fixed in their source); expected text recorded from the reference build, as for protein-models
+EXAMPLES = ["example-rooted", "example-unrooted", "example-rooted-tacg", "example-heterotachy"]
 ATTRIBUTES = ["", "tv", "avx", "avx tv", "sse", "sse tv", "avx2", "avx2 tv",
               "sr", "avx sr", "sse sr", "avx2 sr"]
 
@@ -92,4 +95,16 @@ def test_reference_program_prints_the_expected_output(program, attributes):
             pytest.skip("the program itself skips this attribute set")
     want = expected_output(program)
     problem = same_text(run.stdout, want)
+    assert problem is None, problem
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("program", EXAMPLES)
+def test_reference_example_prints_what_it_prints_with_the_reference(program):
+    exe = os.path.join(BIN, program)
+    if not os.path.exists(exe):
+        pytest.fail(f"{exe} missing: run `make -C oracle reftests` where /root/reference exists")
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    problem = same_text(run.stdout, expected_output(program))
     assert problem is None, problem

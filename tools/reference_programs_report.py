@@ -8,15 +8,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from test_gpu_reference_programs import ATTRIBUTES, BIN, OUT, PROGRAMS, expected_output, same_text  # noqa: E402
+from test_gpu_reference_programs import ATTRIBUTES, BIN, EXAMPLES, OUT, PROGRAMS, expected_output, same_text  # noqa: E402
 
 skip = open(os.path.join(OUT, "skip.out")).read()
 tally = {"identical": 0, "within tolerance": 0, "skipped by the program": 0, "DIFFERENT": 0}
 print(f"{'program':24s} " + " ".join(f"{(a.replace(' ', '+') or 'cpu'):>8s}" for a in ATTRIBUTES))
-for prog in PROGRAMS:
+for prog in PROGRAMS + EXAMPLES:
     want = expected_output(prog)
     row = []
-    for attr in ATTRIBUTES:
+    for attr in (ATTRIBUTES if prog in PROGRAMS else [""]):
         run = subprocess.run([os.path.join(BIN, prog)] + attr.split(), capture_output=True, text=True)
         if run.stdout == skip:
             key, mark = "skipped by the program", "skip"
