@@ -197,7 +197,9 @@ class PllLib:
         # RTLD_LOCAL + DEEPBIND: several libraries exporting the same pll_* names can coexist in one
         # process (each binds to its own definitions). LAZY: a library built without the newick
         # parsers leaves symbols undefined that the hot path never calls.
-        mode = getattr(os, "RTLD_LOCAL", 0) | getattr(os, "RTLD_LAZY", 1) | getattr(os, "RTLD_DEEPBIND", 0)
+        mode = getattr(os, "RTLD_LOCAL", 0) | getattr(os, "RTLD_LAZY", 1)
+        if not os.environ.get("PLL_AMD_NO_DEEPBIND"):  # sanitizer runtimes refuse DEEPBIND (tools/host_asan.sh)
+            mode |= getattr(os, "RTLD_DEEPBIND", 0)
         self.dll = C.CDLL(self.path, mode=mode)
         for table in (_PROTOS, _GPU_PROTOS):
             for name, (res, args) in table.items():
