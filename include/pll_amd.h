@@ -359,6 +359,45 @@ double pll_core_root_loglikelihood_repeats(unsigned int states, unsigned int sit
                                            const double *invar_proportion, const int *invar_indices, const unsigned int *freqs_indices,
                                            double *persite_lnl, unsigned int attrib);
 
+/* flat forms of the derivative path and of the transition matrices (src/pll.h:1181-1273, :2400-2412;
+ * bodies src/core_derivatives.c:26-118, :219-320, :324-470, :474-640, :695-930 and src/core_pmatrix.c:186-247).
+ * Same seam as above: raw host arrays in, a throw-away partition, the device path, the result copied
+ * back - `sumtable` here is a real table in the reference's layout, not a handle. The model arrives per
+ * rate category (eigenvecs[k], freqs[k], prop_invar[k]); pll_core_update_pmatrix indexes its arrays
+ * through params_indices and pmatrix[] through matrix_indices, as the reference does.
+ * pll_core_likelihood_derivatives refuses PLL_ATTRIB_AB_* (the correction needs the partition's extra
+ * entries: pll_compute_likelihood_derivatives serves it). */
+int pll_core_update_sumtable_ii(unsigned int states, unsigned int sites, unsigned int rate_cats, const double *parent_clv,
+                                const double *child_clv, const unsigned int *parent_scaler, const unsigned int *child_scaler,
+                                double *const *eigenvecs, double *const *inv_eigenvecs, double *const *freqs, double *sumtable,
+                                unsigned int attrib);
+int pll_core_update_sumtable_ti(unsigned int states, unsigned int sites, unsigned int rate_cats, const double *parent_clv,
+                                const unsigned char *left_tipchars, const unsigned int *parent_scaler, double *const *eigenvecs,
+                                double *const *inv_eigenvecs, double *const *freqs, const pll_state_t *tipmap,
+                                unsigned int tipmap_size, double *sumtable, unsigned int attrib);
+int pll_core_update_sumtable_repeats(unsigned int states, unsigned int sites, unsigned int parent_sites, unsigned int rate_cats,
+                                     const double *clvp, const double *clvc, const unsigned int *parent_scaler,
+                                     const unsigned int *child_scaler, double *const *eigenvecs, double *const *inv_eigenvecs,
+                                     double *const *freqs, double *sumtable, const unsigned int *parent_site_id,
+                                     const unsigned int *child_site_id, double *bclv_buffer, unsigned int inv, unsigned int attrib);
+int pll_core_update_sumtable_repeats_generic(unsigned int states, unsigned int sites, unsigned int parent_sites,
+                                             unsigned int rate_cats, const double *clvp, const double *clvc,
+                                             const unsigned int *parent_scaler, const unsigned int *child_scaler,
+                                             double *const *eigenvecs, double *const *inv_eigenvecs, double *const *freqs,
+                                             double *sumtable, const unsigned int *parent_site_id,
+                                             const unsigned int *child_site_id, double *bclv_buffer, unsigned int inv,
+                                             unsigned int attrib);
+int pll_core_likelihood_derivatives(unsigned int states, unsigned int sites, unsigned int rate_cats, const double *rate_weights,
+                                    const unsigned int *parent_scaler, const unsigned int *child_scaler, unsigned int parent_ids,
+                                    unsigned int child_ids, const int *invariant, const unsigned int *pattern_weights,
+                                    double branch_length, const double *prop_invar, double *const *freqs, const double *rates,
+                                    double *const *eigenvals, const double *sumtable, double *d_f, double *dd_f,
+                                    unsigned int attrib);
+int pll_core_update_pmatrix(double **pmatrix, unsigned int states, unsigned int rate_cats, const double *rates,
+                            const double *branch_lengths, const unsigned int *matrix_indices, const unsigned int *params_indices,
+                            const double *prop_invar, double *const *eigenvals, double *const *eigenvecs,
+                            double *const *inv_eigenvecs, unsigned int count, unsigned int attrib);
+
 /* ---- branch-length derivatives (src/pll.h:834-852, src/derivatives.c:239-418; SURVEY section 8
  * row f1). `sumtable` is the caller's buffer of sites*rate_cats*states_padded doubles, as in the
  * reference, but it is used as a HANDLE: pll_update_sumtable computes the table into HBM and

@@ -394,3 +394,182 @@ double pll_core_root_loglikelihood_repeats(unsigned int states, unsigned int sit
   return seam_edge(states, sites, rate_cats, clv, scaler, site_id, NULL, NULL, NULL, NULL, NULL, NULL, frequencies, rate_weights,
                    pattern_weights, invar_proportion, invar_indices, freqs_indices, persite_lnl, attrib, 1);
 }
+
+/* ---- derivatives and transition matrices (reference: src/pll.h:1181-1273, :2400-2412; bodies in
+ * src/core_derivatives.c and src/core_pmatrix.c). The flat functions take the model per RATE CATEGORY
+ * (eigenvecs[k], freqs[k], prop_invar[k]: the partition-level callers have applied params_indices
+ * already, src/derivatives.c:56-66), so the seam partition holds one rate matrix per category and the
+ * identity for params_indices. ------------------------------------------------------------------- */
+static unsigned int *seam_identity(unsigned int n)
+{
+  unsigned int *idx = (unsigned int *)malloc((n ? n : 1) * sizeof(unsigned int));
+  if (!idx) pll_set_error(PLL_ERROR_MEM_ALLOC, "pll_core_*: out of memory");
+  for (unsigned int k = 0; idx && k < n; ++k) idx[k] = k;
+  return idx;
+}
+
+/* eigensystem of rate matrix `set` <- the caller's arrays (any of them may be NULL: not needed by the call) */
+static void seam_put_eigen(seam_t *s, unsigned int set, const double *eigenvecs, const double *inv_eigenvecs, const double *eigenvals)
+{
+  pll_partition_t *p = s->p;
+  const size_t sp = p->states_padded;
+  if (eigenvecs) memcpy(p->eigenvecs[set], eigenvecs, p->states * sp * sizeof(double));
+  if (inv_eigenvecs) memcpy(p->inv_eigenvecs[set], inv_eigenvecs, p->states * sp * sizeof(double));
+  if (eigenvals) memcpy(p->eigenvals[set], eigenvals, p->states * sizeof(double));
+  p->eigen_decomp_valid[set] = 1;
+  pll_gpu_invalidate(p, PLL_GPU_DIRTY_EIGEN, (int)set);
+}
+
+static int seam_sumtable(unsigned int states, unsigned int sites, unsigned int rate_cats, const double *left_clv,
+                         const unsigned int *left_scaler, const unsigned int *left_site_id, const unsigned char *left_tipchars,
+                         const pll_state_t *tipmap, const double *right_clv, const unsigned int *right_scaler,
+                         const unsigned int *right_site_id, double *const *eigenvecs, double *const *inv_eigenvecs,
+                         double *const *freqs, double *sumtable, unsigned int attrib)
+{
+  seam_t s;
+  unsigned int *ident = seam_identity(rate_cats);
+  int rc = PLL_FAILURE;
+  if (!ident) return PLL_FAILURE;
+  if (!seam_open(&s, states, sites, rate_cats, 2, 1, rate_cats, attrib))
+  {
+    free(ident);
+    return PLL_FAILURE;
+  }
+  for (unsigned int k = 0; k < rate_cats; ++k)
+  {
+    pll_set_frequencies(s.p, k, freqs[k]);
+    seam_put_eigen(&s, k, eigenvecs[k], inv_eigenvecs[k], NULL);
+  }
+  /* the left operand meets freqs x inv_eigenvecs, the right one eigenvecs (src/core_derivatives.c:440-456);
+   * a tip given by characters is the left one (:608-627) */
+  if (left_tipchars)
+    seam_put_tip(&s, 0, left_tipchars, tipmap, sites);
+  else
+    seam_put_clv(&s, 0, left_clv, left_scaler, sites, NULL, left_site_id);
+  seam_put_clv(&s, 1, right_clv, right_scaler, sites, NULL, right_site_id);
+  rc = pll_update_sumtable(s.p, 1, 2, (!left_tipchars && left_scaler) ? 0 : PLL_SCALE_BUFFER_NONE,
+                           right_scaler ? 1 : PLL_SCALE_BUFFER_NONE, ident, sumtable);
+  if (rc) rc = pll_gpu_sync_sumtable(s.p, sumtable);
+  if (!rc) fprintf(stderr, "libpll_amd: pll_core_update_sumtable_*: [%d] %s\n", pll_errno, pll_errmsg);
+  seam_close(&s);
+  free(ident);
+  return rc;
+}
+
+int pll_core_update_sumtable_ii(unsigned int states, unsigned int sites, unsigned int rate_cats, const double *parent_clv,
+                                const double *child_clv, const unsigned int *parent_scaler, const unsigned int *child_scaler,
+                                double *const *eigenvecs, double *const *inv_eigenvecs, double *const *freqs, double *sumtable,
+                                unsigned int attrib)
+{
+  return seam_sumtable(states, sites, rate_cats, parent_clv, parent_scaler, NULL, NULL, NULL, child_clv, child_scaler, NULL,
+                       eigenvecs, inv_eigenvecs, freqs, sumtable, attrib);
+}
+
+int pll_core_update_sumtable_ti(unsigned int states, unsigned int sites, unsigned int rate_cats, const double *parent_clv,
+                                const unsigned char *left_tipchars, const unsigned int *parent_scaler, double *const *eigenvecs,
+                                double *const *inv_eigenvecs, double *const *freqs, const pll_state_t *tipmap,
+                                unsigned int tipmap_size, double *sumtable, unsigned int attrib)
+{
+  (void)tipmap_size;
+  return seam_sumtable(states, sites, rate_cats, NULL, NULL, NULL, left_tipchars, tipmap, parent_clv, parent_scaler, NULL,
+                       eigenvecs, inv_eigenvecs, freqs, sumtable, attrib);
+}
+
+int pll_core_update_sumtable_repeats_generic(unsigned int states, unsigned int sites, unsigned int parent_sites,
+                                             unsigned int rate_cats, const double *clvp, const double *clvc,
+                                             const unsigned int *parent_scaler, const unsigned int *child_scaler,
+                                             double *const *eigenvecs, double *const *inv_eigenvecs, double *const *freqs,
+                                             double *sumtable, const unsigned int *parent_site_id,
+                                             const unsigned int *child_site_id, double *bclv_buffer, unsigned int inv,
+                                             unsigned int attrib)
+{
+  /* parent_sites / bclv_buffer / inv steer the reference's choice of loop (a per-class pre-product of the
+   * smaller operand, src/core_derivatives.c:60); the table is the same, the operands are expanded here */
+  (void)parent_sites; (void)bclv_buffer; (void)inv;
+  return seam_sumtable(states, sites, rate_cats, clvp, parent_scaler, parent_site_id, NULL, NULL, clvc, child_scaler,
+                       child_site_id, eigenvecs, inv_eigenvecs, freqs, sumtable, attrib);
+}
+
+int pll_core_update_sumtable_repeats(unsigned int states, unsigned int sites, unsigned int parent_sites, unsigned int rate_cats,
+                                     const double *clvp, const double *clvc, const unsigned int *parent_scaler,
+                                     const unsigned int *child_scaler, double *const *eigenvecs, double *const *inv_eigenvecs,
+                                     double *const *freqs, double *sumtable, const unsigned int *parent_site_id,
+                                     const unsigned int *child_site_id, double *bclv_buffer, unsigned int inv, unsigned int attrib)
+{
+  return pll_core_update_sumtable_repeats_generic(states, sites, parent_sites, rate_cats, clvp, clvc, parent_scaler, child_scaler,
+                                                  eigenvecs, inv_eigenvecs, freqs, sumtable, parent_site_id, child_site_id,
+                                                  bclv_buffer, inv, attrib);
+}
+
+int pll_core_likelihood_derivatives(unsigned int states, unsigned int sites, unsigned int rate_cats, const double *rate_weights,
+                                    const unsigned int *parent_scaler, const unsigned int *child_scaler, unsigned int parent_ids,
+                                    unsigned int child_ids, const int *invariant, const unsigned int *pattern_weights,
+                                    double branch_length, const double *prop_invar, double *const *freqs, const double *rates,
+                                    double *const *eigenvals, const double *sumtable, double *d_f, double *dd_f,
+                                    unsigned int attrib)
+{
+  seam_t s;
+  unsigned int *ident;
+  int rc = PLL_FAILURE;
+  /* the scalers only enter the Lewis / Felsenstein ascertainment terms (src/core_derivatives.c:851-924),
+   * which need the partition's extra entries: that form goes through pll_compute_likelihood_derivatives */
+  (void)parent_scaler; (void)child_scaler; (void)parent_ids; (void)child_ids;
+  if (attrib & PLL_ATTRIB_AB_MASK)
+  {
+    pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_core_likelihood_derivatives: the ascertainment bias correction is served by "
+                  "pll_compute_likelihood_derivatives only");
+    fprintf(stderr, "libpll_amd: pll_core_likelihood_derivatives: [%d] %s\n", pll_errno, pll_errmsg);
+    return PLL_FAILURE;
+  }
+  if (!(ident = seam_identity(rate_cats))) return PLL_FAILURE;
+  if (!seam_open(&s, states, sites, rate_cats, 1, 1, rate_cats, attrib))
+  {
+    free(ident);
+    return PLL_FAILURE;
+  }
+  if (seam_model(&s, freqs, rate_weights, pattern_weights, prop_invar, invariant, ident, sites))
+  {
+    pll_set_category_rates(s.p, rates);
+    for (unsigned int k = 0; k < rate_cats; ++k) seam_put_eigen(&s, k, NULL, NULL, eigenvals[k]);
+    rc = pll_compute_likelihood_derivatives(s.p, PLL_SCALE_BUFFER_NONE, PLL_SCALE_BUFFER_NONE, branch_length, ident, sumtable,
+                                            d_f, dd_f);
+  }
+  if (!rc) fprintf(stderr, "libpll_amd: pll_core_likelihood_derivatives: [%d] %s\n", pll_errno, pll_errmsg);
+  seam_close(&s);
+  free(ident);
+  return rc;
+}
+
+int pll_core_update_pmatrix(double **pmatrix, unsigned int states, unsigned int rate_cats, const double *rates,
+                            const double *branch_lengths, const unsigned int *matrix_indices, const unsigned int *params_indices,
+                            const double *prop_invar, double *const *eigenvals, double *const *eigenvecs,
+                            double *const *inv_eigenvecs, unsigned int count, unsigned int attrib)
+{
+  /* here the arrays ARE indexed through params_indices (src/core_pmatrix.c:205-215), and pmatrix[] through
+   * matrix_indices: the seam partition mirrors both index spaces */
+  seam_t s;
+  unsigned int sets = 0, matrices = 0, n;
+  int rc = PLL_FAILURE;
+  for (n = 0; n < rate_cats; ++n)
+    if (params_indices[n] + 1 > sets) sets = params_indices[n] + 1;
+  for (n = 0; n < count; ++n)
+    if (matrix_indices[n] + 1 > matrices) matrices = matrix_indices[n] + 1;
+  if (!count) return PLL_SUCCESS;
+  if (!seam_open(&s, states, 1, rate_cats, 1, matrices, sets, attrib)) return PLL_FAILURE;
+  pll_set_category_rates(s.p, rates);
+  for (n = 0; n < rate_cats; ++n)
+  {
+    const unsigned int set = params_indices[n];
+    seam_put_eigen(&s, set, eigenvecs[set], inv_eigenvecs[set], eigenvals[set]);
+    s.p->prop_invar[set] = prop_invar[set];
+  }
+  rc = pll_update_prob_matrices(s.p, params_indices, matrix_indices, branch_lengths, count);
+  for (n = 0; rc && n < count; ++n)
+  {
+    rc = pll_gpu_sync_pmatrix(s.p, (int)matrix_indices[n]);
+    if (rc) memcpy(pmatrix[matrix_indices[n]], s.p->pmatrix[matrix_indices[n]], matrix_doubles(states, rate_cats, attrib) * sizeof(double));
+  }
+  if (!rc) fprintf(stderr, "libpll_amd: pll_core_update_pmatrix: [%d] %s\n", pll_errno, pll_errmsg);
+  seam_close(&s);
+  return rc;
+}

@@ -260,3 +260,132 @@ def test_repeats_forms(amd_lib, ref_lib):
     np.testing.assert_allclose(res["amd"][0], res["ref"][0], rtol=RTOL, atol=0)
     assert (res["amd"][1] == res["ref"][1]).all()
     assert abs(res["amd"][2] - res["ref"][2]) <= RTOL * abs(res["ref"][2])
+
+
+# ---- flat derivative / transition-matrix functions (reference src/pll.h:1181-1273, :2400-2412) ------
+def padded_rows(mat, sp):
+    out = np.zeros((mat.shape[0], sp))
+    out[:, :mat.shape[1]] = mat
+    return aligned(out)
+
+
+def eigen_arrays(states, sp, sets, seed=0):
+    """per set: (eigenvecs, inv_eigenvecs, eigenvals, freqs) in the partition's array conventions"""
+    rows = []
+    for s in range(sets):
+        exch, freqs = (W.GTR_DNA["exch"], W.GTR_DNA["freqs"]) if states == 4 else W.synthetic_exch(states)
+        freqs = np.asarray(freqs, dtype=np.float64)
+        if s:  # a different model per set
+            rng = np.random.default_rng(seed + s)
+            freqs = freqs * (0.5 + rng.random(states))
+            freqs /= freqs.sum()
+        e = W.eigensystem(exch, freqs)
+        rows.append((padded_rows(e["eigenvecs"][0], sp), padded_rows(e["inv_eigenvecs"][0], sp),
+                     aligned(np.concatenate([e["eigenvals"][0], np.zeros(sp - states)])),
+                     aligned(np.concatenate([freqs, np.zeros(sp - states)]))))
+    return rows
+
+
+def ptr_array(rows, which, index):
+    return (D * len(index))(*[rows[i][which].ctypes.data_as(D) for i in index])
+
+
+@pytest.mark.parametrize("states,rates,arch,per_rate", [(4, 4, api.ARCH_AVX2, False), (4, 4, api.ARCH_CPU, True),
+                                                       (20, 4, api.ARCH_AVX2, False), (7, 3, api.ARCH_CPU, False)])
+def test_flat_sumtable_and_derivatives(amd_lib, ref_lib, states, rates, arch, per_rate):
+    rng = np.random.default_rng(77 + states)
+    n = 257
+    sp = sp_of(states, arch)
+    attrib = arch | (api.RATE_SCALERS if per_rate else 0)
+    sw = rates if per_rate else 1
+    rows = eigen_arrays(states, sp, rates)          # one model per rate category, as the flat functions take them
+    idx = list(range(rates))
+    evec, ievec, evals, fr = (ptr_array(rows, k, idx) for k in range(4))
+    pclv = rand_clv(rng, n, rates, states, sp)
+    cclv = rand_clv(rng, n, rates, states, sp)
+    psc = np.ascontiguousarray(rng.integers(0, 3, size=(n, sw)).astype(np.uint32))
+    csc = np.ascontiguousarray(rng.integers(0, 3, size=(n, sw)).astype(np.uint32))
+    tipmap = np.array([(1 << (c % states)) | (1 << ((c * 3 + 1) % states)) for c in range(256)], dtype=np.uint64)
+    if states == 4:
+        tipmap = np.arange(256, dtype=np.uint64) & 15
+        tipmap[tipmap == 0] = 15
+    chars = np.ascontiguousarray(rng.integers(1, 16 if states == 4 else 200, size=n).astype(np.uint8))
+    # class-compressed operands
+    pid = np.ascontiguousarray(rng.integers(0, 40, size=n).astype(np.uint32)); pid[:40] = np.arange(40)
+    cid = np.ascontiguousarray(rng.integers(0, 90, size=n).astype(np.uint32)); cid[:90] = np.arange(90)
+    weights = np.ascontiguousarray(rng.integers(1, 5, size=n).astype(np.uint32))
+    rate_w = aligned(np.full(rates, 1.0 / rates))
+    cat_rates = aligned(W.gamma_rates_mean(0.6, rates))
+    pinv = aligned(np.full(rates, 0.15))
+    invariant = np.ascontiguousarray(np.where(rng.random(n) < 0.3, rng.integers(0, states, size=n), -1).astype(np.int32))
+
+    tables = {}
+    for tag, lib in (("amd", amd_lib), ("ref", ref_lib)):
+        t = {}
+        f = lib.dll.pll_core_update_sumtable_ii
+        f.restype = C.c_int
+        f.argtypes = [C.c_uint] * 3 + [D, D, U, U, DP, DP, DP, D, C.c_uint]
+        t["ii"] = aligned(np.zeros((n, rates, sp)))
+        assert f(states, n, rates, dp(pclv), dp(cclv), up(psc), up(csc), evec, ievec, fr, dp(t["ii"]), attrib)
+        f = lib.dll.pll_core_update_sumtable_ti
+        f.restype = C.c_int
+        f.argtypes = [C.c_uint] * 3 + [D, B, U, DP, DP, DP, S64, C.c_uint, D, C.c_uint]
+        t["ti"] = aligned(np.zeros((n, rates, sp)))
+        assert f(states, n, rates, dp(pclv), bp(chars), up(psc), evec, ievec, fr, tipmap.ctypes.data_as(S64), 256,
+                 dp(t["ti"]), attrib)
+        f = lib.dll.pll_core_update_sumtable_repeats_generic
+        f.restype = C.c_int
+        f.argtypes = [C.c_uint] * 4 + [D, D, U, U, DP, DP, DP, D, U, U, D, C.c_uint, C.c_uint]
+        t["rep"] = aligned(np.zeros((n, rates, sp)))
+        # the generic form reads operands with the unpadded span (src/core_derivatives.c:241-242): CPU layout only
+        if sp == states:
+            assert f(states, n, 40, rates, dp(pclv), dp(cclv), up(psc), up(csc), evec, ievec, fr, dp(t["rep"]),
+                     up(pid), up(cid), None, 0, attrib)
+        tables[tag] = t
+    for key in ("ii", "ti", "rep"):
+        a, r = tables["amd"][key][..., :states], tables["ref"][key][..., :states]
+        assert np.allclose(a, r, rtol=RTOL, atol=RTOL * np.abs(r).max()), key
+
+    # derivatives from the REFERENCE's table (a table this library did not produce is uploaded as it is)
+    table = tables["ref"]["ii"]
+    for t_len in (0.05, 0.7):
+        out = {}
+        for tag, lib in (("amd", amd_lib), ("ref", ref_lib)):
+            f = lib.dll.pll_core_likelihood_derivatives
+            f.restype = C.c_int
+            f.argtypes = [C.c_uint] * 3 + [D, U, U, C.c_uint, C.c_uint, I, U, C.c_double, D, DP, D, DP, D, D, D, C.c_uint]
+            d1, d2 = C.c_double(0), C.c_double(0)
+            assert f(states, n, rates, dp(rate_w), up(psc), up(csc), n, n, invariant.ctypes.data_as(I), up(weights), t_len,
+                     dp(pinv), fr, dp(cat_rates), evals, dp(table), C.byref(d1), C.byref(d2), attrib)
+            out[tag] = (d1.value, d2.value)
+        assert out["amd"][0] == pytest.approx(out["ref"][0], rel=1e-9, abs=1e-9)
+        assert out["amd"][1] == pytest.approx(out["ref"][1], rel=1e-9, abs=1e-9)
+
+
+@pytest.mark.parametrize("states,rates,arch", [(4, 4, api.ARCH_AVX2), (20, 4, api.ARCH_AVX), (7, 3, api.ARCH_CPU)])
+def test_flat_update_pmatrix(amd_lib, ref_lib, states, rates, arch):
+    sp = sp_of(states, arch)
+    rows = eigen_arrays(states, sp, 2)
+    params = np.ascontiguousarray(np.array([k % 2 for k in range(rates)], dtype=np.uint32))   # two models, mixed over the rates
+    evec, ievec, evals = (ptr_array(rows, k, [0, 1]) for k in range(3))
+    cat_rates = aligned(W.gamma_rates_mean(0.8, rates))
+    pinv = aligned(np.array([0.0, 0.2]))
+    matrix_indices = np.ascontiguousarray(np.array([3, 0, 5], dtype=np.uint32))
+    lengths = aligned(np.array([0.01, 0.3, 2.5]))
+    res = {}
+    for tag, lib in (("amd", amd_lib), ("ref", ref_lib)):
+        f = lib.dll.pll_core_update_pmatrix
+        f.restype = C.c_int
+        f.argtypes = [DP, C.c_uint, C.c_uint, D, D, U, U, D, DP, DP, DP, C.c_uint, C.c_uint]
+        mats = [aligned(np.full((rates, states, sp), -1.0)) for _ in range(6)]
+        arr = (D * 6)(*[m.ctypes.data_as(D) for m in mats])
+        assert f(arr, states, rates, dp(cat_rates), dp(lengths), up(matrix_indices), up(params), dp(pinv), evals, evec, ievec,
+                 3, arch)
+        res[tag] = mats
+    for i in range(6):
+        a, r = res["amd"][i][..., :states], res["ref"][i][..., :states]
+        if i in (0, 3, 5):
+            assert np.allclose(a, r, rtol=RTOL, atol=1e-14), i
+            assert np.allclose(r.sum(axis=-1), 1.0, atol=1e-9)
+        else:
+            assert (a == -1.0).all() and (r == -1.0).all()   # untouched
