@@ -375,6 +375,17 @@ int pll_core_update_sumtable_ti(unsigned int states, unsigned int sites, unsigne
                                 const unsigned char *left_tipchars, const unsigned int *parent_scaler, double *const *eigenvecs,
                                 double *const *inv_eigenvecs, double *const *freqs, const pll_state_t *tipmap,
                                 unsigned int tipmap_size, double *sumtable, unsigned int attrib);
+/* src/pll.h:1217-1226 */
+int pll_core_update_sumtable_ti_4x4(unsigned int sites, unsigned int rate_cats, const double *parent_clv,
+                                    const unsigned char *left_tipchars, const unsigned int *parent_scaler,
+                                    double *const *eigenvecs, double *const *inv_eigenvecs, double *const *freqs,
+                                    double *sumtable, unsigned int attrib);
+/* src/core_likelihood.c:211-223 (exported there, not declared in src/pll.h): unpadded layout */
+double pll_core_root_loglikelihood_repeats_generic(unsigned int states, unsigned int sites, unsigned int rate_cats,
+                                                   const double *clv, const unsigned int *site_id, const unsigned int *scaler,
+                                                   double *const *frequencies, const double *rate_weights,
+                                                   const unsigned int *pattern_weights, const double *invar_proportion,
+                                                   const int *invar_indices, const unsigned int *freqs_indices, double *persite_lnl);
 int pll_core_update_sumtable_repeats(unsigned int states, unsigned int sites, unsigned int parent_sites, unsigned int rate_cats,
                                      const double *clvp, const double *clvc, const unsigned int *parent_scaler,
                                      const unsigned int *child_scaler, double *const *eigenvecs, double *const *inv_eigenvecs,

@@ -573,3 +573,25 @@ int pll_core_update_pmatrix(double **pmatrix, unsigned int states, unsigned int 
   seam_close(&s);
   return rc;
 }
+
+/* 4-state form of the tip case: the characters ARE the state masks (src/core_derivatives.c:474-560) */
+int pll_core_update_sumtable_ti_4x4(unsigned int sites, unsigned int rate_cats, const double *parent_clv,
+                                    const unsigned char *left_tipchars, const unsigned int *parent_scaler,
+                                    double *const *eigenvecs, double *const *inv_eigenvecs, double *const *freqs,
+                                    double *sumtable, unsigned int attrib)
+{
+  return seam_sumtable(4, sites, rate_cats, NULL, NULL, NULL, left_tipchars, NULL, parent_clv, parent_scaler, NULL, eigenvecs,
+                       inv_eigenvecs, freqs, sumtable, attrib);
+}
+
+/* exported by the reference without a declaration in pll.h (src/core_likelihood.c:211-223): unpadded layout */
+double pll_core_root_loglikelihood_repeats_generic(unsigned int states, unsigned int sites, unsigned int rate_cats,
+                                                   const double *clv, const unsigned int *site_id, const unsigned int *scaler,
+                                                   double *const *frequencies, const double *rate_weights,
+                                                   const unsigned int *pattern_weights, const double *invar_proportion,
+                                                   const int *invar_indices, const unsigned int *freqs_indices, double *persite_lnl)
+{
+  return pll_core_root_loglikelihood_repeats(states, sites, rate_cats, clv, site_id, scaler, frequencies, rate_weights,
+                                             pattern_weights, invar_proportion, invar_indices, freqs_indices, persite_lnl,
+                                             PLL_ATTRIB_ARCH_CPU);
+}

@@ -333,6 +333,12 @@ def test_flat_sumtable_and_derivatives(amd_lib, ref_lib, states, rates, arch, pe
         t["ti"] = aligned(np.zeros((n, rates, sp)))
         assert f(states, n, rates, dp(pclv), bp(chars), up(psc), evec, ievec, fr, tipmap.ctypes.data_as(S64), 256,
                  dp(t["ti"]), attrib)
+        t["ti4"] = aligned(np.zeros((n, rates, sp)))
+        if states == 4:
+            f = lib.dll.pll_core_update_sumtable_ti_4x4
+            f.restype = C.c_int
+            f.argtypes = [C.c_uint] * 2 + [D, B, U, DP, DP, DP, D, C.c_uint]
+            assert f(n, rates, dp(pclv), bp(chars), up(psc), evec, ievec, fr, dp(t["ti4"]), attrib)
         f = lib.dll.pll_core_update_sumtable_repeats_generic
         f.restype = C.c_int
         f.argtypes = [C.c_uint] * 4 + [D, D, U, U, DP, DP, DP, D, U, U, D, C.c_uint, C.c_uint]
@@ -342,7 +348,9 @@ def test_flat_sumtable_and_derivatives(amd_lib, ref_lib, states, rates, arch, pe
             assert f(states, n, 40, rates, dp(pclv), dp(cclv), up(psc), up(csc), evec, ievec, fr, dp(t["rep"]),
                      up(pid), up(cid), None, 0, attrib)
         tables[tag] = t
-    for key in ("ii", "ti", "rep"):
+    if states == 4:
+        assert (tables["ref"]["ti4"] == tables["ref"]["ti"]).all()
+    for key in ("ii", "ti", "ti4", "rep"):
         a, r = tables["amd"][key][..., :states], tables["ref"][key][..., :states]
         assert np.allclose(a, r, rtol=RTOL, atol=RTOL * np.abs(r).max()), key
 
@@ -389,3 +397,26 @@ def test_flat_update_pmatrix(amd_lib, ref_lib, states, rates, arch):
             assert np.allclose(r.sum(axis=-1), 1.0, atol=1e-9)
         else:
             assert (a == -1.0).all() and (r == -1.0).all()   # untouched
+
+
+def test_root_loglikelihood_repeats_generic(amd_lib, ref_lib):
+    """the undeclared export of src/core_likelihood.c:211-223 (unpadded layout, no attrib argument)"""
+    rng = np.random.default_rng(5)
+    states, rates, n, classes = 7, 3, 200, 60
+    clv = rand_clv(rng, classes, rates, states, states)
+    site_id = np.ascontiguousarray(rng.integers(0, classes, size=n).astype(np.uint32))
+    scaler = np.ascontiguousarray(rng.integers(0, 2, size=classes).astype(np.uint32))
+    _, freqs = W.synthetic_exch(states)
+    fr, keep = freq_ptrs(np.asarray(freqs, dtype=np.float64), states, 1)
+    rate_w = aligned(np.full(rates, 1.0 / rates))
+    weights = np.ascontiguousarray(rng.integers(1, 4, size=n).astype(np.uint32))
+    fidx = np.zeros(rates, dtype=np.uint32)
+    out = {}
+    for tag, lib in (("amd", amd_lib), ("ref", ref_lib)):
+        f = lib.dll.pll_core_root_loglikelihood_repeats_generic
+        f.restype = C.c_double
+        f.argtypes = [C.c_uint] * 3 + [D, U, U, DP, D, U, D, I, U, D]
+        per = aligned(np.zeros(n))
+        out[tag] = (f(states, n, rates, dp(clv), up(site_id), up(scaler), fr, dp(rate_w), up(weights), None, None, up(fidx), dp(per)), per)
+    assert out["amd"][0] == pytest.approx(out["ref"][0], rel=RTOL)
+    assert np.allclose(out["amd"][1], out["ref"][1], rtol=RTOL, atol=0)
