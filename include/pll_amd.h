@@ -415,7 +415,8 @@ int pll_core_update_pmatrix(double **pmatrix, unsigned int states, unsigned int 
  * remembers which host buffer it stands for; pll_compute_likelihood_derivatives given the same
  * pointer streams the device copy. The host buffer itself is only filled by
  * pll_gpu_sync_sumtable() (or under PLL_AMD_EAGER_MIRROR=1); a table the library has never seen
- * (written by the caller) is uploaded from the host buffer. */
+ * (written by the caller) is uploaded from the host buffer. Up to 16 tables per partition stay
+ * resident (pll_gpu_release_sumtable). */
 int pll_update_sumtable(pll_partition_t *partition, unsigned int parent_clv_index,
                         unsigned int child_clv_index, int parent_scaler_index,
                         int child_scaler_index, const unsigned int *params_indices, double *sumtable);
@@ -486,6 +487,11 @@ int pll_gpu_sync_all(pll_partition_t *partition);
 void pll_gpu_invalidate(pll_partition_t *partition, unsigned int what, int index);
 /* download the device sumtable that stands for this host buffer into it (reference layout) */
 int pll_gpu_sync_sumtable(pll_partition_t *partition, double *sumtable);
+/* a partition keeps up to 16 device sumtables alive, one per host buffer handed to
+ * pll_update_sumtable; beyond that the least recently used is recycled and an evaluation on ITS
+ * handle fails with PLL_ERROR_GPU_RUNTIME (never a silent read of the unwritten host buffer). A
+ * caller that is done with a table (about to free the host buffer) gives its HBM back here. */
+int pll_gpu_release_sumtable(pll_partition_t *partition, const double *sumtable);
 /* stream plumbing: by default each partition owns a stream; a harness may substitute its own
  * (a hipStream_t passed as void*) so that its events see the kernels. pll_update_partials is
  * asynchronous and may hold its last one or two operations back until the next call on the

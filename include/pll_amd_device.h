@@ -184,10 +184,13 @@ typedef struct pllgpu_sumtable
   unsigned int gather;
 } pllgpu_sumtable_t;
 /* replaces pll_core_update_sumtable_{ii,ti,repeats} (src/core_derivatives.c:25-641); the table
- * stays in HBM in one of 4 slots */
+ * stays in HBM in one of PLLGPU_SUMTABLE_SLOTS slots (allocated on first use) */
+#define PLLGPU_SUMTABLE_SLOTS 16
 int pllgpu_update_sumtable(pllgpu_ctx_t *ctx, const pllgpu_sumtable_t *st, unsigned int slot);
 int pllgpu_sumtable_upload(pllgpu_ctx_t *ctx, unsigned int slot, const double *host);
 int pllgpu_sumtable_download(pllgpu_ctx_t *ctx, unsigned int slot, double *host);
+/* give the slot's HBM back (pll_gpu_release_sumtable) */
+int pllgpu_sumtable_release(pllgpu_ctx_t *ctx, unsigned int slot);
 /* replaces pll_core_likelihood_derivatives (src/core_derivatives.c:696-849). Synchronises. */
 /* eval_sites: how many leading table entries enter the sums (sites, or sites + states for the
  * Stamatakis correction, src/core_derivatives.c:733-742) */

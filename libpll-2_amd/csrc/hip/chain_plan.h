@@ -509,6 +509,14 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
     unsigned held_chains = 0;
     for (size_t i = pl->held_from; i < pl->stages.size(); ++i) held_chains += pl->stages[i].nchains;
     if (held_chains > 2 || (c->geo.sites + 63) / 64 > 4096u) pl->held_from = pl->stages.size();
+    // the tail kernel takes BOTH ends in one descriptor pack (an end that is not held counts one
+    // terminal step); every stage record was sized against the pack on its own, two records of the last
+    // stage (different fetch variants) together may not fit: such a plan keeps its descriptors in memory
+    unsigned tail_steps = 0, tail_heads = 0;
+    for (size_t i = pl->held_from; i < pl->stages.size(); ++i)
+      for (unsigned h = pl->stages[i].first_head; h < pl->stages[i].first_head + pl->stages[i].nchains; ++h, ++tail_heads)
+        tail_steps += pl->heads[h].nsteps + 1;
+    if (tail_heads && tail_steps + (2u - std::min(tail_heads, 2u)) > (unsigned)kChainPackSteps) pl->in_kernarg = false;
   }
   pl->bytes += c->last_bytes; // the cherry-cherry groups (build_cc_launches counted them)
   pl->launches = (unsigned)(pl->cc.size() + pl->stages.size());

@@ -112,7 +112,7 @@ struct pllgpu_ctx
   DevBuf<double> evecs, ievecs, brlen;   // device P-matrices: [rate_matrices][S][SP] x 2, staged branch lengths
   DevBuf<unsigned> mindex;               // staged matrix indices
   DevBuf<unsigned> rep_table, rep_rank, rep_blocksum, rep_counts; // site-repeats class computation (kernels_repeats.h)
-  DevBuf<double> sumtable[4];            // device-resident sumtables (tiled like a CLV)
+  DevBuf<double> sumtable[PLLGPU_SUMTABLE_SLOTS]; // device-resident sumtables (tiled like a CLV), allocated on first use
   double *result_dev = nullptr;  // device alias of result_host
   DevBuf<unsigned> pattern_weights;
   DevBuf<int> invariant;
@@ -1189,12 +1189,55 @@ static int scaler_ptr(pllgpu_ctx *c, int idx, const unsigned *&out)
   return 0;
 }
 
+// Work that pllgpu_edge_loglikelihood has taken out of the held state (chain heads, deferred ops) in order
+// to evaluate it inside the log-likelihood kernel. If the call fails before that kernel is launched the
+// host layer has already marked those CLVs and scalers as device-side, so they must still be computed:
+// the guard launches them as ordinary updates on every exit path that does not disarm it.
+struct ClaimedWork
+{
+  pllgpu_ctx *c;
+  int heads[2] = {-1, -1};
+  std::vector<pllgpu_op_t> ops;
+  bool armed = false;
+  explicit ClaimedWork(pllgpu_ctx *ctx) : c(ctx) {}
+  void disarm() { armed = false; }
+  ~ClaimedWork()
+  {
+    if (!armed) return;
+    char keep[sizeof g_err];
+    memcpy(keep, g_err, sizeof keep); // the error that brought us here is the one to report
+    if (c->plan)
+      for (int h : heads)
+        if (h >= 0)
+        {
+          launch_chain_heads(c, *c->plan, (unsigned)h, 1, c->plan->head_variant[h]);
+          ++c->last_launches;
+        }
+    if (!ops.empty())
+    {
+      c->deferred.insert(c->deferred.end(), ops.begin(), ops.end());
+      (void)flush_deferred(c);
+    }
+    (void)hipGetLastError();
+    memcpy(g_err, keep, sizeof keep);
+  }
+};
+
 extern "C" int pllgpu_edge_loglikelihood(pllgpu_ctx_t *c, const pllgpu_edge_t *ed, double *persite_host, double *lnl_out)
 {
   CHECK_CTX_KEEP(c);
   const pllgpu_geometry_t &g = c->geo;
+  // everything that can be checked without touching the held state comes first
   if (ed->parent_clv >= g.nodes || ed->child_clv >= g.nodes || ed->matrix >= g.prob_matrices)
     return fail(PLLGPU_EINVAL, "edge references an index out of range");
+  if (ed->parent_scaler >= (int)g.scale_buffers || ed->child_scaler >= (int)g.scale_buffers)
+    return fail(PLLGPU_EINVAL, "edge references a scale buffer out of range");
+  if (ed->device_result && persite_host) return fail(PLLGPU_EINVAL, "per-site values are not available from an asynchronous evaluation");
+  if (ed->child_is_tip && (ed->child_clv >= g.tips || !c->tipchars[ed->child_clv].p))
+    return fail(PLLGPU_EINVAL, "tip %u has no codes on the device", ed->child_clv);
+  for (unsigned k = 0; k < g.rate_cats; ++k)
+    if (ed->freqs_indices[k] >= g.rate_matrices) return fail(PLLGPU_EINVAL, "freqs_indices[%u] = %u out of range", k, ed->freqs_indices[k]);
+  ClaimedWork claimed(c);
   // held ops (tail fusion): if they produce an end of THIS edge they are evaluated inside the lnL
   // kernel; whatever else is held goes out as ordinary updates first
   TailCall tail;
@@ -1216,16 +1259,33 @@ extern "C" int pllgpu_edge_loglikelihood(pllgpu_ctx_t *c, const pllgpu_edge_t *e
     }
     else
     {
-      // whatever else is held goes out as an ordinary chain launch
-      c->chain_held = false;
-      for (size_t i = pl.held_from; i < pl.stages.size(); ++i)
-        for (unsigned h = pl.stages[i].first_head; h < pl.stages[i].first_head + pl.stages[i].nchains; ++h)
-          if ((int)h != held_p && (int)h != held_c)
-          {
-            launch_chain_heads(c, pl, h, 1, pl.stages[i].variant);
-            ++c->last_launches;
-          }
-      if (int rc = c->block_sums.ensure((pl.entries + 63) / 64)) return rc;
+      // a tail that would not fit its kernarg pack (try_chain_plan keeps such plans in memory: cannot happen
+      // there; defensive): nothing is claimed, both chains go out as ordinary launches
+      if (pl.in_kernarg)
+      {
+        const unsigned np = held_p >= 0 ? pl.heads[held_p].nsteps + 1 : 1u, nc = held_c >= 0 ? pl.heads[held_c].nsteps + 1 : 1u;
+        if (np + nc > (unsigned)kChainPackSteps) held_p = held_c = -1;
+      }
+      if (held_p < 0 && held_c < 0)
+      {
+        if (int rc = launch_held_chains(c)) return rc;
+      }
+      else
+      {
+        if (int rc = c->block_sums.ensure((pl.entries + 63) / 64)) return rc; // before anything is claimed
+        // whatever else is held goes out as an ordinary chain launch
+        c->chain_held = false;
+        claimed.heads[0] = held_p;
+        claimed.heads[1] = held_c;
+        claimed.armed = true;
+        for (size_t i = pl.held_from; i < pl.stages.size(); ++i)
+          for (unsigned h = pl.stages[i].first_head; h < pl.stages[i].first_head + pl.stages[i].nchains; ++h)
+            if ((int)h != held_p && (int)h != held_c)
+            {
+              launch_chain_heads(c, pl, h, 1, pl.stages[i].variant);
+              ++c->last_launches;
+            }
+      }
     }
   }
   if (!c->deferred.empty())
@@ -1248,6 +1308,9 @@ extern "C" int pllgpu_edge_loglikelihood(pllgpu_ctx_t *c, const pllgpu_edge_t *e
       held.swap(c->deferred);
       for (size_t i = 0; i < held.size(); ++i)
         if ((int)i != ia && (int)i != ib) c->deferred.push_back(held[i]);
+      if (ia >= 0) claimed.ops.push_back(held[ia]);
+      if (ib >= 0) claimed.ops.push_back(held[ib]);
+      claimed.armed = true;
       if (!c->deferred.empty())
         if (int rc = flush_deferred(c)) return rc;
       memset(&tail.g, 0, sizeof tail.g);
@@ -1292,7 +1355,6 @@ extern "C" int pllgpu_edge_loglikelihood(pllgpu_ctx_t *c, const pllgpu_edge_t *e
     e.csid = c->ids[ed->child_clv] ? c->site_id[ed->child_clv].p : nullptr;
   }
   e.is_root = 0;
-  if (ed->device_result && persite_host) return fail(PLLGPU_EINVAL, "per-site values are not available from an asynchronous evaluation");
   if (held_p >= 0 || held_c >= 0)
   {
     const ChainPlan &pl = *c->plan;
@@ -1354,7 +1416,9 @@ extern "C" int pllgpu_edge_loglikelihood(pllgpu_ctx_t *c, const pllgpu_edge_t *e
         ct.pack.heads[k] = *hh[k];
       }
     }
-    return run_lnl(c, e, ed->child_is_tip != 0, false, ed->freqs_indices, persite_host, lnl_out, ed->device_result, nullptr, &ct);
+    const int rc = run_lnl(c, e, ed->child_is_tip != 0, false, ed->freqs_indices, persite_host, lnl_out, ed->device_result, nullptr, &ct);
+    if (rc == 0) claimed.disarm();
+    return rc;
   }
   if (use_tail)
   {
@@ -1364,7 +1428,9 @@ extern "C" int pllgpu_edge_loglikelihood(pllgpu_ctx_t *c, const pllgpu_edge_t *e
     tail.g.p.right = e.child;
     tail.g.p.rtip = e.ctip;
     tail.g.p.rscaler = e.cscaler;
-    return run_lnl(c, e, ed->child_is_tip != 0, false, ed->freqs_indices, persite_host, lnl_out, ed->device_result, &tail);
+    const int rc = run_lnl(c, e, ed->child_is_tip != 0, false, ed->freqs_indices, persite_host, lnl_out, ed->device_result, &tail);
+    if (rc == 0) claimed.disarm();
+    return rc;
   }
   return run_lnl(c, e, ed->child_is_tip != 0, ed->gather != 0, ed->freqs_indices, persite_host, lnl_out, ed->device_result);
 }
@@ -1455,7 +1521,7 @@ extern "C" int pllgpu_rates_upload(pllgpu_ctx_t *c, const double *host)
 
 static int sumtable_slot(pllgpu_ctx *c, unsigned slot)
 {
-  if (slot >= 4) return fail(PLLGPU_EINVAL, "sumtable slot %u out of range", slot);
+  if (slot >= PLLGPU_SUMTABLE_SLOTS) return fail(PLLGPU_EINVAL, "sumtable slot %u out of range", slot);
   return c->sumtable[slot].ensure(clv_elems(c, c->geo.sites_alloc));
 }
 
@@ -1526,7 +1592,7 @@ extern "C" int pllgpu_sumtable_upload(pllgpu_ctx_t *c, unsigned slot, const doub
 extern "C" int pllgpu_sumtable_download(pllgpu_ctx_t *c, unsigned slot, double *host)
 {
   CHECK_CTX(c);
-  if (slot >= 4 || !c->sumtable[slot].p) return fail(PLLGPU_EINVAL, "sumtable slot %u is empty", slot);
+  if (slot >= PLLGPU_SUMTABLE_SLOTS || !c->sumtable[slot].p) return fail(PLLGPU_EINVAL, "sumtable slot %u is empty", slot);
   const size_t n = (size_t)c->geo.sites_alloc * c->span;
   if (int rc = c->scratch.ensure(n)) return rc;
   hipLaunchKernelGGL(k_tiled_to_aos, dim3(1024), dim3(256), 0, c->stream, c->sumtable[slot].p, c->scratch.p, c->geo.sites_alloc,
@@ -1537,12 +1603,21 @@ extern "C" int pllgpu_sumtable_download(pllgpu_ctx_t *c, unsigned slot, double *
   return 0;
 }
 
+extern "C" int pllgpu_sumtable_release(pllgpu_ctx_t *c, unsigned slot)
+{
+  CHECK_CTX(c);
+  if (slot >= PLLGPU_SUMTABLE_SLOTS) return fail(PLLGPU_EINVAL, "sumtable slot %u out of range", slot);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->sumtable[slot].release();
+  return 0;
+}
+
 extern "C" int pllgpu_likelihood_derivatives(pllgpu_ctx_t *c, unsigned slot, double branch_length,
                                              const unsigned *params_indices, unsigned eval_sites, double *d_f, double *dd_f)
 {
   CHECK_CTX(c);
   const pllgpu_geometry_t &g = c->geo;
-  if (slot >= 4 || !c->sumtable[slot].p) return fail(PLLGPU_EINVAL, "sumtable slot %u is empty", slot);
+  if (slot >= PLLGPU_SUMTABLE_SLOTS || !c->sumtable[slot].p) return fail(PLLGPU_EINVAL, "sumtable slot %u is empty", slot);
   if (eval_sites == 0 || eval_sites > g.sites_alloc) return fail(PLLGPU_EINVAL, "eval_sites %u out of range", eval_sites);
   if (!c->eigenvals.p || !c->rates.p) return fail(PLLGPU_EINVAL, "eigenvalues / category rates were not uploaded");
   if (int rc = c->diag.ensure((size_t)g.rate_cats * g.states * 4)) return rc;
@@ -1661,7 +1736,7 @@ extern "C" int pllgpu_asc_derivative_terms(pllgpu_ctx_t *c, unsigned slot, int p
   (void)params_indices; // the diag table of the last evaluation already carries them
   const pllgpu_geometry_t &g = c->geo;
   if (g.sites_alloc < g.sites + g.states) return fail(PLLGPU_EINVAL, "the partition has no per-state extra entries");
-  if (slot >= 4 || !c->sumtable[slot].p || !c->diag.p) return fail(PLLGPU_EINVAL, "no derivative evaluation precedes the ascertainment terms");
+  if (slot >= PLLGPU_SUMTABLE_SLOTS || !c->sumtable[slot].p || !c->diag.p) return fail(PLLGPU_EINVAL, "no derivative evaluation precedes the ascertainment terms");
   DevAscDeriv a;
   memset(&a, 0, sizeof a);
   a.table = c->sumtable[slot].p;

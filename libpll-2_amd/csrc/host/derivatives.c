@@ -9,7 +9,10 @@
  *     M2[k][j][i] = eigenvecs[j][i]                 (right end)
  * per rate category k = params_indices[k]; they are rebuilt and uploaded only when an
  * eigensystem, a frequency vector or params_indices changed. The caller's `sumtable` pointer is a
- * handle to one of four device slots (least recently used is recycled).
+ * handle to one of PLLGPU_SUMTABLE_SLOTS device tables (allocated on first use; beyond that the least
+ * recently used is recycled and its handle remembered: an evaluation on a recycled handle fails
+ * loudly instead of reading the caller's never-written buffer). pll_gpu_release_sumtable() gives a
+ * table's HBM back.
  */
 #include <math.h>
 
@@ -21,17 +24,25 @@ static int fail_loudly(const char *what)
   return PLL_FAILURE;
 }
 
+static int was_evicted(const pll_amd_ext_t *x, const double *key)
+{
+  int i;
+  for (i = 0; i < PLLGPU_SUMTABLE_SLOTS; ++i)
+    if (x->sumtable_evicted[i] == key) return 1;
+  return 0;
+}
+
 static int slot_of(pll_amd_ext_t *x, const double *key, int create)
 {
   int i, victim = 0;
-  for (i = 0; i < 4; ++i)
+  for (i = 0; i < PLLGPU_SUMTABLE_SLOTS; ++i)
     if (x->sumtable_key[i] == key)
     {
       x->sumtable_age[i] = ++x->sumtable_clock;
       return i;
     }
   if (!create) return -1;
-  for (i = 0; i < 4; ++i)
+  for (i = 0; i < PLLGPU_SUMTABLE_SLOTS; ++i)
   {
     if (!x->sumtable_key[i])
     {
@@ -40,6 +51,13 @@ static int slot_of(pll_amd_ext_t *x, const double *key, int create)
     }
     if (x->sumtable_age[i] < x->sumtable_age[victim]) victim = i;
   }
+  if (x->sumtable_key[victim])
+  {
+    x->sumtable_evicted[x->sumtable_evicted_next] = x->sumtable_key[victim];
+    x->sumtable_evicted_next = (x->sumtable_evicted_next + 1u) % PLLGPU_SUMTABLE_SLOTS;
+  }
+  for (i = 0; i < PLLGPU_SUMTABLE_SLOTS; ++i) /* the handle is live again */
+    if (x->sumtable_evicted[i] == key) x->sumtable_evicted[i] = NULL;
   x->sumtable_key[victim] = key;
   x->sumtable_age[victim] = ++x->sumtable_clock;
   return victim;
@@ -178,6 +196,28 @@ int pll_gpu_sync_sumtable(pll_partition_t *p, double *sumtable)
   return PLL_SUCCESS;
 }
 
+int pll_gpu_release_sumtable(pll_partition_t *p, const double *sumtable)
+{
+  pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
+  int i;
+  if (!x || !x->ctx)
+  {
+    pll_set_error(PLL_ERROR_GPU_UNAVAILABLE, "pll_gpu_release_sumtable: no MI355X context behind this partition");
+    return fail_loudly("pll_gpu_release_sumtable");
+  }
+  for (i = 0; i < PLLGPU_SUMTABLE_SLOTS; ++i)
+    if (x->sumtable_evicted[i] == sumtable) x->sumtable_evicted[i] = NULL;
+  const int slot = slot_of(x, sumtable, 0);
+  if (slot < 0) return PLL_SUCCESS; /* nothing on the device stands for it (any more) */
+  x->sumtable_key[slot] = NULL;
+  if (pllgpu_sumtable_release(x->ctx, (unsigned)slot) != 0)
+  {
+    pll_set_gpu_error("pll_gpu_release_sumtable");
+    return PLL_FAILURE;
+  }
+  return PLL_SUCCESS;
+}
+
 int pll_compute_likelihood_derivatives(pll_partition_t *p, int parent_scaler_index, int child_scaler_index,
                                        double branch_length, const unsigned int *params_indices,
                                        const double *sumtable, double *d_f, double *dd_f)
@@ -198,6 +238,12 @@ int pll_compute_likelihood_derivatives(pll_partition_t *p, int parent_scaler_ind
   int slot = slot_of(x, sumtable, 0);
   if (slot < 0)
   {
+    if (was_evicted(x, sumtable))
+    {
+      pll_set_error(PLL_ERROR_GPU_RUNTIME, "pll_compute_likelihood_derivatives: the device table of this sumtable was recycled "
+                    "(more than %d live sumtables in one partition); call pll_update_sumtable again", PLLGPU_SUMTABLE_SLOTS);
+      return fail_loudly("pll_compute_likelihood_derivatives");
+    }
     /* a table this library did not produce: the caller's buffer is the truth */
     slot = slot_of(x, sumtable, 1);
     if (pllgpu_sumtable_upload(x->ctx, (unsigned)slot, sumtable) != 0)

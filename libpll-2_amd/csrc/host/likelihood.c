@@ -71,6 +71,25 @@ static int prepare_end(pll_partition_t *p, pll_amd_ext_t *x, unsigned int clv, i
   return 1;
 }
 
+/* A parent end that the device reads as tip codes is evaluated with the two ends swapped (the tip
+ * kernels apply P on the tip side). The reference does that only for PLL_ATTRIB_PATTERN_TIP tips
+ * (src/likelihood.c:612-624); compact indicator tips are this library's own device format, so for
+ * them the swap must not change the value: sum_i p_i pi_i sum_j P_ij c_j is symmetric in (p, c) iff
+ * pi_i P_ij = pi_j P_ji for the frequency set of every rate category. That is known to hold when
+ * pll_update_prob_matrices formed the matrix from the eigensystem of the very parameter set whose
+ * frequencies the caller names in freqs_indices, and that eigensystem is still valid (setting new
+ * frequencies or rates invalidates it). A matrix the caller wrote, or other frequency sets: the tip
+ * is given a dense CLV and the caller's orientation is evaluated as is. */
+static int swap_is_exact(const pll_partition_t *p, const pll_amd_ext_t *x, unsigned int matrix_index,
+                         const unsigned int *freqs_indices)
+{
+  unsigned int k;
+  const unsigned char *formed = x->pmatrix_params + (size_t)matrix_index * p->rate_cats;
+  for (k = 0; k < p->rate_cats; ++k)
+    if (formed[k] == 0xFFu || formed[k] != freqs_indices[k] || !p->eigen_decomp_valid[formed[k]]) return 0;
+  return 1;
+}
+
 static double edge_lnl(pll_partition_t *p, unsigned int parent_clv_index, int parent_scaler_index,
                        unsigned int child_clv_index, int child_scaler_index, unsigned int matrix_index,
                        const unsigned int *freqs_indices, double *persite_lnl, double *device_result)
@@ -96,6 +115,9 @@ static double edge_lnl(pll_partition_t *p, unsigned int parent_clv_index, int pa
     }
     pll_tip_densify(p, parent_clv_index); /* two compact tips: one of them becomes a dense CLV */
   }
+  if (pll_tip_by_codes(p, parent_clv_index) && !(p->attributes & PLL_ATTRIB_PATTERN_TIP) &&
+      !swap_is_exact(p, x, matrix_index, freqs_indices))
+    pll_tip_densify(p, parent_clv_index); /* keep the caller's orientation (src/likelihood.c:626-634) */
   const int ptip = pll_tip_by_codes(p, parent_clv_index);
   const int ctip = pll_tip_by_codes(p, child_clv_index);
   if (!pll_flush_model(p, x) || !pll_flush_pmatrix(p, x, matrix_index, matrix_index) ||

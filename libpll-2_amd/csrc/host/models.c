@@ -280,6 +280,9 @@ int pll_update_prob_matrices(pll_partition_t *p, const unsigned int *params_indi
   {
     x->pmatrix_dirty[matrix_indices[b]] = 0;
     x->pmatrix_stale[matrix_indices[b]] = 1;
+    for (n = 0; n < p->rate_cats; ++n)
+      x->pmatrix_params[(size_t)matrix_indices[b] * p->rate_cats + n] =
+          params_indices[n] < 0xFFu ? (unsigned char)params_indices[n] : 0xFFu;
   }
   if (x->eager_mirror) return pll_gpu_sync_pmatrix(p, -1);
   return PLL_SUCCESS;

@@ -91,6 +91,7 @@ static void free_ext(pll_amd_ext_t *x)
   free(x->freqs_dirty);
   free(x->eigen_dirty);
   free(x->pmatrix_stale);
+  free(x->pmatrix_params);
   free(x->repeats_stale);
   free(x->repeats_count);
   free(x->aux_params);
@@ -343,6 +344,9 @@ pll_partition_t *pll_partition_create(unsigned int tips, unsigned int clv_buffer
   x->eigen_dirty = (unsigned char *)malloc(rate_matrices ? rate_matrices : 1);
   x->pmatrix_stale = (unsigned char *)calloc(prob_matrices ? prob_matrices : 1, 1);
   NEED(x->pmatrix_stale);
+  x->pmatrix_params = (unsigned char *)malloc((size_t)(prob_matrices ? prob_matrices : 1) * rate_cats);
+  NEED(x->pmatrix_params);
+  memset(x->pmatrix_params, 0xFF, (size_t)(prob_matrices ? prob_matrices : 1) * rate_cats);
   x->repeats_stale = (unsigned char *)calloc(p->nodes ? p->nodes : 1, 1);
   x->repeats_count = (unsigned int *)calloc(p->nodes ? p->nodes : 1, sizeof(unsigned int));
   NEED(x->repeats_stale && x->repeats_count);
@@ -789,6 +793,8 @@ void pll_gpu_invalidate(pll_partition_t *p, unsigned int what, int index)
   {
     MARK(pmatrix_dirty, p->prob_matrices, 1);
     MARK(pmatrix_stale, p->prob_matrices, 0); /* the caller wrote the host copy: it is the truth now */
+    for (i = 0; i < p->prob_matrices; ++i)    /* ... and nothing is known about how it was formed */
+      if (index < 0 || i == (unsigned int)index) memset(x->pmatrix_params + (size_t)i * p->rate_cats, 0xFF, p->rate_cats);
   }
   if (what & PLL_GPU_DIRTY_FREQS) MARK(freqs_dirty, p->rate_matrices, 1);
   if (what & PLL_GPU_DIRTY_RATE_WEIGHTS) x->rate_weights_dirty = x->prop_invar_dirty = 1;

@@ -54,15 +54,21 @@ typedef struct pll_amd_ext
    * caller-owned host sumtable each device slot stands for */
   unsigned char *eigen_dirty;   /* [rate_matrices] eigensystem (vectors + values) not yet on the device */
   unsigned char *pmatrix_stale; /* [prob_matrices] computed on the device, host mirror not refreshed */
+  unsigned char *pmatrix_params; /* [prob_matrices][rate_cats] params_indices pll_update_prob_matrices formed the
+                                    matrix with; 0xFF = unknown (written by the caller) */
   unsigned char *repeats_stale; /* [nodes] class maps computed on the device, host mirror not refreshed */
   unsigned int *repeats_count;  /* [nodes] classes the device found (kept even when the node stays uncompressed) */
   int rates_dirty;
   unsigned int eigen_version;   /* bumped whenever an eigensystem or frequency vector changes */
   unsigned int aux_version;     /* eigen_version the device contraction matrices were built from */
   unsigned int *aux_params;     /* [rate_cats] params_indices they were built for */
-  const double *sumtable_key[4];
-  unsigned int sumtable_age[4];
+  const double *sumtable_key[PLLGPU_SUMTABLE_SLOTS];
+  unsigned int sumtable_age[PLLGPU_SUMTABLE_SLOTS];
   unsigned int sumtable_clock;
+  /* handles whose device table was recycled: a derivative evaluation on one of them must fail, not
+   * upload the caller's (never written) buffer */
+  const double *sumtable_evicted[PLLGPU_SUMTABLE_SLOTS];
+  unsigned int sumtable_evicted_next;
   /* scheduler scratch (grown on demand) */
   pllgpu_op_t *gops;
   unsigned int gops_cap;

@@ -167,6 +167,7 @@ _GPU_PROTOS = {
     "pll_gpu_sync_all": (C.c_int, [PartitionP]),
     "pll_gpu_invalidate": (None, [PartitionP, C.c_uint, C.c_int]),
     "pll_gpu_sync_sumtable": (C.c_int, [PartitionP, c_double_p]),
+    "pll_gpu_release_sumtable": (C.c_int, [PartitionP, c_double_p]),
     "pll_gpu_set_stream": (C.c_int, [PartitionP, C.c_void_p]),
     "pll_gpu_get_stream": (C.c_void_p, [PartitionP]),
     "pll_gpu_synchronize": (C.c_int, [PartitionP]),

@@ -101,8 +101,10 @@ def test_derivatives_agree_with_finite_differences_of_lnl(amd_lib):
 
 
 def test_sumtable_handles(amd_lib):
-    """the host pointer is a handle: five live tables recycle the four device slots, a table the
-    library never produced is uploaded from the caller's buffer, sync fills the host buffer"""
+    """the host pointer is a handle: five live tables in one partition all keep their device table
+    (the fifth used to recycle the first one's slot silently), a table the library never
+    produced is uploaded from the caller's buffer, sync fills the host buffer; beyond 16 live tables
+    the least recently used is recycled and an evaluation on ITS handle fails loudly"""
     case = W.make_case("h", 4, 16, 300, seed=9)
     eig = W.eigensystem(case.model["exch"], case.freqs[0])
     e = case.edges[0]
@@ -114,13 +116,25 @@ def test_sumtable_handles(amd_lib):
         for t in tabs:
             s.update_sumtable(edge, t)
         ref = s.derivatives(edge, tabs[4], 0.3)
+        for t in tabs:                              # every one of the five is still resident
+            assert s.derivatives(edge, t, 0.3) == ref
         host = s.read_sumtable(tabs[4])          # fills tabs[4] on the host
         assert np.abs(host).max() > 0
-        assert s.derivatives(edge, tabs[1], 0.3) == ref
-        # tabs[0] lost its slot to tabs[4] and was never synced: all zeros on the host, so using it
-        # means "a caller-written table": the numbers come from the host buffer
-        foreign = s.new_sumtable()
+        foreign = s.new_sumtable()               # "a caller-written table": the numbers come from the host buffer
         foreign[:] = tabs[4]
         got = s.derivatives(edge, foreign, 0.3)
         assert close(got[0], ref[0], sites=300) and close(got[1], ref[1], sites=300)
         assert not amd_lib.pll_gpu_sync_sumtable(s.p, api.dptr(s.new_sumtable()))
+        # 6 tables are live (5 + foreign); 11 more overflow the 16 slots by one: tabs[0] (least recently
+        # used) is recycled, and using it must fail - its host buffer was never written
+        more = [s.new_sumtable() for _ in range(11)]
+        for t in more:
+            s.update_sumtable(edge, t)
+        with pytest.raises(RuntimeError, match="recycled"):
+            s.derivatives(edge, tabs[0], 0.3)
+        assert s.derivatives(edge, tabs[1], 0.3) == ref
+        s.update_sumtable(edge, tabs[0])         # computing it again makes the handle live again
+        assert s.derivatives(edge, tabs[0], 0.3) == ref
+        # a released table frees its slot; the handle then means "caller-written" again
+        assert amd_lib.pll_gpu_release_sumtable(s.p, api.dptr(more[0]))
+        assert not amd_lib.pll_gpu_sync_sumtable(s.p, api.dptr(more[0]))

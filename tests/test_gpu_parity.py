@@ -502,6 +502,103 @@ def test_tail_fusion_shapes(amd_lib, kw, monkeypatch):
         assert (fused[2][k] == plain[2][k]).all()
 
 
+def _two_long_ends_case(sites=900, seed=140):
+    """40 taxa: the evaluated edge joins a 14-tip ladder (13 ops) and a 12-op path whose siblings are
+    cherries. The second op list recomputes just those 25 ops (the cherries stay in HBM): a partial
+    traversal that the chain planner turns into two chains of 12-13 steps in the same (last) stage but
+    different fetch variants - together more steps than one kernarg descriptor pack holds."""
+    tips = 40
+    nxt = [tips]
+
+    def sc(i):
+        return i - tips if i >= tips else -1
+
+    def op(a, b):
+        p = nxt[0]
+        nxt[0] += 1
+        return (p, sc(p), a, a, sc(a), b, b, sc(b))
+
+    ladder, prev = [], 0
+    for t in range(1, 14):
+        ladder.append(op(prev, t))
+        prev = ladder[-1][0]
+    cherries = [op(14 + 2 * k, 15 + 2 * k) for k in range(13)]
+    path, acc = [], cherries[0][0]
+    for k in range(1, 13):
+        path.append(op(acc, cherries[k][0]))
+        acc = path[-1][0]
+    a, b = ladder[-1][0], path[-1][0]
+    assert nxt[0] == 2 * tips - 2
+    base = W.make_case("two-ends", 4, tips, sites, seed=seed, ambiguity_pct=3)
+    base.op_batches = [ladder + cherries + path]
+    base.edges = [(a, sc(a), b, sc(b), a)]
+    return base, ladder + path
+
+
+def test_chain_tail_with_two_long_ends(amd_lib, monkeypatch):
+    """both ends of the evaluated edge are held chains whose steps together exceed one descriptor pack:
+    the evaluation used to fail with -inf and leave the two top CLVs uncomputed"""
+    case, partial = _two_long_ends_case()
+    exp = O.run_case(case)
+    arr = api.make_ops(partial)
+    e = case.edges[0]
+
+    def run():
+        with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+            s.update_partials()
+            full = s.edge_lnl(e)
+            amd_lib.pll_update_partials(s.p, arr, len(partial))
+            again = s.edge_lnl(e)
+            amd_lib.pll_update_partials(s.p, arr, len(partial))
+            top = s.read_clv(e[0]), s.read_clv(e[2])        # held tops through a sync instead of the evaluation
+            return full, again, top
+
+    full, again, top = run()
+    assert np.isfinite(full[0]) and abs(full[0] - exp["lnl"][0]) <= RTOL * abs(exp["lnl"][0])
+    assert again[0] == full[0] and (again[1] == full[1]).all()
+    monkeypatch.setenv("PLL_AMD_NO_CHAINS", "1")
+    pfull, pagain, ptop = run()
+    assert pagain[0] == full[0]
+    assert (top[0] == ptop[0]).all() and (top[1] == ptop[1]).all()
+
+
+def test_failed_evaluation_does_not_lose_held_work(amd_lib):
+    """an evaluation that fails validation (frequency index out of range) right after a traversal must not
+    drop the traversal's held last ops: the next, valid evaluation sees fully computed ends"""
+    for tree, taxa in (("balanced", 16), ("random", 24)):
+        case = W.make_case("held", 4, taxa, 2000, tree=tree, seed=77)
+        exp = O.run_case(case)
+        e = case.edges[0]
+        with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+            s.update_partials()
+            bad = np.full(case.rate_cats, 99, dtype=np.uint32)
+            v = amd_lib.pll_compute_edge_loglikelihood(s.p, e[0], e[1], e[2], e[3], e[4], api.uptr(bad), None)
+            assert v == -np.inf
+            good = s.edge_lnl(e)
+            assert abs(good[0] - exp["lnl"][0]) <= RTOL * abs(exp["lnl"][0])
+            got = s.read_clv(e[0])
+            assert driver.rel_err_normalised(got, s.read_scaler(e[1], e[0]), exp["clv"][e[0]], exp["scaler"].get(e[0])) <= RTOL
+
+
+def test_tip_parent_edge_keeps_the_callers_orientation(amd_lib):
+    """parent end = a tip set through pll_set_tip_states (no PATTERN_TIP), matrix written by the caller
+    and a frequency set per rate category that the matrix is NOT reversible for: swapping the ends (what
+    the tip kernels want) would change the value, so the library must evaluate the orientation it was
+    given (src/likelihood.c:626-634). With a matrix from pll_update_prob_matrices and the
+    matching frequency set the swap is exact and stays in use - both agree with the oracle."""
+    case = W.make_case("orient", 4, 12, 500, tree="caterpillar", seed=61, ambiguity_pct=5)
+    f2 = np.array([0.1, 0.4, 0.15, 0.35])
+    case.freqs = np.stack([case.freqs[0], f2])
+    case.prop_invar = np.zeros(2)
+    case.freqs_indices = np.array([0, 1, 0, 1], dtype=np.uint32)
+    p, ps, c, cs, m = case.edges[0]
+    case.edges = [(c, cs, p, ps, m), (p, ps, c, cs, m)]   # tip as the parent end, then the usual way round
+    exp = O.run_case(case)
+    assert abs(exp["lnl"][0] - exp["lnl"][1]) > 1e-6 * abs(exp["lnl"][1])  # the orientation matters here
+    got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    assert_results_match(got, exp, what="orientation")
+
+
 def test_partitions_in_concurrent_threads(amd_lib):
     """distinct partitions may be driven from distinct threads (no internal threads, no
     global state): four threads, each with its own partition, stream and shape, interleave freely"""
