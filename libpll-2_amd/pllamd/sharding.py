@@ -31,6 +31,35 @@ def shard_case(case: Case, rank, world):
     return Case(**kw)
 
 
+def sort_columns(lib, case: Case):
+    """The alignment the way an application hands it to the likelihood code: through
+    pll_compress_site_patterns (src/compress.c:171-410; here the device radix sort of
+    csrc/hip/compress.hip), i.e. unique columns in lexicographic order plus their multiplicities as
+    pattern weights. The log-likelihood is a weighted sum over columns, so it does not change; sites
+    that share a prefix of tips become neighbours, and a contiguous shard of the sorted alignment
+    holds fewer site-repeat classes per node than the same number of columns taken at random."""
+    import ctypes as C
+    from . import api
+    assert case.sequences is not None and np.all(np.asarray(case.pattern_weights) == 1)
+    n, length = len(case.sequences), case.sites
+    bufs = [C.create_string_buffer(bytes(s), length + 1) for s in case.sequences]
+    arr = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+    m = (C.c_ulonglong * 256)(*[int(v) for v in case.charmap])
+    ln = C.c_int(length)
+    w = lib.pll_compress_site_patterns(arr, m, n, C.byref(ln))
+    if not w:
+        raise RuntimeError(f"pll_compress_site_patterns: [{lib.errno()}] {lib.errmsg()}")
+    weights = api.as_np(w, ln.value, np.uint32).copy()
+    # the weights block came from the library's allocator (free() as in the reference); ctypes leaves it
+    kw = dict(name=case.name + "[sorted]", states=case.states, rate_cats=case.rate_cats, tips=case.tips,
+              sites=ln.value, pmatrix=case.pmatrix, freqs=case.freqs, op_batches=case.op_batches, edges=case.edges,
+              roots=case.roots, attributes=case.attributes, clv_buffers=case.clv_buffers,
+              scale_buffers=case.scale_buffers, rate_weights=case.rate_weights, pattern_weights=weights,
+              prop_invar=case.prop_invar, freqs_indices=case.freqs_indices, dump_clvs=case.dump_clvs,
+              charmap=case.charmap, sequences=[b.raw[:ln.value] for b in bufs], model=case.model)
+    return Case(**kw)
+
+
 def allreduce_sum(value, dist, device=None):
     """sum a Python float over all ranks with one all_reduce of one double (RCCL on GPUs, gloo on
     CPU); identity when torch.distributed is not initialised"""

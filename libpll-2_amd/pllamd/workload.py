@@ -139,6 +139,30 @@ def random_states(tips, sites, states, seed=1, mutate_pct=30):
     return np.where(mut, rnd, anc[None, :]).astype(np.uint8)
 
 
+SECTION_8D_SEED = 88172645463325252
+
+
+def section8d_states(tips, sites, states, mutate_pct=30, seed=SECTION_8D_SEED):
+    """SURVEY 8d to the letter: xorshift64 (13/7/17, output x >> 32) seeded with 88172645463325252;
+    per site an ancestral state u mod states, then every tip in turn copies it unless a draw
+    u mod 100 < 30 replaces it by the state of one more draw. The stream is sequential (170M draws
+    for C4), so it comes from the small C helper built next to the library
+    (csrc/workload/synth_alignment.c -> libpll_workload.so)."""
+    import ctypes as C
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc", "libpll_workload.so")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} not found - build it first (python -c 'import __graft_entry__ as g; g.build()')")
+    dll = C.CDLL(path)
+    fn = dll.pllwl_xorshift_alignment
+    fn.restype = None
+    fn.argtypes = [C.c_uint, C.c_size_t, C.c_uint, C.c_uint, C.POINTER(C.c_uint64), C.c_void_p, C.c_size_t]
+    out = np.zeros((tips, sites), dtype=np.uint8)
+    st = C.c_uint64(seed)
+    fn(tips, sites, states, mutate_pct, C.byref(st), out.ctypes.data, sites)
+    return out
+
+
 def states_to_sequences(st, alphabet):
     lut = np.frombuffer(bytes(alphabet), dtype=np.uint8)
     return [lut[row].tobytes() for row in st]
@@ -226,7 +250,7 @@ def synthetic_exch(states):
 def make_case(name, states, tips, sites, rate_cats=4, tree="balanced", attributes=0, seed=1,
               mutate_pct=30, alpha=0.5, scalers=True, tips_as="states", exch=None, freqs=None,
               brlen_scale=1.0, pinv=0.0, pattern_weights=None, ambiguity_pct=0, partial_pct=0,
-              asc_type=None, asc_weights=None):
+              asc_type=None, asc_weights=None, generator="pcg64", states_matrix=None):
     """One synthetic configuration of SURVEY 8d (C2: states=4,tips=64,sites=100000; C3: 20/64/
     50000; C5: 61/32/20000)."""
     if exch is None:
@@ -244,7 +268,13 @@ def make_case(name, states, tips, sites, rate_cats=4, tree="balanced", attribute
     nmat = 2 * tips - 3
     rates = gamma_rates_mean(alpha, rate_cats)
     pm = pmatrices(exch, freqs, rates, branch_lengths(nmat) * brlen_scale, pinv)
-    st = random_states(tips, sites, states, seed, mutate_pct)
+    if states_matrix is not None:          # the caller's own [tips][sites] states (e.g. a shard of a sorted alignment)
+        st = np.ascontiguousarray(states_matrix, dtype=np.uint8)
+        assert st.shape == (tips, sites)
+    elif generator == "xorshift64":        # SURVEY 8d to the letter (bench.py)
+        st = section8d_states(tips, sites, states, mutate_pct)
+    else:
+        st = random_states(tips, sites, states, seed, mutate_pct)
     kw = {}
     if tips_as == "states":
         if states == 4:

@@ -99,3 +99,50 @@ def test_linearity_and_permutation_at_full_size(amd_lib):
     lnl_p, ps_p, _, _ = run(amd_lib, case_p)
     assert np.array_equal(ps_p, ps1[perm])
     assert abs(lnl_p - lnl1) <= 1e-12 * abs(lnl1)
+
+
+# ---- bench.py's own inputs (SURVEY 8d to the letter) -------------------------------------------------
+def _bench():
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    return importlib.import_module("bench")
+
+
+def _pinned(key):
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "section8d_lnl.json")))[key]
+
+
+@pytest.mark.parametrize("key", ["c2", "c3", "c5"])
+def test_bench_inputs_against_the_pinned_reference_value(amd_lib, key):
+    """the xorshift64 alignment of SURVEY 8d through the HIP path == what the reference's AVX2 path gave
+    for the same bytes in the authoring container (tools/gen_section8d_lnl.py)"""
+    b = _bench()
+    cfg = b.CONFIGS[key]
+    case = b.build_case(cfg, cfg["sites"], 0)
+    lnl, ps, _, _ = run(amd_lib, case)
+    pin = _pinned(key)
+    assert abs(lnl - pin) <= RTOL * abs(pin), (lnl, pin)
+    assert abs(ps.sum() - lnl) <= 1e-11 * abs(lnl)
+
+
+def test_c2_intermediate_clvs_at_full_size(amd_lib, reference):
+    """C2 as bench.py runs it: 56 of the 62 CLVs leave the seven-op kernel through non-temporal stores and
+    are never read back by the traversal - so the root-edge check above cannot see an addressing error in
+    them. Whole CLVs and scalers of a cherry, a level-2 and a level-3 node at both ends of the node range
+    (every tile: first, middle, last) and of the top levels against the reference."""
+    b = _bench()
+    cfg = b.CONFIGS["c2"]
+    case = b.build_case(cfg, cfg["sites"], 0)
+    T = case.tips
+    # level 1: T .. T+31, level 2: T+32 .. T+47, level 3: T+48 .. T+55, level 4: T+56 .. T+59, level 5: T+60, T+61
+    nodes = (T, T + 17, T + 31, T + 32, T + 47, T + 48, T + 55, T + 56, T + 59, T + 60, T + 61)
+    r_lnl, _, r_clv, _ = run(reference, case, clvs=nodes)
+    g_lnl, _, g_clv, _ = run(amd_lib, case, clvs=nodes)
+    for c in nodes:
+        assert g_clv[c][0].shape == (cfg["sites"], 4, 4)
+        err = driver.rel_err_normalised(g_clv[c][0], g_clv[c][1], r_clv[c][0], r_clv[c][1])
+        assert err <= RTOL, (c, err)
+        assert np.array_equal(g_clv[c][1], r_clv[c][1])
+    assert abs(g_lnl - r_lnl) <= RTOL * abs(r_lnl)
