@@ -529,7 +529,7 @@ def _two_long_ends_case(sites=900, seed=140):
         acc = path[-1][0]
     a, b = ladder[-1][0], path[-1][0]
     assert nxt[0] == 2 * tips - 2
-    base = W.make_case("two-ends", 4, tips, sites, seed=seed, ambiguity_pct=3)
+    base = W.make_case("two-ends", 4, tips, sites, seed=seed, ambiguity_pct=3, tree="caterpillar")
     base.op_batches = [ladder + cherries + path]
     base.edges = [(a, sc(a), b, sc(b), a)]
     return base, ladder + path
