@@ -45,7 +45,7 @@ __device__ __forceinline__ void dna_fetch(double (&x)[4], const double *__restri
 // tile: tools/gather_probe.hip measures 5.3 TB/s against 0.42 TB/s for a random permutation of 1M
 // entries (and no loss for in-order access). The flags below travel in DevOp::layout / DevEdge.
 typedef double dbl2 __attribute__((ext_vector_type(2)));
-constexpr unsigned kAosLeft = 1u, kAosRight = 2u, kAosParent = 4u;
+constexpr unsigned kAosLeft = 1u, kAosRight = 2u, kAosParent = 4u, kStreamLeft = 16u, kStreamRight = 32u;
 
 // The 64 entries a wave needs from an entry-contiguous CLV, fetched COOPERATIVELY: eight lanes share
 // an entry (16 bytes each), so one load instruction covers eight whole 128-byte entries and every
@@ -58,14 +58,29 @@ struct DnaCoop
   dbl2 piece[8];
 };
 
-__device__ __forceinline__ void dna_coop_issue(DnaCoop &c, const double *__restrict__ clv, unsigned entry, unsigned lane)
+// stream: the child holds about as many entries as the parent, so every entry is wanted once - streaming
+// loads, like the dense kernels. A well-compressed child is a small table that every tile of the parent
+// gathers from again and again: it must stay in L2, plain loads (kStreamLeft / kStreamRight, set by the host).
+__device__ __forceinline__ void dna_coop_issue(DnaCoop &c, const double *__restrict__ clv, unsigned entry, unsigned lane, bool stream)
 {
   const unsigned sub = lane & 7u, grp = lane >> 3;
-#pragma unroll
-  for (unsigned q = 0; q < 8; ++q)
+  if (stream) // wave-uniform
   {
-    const unsigned e = __shfl(entry, q * 8u + grp, 64);
-    c.piece[q] = __builtin_nontemporal_load(reinterpret_cast<const dbl2 *>(clv + (size_t)e * 16) + sub);
+#pragma unroll
+    for (unsigned q = 0; q < 8; ++q)
+    {
+      const unsigned e = __shfl(entry, q * 8u + grp, 64);
+      c.piece[q] = __builtin_nontemporal_load(reinterpret_cast<const dbl2 *>(clv + (size_t)e * 16) + sub);
+    }
+  }
+  else
+  {
+#pragma unroll
+    for (unsigned q = 0; q < 8; ++q)
+    {
+      const unsigned e = __shfl(entry, q * 8u + grp, 64);
+      c.piece[q] = *(reinterpret_cast<const dbl2 *>(clv + (size_t)e * 16) + sub);
+    }
   }
 }
 
@@ -142,8 +157,8 @@ __global__ __launch_bounds__(256) void k_partials_dna(const OpPack pack, int sca
     {
       DnaCoop pl, pr;
       double *mine = transpose + (size_t)wave * 64 * kAosRow;
-      if (!LTIP && laos) dna_coop_issue(pl, op.left, le, lane);
-      if (!RTIP && raos) dna_coop_issue(pr, op.right, re, lane);
+      if (!LTIP && laos) dna_coop_issue(pl, op.left, le, lane, (op.layout & kStreamLeft) != 0);
+      if (!RTIP && raos) dna_coop_issue(pr, op.right, re, lane, (op.layout & kStreamRight) != 0);
       if (!LTIP && laos) dna_coop_finish(pl, mine, lane, kAosRow, cl);
       if (!RTIP && raos) dna_coop_finish(pr, mine, lane, kAosRow, cr);
     }
@@ -306,8 +321,8 @@ __global__ __launch_bounds__(256) void k_edge_dna(const DevEdge e, unsigned tile
       DnaCoop qp, qc;
       double *mine = transpose + (size_t)wave * 64 * kAosRow;
       const bool cfetch = !CTIP && !e.is_root && caos;
-      if (paos) dna_coop_issue(qp, e.parent, pe, lane);
-      if (cfetch) dna_coop_issue(qc, e.child, ce, lane);
+      if (paos) dna_coop_issue(qp, e.parent, pe, lane, (e.layout & kStreamLeft) != 0);
+      if (cfetch) dna_coop_issue(qc, e.child, ce, lane, (e.layout & kStreamRight) != 0);
       if (paos) dna_coop_finish(qp, mine, lane, kAosRow, cp);
       if (cfetch) dna_coop_finish(qc, mine, lane, kAosRow, cc);
     }
@@ -779,6 +794,201 @@ __global__ __launch_bounds__(256) void k_partials_dna_cc(const CCPack pack, unsi
       dna_store<true>(g.p, off, n, valid, mode, v, sc);
     else
       dna_store<false>(g.p, off, n, valid, mode, v, sc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Site repeats, the bottom of the tree. Near the tips a class-compressed node holds a handful of
+// entries (a DNA cherry: at most 16, a 4-tip clade: 256, an 8-tip clade a few thousand), so the level
+// scheduler spends its time on launches that each wait for the one before: C4's shard took 40 us for
+// four launches with almost no work in them. Here every op whose subtree consists of tips only and is
+// at most three ops deep is evaluated FROM THE TIP CODES: the lane of a parent entry follows the
+// entry-indexed child maps (kernels_repeats.h) down to the tip classes, forms the ops on its way back
+// up in registers (the arithmetic of the other 4x4 kernels, bit for bit) and stores the CLV and scaler
+// of the op it stands for. Nothing such an op reads is produced by this traversal, so ALL of them -
+// cherries, the ops above them, the ops above those - run in ONE launch (grid.y = op), each computed
+// for its own entries; an op that is the child of another is computed twice (once for each of its own
+// entries, once more per entry of its parent - a few thousand entries of arithmetic against a launch).
+//
+// The subtree of an item is FLATTENED by the host into heap positions: 0 the op itself, 2p+1 / 2p+2 the
+// children of position p; positions 0..6 may be ops ("nodes"), 1..14 may be tips. The kernel walks it
+// breadth-first - all map look-ups of a level are issued together, then all tip codes - so a lane waits
+// for memory four times, not once per op (the first version recursed op by op: 45 us for the same work).
+struct SubNode // an op of the subtree: matrices of its two children, entry maps to them
+{
+  const double *lmat, *rmat;
+  const unsigned *lent, *rent; // this op's entry -> child entry; null = the same entry
+};
+
+struct SubItem // 384 bytes, read through the scalar path from a device array
+{
+  double *parent;
+  unsigned *pscaler;
+  SubNode node[7];
+  const unsigned char *tip[14]; // tip[q] = codes of the tip at position q + 1 (one per tip entry)
+  unsigned entries;
+  unsigned node_mask;   // bit p: position p is an op (bit 0 always)
+  unsigned tip_mask;    // bit p: position p is a tip
+  unsigned scaler_mask; // bit p: the op at position p has a scaler (its scaling decision is taken)
+  unsigned flags;       // kSubAos
+  unsigned pad;
+};
+constexpr unsigned kSubAos = 4u; // the parent is class-compressed: entry-contiguous [entry][16]
+typedef const SubItem __attribute__((address_space(4))) *csubitem_p;
+
+// Work split as in the chain kernels further down: a workgroup of four waves owns one 64-entry tile, wave k
+// the rate category k (four values per lane and position). The first versions gave a wave all four rates:
+// 1900 vector instructions and 112 matrix fetches through the scalar path per tile, one wave at a time per
+// SIMD - 46 us for C4's shard, nearly all of it waiting for the scalar loads of the next matrix. A quarter of
+// that per wave and four times the waves hide it. What the rates of an entry share is the per-site scaling
+// decision (SM 1): one ballot exchange through LDS per LEVEL of the subtree (three barriers).
+template <int SM>
+__device__ __forceinline__ void dna_sub_level(csubitem_p it, unsigned node_mask, unsigned scaler_mask, unsigned rate, int first, int count,
+                                              const double (*below)[4], const unsigned *sc_below, const unsigned (&code)[15], double (*out)[4],
+                                              unsigned *sc_out, unsigned long long (*ballots)[4])
+{
+  // positions first .. first + count - 1; their children sit in below[2 i], below[2 i + 1] (values already scaled)
+  bool small[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+  {
+    if (i >= count) break;
+    const int pos = first + i;
+    small[i] = false;
+    if ((node_mask >> pos) & 1u) // wave-uniform
+    {
+      double a[4], b[4];
+      dna_matvec(a, as_const(it->node[pos].lmat) + rate * 16u, below[2 * i]);
+      dna_matvec(b, as_const(it->node[pos].rmat) + rate * 16u, below[2 * i + 1]);
+      bool s = true;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+      {
+        out[i][j] = a[j] * b[j];
+        s = s && (out[i][j] < PLLGPU_SCALE_THRESHOLD);
+      }
+      small[i] = s && ((scaler_mask >> pos) & 1u);
+      if (SM == 1 && ((scaler_mask >> pos) & 1u))
+      {
+        const unsigned long long mine = __ballot(s);
+        if ((threadIdx.x & 63u) == 0u) ballots[pos][rate] = mine;
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[i][j] = (code[pos] >> j) & 1u ? 1.0 : 0.0;
+    }
+  }
+  if (SM == 1) __syncthreads(); // workgroup-uniform: every wave of the tile walks the same positions
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+  {
+    if (i >= count) break;
+    const int pos = first + i;
+    sc_out[i] = 0u;
+    if (!((node_mask >> pos) & 1u) || !((scaler_mask >> pos) & 1u)) continue;
+    bool s = small[i];
+    if (SM == 1)
+    {
+      const unsigned long long all = ballots[pos][0] & ballots[pos][1] & ballots[pos][2] & ballots[pos][3];
+      s = (all >> (threadIdx.x & 63u)) & 1ull;
+    }
+    if (s)
+    {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[i][j] *= PLLGPU_SCALE_FACTOR;
+    }
+    sc_out[i] = sc_below[2 * i] + sc_below[2 * i + 1] + (s ? 1u : 0u);
+  }
+}
+
+// grid.x = the tiles of the launch's items laid end to end; tiles.first[i] = tiles before item i (by value in
+// the kernarg segment: a workgroup finds its item by bisection over words it already has in the scalar cache)
+constexpr int kSubItemsPerLaunch = 127;
+struct SubTiles
+{
+  unsigned first[kSubItemsPerLaunch + 1];
+};
+
+template <int SM>
+__global__ __launch_bounds__(256) void k_partials_dna_sub(const SubItem *items, const SubTiles tiles, unsigned nitems)
+{
+  __shared__ unsigned long long ballots[7][4];
+  unsigned lo = 0, hi = nitems; // first[lo] <= blockIdx.x < first[hi]
+  while (hi - lo > 1u)
+  {
+    const unsigned mid = (lo + hi) >> 1;
+    if (tiles.first[mid] <= blockIdx.x) lo = mid; else hi = mid;
+  }
+  csubitem_p it = (csubitem_p)(uintptr_t)items + lo;
+  const unsigned entries = it->entries;
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned rate = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned tile = blockIdx.x - tiles.first[lo];
+  const unsigned node_mask = it->node_mask, tip_mask = it->tip_mask, scaler_mask = it->scaler_mask, flags = it->flags;
+  const unsigned n0 = tile * 64u + lane;
+  const bool valid = n0 < entries;
+  const unsigned n = valid ? n0 : entries - 1;
+  // breadth-first: the entry of every position, then the codes of the tips
+  unsigned e[15];
+  e[0] = n;
+#pragma unroll
+  for (int p = 0; p < 7; ++p)
+  {
+    e[2 * p + 1] = e[2 * p + 2] = 0u;
+    if ((node_mask >> p) & 1u)
+    {
+      const unsigned *lent = it->node[p].lent, *rent = it->node[p].rent;
+      e[2 * p + 1] = lent ? lent[e[p]] : e[p];
+      e[2 * p + 2] = rent ? rent[e[p]] : e[p];
+    }
+  }
+  unsigned code[15];
+  code[0] = 0u;
+#pragma unroll
+  for (int p = 1; p < 15; ++p)
+  {
+    code[p] = 0u;
+    if ((tip_mask >> p) & 1u) code[p] = it->tip[p - 1][e[p]];
+  }
+  // bottom-up, level by level
+  double v3[8][4], v2[4][4], v1[2][4], v0[1][4];
+  unsigned s3[8], s2[4], s1[2], s0[1];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+  {
+    s3[i] = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v3[i][j] = (code[7 + i] >> j) & 1u ? 1.0 : 0.0;
+  }
+  dna_sub_level<SM>(it, node_mask, scaler_mask, rate, 3, 4, v3, s3, code, v2, s2, ballots);
+  dna_sub_level<SM>(it, node_mask, scaler_mask, rate, 1, 2, v2, s2, code, v1, s1, ballots);
+  dna_sub_level<SM>(it, node_mask, scaler_mask, rate, 0, 1, v1, s1, code, v0, s0, ballots);
+  if (!valid) return;
+  unsigned *__restrict__ pscaler = it->pscaler;
+  if (pscaler)
+  {
+    if (SM == 2) pscaler[(size_t)n * 4u + rate] = s0[0];
+    else if (rate == 0u) pscaler[n] = s0[0];
+  }
+  double *__restrict__ parent = it->parent;
+  if (flags & kSubAos)
+  {
+    dbl2 *w = reinterpret_cast<dbl2 *>(parent + (size_t)n * 16 + rate * 4u);
+    dbl2 lo, hi;
+    lo.x = v0[0][0];
+    lo.y = v0[0][1];
+    hi.x = v0[0][2];
+    hi.y = v0[0][3];
+    w[0] = lo;
+    w[1] = hi;
+  }
+  else
+  {
+    double *__restrict__ out = parent + (size_t)tile * kDnaTile + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[(rate * 4u + i) * 64] = v0[0][i];
   }
 }
 

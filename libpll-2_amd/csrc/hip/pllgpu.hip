@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "kernels_common.h"
@@ -136,7 +137,46 @@ struct pllgpu_ctx
   struct ChainPlan *plan = nullptr; // the last chain plan, re-launched as is when the same list comes again
   bool chain_held = false;          // the plan's last stage has not been launched yet (chain tail, kernels_dna.h)
   DevBuf<unsigned char> chain_dev;  // its descriptors
+  // level-scheduled lists: the launches of a planned list are kept (descriptor packs by value) and replayed
+  // as they are when the same list comes again while nothing they point at has moved (LevelPlan below)
+  unsigned long long maps_epoch = 1; // bumped whenever class maps / class counts of a node change
+  std::vector<struct LevelPlan *> level_plans;
+  struct LevelPlan *recording = nullptr;
+  int launch_rc = 0;                // a launch helper that failed inside emit()
+  unsigned long long plan_stamp = 0;
+  bool plan_cache = true;           // PLL_AMD_NO_PLAN_CACHE=1 plans every call afresh
+  int gather_stream = 0;            // PLL_AMD_GATHER_STREAM: 1 always streaming loads from compressed children, -1 never, 0 by size
+  bool subtrees = false;            // DNA + site repeats: all-tip subtrees straight from the tip codes (subtree_plan.h)
+  DevBuf<unsigned char> sub_dev;    // their descriptors on the device ...
+  std::vector<SubItem> sub_cache, sub_build; // ... and what that array holds / the list being planned
+  unsigned long long sub_epoch = 0;
 };
+
+// what pllgpu_update_partials did for one op list through the level scheduler: its launches, in order, with
+// their descriptor packs captured by value; the ops it held back for the log-likelihood kernel; the CLV layout
+// flags resolve_op() left behind. Valid while no device block has been (re)allocated (g_alloc_epoch) and no
+// class map has changed (maps_epoch).
+struct LevelPlan
+{
+  std::vector<pllgpu_op_t> key;
+  unsigned long long alloc_epoch = 0, maps_epoch = 0;
+  std::vector<std::function<void()>> launches;
+  std::vector<pllgpu_op_t> deferred;
+  std::vector<std::pair<unsigned, unsigned char>> aos; // (node, entry-contiguous?) as the list leaves them
+  unsigned nlaunches = 0;
+  double bytes = 0.0;
+  bool any_aos = false;
+  unsigned long long used = 0; // LRU stamp
+};
+constexpr size_t kLevelPlans = 4;
+
+// run a launch now and, while a plan is being recorded, keep it
+template <class F>
+static inline void emit(pllgpu_ctx *c, F &&fn)
+{
+  fn();
+  if (c->recording) c->recording->launches.emplace_back(std::forward<F>(fn));
+}
 
 static inline int use(pllgpu_ctx *c)
 {
@@ -184,6 +224,12 @@ static void derive_geometry(pllgpu_ctx *c)
   c->chains = c->fuse;
   if (const char *v = getenv("PLL_AMD_NO_CHAINS"))
     if (*v && *v != '0') c->chains = false;
+  if (const char *v = getenv("PLL_AMD_GATHER_STREAM")) c->gather_stream = atoi(v);
+  if (const char *v = getenv("PLL_AMD_NO_PLAN_CACHE"))
+    if (*v && *v != '0') c->plan_cache = false;
+  c->subtrees = c->dna_fast;
+  if (const char *v = getenv("PLL_AMD_NO_SUBTREES")) // A/B switch: the bottom levels under site repeats go level by level
+    if (*v && *v != '0') c->subtrees = false;
   c->tiled = true; // every shape keeps CLVs in the tiled sites-contiguous layout
   // 33..64 states: CLV updates on the fp64 matrix pipe (kernels_mfma.h); PLL_AMD_NO_MFMA=1 keeps the FMA kernel
   c->use_mfma = (g.states > 32 && g.rate_cats <= 16);
@@ -301,7 +347,10 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->chain_held = false;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   drop_chain_plan(c);
+  for (LevelPlan *lp : c->level_plans) delete lp;
+  c->level_plans.clear();
   c->chain_dev.release();
+  c->sub_dev.release();
   for (auto &b : c->clv) b.release();
   for (auto &b : c->scaler) b.release();
   for (auto &b : c->tipchars) b.release();
@@ -543,6 +592,7 @@ extern "C" int pllgpu_repeats_upload(pllgpu_ctx_t *c, unsigned node, const unsig
   CHECK_CTX(c);
   if (node >= c->geo.nodes) return fail(PLLGPU_EINVAL, "node %u out of range", node);
   c->ids[node] = ids;
+  ++c->maps_epoch;
   c->rep_left[node] = c->rep_right[node] = -1; // host-built maps: no entry-indexed child maps
   if (!ids) return 0;
   if (int rc = c->site_id[node].ensure(c->geo.sites_alloc)) return rc;
@@ -572,6 +622,10 @@ static int resolve_op(pllgpu_ctx *c, const pllgpu_op_t &o, DevOp &d)
   if (!(o.flags & PLLGPU_OP_LEFT_TIP) && c->clv_aos[o.left_clv]) d.layout |= kAosLeft;
   if (!(o.flags & PLLGPU_OP_RIGHT_TIP) && c->clv_aos[o.right_clv]) d.layout |= kAosRight;
   if (d.layout && !(o.flags & PLLGPU_OP_GATHER)) return fail(PLLGPU_EINVAL, "a class-compressed CLV met an operation without the gather flag");
+  // a compressed child with about as many entries as the parent is read once per entry: streaming loads;
+  // a much smaller one is a table the parent's tiles keep coming back to: cacheable loads
+  if ((d.layout & kAosLeft) && c->gather_stream >= 0 && (c->gather_stream > 0 || (size_t)c->ids[o.left_clv] * 2u > o.parent_entries)) d.layout |= kStreamLeft;
+  if ((d.layout & kAosRight) && c->gather_stream >= 0 && (c->gather_stream > 0 || (size_t)c->ids[o.right_clv] * 2u > o.parent_entries)) d.layout |= kStreamRight;
   if (o.flags & PLLGPU_OP_LEFT_TIP)
   {
     if (o.left_clv >= g.tips || !c->tipchars[o.left_clv].p) return fail(PLLGPU_EINVAL, "tip %u has no codes on the device", o.left_clv);
@@ -769,6 +823,7 @@ static int launch_partials(pllgpu_ctx *c, const OpPack &pack, unsigned nops, uns
 
 #include "fusion_plan.h"
 #include "chain_plan.h"
+#include "subtree_plan.h"
 
 // launch the held ops as ordinary updates (they are mutually independent: one level)
 static int flush_deferred(pllgpu_ctx *c)
@@ -797,17 +852,11 @@ static int flush_deferred(pllgpu_ctx *c)
   return 0;
 }
 
-extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, unsigned count)
+// the level scheduler: plan the list and launch it (every launch through emit(), so that a plan being
+// recorded keeps it)
+static int plan_and_launch_levels(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count)
 {
-  CHECK_CTX(c);
-  c->last_launches = 0;
-  c->last_bytes = 0.0;
-  {
-    bool used = false;
-    if (int rc = try_chain_plan(c, ops, count, used)) return rc;
-    if (used) return 0;
-    c->last_bytes = 0.0;
-  }
+  c->launch_rc = 0;
   std::vector<int> role;
   std::vector<FusedGroup> groups;
   plan_fusion(c->fuse, c->fuse_cc, c->geo.nodes, ops, count, role, groups);
@@ -832,6 +881,20 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
         c->last_bytes += op_traffic(c, ops[o], true, true);
       }
   }
+  // site repeats: every all-tip subtree of up to three ops' depth in one launch, before the levels (role 4)
+  {
+    unsigned nsub = 0, sub_entries = 0;
+    if (int rc = plan_subtrees(c, ops, count, role, nsub, sub_entries)) return rc;
+    if (nsub)
+    {
+      c->last_launches += (nsub + (unsigned)kSubItemsPerLaunch - 1) / (unsigned)kSubItemsPerLaunch;
+      emit(c, [c, items = c->sub_build]() {
+        if (int rc = upload_subtrees(c, items)) c->launch_rc = rc;
+        else launch_subtrees(c, (unsigned)items.size());
+      });
+      if (c->launch_rc) return c->launch_rc;
+    }
+  }
   size_t gi_sorted = 0;
   if (!groups.empty())
     std::stable_sort(groups.begin(), groups.end(), [](const FusedGroup &x, const FusedGroup &y) { return x.level < y.level; });
@@ -852,7 +915,11 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
         int lrc = 0;
         auto flush = [&]() {
           if (!nops) return;
-          if (int rc = launch_partials(c, pack, nops, maxent, kind, ga != 0)) lrc = rc;
+          const bool gather = ga != 0;
+          emit(c, [c, pack, nops, maxent, kind, gather]() {
+            if (int rc = launch_partials(c, pack, nops, maxent, kind, gather)) c->launch_rc = rc;
+          });
+          if (c->launch_rc) lrc = c->launch_rc;
           ++c->last_launches;
           nops = 0;
           maxent = 0;
@@ -882,7 +949,10 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
       if (int rc = build_cc_launches(c, ops, groups, g0, gi_sorted, ccl)) return rc;
       for (const CCLaunch &l : ccl)
       {
-        if (int rc = launch_cc(c, l.pack, l.n, l.entries, l.lk, CK_FCC)) return rc;
+        emit(c, [c, l]() {
+          if (int rc = launch_cc(c, l.pack, l.n, l.entries, l.lk, CK_FCC)) c->launch_rc = rc;
+        });
+        if (c->launch_rc) return c->launch_rc;
         ++c->last_launches;
       }
     }
@@ -893,7 +963,10 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
         unsigned n = 0, entries = 0;
         auto flush = [&]() -> int {
           if (!n) return 0;
-          if (int rc = launch_fused(c, pack, n, entries, lk, rk)) return rc;
+          emit(c, [c, pack, n, entries, lk, rk]() {
+            if (int rc = launch_fused(c, pack, n, entries, lk, rk)) c->launch_rc = rc;
+          });
+          if (c->launch_rc) return c->launch_rc;
           ++c->last_launches;
           n = 0;
           return 0;
@@ -945,6 +1018,71 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PLLGPU_ERUNTIME, "kernel launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, unsigned count)
+{
+  CHECK_CTX(c);
+  c->last_launches = 0;
+  c->last_bytes = 0.0;
+  {
+    bool used = false;
+    if (int rc = try_chain_plan(c, ops, count, used)) return rc;
+    if (used) return 0;
+    c->last_bytes = 0.0;
+  }
+  if (c->plan_cache)
+  {
+    const unsigned long long epoch = g_alloc_epoch.load(std::memory_order_relaxed);
+    for (LevelPlan *lp : c->level_plans)
+      if (lp->alloc_epoch == epoch && lp->maps_epoch == c->maps_epoch && lp->key.size() == count &&
+          memcmp(lp->key.data(), ops, count * sizeof(pllgpu_op_t)) == 0)
+      {
+        // the same list, nothing it points at has moved: the same launches
+        for (const auto &a : lp->aos) c->clv_aos[a.first] = a.second;
+        if (lp->any_aos) c->any_aos = true;
+        c->deferred = lp->deferred;
+        c->launch_rc = 0;
+        for (const auto &fn : lp->launches) fn();
+        c->last_launches = lp->nlaunches;
+        c->last_bytes = lp->bytes;
+        lp->used = ++c->plan_stamp;
+        if (c->launch_rc) return c->launch_rc;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(PLLGPU_ERUNTIME, "kernel launch failed: %s", hipGetErrorString(e));
+        return 0;
+      }
+  }
+  LevelPlan *lp = c->plan_cache ? new LevelPlan() : nullptr;
+  c->recording = lp;
+  const int rc = plan_and_launch_levels(c, ops, count);
+  c->recording = nullptr;
+  if (!lp) return rc;
+  if (rc)
+  {
+    delete lp;
+    return rc;
+  }
+  lp->key.assign(ops, ops + count);
+  lp->alloc_epoch = g_alloc_epoch.load(std::memory_order_relaxed); // after the planning: it may have allocated
+  lp->maps_epoch = c->maps_epoch;
+  lp->deferred = c->deferred;
+  for (unsigned i = 0; i < count; ++i) lp->aos.emplace_back(ops[i].parent_clv, c->clv_aos[ops[i].parent_clv]);
+  lp->any_aos = c->any_aos;
+  lp->nlaunches = c->last_launches;
+  lp->bytes = c->last_bytes;
+  lp->used = ++c->plan_stamp;
+  if (c->level_plans.size() >= kLevelPlans)
+  {
+    size_t victim = 0;
+    for (size_t i = 1; i < c->level_plans.size(); ++i)
+      if (c->level_plans[i]->used < c->level_plans[victim]->used) victim = i;
+    delete c->level_plans[victim];
+    c->level_plans[victim] = lp;
+  }
+  else
+    c->level_plans.push_back(lp);
   return 0;
 }
 
@@ -1856,6 +1994,7 @@ extern "C" int pllgpu_repeats_set_ids(pllgpu_ctx_t *c, unsigned node, unsigned i
 {
   CHECK_CTX(c);
   if (node >= c->geo.nodes) return fail(PLLGPU_EINVAL, "node %u out of range", node);
+  if (c->ids[node] != ids) ++c->maps_epoch;
   c->ids[node] = ids;
   if (!ids) c->rep_left[node] = c->rep_right[node] = -1;
   return 0;
@@ -1914,6 +2053,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
       if (int rc = c->rent[o.parent].ensure(g.sites_alloc)) return rc;
       c->rep_left[o.parent] = (int)o.left;
       c->rep_right[o.parent] = (int)o.right;
+      ++c->maps_epoch;
       RepOp &r = pk.ops[i];
       r.lid = c->site_id[o.left].p;
       r.rid = c->site_id[o.right].p;

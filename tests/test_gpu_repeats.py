@@ -99,3 +99,40 @@ def test_maps_survive_partial_traversals(amd_lib, ref_lib):
             vals[lib.is_amd] = (a, b, c)
     assert vals[True][0] == vals[True][1] == vals[True][2]
     assert abs(vals[True][0] - vals[False][0]) <= 1e-10 * abs(vals[False][0])
+
+
+@pytest.mark.parametrize("kw", [dict(tips=64, sites=5000, mutate_pct=4, seed=31),                                   # balanced: levels 1-3 collapse
+                                dict(tips=128, sites=20000, mutate_pct=30, seed=32),                                 # C4's shape, L3 keeps thousands of classes
+                                dict(tips=33, sites=3000, tree="random", mutate_pct=3, seed=33),                     # cherries, (tip, cherry), deeper clades
+                                dict(tips=40, sites=2000, tree="random", mutate_pct=2, seed=34, attributes=api.RATE_SCALERS),
+                                dict(tips=300, sites=500, tree="caterpillar", mutate_pct=1, seed=35, brlen_scale=4),  # deep: scaling above the subtrees
+                                dict(tips=16, sites=700, mutate_pct=50, seed=36),                                    # poor compression: uncompressed parents over compressed children
+                                dict(tips=24, sites=900, tree="random", mutate_pct=5, seed=37, ambiguity_pct=10, partial_pct=5)],
+                         ids=lambda k: "t%d-n%d-%s" % (k["tips"], k["sites"], k.get("tree", "balanced")))
+def test_tip_rooted_subtrees_are_bit_identical(amd_lib, monkeypatch, kw):
+    """site repeats: ops whose subtree is tips only (up to three ops deep) are evaluated from the tip
+    codes in one launch (k_partials_dna_sub) - every CLV, scaler vector and the log-likelihood must equal,
+    bit for bit, what the level-by-level gather kernels produce, and agree with the oracle"""
+    from compare import assert_results_match
+    from oracle import oracle as O
+    kw = dict(kw)
+    attrs = api.SITE_REPEATS | kw.pop("attributes", 0)
+    case = W.make_case("sub", 4, attributes=attrs, **kw)
+    fast = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        launches_fast = amd_lib.pll_gpu_last_launch_count(s.p)
+        s.update_partials(update_repeats=0)                 # cached descriptors
+        again = s.edge_lnl(case.edges[0], persite=False)[0]
+    monkeypatch.setenv("PLL_AMD_NO_SUBTREES", "1")
+    plain = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        launches_plain = amd_lib.pll_gpu_last_launch_count(s.p)
+    assert launches_fast <= launches_plain
+    assert fast["lnl"] == plain["lnl"] and again == plain["lnl"][0]
+    for k in plain["clv"]:
+        assert np.array_equal(fast["clv"][k], plain["clv"][k]), k
+        if k in plain["scaler"]:
+            assert np.array_equal(fast["scaler"][k], plain["scaler"][k]), k
+    assert_results_match(fast, O.run_case(case), what="subtrees")

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""One GPU: what BASELINE configs[3] would do on N GPUs. The pattern-sorted 1M-site alignment is cut into
+N shards exactly as bench.py --gpus N does; the whole alignment and every shard are timed one after another
+on this device with bench.py's own step (pll_update_partials + edge log-likelihood, class maps re-used).
+projected speedup = t(whole) / (max over shards t(shard) + all-reduce); the all-reduce of one double costs
+what bench.py measures for it at world size 1 (PLL_BENCH_FORCE_DIST=1: ~15 us) unless --allreduce-us says
+otherwise.
+
+    python tools/c4_projection.py [--shards 8] [--steps 20] [--shard-only R]   -> one JSON line
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "libpll-2_amd"))
+
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shards", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--sites", type=int, default=0)
+    ap.add_argument("--allreduce-us", type=float, default=15.0)
+    ap.add_argument("--shard-only", type=int, default=-1, help="time just this shard (profiling runs)")
+    ap.add_argument("--unsorted", action="store_true", help="cut the alignment as generated (no pattern sort)")
+    args = ap.parse_args()
+    from pllamd import api, driver, sharding
+
+    class H:  # no collectives here
+        dist = None
+        world = 1
+        rank = 0
+        on_device = False
+
+    cfg = bench.CONFIGS["c4"]
+    lib = api.PllLib()
+    full = bench.build_case(cfg, args.sites or cfg["sites"], api.SITE_REPEATS)
+    total_sites = full.sites
+    if not args.unsorted:
+        full = sharding.sort_columns(lib, full)
+    out = {"total_sites": total_sites, "patterns": full.sites, "shards": args.shards, "sorted": not args.unsorted}
+
+    def time_case(case):
+        r = bench.Runner(H, lib, api, driver, case, True, collective=False)
+        dt, lnl = r.timed(args.warmup, args.steps)
+        lv = r.level_entries()
+        extra, _ = r.repeats_update_ms(reps=3)
+        r.close()
+        return dt / args.steps * 1e3, lnl, lv, extra
+
+    if args.shard_only < 0:
+        t1, lnl1, lv1, rep1 = time_case(full)
+        out.update(t1_ms=round(t1, 4), lnl_unsharded=lnl1, entries_per_level_unsharded=lv1, repeats_update_ms_unsharded=round(rep1, 3))
+    ts, lnls, lvs, reps = [], [], [], []
+    for r in (range(args.shards) if args.shard_only < 0 else [args.shard_only]):
+        t, lnl, lv, rep = time_case(sharding.shard_case(full, r, args.shards))
+        ts.append(round(t, 4))
+        lnls.append(lnl)
+        lvs.append(lv)
+        reps.append(round(rep, 3))
+    out.update(shard_ms=ts, shard_entries_per_level=lvs, shard_repeats_update_ms=reps)
+    if args.shard_only < 0:
+        tn = max(ts) + args.allreduce_us * 1e-3
+        out.update(allreduce_us=args.allreduce_us, projected_tN_ms=round(tn, 4), projected_speedup=round(out["t1_ms"] / tn, 3),
+                   lnl_sum_of_shards=float(sum(lnls)), lnl_rel_diff=abs(sum(lnls) - lnl1) / abs(lnl1),
+                   entries_sum_over_shards_div_unsharded=round(sum(sum(x) for x in lvs) / sum(lv1), 4))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
