@@ -114,10 +114,13 @@ extern "C" int pllgpu_compress_patterns(const unsigned char *encoded, unsigned c
     snprintf(g_cerr, sizeof g_cerr, "no HIP device visible");
     return PLLGPU_ENODEVICE;
   }
+  int prev_device = -1;
+  if (hipGetDevice(&prev_device) != hipSuccess) prev_device = -1;
   if (device < 0)
   {
+    // PLL_AMD_DEVICE=<n>, else (unset or "auto") the calling thread's current device - like pllgpu_create
     const char *env = getenv("PLL_AMD_DEVICE");
-    device = env ? atoi(env) : 0;
+    device = (env && strcmp(env, "auto") != 0) ? atoi(env) : (prev_device >= 0 ? prev_device : 0);
   }
   if (device >= ndev || !count || !length)
   {
@@ -206,5 +209,6 @@ done:
   (void)hipFree(d_keys2);
   (void)hipFree(d_tmp);
   if (st) (void)hipStreamDestroy(st);
+  if (prev_device >= 0 && prev_device != device) (void)hipSetDevice(prev_device); // leave the thread's device as found
   return rc;
 }

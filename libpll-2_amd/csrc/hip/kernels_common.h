@@ -100,6 +100,7 @@ struct DevEdge
   int per_rate;
   int is_root;
   unsigned layout;               // 4x4 kernels: kAosParent | kAosLeft (= child) for entry-contiguous CLVs
+  int fenced;                    // PLL_AMD_FENCED_HANDOFF=1: the result hand-off with release / acquire fences (diagnosis)
   unsigned char fidx[kMaxRates]; // freqs_indices
 };
 
@@ -178,6 +179,29 @@ __device__ __forceinline__ double partial_load(const double *p)
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The three ordering points of such a hand-off. Default: wait for the wave's own stores (they were performed at
+// the coherent level), nothing else. fenced (PLL_AMD_FENCED_HANDOFF=1, a diagnosis switch): the textbook form
+// inside the HIP memory model - release fence before the ticket / the sequence word, acquire fence in the
+// workgroup that arrived last - at the price of an L2 write-back per workgroup.
+__device__ __forceinline__ void handoff_before_ticket(int fenced)
+{
+  if (fenced)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void handoff_after_last_ticket(int fenced)
+{
+  if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ void handoff_before_sequence(int fenced)
+{
+  if (fenced)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 __device__ __forceinline__ void publish_block_sum(const DevEdge &e, double wave_value, unsigned nsum_waves)
 {
   __shared__ double ws[4];
@@ -190,9 +214,10 @@ __device__ __forceinline__ void publish_block_sum(const DevEdge &e, double wave_
     double s = ws[0];
     for (unsigned w = 1; w < nw; ++w) s += ws[w];
     partial_store(&e.block_sums[blockIdx.x], s);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the partial has been performed before the ticket is taken
+    handoff_before_ticket(e.fenced); // the partial has been performed before the ticket is taken
     const unsigned ticket = __hip_atomic_fetch_add(e.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last = (ticket == gridDim.x - 1) ? 1u : 0u;
+    if (last) handoff_after_last_ticket(e.fenced);
   }
   __syncthreads();
   if (!last) return;
@@ -210,7 +235,7 @@ __device__ __forceinline__ void publish_block_sum(const DevEdge &e, double wave_
     // result[0] = value, then result[1] = this call's sequence number with system-scope release:
     // the host polls the sequence word in mapped memory instead of paying a stream synchronise
     __hip_atomic_store(e.result, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the value is in host memory before the sequence word follows
+    handoff_before_sequence(e.fenced); // the value is in host memory before the sequence word follows
     __hip_atomic_store(e.result + 1, e.sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }

@@ -31,6 +31,7 @@ struct DevDeriv
   double *result;               // mapped: [0] d_f, [1] sequence, [2] dd_f
   double sequence;
   unsigned sites;
+  int fenced;                   // kernels_common.h: handoff_*
   unsigned char fidx[kMaxRates];
 };
 
@@ -161,9 +162,10 @@ __global__ __launch_bounds__(256) void k_derivatives(const DevDeriv d, const Gen
     // hand-off without fences (kernels_common.h: partial_store)
     partial_store(&d.block_sums[blockIdx.x], (ws[0][0] + ws[0][1]) + (ws[0][2] + ws[0][3]));
     partial_store(&d.block_sums[1024 + blockIdx.x], (ws[1][0] + ws[1][1]) + (ws[1][2] + ws[1][3]));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    handoff_before_ticket(d.fenced);
     const unsigned ticket = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last = (ticket == gridDim.x - 1) ? 1u : 0u;
+    if (last) handoff_after_last_ticket(d.fenced);
   }
   __syncthreads();
   if (!last) return;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256) void k_derivatives(const DevDeriv d, const Gen
     __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(d.result, (ws[0][0] + ws[0][1]) + (ws[0][2] + ws[0][3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(d.result + 2, (ws[1][0] + ws[1][1]) + (ws[1][2] + ws[1][3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the values are in host memory before the sequence word follows
+    handoff_before_sequence(d.fenced); // the values are in host memory before the sequence word follows
     __hip_atomic_store(d.result + 1, d.sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }

@@ -1497,10 +1497,11 @@ __device__ __forceinline__ void chain_edge_body(const DevEdge &e, const SRC src,
     const double tile_sum = wave_sum(site);
     if (lane == 0)
     {
-      partial_store(&e.block_sums[blockIdx.x], tile_sum); // kernels_common.h: no fences in the hand-off
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      partial_store(&e.block_sums[blockIdx.x], tile_sum); // kernels_common.h: no fences in the hand-off by default
+      handoff_before_ticket(e.fenced);
       const unsigned ticket = __hip_atomic_fetch_add(e.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       last = (ticket == gridDim.x - 1) ? 1u : 0u;
+      if (last) handoff_after_last_ticket(e.fenced);
     }
   }
   __syncthreads();
@@ -1526,7 +1527,7 @@ __device__ __forceinline__ void chain_edge_body(const DevEdge &e, const SRC src,
     for (unsigned w = 1; w < 4u; ++w) t += ws[w];
     __hip_atomic_store(e.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(e.result, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the value is in host memory before the sequence word follows
+    handoff_before_sequence(e.fenced); // the value is in host memory before the sequence word follows
     __hip_atomic_store(e.result + 1, e.sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }

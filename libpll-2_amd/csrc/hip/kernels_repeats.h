@@ -16,6 +16,7 @@
 // one memset before the level instead of the reference's to-clean list.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "kernels_common.h"
 
 constexpr int kRepOps = 32;           // ops per launch
 constexpr unsigned kRepBlock = 1024;  // sites per workgroup: 256 threads x 4 consecutive sites
@@ -44,6 +45,7 @@ struct RepPack
   unsigned sequence;
   unsigned sites;
   unsigned nblk;
+  int fenced;            // kernels_common.h: handoff_*
 };
 
 __device__ __forceinline__ unsigned rep_cell(const RepOp &o, unsigned s)
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void k_rep_rank(const RepPack p)
     const unsigned cnt = before + total;
     p.counts[blockIdx.y] = cnt;
     __hip_atomic_store(&p.host_counts[blockIdx.y], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    handoff_before_sequence(p.fenced);
     const unsigned t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t == gridDim.y - 1u)
     {

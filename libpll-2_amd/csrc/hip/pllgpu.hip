@@ -143,6 +143,7 @@ struct pllgpu_ctx
   std::vector<struct LevelPlan *> level_plans;
   struct LevelPlan *recording = nullptr;
   int launch_rc = 0;                // a launch helper that failed inside emit()
+  int fenced = 0;                   // PLL_AMD_FENCED_HANDOFF=1 (kernels_common.h: handoff_*)
   unsigned long long plan_stamp = 0;
   bool plan_cache = true;           // PLL_AMD_NO_PLAN_CACHE=1 plans every call afresh
   int gather_stream = 0;            // PLL_AMD_GATHER_STREAM: 1 always streaming loads from compressed children, -1 never, 0 by size
@@ -182,6 +183,36 @@ static inline int use(pllgpu_ctx *c)
 {
   HIP_TRY(hipSetDevice(c->device));
   return 0;
+}
+
+// Every entry point works on the context's device and leaves the calling thread's current HIP device as it
+// found it (the thread may belong to torch or to another HIP user with a different device selected).
+struct DeviceScope
+{
+  int prev = -1, rc = 0;
+  explicit DeviceScope(pllgpu_ctx *c)
+  {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != c->device) rc = use(c);
+    else prev = -1; // nothing to restore
+  }
+  ~DeviceScope()
+  {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+// hipFuncSetAttribute applies to the CURRENT device: once per (kernel, device), not once per process
+#include <mutex>
+#include <set>
+static void raise_lds_limit(const void *fn, int device)
+{
+  static std::mutex mu;
+  static std::set<std::pair<const void *, int>> done;
+  std::lock_guard<std::mutex> g(mu);
+  if (done.count({fn, device})) return;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  done.insert({fn, device});
 }
 
 extern "C" const char *pllgpu_last_error(void) { return g_err; }
@@ -225,6 +256,8 @@ static void derive_geometry(pllgpu_ctx *c)
   if (const char *v = getenv("PLL_AMD_NO_CHAINS"))
     if (*v && *v != '0') c->chains = false;
   if (const char *v = getenv("PLL_AMD_GATHER_STREAM")) c->gather_stream = atoi(v);
+  if (const char *v = getenv("PLL_AMD_FENCED_HANDOFF"))
+    if (*v && *v != '0') c->fenced = 1;
   if (const char *v = getenv("PLL_AMD_NO_PLAN_CACHE"))
     if (*v && *v != '0') c->plan_cache = false;
   c->subtrees = c->dna_fast;
@@ -263,8 +296,14 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   }
   if (device < 0)
   {
+    // PLL_AMD_DEVICE=<n>: that device; PLL_AMD_DEVICE=auto: new partitions go round-robin over the visible
+    // devices (thread-per-partition callers such as RAxML-NG use every GPU of the node without a code change);
+    // unset: the calling thread's current HIP device
     const char *env = getenv("PLL_AMD_DEVICE");
-    if (env)
+    static std::atomic<unsigned> next_device{0};
+    if (env && strcmp(env, "auto") == 0)
+      device = (int)(next_device.fetch_add(1, std::memory_order_relaxed) % (unsigned)n);
+    else if (env)
       device = atoi(env);
     else if (hipGetDevice(&device) != hipSuccess)
       device = 0;
@@ -296,7 +335,8 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   c->geo = *geo;
   c->device = device;
   derive_geometry(c);
-  bool ok = hipSetDevice(device) == hipSuccess &&
+  DeviceScope device_scope_(c); // the caller's current device comes back when this function returns
+  bool ok = device_scope_.rc == 0 && hipSetDevice(device) == hipSuccess &&
             hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipHostMalloc((void **)&c->result_host, kResultBytes, hipHostMallocMapped) == hipSuccess &&
@@ -342,7 +382,7 @@ static void drop_chain_plan(pllgpu_ctx *c);
 extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
 {
   if (!c) return;
-  (void)hipSetDevice(c->device);
+  DeviceScope device_scope_(c);
   c->deferred.clear(); // results nobody will ask for
   c->chain_held = false;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -398,7 +438,8 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
 static int flush_deferred(pllgpu_ctx *c);
 #define CHECK_CTX_KEEP(c)                    \
   if (!(c)) return fail(PLLGPU_EINVAL, "null context"); \
-  if (int rc_ = use(c)) return rc_
+  DeviceScope device_scope_(c);              \
+  if (device_scope_.rc) return device_scope_.rc
 #define CHECK_CTX(c)                                   \
   CHECK_CTX_KEEP(c);                                   \
   if (!(c)->deferred.empty() || (c)->chain_held)       \
@@ -771,12 +812,7 @@ static int launch_mfma(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigne
 #define MF_LAUNCH(LT, RT, GA)                                                                                   \
   do                                                                                                            \
   {                                                                                                             \
-    static bool attr_set = false;                                                                               \
-    if (!attr_set)                                                                                              \
-    {                                                                                                           \
-      (void)hipFuncSetAttribute((const void *)k_partials_mfma<LT, RT, GA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      attr_set = true;                                                                                          \
-    }                                                                                                           \
+    raise_lds_limit((const void *)k_partials_mfma<LT, RT, GA>, c->device);                                      \
     hipLaunchKernelGGL((k_partials_mfma<LT, RT, GA>), grid, block, lds, c->stream, pack, c->gg, tm, ipw, fb, fstride); \
   } while (0)
   if (kind == 0)
@@ -1218,6 +1254,7 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
   memcpy(&seq_bits, &c->seq, sizeof seq_bits);
   e.sites = g.sites;
   e.per_rate = g.per_rate_scalers ? 1 : 0;
+  e.fenced = c->fenced;
 
   const unsigned tiles = (g.sites + 63) / 64;
   const unsigned max_blocks = 1024;
@@ -1604,7 +1641,11 @@ extern "C" void *pllgpu_get_stream(const pllgpu_ctx_t *cc)
 {
   // a caller who asks for the stream is about to order its own work against ours: nothing may be held back
   pllgpu_ctx *c = const_cast<pllgpu_ctx *>(cc);
-  if (c && (!c->deferred.empty() || c->chain_held) && use(c) == 0) (void)flush_deferred(c);
+  if (c && (!c->deferred.empty() || c->chain_held))
+  {
+    DeviceScope device_scope_(c);
+    if (device_scope_.rc == 0) (void)flush_deferred(c);
+  }
   return c ? (void *)c->stream : nullptr;
 }
 
@@ -1624,7 +1665,9 @@ extern "C" int pllgpu_timer_start(pllgpu_ctx_t *c)
 
 extern "C" double pllgpu_timer_stop(pllgpu_ctx_t *c)
 {
-  if (!c || use(c)) return -1.0;
+  if (!c) return -1.0;
+  DeviceScope device_scope_(c);
+  if (device_scope_.rc) return -1.0;
   if ((!c->deferred.empty() || c->chain_held) && flush_deferred(c)) return -1.0;
   float ms = 0;
   if (hipEventRecord(c->ev1, c->stream) != hipSuccess || hipEventSynchronize(c->ev1) != hipSuccess ||
@@ -1794,6 +1837,7 @@ extern "C" int pllgpu_likelihood_derivatives(pllgpu_ctx_t *c, unsigned slot, dou
   c->seq += 1.0;
   dv.sequence = c->seq;
   dv.sites = eval_sites;
+  dv.fenced = c->fenced;
   unsigned long long seq_bits;
   memcpy(&seq_bits, &c->seq, sizeof seq_bits);
   const unsigned tiles = (eval_sites + 63) / 64;
@@ -1950,12 +1994,7 @@ extern "C" int pllgpu_update_pmatrices(pllgpu_ctx_t *c, const unsigned *params_i
   d.SP = g.states_padded;
   d.SPT = c->gg.SPT;
   const size_t lds = (size_t)2 * g.states * (g.states | 1u) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set)
-  {
-    (void)hipFuncSetAttribute((const void *)k_pmatrix, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  raise_lds_limit((const void *)k_pmatrix, c->device);
   for (unsigned first = 0; first < count; first += 65535u) // gridDim.x stays far below its limit; y = rate
   {
     const unsigned nb = std::min(count - first, 65535u);
@@ -2075,6 +2114,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     pk.sequence = ++c->rep_seq;
     pk.sites = sites;
     pk.nblk = nblk;
+    pk.fenced = c->fenced;
     HIP_TRY(hipMemsetAsync(c->rep_table.p, 0xFF, cells * sizeof(unsigned), c->stream));
     const dim3 grid(nblk, n), block(256);
     hipLaunchKernelGGL(k_rep_mark, grid, block, 0, c->stream, pk);

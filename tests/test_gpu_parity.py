@@ -599,6 +599,33 @@ def test_tip_parent_edge_keeps_the_callers_orientation(amd_lib):
     assert_results_match(got, exp, what="orientation")
 
 
+def test_fenced_handoff_and_auto_device_switches(amd_lib, monkeypatch):
+    """PLL_AMD_FENCED_HANDOFF=1 puts release / acquire fences back into the result hand-off of the reduction
+    kernels (edge and root lnL, chain tail, derivatives, class counts): the same bits, only slower.
+    PLL_AMD_DEVICE=auto deals new partitions round-robin over the visible devices (one here)."""
+    cases = [W.make_case("fence-dna", 4, 64, 5000, seed=201),                                    # chain tail
+             W.make_case("fence-rep", 4, 32, 3000, seed=202, attributes=api.SITE_REPEATS, mutate_pct=5),
+             W.make_case("fence-aa", 20, 8, 900, seed=203), W.make_case("fence-61", 61, 8, 300, seed=204)]
+
+    def observe():
+        out = []
+        for case in cases:
+            with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+                s.update_partials()
+                v, ps = s.edge_lnl(case.edges[0])
+                r = s.root_lnl((case.edges[0][0], case.edges[0][1]), persite=False)[0]
+                ids = [s.entries(c) for c in range(case.tips, case.tips + case.clv_buffers)]
+                out.append((v, ps.copy(), r, ids))
+        return out
+
+    plain = observe()
+    monkeypatch.setenv("PLL_AMD_FENCED_HANDOFF", "1")
+    monkeypatch.setenv("PLL_AMD_DEVICE", "auto")
+    fenced = observe()
+    for a, b in zip(plain, fenced):
+        assert a[0] == b[0] and a[2] == b[2] and a[3] == b[3] and np.array_equal(a[1], b[1])
+
+
 def test_partitions_in_concurrent_threads(amd_lib):
     """distinct partitions may be driven from distinct threads (no internal threads, no
     global state): four threads, each with its own partition, stream and shape, interleave freely"""
