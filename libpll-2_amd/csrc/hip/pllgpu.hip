@@ -112,7 +112,9 @@ struct pllgpu_ctx
   DevBuf<double> eigenvals, rates, diag; // derivatives: [rate_matrices][SP], [R], [R][S][4]
   DevBuf<double> evecs, ievecs, brlen;   // device P-matrices: [rate_matrices][S][SP] x 2, staged branch lengths
   DevBuf<unsigned> mindex;               // staged matrix indices
-  DevBuf<unsigned> rep_table, rep_rank, rep_blocksum, rep_counts; // site-repeats class computation (kernels_repeats.h)
+  DevBuf<unsigned> rep_table, rep_blocksum, rep_counts; // site-repeats class computation (kernels_repeats.h)
+  DevBuf<unsigned char> rep_ops;         // its op descriptors of one batch
+  std::vector<RepOp> rep_ops_host;
   DevBuf<double> sumtable[PLLGPU_SUMTABLE_SLOTS]; // device-resident sumtables (tiled like a CLV), allocated on first use
   double *result_dev = nullptr;  // device alias of result_host
   DevBuf<unsigned> pattern_weights;
@@ -414,7 +416,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->brlen.release();
   c->mindex.release();
   c->rep_table.release();
-  c->rep_rank.release();
+  c->rep_ops.release();
   c->rep_blocksum.release();
   c->rep_counts.release();
   c->rates.release();
@@ -2075,13 +2077,13 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
       cells += need;
       ++n;
     }
-    if (cells >= 0xFFFFFFFFull) return fail(PLLGPU_EINVAL, "repeats table of %zu cells exceeds 32-bit addressing", cells);
+    if (cells >= 0x7FFFFFFFull) return fail(PLLGPU_EINVAL, "repeats table of %zu cells exceeds 31-bit addressing", cells);
     if (int rc = c->rep_table.ensure(cells)) return rc;
-    if (int rc = c->rep_rank.ensure((size_t)kRepOps * sites)) return rc;
     if (int rc = c->rep_blocksum.ensure((size_t)kRepOps * nblk)) return rc;
     if (int rc = c->rep_counts.ensure(kRepOps)) return rc;
-    RepPack pk;
-    memset(&pk, 0, sizeof pk);
+    if (int rc = c->rep_ops.ensure((size_t)kRepOps * sizeof(RepOp))) return rc;
+    std::vector<RepOp> &rops = c->rep_ops_host;
+    rops.assign(n, RepOp());
     size_t off = 0;
     for (unsigned i = 0; i < n; ++i)
     {
@@ -2093,19 +2095,25 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
       c->rep_left[o.parent] = (int)o.left;
       c->rep_right[o.parent] = (int)o.right;
       ++c->maps_epoch;
-      RepOp &r = pk.ops[i];
+      RepOp &r = rops[i];
       r.lid = c->site_id[o.left].p;
       r.rid = c->site_id[o.right].p;
       r.psid = c->site_id[o.parent].p;
       r.pids = c->id_site[o.parent].p;
       r.lent = c->lent[o.parent].p;
       r.rent = c->rent[o.parent].p;
-      r.rank = c->rep_rank.p + (size_t)i * sites;
       r.blocksum = c->rep_blocksum.p + (size_t)i * nblk;
       r.nleft = o.nleft;
+      r.ncells = o.nleft * o.nright;
       r.tab_off = (unsigned)off;
+      r.pad = 0;
       off += (size_t)o.nleft * o.nright;
     }
+    RepPack pk;
+    memset(&pk, 0, sizeof pk);
+    // pageable source: staged before hipMemcpyAsync returns; ordered behind the previous batch's kernels
+    HIP_TRY(hipMemcpyAsync(c->rep_ops.p, rops.data(), n * sizeof(RepOp), hipMemcpyHostToDevice, c->stream));
+    pk.ops = reinterpret_cast<const RepOp *>(c->rep_ops.p);
     pk.table = c->rep_table.p;
     pk.counts = c->rep_counts.p;
     pk.host_counts = c->rep_host_dev;
@@ -2117,7 +2125,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     pk.fenced = c->fenced;
     HIP_TRY(hipMemsetAsync(c->rep_table.p, 0xFF, cells * sizeof(unsigned), c->stream));
     const dim3 grid(nblk, n), block(256);
-    hipLaunchKernelGGL(k_rep_mark, grid, block, 0, c->stream, pk);
+    hipLaunchKernelGGL(k_rep_mark, dim3((sites + kRepMarkSites - 1) / kRepMarkSites, n), block, kRepLdsCells * sizeof(unsigned), c->stream, pk);
     hipLaunchKernelGGL(k_rep_count, grid, block, 0, c->stream, pk);
     hipLaunchKernelGGL(k_rep_rank, grid, block, 0, c->stream, pk);
     hipLaunchKernelGGL(k_rep_assign, grid, block, 0, c->stream, pk);
