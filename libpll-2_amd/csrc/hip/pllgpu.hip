@@ -149,6 +149,9 @@ struct pllgpu_ctx
   unsigned long long plan_stamp = 0;
   bool plan_cache = true;           // PLL_AMD_NO_PLAN_CACHE=1 plans every call afresh
   int gather_stream = 0;            // PLL_AMD_GATHER_STREAM: 1 always streaming loads from compressed children, -1 never, 0 by size
+  DevBuf<double> cherry_tab;        // k_cherry_tables: [cherry][rate][code pair][state] of the launch being issued
+  unsigned tip_ncodes = 0;          // codes in use: 1 + the highest code with a non-empty mask
+  bool fuse_generic = false;        // FMA-path shapes: (tip x tip, tip x tip -> inner x inner) groups (kernels_generic.h: k_partials_tiled_cc)
   bool subtrees = false;            // DNA + site repeats: all-tip subtrees straight from the tip codes (subtree_plan.h)
   DevBuf<unsigned char> sub_dev;    // their descriptors on the device ...
   std::vector<SubItem> sub_cache, sub_build; // ... and what that array holds / the list being planned
@@ -206,15 +209,20 @@ struct DeviceScope
 
 // hipFuncSetAttribute applies to the CURRENT device: once per (kernel, device), not once per process
 #include <mutex>
-#include <set>
-static void raise_lds_limit(const void *fn, int device)
+#include <map>
+static void raise_lds_limit(const void *fn, int device, size_t dynamic_bytes)
 {
+  // dynamic LDS beyond the default limit has to be announced per kernel; the kernel's static LDS counts
+  // against the 160 KB as well, so only what a launch needs is asked for (the largest request so far)
   static std::mutex mu;
-  static std::set<std::pair<const void *, int>> done;
+  static std::map<std::pair<const void *, int>, size_t> done;
   std::lock_guard<std::mutex> g(mu);
-  if (done.count({fn, device})) return;
-  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  done.insert({fn, device});
+  size_t &have = done[{fn, device}];
+  if (dynamic_bytes <= have || dynamic_bytes <= 32 * 1024) return;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_bytes) != hipSuccess)
+    (void)hipGetLastError(); // the launch itself will report what is wrong
+  else
+    have = dynamic_bytes;
 }
 
 extern "C" const char *pllgpu_last_error(void) { return g_err; }
@@ -270,6 +278,10 @@ static void derive_geometry(pllgpu_ctx *c)
   c->use_mfma = (g.states > 32 && g.rate_cats <= 16);
   if (const char *v = getenv("PLL_AMD_NO_MFMA"))
     if (*v && *v != '0') c->use_mfma = false;
+  // any-state FMA path: cherry-cherry groups need one wave per rate category
+  c->fuse_generic = !c->dna_fast && !c->use_mfma && g.rate_cats <= 4 && gg.nchunks == 1;
+  if (const char *v = getenv("PLL_AMD_NO_FUSE"))
+    if (*v && *v != '0') c->fuse_generic = false;
   c->pm_stride = (size_t)g.rate_cats * g.states * gg.SPT;
   c->span = g.rate_cats * g.states_padded;
 }
@@ -393,6 +405,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->level_plans.clear();
   c->chain_dev.release();
   c->sub_dev.release();
+  c->cherry_tab.release();
   for (auto &b : c->clv) b.release();
   for (auto &b : c->scaler) b.release();
   for (auto &b : c->tipchars) b.release();
@@ -544,6 +557,10 @@ extern "C" int pllgpu_tipmap_upload(pllgpu_ctx_t *c, const unsigned long long *h
   HIP_TRY(hipMemcpyAsync(c->tipmap.p, host, std::min(count, 256u) * sizeof(unsigned long long),
                          hipMemcpyHostToDevice, c->stream));
   c->tipmap_set = true;
+  c->tip_ncodes = 0;
+  for (unsigned i = 0; i < std::min(count, 256u); ++i)
+    if (host[i]) c->tip_ncodes = i + 1;
+  ++c->maps_epoch; // cached launches carry the code count
   return 0;
 }
 
@@ -769,6 +786,47 @@ static void launch_generic(pllgpu_ctx *c, const OpPack &pack, unsigned nops, uns
 #undef GEN_LAUNCH
 }
 
+// (tip x tip, tip x tip -> inner x inner) groups of an FMA-path shape: workgroup = tile(s), wave = rate category
+template <int ICH>
+static int launch_tiled_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries)
+{
+  const unsigned tiles = (entries + 63) / 64, R = c->gg.R, S = c->gg.S;
+  const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
+  const unsigned ncodes = c->tipmap_set ? c->tip_ncodes : (1u << S); // without a map a code is its own mask (S <= 4 then)
+  const size_t per_cherry = (size_t)R * ncodes * ncodes * cherry_row(S);
+  if (int rc = c->cherry_tab.ensure(per_cherry * 2 * ngroups)) return rc;
+  CherryMats mats;
+  memset(&mats, 0, sizeof mats);
+  for (unsigned i = 0; i < ngroups; ++i)
+  {
+    mats.lmat[2 * i] = pack.g[i].a.lmat;
+    mats.rmat[2 * i] = pack.g[i].a.rmat;
+    mats.lmat[2 * i + 1] = pack.g[i].b.lmat;
+    mats.rmat[2 * i + 1] = pack.g[i].b.rmat;
+  }
+  const size_t tab_lds = (size_t)2 * ncodes * S * sizeof(double);
+  raise_lds_limit((const void *)k_cherry_tables, c->device, tab_lds);
+  hipLaunchKernelGGL(k_cherry_tables, dim3(2 * ngroups, R), dim3(256), tab_lds, c->stream, mats, c->gg, tm, ncodes, c->cherry_tab.p);
+  // workgroup = tile, wave = rate category. One tile per workgroup: a tile's stores come last, and a wave that went
+  // on to another tile would wait for them with its first load
+  const unsigned tpb = 1;
+  dim3 grid((tiles + tpb - 1) / tpb, ngroups), block(64u * R);
+  hipLaunchKernelGGL((k_partials_tiled_cc<ICH>), grid, block, 0, c->stream, pack, c->gg, c->cherry_tab.p, ncodes, entries, tpb);
+  return 0;
+}
+
+static int launch_tiled_cc(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries)
+{
+  switch (c->ich)
+  {
+    case 4: return launch_tiled_cc_t<4>(c, pack, ngroups, entries);
+    case 8: return launch_tiled_cc_t<8>(c, pack, ngroups, entries);
+    case 16: return launch_tiled_cc_t<16>(c, pack, ngroups, entries);
+    case 20: return launch_tiled_cc_t<20>(c, pack, ngroups, entries);
+    default: return launch_tiled_cc_t<32>(c, pack, ngroups, entries);
+  }
+}
+
 static void launch_dna(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
 {
   // one wave per 64-site tile; a wave takes tpw consecutive tiles so that ~4096 workgroups exist
@@ -814,7 +872,7 @@ static int launch_mfma(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigne
 #define MF_LAUNCH(LT, RT, GA)                                                                                   \
   do                                                                                                            \
   {                                                                                                             \
-    raise_lds_limit((const void *)k_partials_mfma<LT, RT, GA>, c->device);                                      \
+    raise_lds_limit((const void *)k_partials_mfma<LT, RT, GA>, c->device, lds);                                      \
     hipLaunchKernelGGL((k_partials_mfma<LT, RT, GA>), grid, block, lds, c->stream, pack, c->gg, tm, ipw, fb, fstride); \
   } while (0)
   if (kind == 0)
@@ -897,7 +955,24 @@ static int plan_and_launch_levels(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigne
   c->launch_rc = 0;
   std::vector<int> role;
   std::vector<FusedGroup> groups;
-  plan_fusion(c->fuse, c->fuse_cc, c->geo.nodes, ops, count, role, groups);
+  // FMA-path groups look their cherries up in a table over all pairs of tip codes: only for a sane number of codes
+  const bool generic_groups = c->fuse_generic && (c->tipmap_set ? c->tip_ncodes : (1u << std::min(c->gg.S, 8u))) <= 64u;
+  plan_fusion(c->fuse || generic_groups, c->fuse_cc, c->geo.nodes, ops, count, role, groups);
+  if (generic_groups)
+  {
+    // of the groups the 4x4 planner knows, the FMA-path kernels have one: both children cherries
+    std::vector<FusedGroup> keep;
+    for (const FusedGroup &gq : groups)
+      if (gq.lk == CK_FTT && gq.rk == CK_FTT && gq.a >= 0 && gq.b >= 0)
+        keep.push_back(gq);
+      else
+      {
+        role[gq.p] = 0;
+        if (gq.a >= 0) role[gq.a] = 0;
+        if (gq.b >= 0) role[gq.b] = 0;
+      }
+    groups.swap(keep);
+  }
   // tail fusion: the plain ops of the last level (at most two: the ends of the edge a caller evaluates
   // next) are accepted but not launched yet - role 3
   if (c->defer_tail && count)
@@ -1001,9 +1076,14 @@ static int plan_and_launch_levels(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigne
         unsigned n = 0, entries = 0;
         auto flush = [&]() -> int {
           if (!n) return 0;
-          emit(c, [c, pack, n, entries, lk, rk]() {
-            if (int rc = launch_fused(c, pack, n, entries, lk, rk)) c->launch_rc = rc;
-          });
+          if (!c->dna_fast)
+            emit(c, [c, pack, n, entries]() {
+              if (int rc = launch_tiled_cc(c, pack, n, entries)) c->launch_rc = rc;
+            });
+          else
+            emit(c, [c, pack, n, entries, lk, rk]() {
+              if (int rc = launch_fused(c, pack, n, entries, lk, rk)) c->launch_rc = rc;
+            });
           if (c->launch_rc) return c->launch_rc;
           ++c->last_launches;
           n = 0;
@@ -1996,7 +2076,7 @@ extern "C" int pllgpu_update_pmatrices(pllgpu_ctx_t *c, const unsigned *params_i
   d.SP = g.states_padded;
   d.SPT = c->gg.SPT;
   const size_t lds = (size_t)2 * g.states * (g.states | 1u) * sizeof(double);
-  raise_lds_limit((const void *)k_pmatrix, c->device);
+  raise_lds_limit((const void *)k_pmatrix, c->device, lds);
   for (unsigned first = 0; first < count; first += 65535u) // gridDim.x stays far below its limit; y = rate
   {
     const unsigned nb = std::min(count - first, 65535u);

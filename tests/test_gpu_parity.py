@@ -330,6 +330,49 @@ def test_dna_without_fusion(amd_lib, kw, monkeypatch):
             assert (fused["scaler"][k] == plain["scaler"][k]).all()
 
 
+@pytest.mark.parametrize("kw", [dict(states=20, tips=16, sites=1500, seed=301),
+                                dict(states=20, tips=64, sites=700, seed=302, attributes=api.RATE_SCALERS),
+                                dict(states=20, tips=16, sites=333, seed=303, attributes=api.PATTERN_TIP, ambiguity_pct=8, partial_pct=6),  # masks with several states
+                                dict(states=7, tips=32, sites=900, seed=304, ambiguity_pct=5),
+                                dict(states=5, tips=16, sites=400, seed=305, attributes=api.RATE_SCALERS | api.PATTERN_TIP, partial_pct=10),
+                                dict(states=20, tips=8, sites=500, seed=306, tiny_p=1e-80),   # near-identity matrices: a cherry of two different states is all below 2^-256 -> rescaled
+                                dict(states=20, tips=8, sites=500, seed=307, tiny_p=1e-80, attributes=api.RATE_SCALERS),
+                                dict(states=20, tips=16, sites=300, seed=308, rate_cats=2), dict(states=20, tips=16, sites=300, seed=309, rate_cats=1),
+                                dict(states=20, tips=24, sites=600, seed=310, tree="random"), dict(states=32, tips=16, sites=200, seed=311),
+                                dict(states=20, tips=16, sites=300, seed=312, scalers=False)], ids=_id)
+def test_cherry_groups_of_fma_shapes_are_bit_identical(amd_lib, kw, monkeypatch):
+    """any-state FMA path: an op over two cherries is evaluated together with them (k_partials_tiled_cc), its
+    contraction fed from the staged tip matrices instead of HBM; PLL_AMD_NO_FUSE=1 launches level by level -
+    the same numbers, bit for bit, including the cherries' and the parent's scaling decisions"""
+    kw = dict(kw)
+    tiny = kw.pop("tiny_p", None)
+    case = W.make_case("ccg", **kw)
+    if tiny:  # P = (1 - (s - 1) eps) on the diagonal, eps elsewhere (numpy's expm cannot produce such entries)
+        s_ = case.states
+        case.pmatrix[:] = np.full((s_, s_), tiny) + np.eye(s_) * (1.0 - s_ * tiny)
+    fused = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        nf = amd_lib.pll_gpu_last_launch_count(s.p)
+    monkeypatch.setenv("PLL_AMD_NO_FUSE", "1")
+    plain = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        npl = amd_lib.pll_gpu_last_launch_count(s.p)
+    exp = O.run_case(case)
+    assert_results_match(plain, exp, what=_id(kw))
+    if kw.get("tree", "balanced") == "balanced" and kw.get("rate_cats", 4) <= 4:
+        assert nf < npl, (nf, npl)  # the cherries' launch is gone
+    assert fused["lnl"] == plain["lnl"]
+    for k in plain["clv"]:
+        assert np.array_equal(fused["clv"][k], plain["clv"][k]), k
+        if k in plain["scaler"]:
+            assert np.array_equal(fused["scaler"][k], plain["scaler"][k]), k
+    if tiny:
+        cherries = [op[0] for op in case.op_batches[0] if op[2] < case.tips and op[5] < case.tips]
+        assert sum(int(plain["scaler"][c].sum()) for c in cherries) > 0  # cherries were rescaled
+
+
 def test_fusion_plan_on_a_balanced_tree(amd_lib, monkeypatch):
     """64 taxa, full traversal: 8 groups of seven ops (complete 8-tip subtrees: four cherries, two ops
     above them, one above those) in one launch; the top six ops are two chains that end in the two
