@@ -282,33 +282,39 @@ __global__ __launch_bounds__(256) void k_cherry_tables(const CherryMats mats, co
 
 typedef double gen_dbl2 __attribute__((ext_vector_type(2)));
 
-// the cherry's CLV column of this (entry, rate): the lane's table row (read a second time: it is in the vector
-// cache), times 2^256 if the cherry was rescaled, in one burst of stores
+// the cherry's CLV column of this (entry, rate): the lane's table row, copied in one burst of stores (stores that
+// trickle out of the contraction loop one row at a time reached 3.1 TB/s on C3, a pure copy like this one 4+)
 template <int ICH>
-__device__ __forceinline__ void cherry_store(const double *__restrict__ row, unsigned S, double *__restrict__ out, bool scaled)
+__device__ __forceinline__ void cherry_store(const double *__restrict__ row, unsigned S, double *__restrict__ out, bool valid, bool &small)
 {
   const gen_dbl2 *r2 = reinterpret_cast<const gen_dbl2 *>(row);
   gen_dbl2 v[(ICH + 1) / 2];
 #pragma unroll
   for (int jc = 0; jc < (ICH + 1) / 2; ++jc) v[jc] = 2 * jc < (int)S ? r2[jc] : gen_dbl2{0.0, 0.0};
-  const double f = scaled ? PLLGPU_SCALE_FACTOR : 1.0; // exact either way
+  small = true;
 #pragma unroll
   for (int jc = 0; jc < (ICH + 1) / 2; ++jc)
   {
-    if (2 * jc < (int)S) __builtin_nontemporal_store(v[jc].x * f, out + (size_t)(2 * jc) * 64);
-    if (2 * jc + 1 < (int)S) __builtin_nontemporal_store(v[jc].y * f, out + (size_t)(2 * jc + 1) * 64);
+    if (2 * jc < (int)S)
+    {
+      small = small && (v[jc].x < PLLGPU_SCALE_THRESHOLD);
+      if (valid) __builtin_nontemporal_store(v[jc].x, out + (size_t)(2 * jc) * 64);
+    }
+    if (2 * jc + 1 < (int)S)
+    {
+      small = small && (v[jc].y < PLLGPU_SCALE_THRESHOLD);
+      if (valid) __builtin_nontemporal_store(v[jc].y, out + (size_t)(2 * jc + 1) * 64);
+    }
   }
 }
 
-// acc[i] = sum_j PT[k][j][i] x_j with x = the lane's table row; small = every x_j below the scaling threshold
+// acc[i] = sum_j PT[k][j][i] x_j with x = the lane's table row (second read: from the vector cache)
 template <int ICH>
-__device__ __forceinline__ void cherry_contract(double (&acc)[ICH], bool &small, const double *__restrict__ row, const double *pt, unsigned k,
-                                                const GenGeo &g)
+__device__ __forceinline__ void cherry_contract(double (&acc)[ICH], const double *__restrict__ row, const double *pt, unsigned k, const GenGeo &g)
 {
   cdouble_p p = as_const(pt) + ((size_t)k * g.S) * g.SPT;
 #pragma unroll
   for (int i = 0; i < ICH; ++i) acc[i] = 0.0;
-  small = true;
   const gen_dbl2 *r2 = reinterpret_cast<const gen_dbl2 *>(row);
   const unsigned half = cherry_row(g.S) / 2u;
 #pragma unroll 2
@@ -317,14 +323,12 @@ __device__ __forceinline__ void cherry_contract(double (&acc)[ICH], bool &small,
     const gen_dbl2 v = r2[jc];
     const unsigned j = 2u * jc;
     {
-      small = small && (v.x < PLLGPU_SCALE_THRESHOLD);
       cdouble_p pj = p + (size_t)j * g.SPT;
 #pragma unroll
       for (int i = 0; i < ICH; ++i) acc[i] = fma(pj[i], v.x, acc[i]);
     }
     if (j + 1u < g.S)
     {
-      small = small && (v.y < PLLGPU_SCALE_THRESHOLD);
       cdouble_p pj = p + (size_t)(j + 1u) * g.SPT;
 #pragma unroll
       for (int i = 0; i < ICH; ++i) acc[i] = fma(pj[i], v.y, acc[i]);
@@ -359,14 +363,12 @@ __global__ __launch_bounds__(256) void k_partials_tiled_cc(const FusePack pack, 
     const size_t base = (size_t)tile * g.tile_sz + lane + col;
     double *__restrict__ outa = grp.a.parent + base, *__restrict__ outb = grp.b.parent + base, *__restrict__ outp = grp.p.parent + base;
 
-    // everything this tile READS comes first, everything it writes last: a wave waits for its loads through a
-    // counter that its earlier stores sit in as well, so a store issued before a load makes that load's wait a
-    // wait for the store to reach memory (with the stores first the kernel's time was the SUM of its store time
-    // and its arithmetic: 507 us for C3's bottom two levels, as long as the two launches it replaces)
     double A[ICH], B[ICH];
     bool sa, sb;
-    cherry_contract<ICH>(A, sa, ta + (size_t)pa * SR, grp.p.lmat, k, g);
-    cherry_contract<ICH>(B, sb, tb + (size_t)pb * SR, grp.p.rmat, k, g);
+    cherry_store<ICH>(ta + (size_t)pa * SR, g.S, outa, valid, sa);
+    cherry_store<ICH>(tb + (size_t)pb * SR, g.S, outb, valid, sb);
+    cherry_contract<ICH>(A, ta + (size_t)pa * SR, grp.p.lmat, k, g);
+    cherry_contract<ICH>(B, tb + (size_t)pb * SR, grp.p.rmat, k, g);
     sa = sa && ma != 0;
     sb = sb && mb != 0;
     // the cherries' scaling decisions: per rate they are this wave's own, per site the rates meet in LDS
@@ -384,15 +386,32 @@ __global__ __launch_bounds__(256) void k_partials_tiled_cc(const FusePack pack, 
       sa = sa && ma != 0;
       sb = sb && mb != 0;
     }
+    auto rescale_stored = [&](double *colp) { // rare: the entry's stored column of this rate, written by this lane
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      for (unsigned s = 0; s < g.S; ++s)
+      {
+        const double v = __builtin_nontemporal_load(colp + (size_t)s * 64);
+        __builtin_nontemporal_store(v * PLLGPU_SCALE_FACTOR, colp + (size_t)s * 64);
+      }
+    };
     if (sa)
     {
+      if (valid) rescale_stored(outa);
 #pragma unroll
       for (int i = 0; i < ICH; ++i) A[i] *= PLLGPU_SCALE_FACTOR;
     }
     if (sb)
     {
+      if (valid) rescale_stored(outb);
 #pragma unroll
       for (int i = 0; i < ICH; ++i) B[i] *= PLLGPU_SCALE_FACTOR;
+    }
+    if (valid)
+    {
+      if (ma == 2) grp.a.pscaler[(size_t)n * g.R + k] = sa ? 1u : 0u;
+      if (mb == 2) grp.b.pscaler[(size_t)n * g.R + k] = sb ? 1u : 0u;
+      if (k == 0 && ma == 1) grp.a.pscaler[n] = sa ? 1u : 0u;
+      if (k == 0 && mb == 1) grp.b.pscaler[n] = sb ? 1u : 0u;
     }
     // the parent
     bool sp = mp != 0;
@@ -412,12 +431,6 @@ __global__ __launch_bounds__(256) void k_partials_tiled_cc(const FusePack pack, 
     }
     if (valid)
     {
-      cherry_store<ICH>(ta + (size_t)pa * SR, g.S, outa, sa);
-      cherry_store<ICH>(tb + (size_t)pb * SR, g.S, outb, sb);
-      if (ma == 2) grp.a.pscaler[(size_t)n * g.R + k] = sa ? 1u : 0u;
-      if (mb == 2) grp.b.pscaler[(size_t)n * g.R + k] = sb ? 1u : 0u;
-      if (k == 0 && ma == 1) grp.a.pscaler[n] = sa ? 1u : 0u;
-      if (k == 0 && mb == 1) grp.b.pscaler[n] = sb ? 1u : 0u;
 #pragma unroll
       for (int i = 0; i < ICH; ++i)
         if (i < (int)g.S) outp[(size_t)i * 64] = sp ? A[i] * PLLGPU_SCALE_FACTOR : A[i];

@@ -40,8 +40,18 @@
 // column reads of the tip route (address ~ state >> 2) over the banks; the MFMA operand reads (16
 // consecutive doubles of one fragment, broadcast to the four blocks) do not care
 constexpr unsigned kFrag = 17;
-constexpr unsigned kFragArray = 256 * kFrag; // doubles per staged matrix
-constexpr int kMfmaRowsumOff = 2 * kFragArray; // doubles: after the two fragment arrays come 2 x 64 row sums
+// NG = number of 4-state groups the kernels are compiled for: 16 (33..64 states), 8 (21..32), 5 (17..20: the
+// 20-state protein models - the coefficient delivery is what the matrix pipe is used for there too, the
+// scalar-load-fed FMA contraction of kernels_generic.h reaches a third of the fp64 rate)
+template <int NG> struct MfmaGeo
+{
+  static constexpr unsigned frag_array = NG * NG * kFrag;  // doubles per staged matrix
+  static constexpr unsigned rowsum_off = 2 * frag_array;    // doubles: after the two fragment arrays come 2 x 4 NG row sums
+  static constexpr unsigned lds_doubles = rowsum_off + 2 * 4 * NG;
+  static constexpr int chunk = (NG % 4 == 0 && NG > 8) ? 4 : NG; // parent state groups per D_right pass
+};
+constexpr unsigned kFragArray = MfmaGeo<16>::frag_array;
+constexpr int kMfmaRowsumOff = MfmaGeo<16>::rowsum_off;
 
 struct MfmaItem
 {
@@ -96,24 +106,27 @@ __device__ __forceinline__ bool mfma_simple_tips(const unsigned long long m[2], 
 // (P x)[4 ig + row] for a simple tip: column `code` of P, or the row sum for a gap - one LDS read.
 // frag[ig][jg][kk][ii] = P[4ig+ii][4jg+kk]; the lane wants P[4ig + row][code]: not this lane's own
 // fragment element, so a per-lane address.
+template <int NG = 16>
 __device__ __forceinline__ double mfma_tip_column(const double *__restrict__ frag, const double *__restrict__ rowsum,
                                                   unsigned long long m, unsigned long long full, unsigned row, int ig)
 {
   const unsigned code = (unsigned)__ffsll((long long)m) - 1u;
-  const double *p = m == full ? rowsum + 4 * ig + row : frag + (ig * 16 + (code >> 2)) * kFrag + (code & 3u) * 4u + row;
+  const double *p = m == full ? rowsum + 4 * ig + row : frag + (ig * NG + (code >> 2)) * kFrag + (code & 3u) * 4u + row;
   return *p;
 }
 
-template <bool LTIP, bool RTIP, bool GATHER>
-__global__ __launch_bounds__(256, 2) void k_partials_mfma(const OpPack pack, const GenGeo g,
+template <int NG, bool LTIP, bool RTIP, bool GATHER>
+__global__ __launch_bounds__(256, NG > 8 ? 2 : 4) void k_partials_mfma(const OpPack pack, const GenGeo g,
                                                           const unsigned long long *__restrict__ tipmap,
                                                           unsigned items_per_wave, unsigned char *__restrict__ flagbuf,
                                                           unsigned flag_stride /* bytes per (op, rate) */)
 {
   extern __shared__ double lds[];
-  double *PL = lds;                 // [16 ig][16 jg][4 k][4 i]
-  double *PR = lds + kFragArray;
-  double *RS = lds + kMfmaRowsumOff; // row sums of P_left [64], P_right [64]
+  typedef MfmaGeo<NG> MG;
+  constexpr int CH = MG::chunk;
+  double *PL = lds;                 // [NG ig][NG jg][4 k][4 i]
+  double *PR = lds + MG::frag_array;
+  double *RS = lds + MG::rowsum_off; // row sums of P_left [4 NG], P_right [4 NG]
 
   const DevOp &op = pack.ops[blockIdx.y];
   const unsigned lane = threadIdx.x & 63u;
@@ -129,9 +142,9 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma(const OpPack pack, con
   const unsigned long long full = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
 
   // stage fragments: frag[ig][jg][kk][ii] = P[4ig+ii][4jg+kk] = PT[k][4jg+kk][4ig+ii]
-  for (unsigned idx = threadIdx.x; idx < 4096; idx += 256)
+  for (unsigned idx = threadIdx.x; idx < NG * NG * 16u; idx += 256)
   {
-    const unsigned ii = idx & 3u, kk = (idx >> 2) & 3u, jg = (idx >> 4) & 15u, ig = idx >> 8;
+    const unsigned ii = idx & 3u, kk = (idx >> 2) & 3u, jg = (idx >> 4) % NG, ig = (idx >> 4) / NG;
     const unsigned j = 4 * jg + kk, i = 4 * ig + ii;
     double l = 0.0, r = 0.0;
     if (j < S && i < g.SPT)
@@ -145,13 +158,13 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma(const OpPack pack, con
   __syncthreads();
   if (LTIP || RTIP)
   {
-    if (threadIdx.x < 128)
+    if (threadIdx.x < 8 * NG)
     {
       // row sums in ascending j like the reference's set-bit walk (core_partials.c:480-489)
-      const double *F = threadIdx.x < 64 ? PL : PR;
-      const unsigned i = threadIdx.x & 63u;
+      const double *F = threadIdx.x < 4 * NG ? PL : PR;
+      const unsigned i = threadIdx.x % (4 * NG);
       double s = 0.0;
-      for (unsigned j = 0; j < S; ++j) s += F[((i >> 2) * 16 + (j >> 2)) * kFrag + (j & 3u) * 4 + (i & 3u)];
+      for (unsigned j = 0; j < S; ++j) s += F[((i >> 2) * NG + (j >> 2)) * kFrag + (j & 3u) * 4 + (i & 3u)];
       RS[threadIdx.x] = s;
     }
     __syncthreads();
@@ -164,11 +177,11 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma(const OpPack pack, con
   // x: CLV fragments of the inner child in flight - the left one, then the right one (ii), or
   // the right one only (ti); tip children take their 0/1 x from the mask on the fly
   MfmaItem cur = mfma_item<LTIP, RTIP, GATHER>(op, g, tipmap, item0, col, k);
-  double x[16][2];
+  double x[NG][2];
   if (!LTIP || !RTIP)
   {
 #pragma unroll
-    for (int jg = 0; jg < 16; ++jg)
+    for (int jg = 0; jg < NG; ++jg)
 #pragma unroll
       for (int sg = 0; sg < 2; ++sg) x[jg][sg] = mfma_x<false>(LTIP ? cur.rb[sg] : cur.lb[sg], 0, S, 4 * jg + row);
   }
@@ -179,29 +192,29 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma(const OpPack pack, con
     MfmaItem nxt = cur;
     if (has_next) nxt = mfma_item<LTIP, RTIP, GATHER>(op, g, tipmap, item0 + it + 1, col, k);
 
-    double DL[16][2];
+    double DL[NG][2];
     // ---- left child: all 16 parent state groups
     const bool lsimple = LTIP && mfma_simple_tips(cur.lm, full);
     if (lsimple)
     {
 #pragma unroll
-      for (int ig = 0; ig < 16; ++ig)
+      for (int ig = 0; ig < NG; ++ig)
 #pragma unroll
-        for (int sg = 0; sg < 2; ++sg) DL[ig][sg] = mfma_tip_column(PL, RS, cur.lm[sg], full, row, ig);
+        for (int sg = 0; sg < 2; ++sg) DL[ig][sg] = mfma_tip_column<NG>(PL, RS, cur.lm[sg], full, row, ig);
     }
     else
     {
 #pragma unroll
-      for (int ig = 0; ig < 16; ++ig) DL[ig][0] = DL[ig][1] = 0.0;
+      for (int ig = 0; ig < NG; ++ig) DL[ig][0] = DL[ig][1] = 0.0;
 #pragma unroll
-      for (int jg = 0; jg < 16; ++jg)
+      for (int jg = 0; jg < NG; ++jg)
       {
         const double x0 = LTIP ? mfma_x<true>(nullptr, cur.lm[0], S, 4 * jg + row) : x[jg][0];
         const double x1 = LTIP ? mfma_x<true>(nullptr, cur.lm[1], S, 4 * jg + row) : x[jg][1];
 #pragma unroll
-        for (int ig = 0; ig < 16; ++ig)
+        for (int ig = 0; ig < NG; ++ig)
         {
-          const double a = PL[(ig * 16 + jg) * kFrag + fragoff];
+          const double a = PL[(ig * NG + jg) * kFrag + fragoff];
           DL[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x0, DL[ig][0], 0, 0, 0);
           DL[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x1, DL[ig][1], 0, 0, 0);
         }
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma(const OpPack pack, con
     if (rsimple)
     {
 #pragma unroll
-      for (int ig = 0; ig < 16; ++ig)
+      for (int ig = 0; ig < NG; ++ig)
       {
         const unsigned i = 4 * ig + row;
         if (i < S)
@@ -233,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma(const OpPack pack, con
 #pragma unroll
           for (int sg = 0; sg < 2; ++sg)
           {
-            const double v = DL[ig][sg] * mfma_tip_column(PR, RS, cur.rm[sg], full, row, ig);
+            const double v = DL[ig][sg] * mfma_tip_column<NG>(PR, RS + 4 * NG, cur.rm[sg], full, row, ig);
             small[sg] = small[sg] && (v < PLLGPU_SCALE_THRESHOLD);
             if (cur.valid[sg]) pb[sg][(size_t)i * 64] = v;
           }
@@ -243,41 +256,41 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma(const OpPack pack, con
     else
     {
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+      for (int c = 0; c < NG / CH; ++c)
       {
-        double DR[4][2];
+        double DR[CH][2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) DR[q][0] = DR[q][1] = 0.0;
+        for (int q = 0; q < CH; ++q) DR[q][0] = DR[q][1] = 0.0;
 #pragma unroll
-        for (int jg = 0; jg < 16; ++jg)
+        for (int jg = 0; jg < NG; ++jg)
         {
           const double x0 = RTIP ? mfma_x<true>(nullptr, cur.rm[0], S, 4 * jg + row) : x[jg][0];
           const double x1 = RTIP ? mfma_x<true>(nullptr, cur.rm[1], S, 4 * jg + row) : x[jg][1];
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
+          for (int q = 0; q < CH; ++q)
           {
-            const double a = PR[((c * 4 + q) * 16 + jg) * kFrag + fragoff];
+            const double a = PR[((c * CH + q) * NG + jg) * kFrag + fragoff];
             DR[q][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x0, DR[q][0], 0, 0, 0);
             DR[q][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x1, DR[q][1], 0, 0, 0);
           }
           // last chunk: x[jg] of this item is dead, request the next item's first inner child
-          if (c == 3 && !RTIP && has_next)
+          if (c == NG / CH - 1 && !RTIP && has_next)
           {
             x[jg][0] = mfma_x<false>(LTIP ? nxt.rb[0] : nxt.lb[0], 0, S, 4 * jg + row);
             x[jg][1] = mfma_x<false>(LTIP ? nxt.rb[1] : nxt.lb[1], 0, S, 4 * jg + row);
           }
-          if (c == 3 || (jg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+          if (c == NG / CH - 1 || (jg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < CH; ++q)
         {
-          const unsigned i = 4 * (c * 4 + q) + row;
+          const unsigned i = 4 * (c * CH + q) + row;
           if (i < S)
           {
 #pragma unroll
             for (int sg = 0; sg < 2; ++sg)
             {
-              const double v = DL[c * 4 + q][sg] * DR[q][sg];
+              const double v = DL[c * CH + q][sg] * DR[q][sg];
               small[sg] = small[sg] && (v < PLLGPU_SCALE_THRESHOLD);
               if (cur.valid[sg]) pb[sg][(size_t)i * 64] = v;
             }
@@ -336,6 +349,320 @@ __global__ __launch_bounds__(256) void k_mfma_scale_epilogue(const OpPack pack, 
         for (unsigned q = 0; q < S; ++q) base[((size_t)k * S + q) * 64] *= PLLGPU_SCALE_FACTOR;
       op.pscaler[(size_t)n * R + k] = (op.lscaler ? op.lscaler[(size_t)le * R + k] : 0u) +
                                       (op.rscaler ? op.rscaler[(size_t)re * R + k] : 0u) + (sm ? 1u : 0u);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (tip x tip, tip x tip -> inner x inner) groups on the matrix pipe (C3: 20 states, NG = 5): an op P whose two
+// children are cherries produced by the same call is evaluated together with them; nothing is read back from
+// HBM. A cherry entry for the lane's states j = 4 jg + row is a product of two tip columns (read from the
+// LDS-staged fragments, exactly what k_partials_mfma<.., true, true> stores) - and that register layout IS the
+// B operand of the next MFMA stage (D and B share their lane map), so P's contraction starts from registers:
+// D_left = P_left x_a, D_right = P_right x_b, 2 x NG x NG MFMAs per 16 sites with their coefficients from LDS.
+// (The FMA kernels feed every multiply-add a fresh coefficient through the scalar path and reach a third of the
+// fp64 rate: for 20 states that contraction takes as long as the group's 1.5 GB of stores, and the two did not
+// overlap - kernels_generic.h. Here the contraction is a fraction of the store time.)
+// The arithmetic per op is that of k_partials_mfma, in the same order: bit-identical to the level-by-level
+// launches on this pipe. Scaling: the cherries' decisions come from k_cherry_bits (every rate's answer per pair of
+// tip codes) and are applied in registers before the parent is formed; the parent's own "all below 2^-256" bits
+// go to flagbuf per (group, rate, entry) and k_mfma_scale_epilogue applies them, as for any op of this pipe.
+// grid = (item blocks, groups, rate categories); LDS: fragments of a.l, a.r, b.l, b.r, p.l, p.r + the four tip
+// matrices' row sums.
+// Which cherries are rescaled? A cherry entry depends on the two tip codes only, so "all S values of rate k
+// below 2^-256" is a property of (cherry, rate, code pair): bits[cherry][code_l * ncodes + code_r] has bit k set
+// when it holds. k_partials_mfma_cc runs one rate category per workgroup, but the per-site decision needs all of
+// them and has to be known BEFORE the parent's contraction (the parent is formed from the rescaled cherry);
+// with this small table every workgroup knows every rate's answer. Values as the kernels form them: ascending
+// sums over the set bits of each mask, then the product (src/core_partials.c:1166-1209). grid = cherries.
+struct CherryTips // by value: the tip matrices of up to 2 x kMaxGroups cherries
+{
+  const double *lmat[2 * kMaxGroups];
+  const double *rmat[2 * kMaxGroups];
+};
+
+__global__ __launch_bounds__(256) void k_cherry_bits(const CherryTips mats, const GenGeo g, const unsigned long long *__restrict__ tipmap,
+                                                      unsigned ncodes, unsigned short *__restrict__ bits)
+{
+  extern __shared__ double cols[]; // [2][ncodes][S]
+  const unsigned c = blockIdx.x, S = g.S, npairs = ncodes * ncodes;
+  unsigned short mine[4] = {0, 0, 0, 0}; // pairs threadIdx.x + 256 q, q < 4 (ncodes <= 32)
+  for (unsigned k = 0; k < g.R; ++k)
+  {
+    const double *lm = mats.lmat[c] + (size_t)k * S * g.SPT, *rm = mats.rmat[c] + (size_t)k * S * g.SPT;
+    __syncthreads();
+    for (unsigned idx = threadIdx.x; idx < ncodes * S; idx += 256u)
+    {
+      const unsigned code = idx / S, i = idx % S;
+      const unsigned long long mask = tipmap ? tipmap[code] : (unsigned long long)code;
+      double a = 0.0, b = 0.0;
+      for (unsigned m = 0; m < S; ++m)
+        if ((mask >> m) & 1ull)
+        {
+          a += lm[(size_t)m * g.SPT + i];
+          b += rm[(size_t)m * g.SPT + i];
+        }
+      cols[idx] = a;
+      cols[ncodes * S + idx] = b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (unsigned q = 0; q < 4; ++q)
+    {
+      const unsigned pr = threadIdx.x + 256u * q;
+      if (pr >= npairs) break;
+      const double *cl = cols + (pr / ncodes) * S, *cr = cols + ncodes * S + (pr % ncodes) * S;
+      bool small = true;
+      for (unsigned i = 0; i < S; ++i) small = small && (cl[i] * cr[i] < PLLGPU_SCALE_THRESHOLD);
+      if (small) mine[q] |= (unsigned short)(1u << k);
+    }
+  }
+#pragma unroll
+  for (unsigned q = 0; q < 4; ++q)
+  {
+    const unsigned pr = threadIdx.x + 256u * q;
+    if (pr < npairs) bits[(size_t)c * npairs + pr] = mine[q];
+  }
+}
+
+template <int NG>
+__global__ __launch_bounds__(256, 4) void k_partials_mfma_cc(const FusePack pack, const GenGeo g, const unsigned long long *__restrict__ tipmap,
+                                                             unsigned entries, unsigned items_per_wave, unsigned char *__restrict__ flagbuf,
+                                                             unsigned flag_stride, const unsigned short *__restrict__ bits, unsigned ncodes)
+{
+  typedef MfmaGeo<NG> MG;
+  extern __shared__ double lds[];
+  double *F[6];
+#pragma unroll
+  for (int m = 0; m < 6; ++m) F[m] = lds + (size_t)m * MG::frag_array; // a.l a.r b.l b.r p.l p.r
+  double *RS = lds + 6u * MG::frag_array;                               // [4][4 NG] row sums of the tip matrices
+
+  const FGroup &grp = pack.g[blockIdx.y];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned row = lane >> 4, col = lane & 15u;
+  const unsigned S = g.S, k = blockIdx.z;
+  const unsigned nitems = (entries + 31u) / 32u;
+  if (blockIdx.x * 4u * items_per_wave >= nitems) return; // whole workgroup
+  const unsigned fragoff = row * 4u + (lane & 3u);
+  const unsigned long long full = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
+  {
+    const double *src[6] = {grp.a.lmat, grp.a.rmat, grp.b.lmat, grp.b.rmat, grp.p.lmat, grp.p.rmat};
+    for (unsigned idx = threadIdx.x; idx < NG * NG * 16u; idx += 256)
+    {
+      const unsigned ii = idx & 3u, kk = (idx >> 2) & 3u, jg = (idx >> 4) % NG, ig = (idx >> 4) / NG;
+      const unsigned j = 4 * jg + kk, i = 4 * ig + ii;
+      const bool in = j < S && i < g.SPT;
+      const size_t off = ((size_t)k * S + j) * g.SPT + i;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) F[m][(idx >> 4) * kFrag + (idx & 15u)] = in ? src[m][off] : 0.0;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16 * NG)
+  {
+    // row sums in ascending j like the reference's set-bit walk (core_partials.c:480-489)
+    const unsigned m = threadIdx.x / (4 * NG), i = threadIdx.x % (4 * NG);
+    double s = 0.0;
+    for (unsigned j = 0; j < S; ++j) s += F[m][((i >> 2) * NG + (j >> 2)) * kFrag + (j & 3u) * 4 + (i & 3u)];
+    RS[threadIdx.x] = s;
+  }
+  __syncthreads();
+  const int ma = grp.a.pscaler ? g.scale_mode : 0, mb = grp.b.pscaler ? g.scale_mode : 0, mp = grp.p.pscaler ? g.scale_mode : 0;
+  const unsigned item0 = (blockIdx.x * 4u + wave) * items_per_wave;
+  if (item0 >= nitems) return; // no barriers below
+  const unsigned nmine = min(items_per_wave, nitems - item0);
+
+  for (unsigned it = 0; it < nmine; ++it)
+  {
+    unsigned e[2];
+    bool valid[2];
+    unsigned long long m[4][2];
+    bool scale_a[2], scale_b[2]; // is the cherry entry rescaled (for this rate category)?
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg)
+    {
+      e[sg] = (item0 + it) * 32u + sg * 16u + col;
+      valid[sg] = e[sg] < entries;
+      const unsigned nn = valid[sg] ? e[sg] : entries - 1;
+      const unsigned c0 = grp.a.ltip[nn], c1 = grp.a.rtip[nn], c2 = grp.b.ltip[nn], c3 = grp.b.rtip[nn];
+      {
+        const unsigned npairs = ncodes * ncodes, allr = (1u << g.R) - 1u;
+        const unsigned ba = bits[(size_t)(2u * blockIdx.y) * npairs + c0 * ncodes + c1];
+        const unsigned bb = bits[(size_t)(2u * blockIdx.y + 1u) * npairs + c2 * ncodes + c3];
+        scale_a[sg] = ma == 1 ? ba == allr : ma == 2 ? ((ba >> k) & 1u) != 0 : false;
+        scale_b[sg] = mb == 1 ? bb == allr : mb == 2 ? ((bb >> k) & 1u) != 0 : false;
+      }
+      m[0][sg] = tipmap ? tipmap[c0] : (unsigned long long)c0;
+      m[1][sg] = tipmap ? tipmap[c1] : (unsigned long long)c1;
+      m[2][sg] = tipmap ? tipmap[c2] : (unsigned long long)c2;
+      m[3][sg] = tipmap ? tipmap[c3] : (unsigned long long)c3;
+    }
+    // a cherry in the lane's states j = 4 jg + row: (P_l x_l)_j (P_r x_r)_j, like k_partials_mfma<.., true, true>
+    auto cherry = [&](int t0, double (&x)[NG][2], bool (&small)[2]) {
+      const bool lsimple = mfma_simple_tips(m[t0], full), rsimple = mfma_simple_tips(m[t0 + 1], full);
+      double DLc[NG][2];
+      if (lsimple)
+      {
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig)
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg) DLc[ig][sg] = mfma_tip_column<NG>(F[t0], RS + t0 * 4 * NG, m[t0][sg], full, row, ig);
+      }
+      else
+      {
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig) DLc[ig][0] = DLc[ig][1] = 0.0;
+#pragma unroll
+        for (int jg = 0; jg < NG; ++jg)
+        {
+          const double x0 = mfma_x<true>(nullptr, m[t0][0], S, 4 * jg + row), x1 = mfma_x<true>(nullptr, m[t0][1], S, 4 * jg + row);
+#pragma unroll
+          for (int ig = 0; ig < NG; ++ig)
+          {
+            const double a = F[t0][(ig * NG + jg) * kFrag + fragoff];
+            DLc[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x0, DLc[ig][0], 0, 0, 0);
+            DLc[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x1, DLc[ig][1], 0, 0, 0);
+          }
+        }
+      }
+      small[0] = small[1] = true;
+      if (rsimple)
+      {
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig)
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg)
+          {
+            x[ig][sg] = DLc[ig][sg] * mfma_tip_column<NG>(F[t0 + 1], RS + (t0 + 1) * 4 * NG, m[t0 + 1][sg], full, row, ig);
+            if (4 * ig + row < S) small[sg] = small[sg] && (x[ig][sg] < PLLGPU_SCALE_THRESHOLD);
+          }
+      }
+      else
+      {
+        double DRc[NG][2];
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig) DRc[ig][0] = DRc[ig][1] = 0.0;
+#pragma unroll
+        for (int jg = 0; jg < NG; ++jg)
+        {
+          const double x0 = mfma_x<true>(nullptr, m[t0 + 1][0], S, 4 * jg + row), x1 = mfma_x<true>(nullptr, m[t0 + 1][1], S, 4 * jg + row);
+#pragma unroll
+          for (int ig = 0; ig < NG; ++ig)
+          {
+            const double a = F[t0 + 1][(ig * NG + jg) * kFrag + fragoff];
+            DRc[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x0, DRc[ig][0], 0, 0, 0);
+            DRc[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x1, DRc[ig][1], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig)
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg)
+          {
+            x[ig][sg] = DLc[ig][sg] * DRc[ig][sg];
+            if (4 * ig + row < S) small[sg] = small[sg] && (x[ig][sg] < PLLGPU_SCALE_THRESHOLD);
+          }
+      }
+    };
+    // store the lane's states of an op's CLV entry (both site groups)
+    auto put = [&](const FOp &op, const double (&v)[NG][2], bool stream) {
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg)
+      {
+        double *pb = op.parent + (size_t)(e[sg] >> 6) * g.tile_sz + (e[sg] & 63u) + (size_t)k * S * 64;
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig)
+        {
+          const unsigned i = 4 * ig + row;
+          if (i < S && valid[sg])
+          {
+            if (stream)
+              __builtin_nontemporal_store(v[ig][sg], pb + (size_t)i * 64);
+            else
+              pb[(size_t)i * 64] = v[ig][sg];
+          }
+        }
+      }
+    };
+    // a cherry's scaler entry: its own decision (children are tips)
+    auto put_scaler = [&](const FOp &op, int mode, const bool (&scaled)[2]) {
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg)
+        if (row == 0 && valid[sg])
+        {
+          if (mode == 2) op.pscaler[(size_t)e[sg] * g.R + k] = scaled[sg] ? 1u : 0u;
+          if (mode == 1 && k == 0) op.pscaler[e[sg]] = scaled[sg] ? 1u : 0u;
+        }
+    };
+    double xa[NG][2], xb[NG][2];
+    bool sa[2], sb[2]; // this rate's own "all small" (the table says the same; only the table knows the other rates)
+    cherry(0, xa, sa);
+    cherry(2, xb, sb);
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg)
+    {
+      if (scale_a[sg])
+      {
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig) xa[ig][sg] *= PLLGPU_SCALE_FACTOR;
+      }
+      if (scale_b[sg])
+      {
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig) xb[ig][sg] *= PLLGPU_SCALE_FACTOR;
+      }
+    }
+    // the parent: both contractions from registers
+    double DL[NG][2], DR[NG][2];
+#pragma unroll
+    for (int ig = 0; ig < NG; ++ig) DL[ig][0] = DL[ig][1] = DR[ig][0] = DR[ig][1] = 0.0;
+#pragma unroll
+    for (int jg = 0; jg < NG; ++jg)
+    {
+#pragma unroll
+      for (int ig = 0; ig < NG; ++ig)
+      {
+        const double a = F[4][(ig * NG + jg) * kFrag + fragoff];
+        DL[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, xa[jg][0], DL[ig][0], 0, 0, 0);
+        DL[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, xa[jg][1], DL[ig][1], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int jg = 0; jg < NG; ++jg)
+    {
+#pragma unroll
+      for (int ig = 0; ig < NG; ++ig)
+      {
+        const double a = F[5][(ig * NG + jg) * kFrag + fragoff];
+        DR[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, xb[jg][0], DR[ig][0], 0, 0, 0);
+        DR[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, xb[jg][1], DR[ig][1], 0, 0, 0);
+      }
+    }
+    bool sp[2] = {true, true};
+#pragma unroll
+    for (int ig = 0; ig < NG; ++ig)
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg)
+      {
+        DL[ig][sg] *= DR[ig][sg];
+        if (4 * ig + row < S) sp[sg] = sp[sg] && (DL[ig][sg] < PLLGPU_SCALE_THRESHOLD);
+      }
+    put(grp.a, xa, true);
+    put(grp.b, xb, true);
+    put(grp.p, DL, false);
+    if (ma) put_scaler(grp.a, ma, scale_a);
+    if (mb) put_scaler(grp.b, mb, scale_b);
+    if (mp)
+    {
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg)
+      {
+        int sm = sp[sg] ? 1 : 0; // a site's states are spread over the four row groups of the wave
+        sm &= __shfl_xor(sm, 16, 64);
+        sm &= __shfl_xor(sm, 32, 64);
+        if (row == 0 && valid[sg]) flagbuf[((size_t)blockIdx.y * g.R + k) * flag_stride + e[sg]] = (unsigned char)sm;
+      }
     }
   }
 }

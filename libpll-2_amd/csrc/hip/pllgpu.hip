@@ -91,6 +91,7 @@ struct pllgpu_ctx
   int ich = 0;
   bool dna_fast = false;
   bool use_mfma = false;
+  int mfma_ng = 16;         // 4-state groups the MFMA kernels run with: 16 (33..64 states), 8 (21..32), 5 (17..20)
   bool tiled = false;       // generic shapes keep CLVs in the tiled sites-contiguous layout
   DevBuf<double> scratch;   // host-layout staging for mirror copies of tiled CLVs
   size_t pm_stride = 0; // doubles per matrix in PT layout
@@ -149,8 +150,10 @@ struct pllgpu_ctx
   unsigned long long plan_stamp = 0;
   bool plan_cache = true;           // PLL_AMD_NO_PLAN_CACHE=1 plans every call afresh
   int gather_stream = 0;            // PLL_AMD_GATHER_STREAM: 1 always streaming loads from compressed children, -1 never, 0 by size
+  DevBuf<unsigned short> cherry_bits; // k_cherry_bits: which cherry entries are rescaled, per pair of tip codes
   DevBuf<double> cherry_tab;        // k_cherry_tables: [cherry][rate][code pair][state] of the launch being issued
   unsigned tip_ncodes = 0;          // codes in use: 1 + the highest code with a non-empty mask
+  bool fuse_mfma = false;           // 17..32 states on the matrix pipe: the same groups (kernels_mfma.h: k_partials_mfma_cc)
   bool fuse_generic = false;        // FMA-path shapes: (tip x tip, tip x tip -> inner x inner) groups (kernels_generic.h: k_partials_tiled_cc)
   bool subtrees = false;            // DNA + site repeats: all-tip subtrees straight from the tip codes (subtree_plan.h)
   DevBuf<unsigned char> sub_dev;    // their descriptors on the device ...
@@ -275,13 +278,25 @@ static void derive_geometry(pllgpu_ctx *c)
     if (*v && *v != '0') c->subtrees = false;
   c->tiled = true; // every shape keeps CLVs in the tiled sites-contiguous layout
   // 33..64 states: CLV updates on the fp64 matrix pipe (kernels_mfma.h); PLL_AMD_NO_MFMA=1 keeps the FMA kernel
-  c->use_mfma = (g.states > 32 && g.rate_cats <= 16);
+  {
+    // PLL_AMD_MFMA_MIN_STATES: from how many states on the CLV updates run on the matrix pipe
+    unsigned min_states = 33;
+    if (const char *v = getenv("PLL_AMD_MFMA_MIN_STATES")) min_states = (unsigned)std::max(17, atoi(v));
+    c->use_mfma = (g.states >= min_states && g.rate_cats <= 16);
+    c->mfma_ng = g.states > 32 ? 16 : g.states > 20 ? 8 : 5;
+  }
   if (const char *v = getenv("PLL_AMD_NO_MFMA"))
     if (*v && *v != '0') c->use_mfma = false;
   // any-state FMA path: cherry-cherry groups need one wave per rate category
-  c->fuse_generic = !c->dna_fast && !c->use_mfma && g.rate_cats <= 4 && gg.nchunks == 1;
+  // Both group kernels are OPT-IN (PLL_AMD_FUSE_GENERIC=1): bit-identical to the level-by-level launches and one
+  // launch shorter, but on C3 (20 states) neither beats them - same-box runs: level path 3.86-3.91 G updates/s,
+  // table-fed FMA groups 3.74-3.81, matrix-pipe groups 3.67-3.70 (profiles/README.md, round 2)
+  bool opt_in = false;
+  if (const char *v = getenv("PLL_AMD_FUSE_GENERIC")) opt_in = *v && *v != '0';
   if (const char *v = getenv("PLL_AMD_NO_FUSE"))
-    if (*v && *v != '0') c->fuse_generic = false;
+    if (*v && *v != '0') opt_in = false;
+  c->fuse_generic = opt_in && !c->dna_fast && !c->use_mfma && g.rate_cats <= 4 && gg.nchunks == 1;
+  c->fuse_mfma = opt_in && c->use_mfma && c->mfma_ng <= 8;
   c->pm_stride = (size_t)g.rate_cats * g.states * gg.SPT;
   c->span = g.rate_cats * g.states_padded;
 }
@@ -406,6 +421,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->chain_dev.release();
   c->sub_dev.release();
   c->cherry_tab.release();
+  c->cherry_bits.release();
   for (auto &b : c->clv) b.release();
   for (auto &b : c->scaler) b.release();
   for (auto &b : c->tipchars) b.release();
@@ -807,9 +823,8 @@ static int launch_tiled_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngrou
   const size_t tab_lds = (size_t)2 * ncodes * S * sizeof(double);
   raise_lds_limit((const void *)k_cherry_tables, c->device, tab_lds);
   hipLaunchKernelGGL(k_cherry_tables, dim3(2 * ngroups, R), dim3(256), tab_lds, c->stream, mats, c->gg, tm, ncodes, c->cherry_tab.p);
-  // workgroup = tile, wave = rate category. One tile per workgroup: a tile's stores come last, and a wave that went
-  // on to another tile would wait for them with its first load
-  const unsigned tpb = 1;
+  // workgroup = tile, wave = rate category; a few tiles per workgroup so that ~4096 workgroups exist
+  const unsigned tpb = std::max(1u, std::min(8u, (unsigned)(((size_t)tiles * ngroups) / 4096u)));
   dim3 grid((tiles + tpb - 1) / tpb, ngroups), block(64u * R);
   hipLaunchKernelGGL((k_partials_tiled_cc<ICH>), grid, block, 0, c->stream, pack, c->gg, c->cherry_tab.p, ncodes, entries, tpb);
   return 0;
@@ -852,16 +867,19 @@ static void launch_dna(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigne
 #undef DNA_LAUNCH
 }
 
-// large state spaces: fp64 MFMA 4x4x4 kernel, matrices staged in LDS (kernels_mfma.h)
-static int launch_mfma(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
+// fp64 MFMA 4x4x4 kernels, matrices staged in LDS (kernels_mfma.h): NG = number of 4-state groups
+template <int NG>
+static int launch_mfma_t(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
 {
   const unsigned R = c->gg.R;
   const unsigned items = (maxent + 31) / 32; // 32 sites per item
-  // aim at two workgroups of four waves on every CU (2048 waves); more work -> more items per wave
-  unsigned ipw = (unsigned)(((size_t)items * nops * R + 2047) / 2048);
-  ipw = std::max(1u, ipw);
+  // aim at two workgroups of four waves on every CU (2048 waves) - four where the small shapes leave room;
+  // more work -> more items per wave
+  const unsigned want = NG > 8 ? 2048u : 4096u;
+  unsigned ipw = (unsigned)(((size_t)items * nops * R + want - 1) / want);
+  ipw = std::max(1u, std::min(ipw, NG > 8 ? ~0u : 8u));
   dim3 grid((items + 4 * ipw - 1) / (4 * ipw), nops, R), block(256);
-  const size_t lds = (kMfmaRowsumOff + 128) * sizeof(double);
+  const size_t lds = MfmaGeo<NG>::lds_doubles * sizeof(double);
   const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
   bool scaling = false;
   for (unsigned i = 0; i < nops; ++i) scaling = scaling || pack.ops[i].pscaler != nullptr;
@@ -872,8 +890,8 @@ static int launch_mfma(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigne
 #define MF_LAUNCH(LT, RT, GA)                                                                                   \
   do                                                                                                            \
   {                                                                                                             \
-    raise_lds_limit((const void *)k_partials_mfma<LT, RT, GA>, c->device, lds);                                      \
-    hipLaunchKernelGGL((k_partials_mfma<LT, RT, GA>), grid, block, lds, c->stream, pack, c->gg, tm, ipw, fb, fstride); \
+    raise_lds_limit((const void *)k_partials_mfma<NG, LT, RT, GA>, c->device, lds);                             \
+    hipLaunchKernelGGL((k_partials_mfma<NG, LT, RT, GA>), grid, block, lds, c->stream, pack, c->gg, tm, ipw, fb, fstride); \
   } while (0)
   if (kind == 0)
   {
@@ -897,6 +915,70 @@ static int launch_mfma(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigne
       hipLaunchKernelGGL((k_mfma_scale_epilogue<false>), eg, dim3(256), 0, c->stream, pack, c->gg, fb, fstride);
   }
   return 0;
+}
+
+// (tip x tip, tip x tip -> inner x inner) groups on the matrix pipe (kernels_mfma.h: k_partials_mfma_cc)
+template <int NG>
+static int launch_mfma_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries)
+{
+  const unsigned R = c->gg.R, S = c->gg.S;
+  const unsigned items = (entries + 31) / 32;
+  unsigned ipw = (unsigned)(((size_t)items * ngroups * R + 4095) / 4096);
+  ipw = std::max(1u, std::min(ipw, 8u));
+  dim3 grid((items + 4 * ipw - 1) / (4 * ipw), ngroups, R), block(256);
+  const size_t lds = (6u * MfmaGeo<NG>::frag_array + 16u * NG) * sizeof(double);
+  const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
+  const unsigned ncodes = c->tip_ncodes;
+  // which cherries are rescaled: per pair of tip codes, every rate's answer (k_cherry_bits)
+  if (int rc = c->cherry_bits.ensure((size_t)2 * kMaxGroups * ncodes * ncodes)) return rc;
+  CherryTips tips;
+  memset(&tips, 0, sizeof tips);
+  OpPack parents; // the group parents as plain ops: what the scaling epilogue works on
+  memset(&parents, 0, sizeof parents);
+  bool scaling = false;
+  for (unsigned i = 0; i < ngroups; ++i)
+  {
+    tips.lmat[2 * i] = pack.g[i].a.lmat;
+    tips.rmat[2 * i] = pack.g[i].a.rmat;
+    tips.lmat[2 * i + 1] = pack.g[i].b.lmat;
+    tips.rmat[2 * i + 1] = pack.g[i].b.rmat;
+    DevOp &d = parents.ops[i];
+    d.parent = pack.g[i].p.parent;
+    d.pscaler = pack.g[i].p.pscaler;
+    d.lscaler = pack.g[i].a.pscaler;
+    d.rscaler = pack.g[i].b.pscaler;
+    d.entries = entries;
+    scaling = scaling || d.pscaler != nullptr;
+  }
+  scaling = scaling && c->gg.scale_mode != 0;
+  const size_t bits_lds = (size_t)2 * ncodes * S * sizeof(double);
+  raise_lds_limit((const void *)k_cherry_bits, c->device, bits_lds);
+  hipLaunchKernelGGL(k_cherry_bits, dim3(2 * ngroups), dim3(256), bits_lds, c->stream, tips, c->gg, tm, ncodes, c->cherry_bits.p);
+  const unsigned fstride = (entries + 63u) & ~63u;
+  if (scaling && c->mfma_flags.ensure((size_t)kMaxOpsPerLaunch * R * fstride)) return PLLGPU_ENOMEM;
+  raise_lds_limit((const void *)k_partials_mfma_cc<NG>, c->device, lds);
+  hipLaunchKernelGGL((k_partials_mfma_cc<NG>), grid, block, lds, c->stream, pack, c->gg, tm, entries, ipw, c->mfma_flags.p, fstride,
+                     c->cherry_bits.p, ncodes);
+  if (scaling)
+    hipLaunchKernelGGL((k_mfma_scale_epilogue<false>), dim3((entries + 255) / 256, ngroups), dim3(256), 0, c->stream, parents, c->gg,
+                       c->mfma_flags.p, fstride);
+  return 0;
+}
+
+static int launch_mfma_cc(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries)
+{
+  if (c->mfma_ng == 5) return launch_mfma_cc_t<5>(c, pack, ngroups, entries);
+  return launch_mfma_cc_t<8>(c, pack, ngroups, entries);
+}
+
+static int launch_mfma(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
+{
+  switch (c->mfma_ng)
+  {
+    case 5: return launch_mfma_t<5>(c, pack, nops, maxent, kind, gather);
+    case 8: return launch_mfma_t<8>(c, pack, nops, maxent, kind, gather);
+    default: return launch_mfma_t<16>(c, pack, nops, maxent, kind, gather);
+  }
 }
 
 static int launch_partials(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
@@ -956,7 +1038,8 @@ static int plan_and_launch_levels(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigne
   std::vector<int> role;
   std::vector<FusedGroup> groups;
   // FMA-path groups look their cherries up in a table over all pairs of tip codes: only for a sane number of codes
-  const bool generic_groups = c->fuse_generic && (c->tipmap_set ? c->tip_ncodes : (1u << std::min(c->gg.S, 8u))) <= 64u;
+  const bool generic_groups = (c->fuse_mfma && c->tipmap_set && c->tip_ncodes <= 32u) ||
+                              (c->fuse_generic && (c->tipmap_set ? c->tip_ncodes : (1u << std::min(c->gg.S, 8u))) <= 64u);
   plan_fusion(c->fuse || generic_groups, c->fuse_cc, c->geo.nodes, ops, count, role, groups);
   if (generic_groups)
   {
@@ -1076,7 +1159,11 @@ static int plan_and_launch_levels(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigne
         unsigned n = 0, entries = 0;
         auto flush = [&]() -> int {
           if (!n) return 0;
-          if (!c->dna_fast)
+          if (c->use_mfma)
+            emit(c, [c, pack, n, entries]() {
+              if (int rc = launch_mfma_cc(c, pack, n, entries)) c->launch_rc = rc;
+            });
+          else if (!c->dna_fast)
             emit(c, [c, pack, n, entries]() {
               if (int rc = launch_tiled_cc(c, pack, n, entries)) c->launch_rc = rc;
             });
@@ -1341,7 +1428,7 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
   const unsigned tiles = (g.sites + 63) / 64;
   const unsigned max_blocks = 1024;
   unsigned blocks, tpw;
-  if (c->use_mfma && !e.is_root)
+  if (c->use_mfma && c->mfma_ng == 16 && !e.is_root)
   {
     // 33..64 states: P x on the matrix pipe (kernels_mfma.h: k_edge_mfma); 16 items of 32 sites per
     // workgroup and round

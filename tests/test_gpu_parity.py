@@ -340,11 +340,17 @@ def test_dna_without_fusion(amd_lib, kw, monkeypatch):
                                 dict(states=20, tips=16, sites=300, seed=308, rate_cats=2), dict(states=20, tips=16, sites=300, seed=309, rate_cats=1),
                                 dict(states=20, tips=24, sites=600, seed=310, tree="random"), dict(states=32, tips=16, sites=200, seed=311),
                                 dict(states=20, tips=16, sites=300, seed=312, scalers=False)], ids=_id)
-def test_cherry_groups_of_fma_shapes_are_bit_identical(amd_lib, kw, monkeypatch):
+@pytest.mark.parametrize("pipe", ["fma", "mfma"])
+def test_cherry_groups_of_fma_shapes_are_bit_identical(amd_lib, kw, pipe, monkeypatch):
     """any-state FMA path: an op over two cherries is evaluated together with them (k_partials_tiled_cc), its
     contraction fed from the staged tip matrices instead of HBM; PLL_AMD_NO_FUSE=1 launches level by level -
     the same numbers, bit for bit, including the cherries' and the parent's scaling decisions"""
     kw = dict(kw)
+    monkeypatch.setenv("PLL_AMD_FUSE_GENERIC", "1")  # the group kernels of these shapes are opt-in
+    if pipe == "mfma":  # the same groups on the matrix pipe (k_partials_mfma_cc), 17..32 states
+        if kw["states"] < 17:
+            pytest.skip("the matrix-pipe kernels start at 17 states")
+        monkeypatch.setenv("PLL_AMD_MFMA_MIN_STATES", "17")
     tiny = kw.pop("tiny_p", None)
     case = W.make_case("ccg", **kw)
     if tiny:  # P = (1 - (s - 1) eps) on the diagonal, eps elsewhere (numpy's expm cannot produce such entries)
@@ -667,6 +673,29 @@ def test_fenced_handoff_and_auto_device_switches(amd_lib, monkeypatch):
     fenced = observe()
     for a, b in zip(plain, fenced):
         assert a[0] == b[0] and a[2] == b[2] and a[3] == b[3] and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("kw", [dict(states=61, tips=8, sites=300, seed=401, ambiguity_pct=30),      # gaps on both sides of tip x tip ops
+                                dict(states=61, tips=8, sites=300, seed=402, ambiguity_pct=30, attributes=api.PATTERN_TIP | api.RATE_SCALERS),
+                                dict(states=48, tips=16, sites=200, seed=403, ambiguity_pct=20, partial_pct=10),
+                                dict(states=20, tips=16, sites=700, seed=404, ambiguity_pct=20, partial_pct=5),
+                                dict(states=20, tips=32, sites=500, seed=405, attributes=api.SITE_REPEATS, mutate_pct=4, ambiguity_pct=5),
+                                dict(states=20, tips=150, sites=300, seed=406, tree="caterpillar", brlen_scale=6),             # deep: rescaling
+                                dict(states=20, tips=150, sites=300, seed=407, tree="caterpillar", brlen_scale=6, attributes=api.RATE_SCALERS),
+                                dict(states=17, tips=8, sites=200, seed=408), dict(states=25, tips=8, sites=200, seed=409, ambiguity_pct=10),
+                                dict(states=32, tips=8, sites=200, seed=410, partial_pct=10)], ids=_id)
+def test_matrix_pipe_kernels_for_all_group_counts(amd_lib, kw, monkeypatch):
+    """k_partials_mfma compiled for 5, 8 and 16 state groups (17..20, 21..32, 33..64 states) against the oracle:
+    tip x tip / tip x inner / inner x inner, gaps and partial ambiguities on either side (a gap on the RIGHT tip
+    used to take the LEFT matrix's row sums), site repeats, trees deep enough to rescale"""
+    monkeypatch.setenv("PLL_AMD_MFMA_MIN_STATES", "17")
+    case = W.make_case("mfma", **kw)
+    got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    exp = O.run_case(case)
+    assert_results_match(got, exp, what=_id(kw))
+    if kw.get("brlen_scale", 1) > 1:
+        assert sum(int(v.sum()) for v in got["scaler"].values()) > 0
+        assert scalers_equal(got, exp)
 
 
 def test_partitions_in_concurrent_threads(amd_lib):
