@@ -30,14 +30,44 @@
 
 // acc[i] = sum_j PT[k][j][c*ICH + i] * x_j ; x_j from a tiled CLV (stride 64 between states) or
 // from a tip mask
+// xs = distance between consecutive states of the lane's (entry, rate): 64 in a tiled CLV, 1 in an
+// entry-contiguous one (class-compressed node, see below)
 template <int ICH, bool TIP>
 __device__ __forceinline__ void contract(double (&acc)[ICH], const double *pt, unsigned k, unsigned c,
                                          const GenGeo &g, const double *__restrict__ x /* &clv[..][k][0][lane] */,
-                                         unsigned long long mask)
+                                         unsigned long long mask, unsigned xs = 64)
 {
   cdouble_p p = as_const(pt) + ((size_t)k * g.S) * g.SPT + c * ICH;
 #pragma unroll
   for (int i = 0; i < ICH; ++i) acc[i] = 0.0;
+  if (!TIP && xs == 1u && !(g.SP & 1u)) // wave-uniform: entry-contiguous child (even stride: 16-byte aligned), two states per
+  {                                      // load; a compressed child is a table its parent's entries keep coming back to: cacheable
+    typedef double c_dbl2 __attribute__((ext_vector_type(2)));
+    const c_dbl2 *x2 = reinterpret_cast<const c_dbl2 *>(x);
+#pragma unroll 2
+    for (unsigned jc = 0; jc < (g.S + 1u) / 2u; ++jc)
+    {
+      const unsigned j = 2u * jc;
+      c_dbl2 v;
+      if (j + 1u < g.S)
+        v = x2[jc];
+      else
+      {
+        v.x = x[j]; // odd S: the last state alone (the pair would reach into the next rate's values: harmless but unaligned-safe this way)
+        v.y = 0.0;
+      }
+      cdouble_p pj = p + (size_t)j * g.SPT;
+#pragma unroll
+      for (int i = 0; i < ICH; ++i) acc[i] = fma(pj[i], v.x, acc[i]);
+      if (j + 1u < g.S)
+      {
+        cdouble_p pj1 = pj + g.SPT;
+#pragma unroll
+        for (int i = 0; i < ICH; ++i) acc[i] = fma(pj1[i], v.y, acc[i]);
+      }
+    }
+    return;
+  }
 #pragma unroll 4
   for (unsigned j = 0; j < g.S; ++j)
   {
@@ -45,7 +75,7 @@ __device__ __forceinline__ void contract(double (&acc)[ICH], const double *pt, u
     if (TIP)
       xj = ((mask >> j) & 1ull) ? 1.0 : 0.0;
     else
-      xj = __builtin_nontemporal_load(x + (size_t)j * 64); // read-once stream, see kernels_dna.h
+      xj = __builtin_nontemporal_load(x + (size_t)j * xs); // read-once stream, see kernels_dna.h
     cdouble_p pj = p + (size_t)j * g.SPT;
 #pragma unroll
     for (int i = 0; i < ICH; ++i) acc[i] = fma(pj[i], xj, acc[i]);
@@ -135,18 +165,29 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
     unsigned long long lmask = 0, rmask = 0;
     if (LTIP) lmask = tipmap ? tipmap[op.ltip[le]] : (unsigned long long)op.ltip[le];
     if (RTIP) rmask = tipmap ? tipmap[op.rtip[re]] : (unsigned long long)op.rtip[re];
-    const double *__restrict__ lx = LTIP ? nullptr : op.left + tiled_base(le, g.tile_sz);
-    const double *__restrict__ rx = RTIP ? nullptr : op.right + tiled_base(re, g.tile_sz);
-    double *__restrict__ out = op.parent + (size_t)tile * g.tile_sz + lane;
+    // Class-compressed nodes (site repeats) keep their CLV ENTRY-CONTIGUOUS on the device - the host's own
+    // [entry][rate][states_padded] - for every shape, as the 4 x 4 kernels do (kernels_dna.h): the children of a
+    // gathering op are addressed through class maps, and a lane's 20 states of one rate are then 160 contiguous
+    // bytes instead of 20 pieces in 20 rows of a tile (C3 with site repeats: the launch that reads the compressed
+    // level-2 nodes took 579 us - every 8-byte value its own cache line - against 60 us for the same ops without
+    // repeats). xs / ks: distance between states / between rate categories of the lane's entry.
+    const bool laos = GATHER && !LTIP && (op.layout & kAosLeft), raos = GATHER && !RTIP && (op.layout & kAosRight),
+               paos = GATHER && (op.layout & kAosParent);
+    const unsigned espan = g.R * g.SP;
+    const double *__restrict__ lx = LTIP ? nullptr : laos ? op.left + (size_t)le * espan : op.left + tiled_base(le, g.tile_sz);
+    const double *__restrict__ rx = RTIP ? nullptr : raos ? op.right + (size_t)re * espan : op.right + tiled_base(re, g.tile_sz);
+    const unsigned lxs = laos ? 1u : 64u, rxs = raos ? 1u : 64u, pxs = paos ? 1u : 64u;
+    const size_t lks = laos ? g.SP : (size_t)g.S * 64, rks = raos ? g.SP : (size_t)g.S * 64, pks = paos ? g.SP : (size_t)g.S * 64;
+    double *__restrict__ out = paos ? op.parent + (size_t)n * espan : op.parent + (size_t)tile * g.tile_sz + lane;
 
     auto rescale_rate = [&](unsigned k) {
       // this lane's stored column of rate k: same lane wrote it; order the accesses explicitly
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      double *col = out + (size_t)k * g.S * 64;
+      double *col = out + (size_t)k * pks;
       for (unsigned s = 0; s < g.S; ++s)
       {
-        const double v = __builtin_nontemporal_load(col + (size_t)s * 64);
-        col[(size_t)s * 64] = v * PLLGPU_SCALE_FACTOR;
+        const double v = __builtin_nontemporal_load(col + (size_t)s * pxs);
+        col[(size_t)s * pxs] = v * PLLGPU_SCALE_FACTOR;
       }
     };
 
@@ -168,12 +209,12 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
         if (lsimple)
           tip_columns<ICH>(A, lstage, c, g, lmask, full);
         else
-          contract<ICH, LTIP>(A, op.lmat, k, c, g, LTIP ? nullptr : lx + (size_t)k * g.S * 64, lmask);
+          contract<ICH, LTIP>(A, op.lmat, k, c, g, LTIP ? nullptr : lx + (size_t)k * lks, lmask, lxs);
         if (rsimple)
           tip_columns<ICH>(B, rstage, c, g, rmask, full);
         else
-          contract<ICH, RTIP>(B, op.rmat, k, c, g, RTIP ? nullptr : rx + (size_t)k * g.S * 64, rmask);
-        double *dst = out + ((size_t)k * g.S + c * ICH) * 64;
+          contract<ICH, RTIP>(B, op.rmat, k, c, g, RTIP ? nullptr : rx + (size_t)k * rks, rmask, rxs);
+        double *dst = out + (size_t)k * pks + (size_t)(c * ICH) * pxs;
 #pragma unroll
         for (int i = 0; i < ICH; ++i)
           if (c * ICH + i < g.S)
@@ -182,13 +223,15 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
             small = small && (v < PLLGPU_SCALE_THRESHOLD);
             if (valid)
             {
-              if (LTIP && RTIP)
+              if (LTIP && RTIP && !paos)
                 __builtin_nontemporal_store(v, dst + (size_t)i * 64); // a tip x tip launch is pure store traffic, far beyond the caches: 260 -> 251 us for C3's 32 ops
               else
-                dst[(size_t)i * 64] = v;
+                dst[(size_t)i * pxs] = v;
             }
           }
       }
+      if (paos && valid) // the padding lanes of the host layout stay zero
+        for (unsigned s = g.S; s < g.SP; ++s) out[(size_t)k * pks + s] = 0.0;
       if (mode == 2)
       {
         if (valid)
@@ -479,8 +522,12 @@ __global__ __launch_bounds__(256) void k_edge_tiled(const DevEdge e, const GenGe
     }
     unsigned long long cmask = 0;
     if (CTIP) cmask = tipmap ? tipmap[e.ctip[ce]] : (unsigned long long)e.ctip[ce];
-    const double *__restrict__ px = e.parent + tiled_base(pe, g.tile_sz);
-    const double *__restrict__ cx = (CTIP || e.is_root) ? nullptr : e.child + tiled_base(ce, g.tile_sz);
+    const bool paos = GATHER && (e.layout & kAosParent), caos = GATHER && !CTIP && (e.layout & kAosLeft); // entry-contiguous ends
+    const unsigned espan = g.R * g.SP;
+    const double *__restrict__ px = paos ? e.parent + (size_t)pe * espan : e.parent + tiled_base(pe, g.tile_sz);
+    const double *__restrict__ cx = (CTIP || e.is_root) ? nullptr : caos ? e.child + (size_t)ce * espan : e.child + tiled_base(ce, g.tile_sz);
+    const unsigned pxs = paos ? 1u : 64u, cxs = caos ? 1u : 64u;
+    const size_t pks = paos ? g.SP : (size_t)g.S * 64, cks = caos ? g.SP : (size_t)g.S * 64;
 
     unsigned scal;
     if (e.per_rate)
@@ -510,12 +557,12 @@ __global__ __launch_bounds__(256) void k_edge_tiled(const DevEdge e, const GenGe
           for (int i = 0; i < ICH; ++i) B[i] = 1.0;
         }
         else
-          contract<ICH, CTIP>(B, e.mat, k, c, g, CTIP ? nullptr : cx + (size_t)k * g.S * 64, cmask);
+          contract<ICH, CTIP>(B, e.mat, k, c, g, CTIP ? nullptr : cx + (size_t)k * cks, cmask, cxs);
         cdouble_p pi = as_const(e.freqs) + (size_t)fi * g.SP + c * ICH;
-        const double *pk = px + ((size_t)k * g.S + c * ICH) * 64;
+        const double *pk = px + (size_t)k * pks + (size_t)(c * ICH) * pxs;
 #pragma unroll
         for (int i = 0; i < ICH; ++i)
-          if (c * ICH + i < g.S) tr = fma(__builtin_nontemporal_load(pk + (size_t)i * 64) * pi[i], B[i], tr);
+          if (c * ICH + i < g.S) tr = fma(__builtin_nontemporal_load(pk + (size_t)i * pxs) * pi[i], B[i], tr);
       }
       if (e.per_rate)
       {

@@ -153,6 +153,7 @@ struct pllgpu_ctx
   DevBuf<unsigned short> cherry_bits; // k_cherry_bits: which cherry entries are rescaled, per pair of tip codes
   DevBuf<double> cherry_tab;        // k_cherry_tables: [cherry][rate][code pair][state] of the launch being issued
   unsigned tip_ncodes = 0;          // codes in use: 1 + the highest code with a non-empty mask
+  bool generic_aos = true;          // PLL_AMD_NO_GENERIC_AOS=1: compressed nodes of non-4x4 shapes stay tiled (A/B)
   bool fuse_mfma = false;           // 17..32 states on the matrix pipe: the same groups (kernels_mfma.h: k_partials_mfma_cc)
   bool fuse_generic = false;        // FMA-path shapes: (tip x tip, tip x tip -> inner x inner) groups (kernels_generic.h: k_partials_tiled_cc)
   bool subtrees = false;            // DNA + site repeats: all-tip subtrees straight from the tip codes (subtree_plan.h)
@@ -269,6 +270,8 @@ static void derive_geometry(pllgpu_ctx *c)
   if (const char *v = getenv("PLL_AMD_NO_CHAINS"))
     if (*v && *v != '0') c->chains = false;
   if (const char *v = getenv("PLL_AMD_GATHER_STREAM")) c->gather_stream = atoi(v);
+  if (const char *v = getenv("PLL_AMD_NO_GENERIC_AOS"))
+    if (*v && *v != '0') c->generic_aos = false;
   if (const char *v = getenv("PLL_AMD_FENCED_HANDOFF"))
     if (*v && *v != '0') c->fenced = 1;
   if (const char *v = getenv("PLL_AMD_NO_PLAN_CACHE"))
@@ -301,16 +304,18 @@ static void derive_geometry(pllgpu_ctx *c)
   c->span = g.rate_cats * g.states_padded;
 }
 
-// 4 states x 4 rates: a node that holds fewer entries than sites is class-compressed (site repeats);
-// its CLV stays entry-contiguous on the device (kernels_dna.h: gathers read whole entries)
+// A node that holds fewer entries than sites is class-compressed (site repeats): its CLV stays
+// entry-contiguous on the device, in the host's own layout [entry][rate][states_padded] - gathers then read
+// whole entries (kernels_dna.h, kernels_generic.h). The matrix-pipe kernels (33..64 states) keep the tiled layout.
 static inline bool aos_entries(const pllgpu_ctx *c, unsigned entries)
 {
-  return c->dna_fast && entries != c->geo.sites_alloc;
+  return (c->dna_fast || (c->generic_aos && !c->use_mfma)) && entries != c->geo.sites_alloc;
 }
 
 // doubles of device storage for `entries` entries of one CLV
 static inline size_t clv_elems(const pllgpu_ctx *c, unsigned entries)
 {
+  if (aos_entries(c, entries)) return (size_t)entries * c->span;
   if (c->tiled) return (size_t)((entries + 63u) / 64u) * c->gg.tile_sz;
   return (size_t)entries * c->span;
 }
