@@ -30,18 +30,40 @@
 
 // acc[i] = sum_j PT[k][j][c*ICH + i] * x_j ; x_j from a tiled CLV (stride 64 between states) or
 // from a tip mask
-// xs = distance between consecutive states of the lane's (entry, rate): 64 in a tiled CLV, 1 in an
-// entry-contiguous one (class-compressed node, see below)
 template <int ICH, bool TIP>
 __device__ __forceinline__ void contract(double (&acc)[ICH], const double *pt, unsigned k, unsigned c,
                                          const GenGeo &g, const double *__restrict__ x /* &clv[..][k][0][lane] */,
-                                         unsigned long long mask, unsigned xs = 64)
+                                         unsigned long long mask)
 {
   cdouble_p p = as_const(pt) + ((size_t)k * g.S) * g.SPT + c * ICH;
 #pragma unroll
   for (int i = 0; i < ICH; ++i) acc[i] = 0.0;
-  if (!TIP && xs == 1u && !(g.SP & 1u)) // wave-uniform: entry-contiguous child (even stride: 16-byte aligned), two states per
-  {                                      // load; a compressed child is a table its parent's entries keep coming back to: cacheable
+#pragma unroll 4
+  for (unsigned j = 0; j < g.S; ++j)
+  {
+    double xj;
+    if (TIP)
+      xj = ((mask >> j) & 1ull) ? 1.0 : 0.0;
+    else
+      xj = __builtin_nontemporal_load(x + (size_t)j * 64); // read-once stream, see kernels_dna.h
+    cdouble_p pj = p + (size_t)j * g.SPT;
+#pragma unroll
+    for (int i = 0; i < ICH; ++i) acc[i] = fma(pj[i], xj, acc[i]);
+  }
+}
+
+// the same from an ENTRY-CONTIGUOUS child (class-compressed node, see k_partials_tiled): x = the lane's S
+// consecutive values of rate k. Two states per 16-byte load where the host stride keeps them aligned; a
+// compressed child is a table its parent's entries keep coming back to: cacheable loads.
+template <int ICH>
+__device__ __forceinline__ void contract_aos(double (&acc)[ICH], const double *pt, unsigned k, unsigned c, const GenGeo &g,
+                                             const double *__restrict__ x)
+{
+  cdouble_p p = as_const(pt) + ((size_t)k * g.S) * g.SPT + c * ICH;
+#pragma unroll
+  for (int i = 0; i < ICH; ++i) acc[i] = 0.0;
+  if (!(g.SP & 1u)) // wave-uniform
+  {
     typedef double c_dbl2 __attribute__((ext_vector_type(2)));
     const c_dbl2 *x2 = reinterpret_cast<const c_dbl2 *>(x);
 #pragma unroll 2
@@ -53,7 +75,7 @@ __device__ __forceinline__ void contract(double (&acc)[ICH], const double *pt, u
         v = x2[jc];
       else
       {
-        v.x = x[j]; // odd S: the last state alone (the pair would reach into the next rate's values: harmless but unaligned-safe this way)
+        v.x = x[j];
         v.y = 0.0;
       }
       cdouble_p pj = p + (size_t)j * g.SPT;
@@ -71,11 +93,7 @@ __device__ __forceinline__ void contract(double (&acc)[ICH], const double *pt, u
 #pragma unroll 4
   for (unsigned j = 0; j < g.S; ++j)
   {
-    double xj;
-    if (TIP)
-      xj = ((mask >> j) & 1ull) ? 1.0 : 0.0;
-    else
-      xj = __builtin_nontemporal_load(x + (size_t)j * xs); // read-once stream, see kernels_dna.h
+    const double xj = x[j];
     cdouble_p pj = p + (size_t)j * g.SPT;
 #pragma unroll
     for (int i = 0; i < ICH; ++i) acc[i] = fma(pj[i], xj, acc[i]);
@@ -123,6 +141,11 @@ __device__ __forceinline__ size_t tiled_base(unsigned e, unsigned tile_sz)
   return (size_t)(e >> 6) * tile_sz + (e & 63u);
 }
 
+// Registers: ARCHITECTED PLUS ACCUMULATION count against the 512 of a SIMD lane - the two halves of gfx950's unified
+// file (rocprofv3's VGPR_Count shows only the first half: this kernel "has 68"). The 20-state inner x inner
+// instantiation sits at 127 = four waves per SIMD; two more and it runs three (C3: 3.86 -> 3.52 G updates/s), and a
+// forced bound (__launch_bounds__(256, 4)) makes the compiler give up its prefetching instead (3.1 G). Hence the
+// entry-contiguous addressing below lives in branches of its own that only the GATHER instantiations contain.
 template <int ICH, bool LTIP, bool RTIP, bool GATHER>
 __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const GenGeo g,
                                                         const unsigned long long *__restrict__ tipmap, unsigned tip_lds,
@@ -176,18 +199,22 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
     const unsigned espan = g.R * g.SP;
     const double *__restrict__ lx = LTIP ? nullptr : laos ? op.left + (size_t)le * espan : op.left + tiled_base(le, g.tile_sz);
     const double *__restrict__ rx = RTIP ? nullptr : raos ? op.right + (size_t)re * espan : op.right + tiled_base(re, g.tile_sz);
-    const unsigned lxs = laos ? 1u : 64u, rxs = raos ? 1u : 64u, pxs = paos ? 1u : 64u;
-    const size_t lks = laos ? g.SP : (size_t)g.S * 64, rks = raos ? g.SP : (size_t)g.S * 64, pks = paos ? g.SP : (size_t)g.S * 64;
-    double *__restrict__ out = paos ? op.parent + (size_t)n * espan : op.parent + (size_t)tile * g.tile_sz + lane;
+    double *__restrict__ out = (GATHER && paos) ? op.parent + (size_t)n * espan : op.parent + (size_t)tile * g.tile_sz + lane;
 
     auto rescale_rate = [&](unsigned k) {
       // this lane's stored column of rate k: same lane wrote it; order the accesses explicitly
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      double *col = out + (size_t)k * pks;
+      if (GATHER && paos)
+      {
+        double *col = out + (size_t)k * g.SP;
+        for (unsigned s = 0; s < g.S; ++s) col[s] *= PLLGPU_SCALE_FACTOR;
+        return;
+      }
+      double *col = out + (size_t)k * g.S * 64;
       for (unsigned s = 0; s < g.S; ++s)
       {
-        const double v = __builtin_nontemporal_load(col + (size_t)s * pxs);
-        col[(size_t)s * pxs] = v * PLLGPU_SCALE_FACTOR;
+        const double v = __builtin_nontemporal_load(col + (size_t)s * 64);
+        col[(size_t)s * 64] = v * PLLGPU_SCALE_FACTOR;
       }
     };
 
@@ -209,29 +236,54 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
         if (lsimple)
           tip_columns<ICH>(A, lstage, c, g, lmask, full);
         else
-          contract<ICH, LTIP>(A, op.lmat, k, c, g, LTIP ? nullptr : lx + (size_t)k * lks, lmask, lxs);
+        {
+          if (GATHER && laos) // wave-uniform
+            contract_aos<ICH>(A, op.lmat, k, c, g, lx + (size_t)k * g.SP);
+          else
+            contract<ICH, LTIP>(A, op.lmat, k, c, g, LTIP ? nullptr : lx + (size_t)k * g.S * 64, lmask);
+        }
         if (rsimple)
           tip_columns<ICH>(B, rstage, c, g, rmask, full);
         else
-          contract<ICH, RTIP>(B, op.rmat, k, c, g, RTIP ? nullptr : rx + (size_t)k * rks, rmask, rxs);
-        double *dst = out + (size_t)k * pks + (size_t)(c * ICH) * pxs;
+        {
+          if (GATHER && raos)
+            contract_aos<ICH>(B, op.rmat, k, c, g, rx + (size_t)k * g.SP);
+          else
+            contract<ICH, RTIP>(B, op.rmat, k, c, g, RTIP ? nullptr : rx + (size_t)k * g.S * 64, rmask);
+        }
+        if (GATHER && paos) // wave-uniform: entry-contiguous parent
+        {
+          double *dst = out + (size_t)k * g.SP + c * ICH;
 #pragma unroll
-        for (int i = 0; i < ICH; ++i)
-          if (c * ICH + i < g.S)
-          {
-            const double v = A[i] * B[i];
-            small = small && (v < PLLGPU_SCALE_THRESHOLD);
-            if (valid)
+          for (int i = 0; i < ICH; ++i)
+            if (c * ICH + i < g.S)
             {
-              if (LTIP && RTIP && !paos)
-                __builtin_nontemporal_store(v, dst + (size_t)i * 64); // a tip x tip launch is pure store traffic, far beyond the caches: 260 -> 251 us for C3's 32 ops
-              else
-                dst[(size_t)i * pxs] = v;
+              const double v = A[i] * B[i];
+              small = small && (v < PLLGPU_SCALE_THRESHOLD);
+              if (valid) dst[i] = v;
             }
-          }
+        }
+        else
+        {
+          double *dst = out + ((size_t)k * g.S + c * ICH) * 64;
+#pragma unroll
+          for (int i = 0; i < ICH; ++i)
+            if (c * ICH + i < g.S)
+            {
+              const double v = A[i] * B[i];
+              small = small && (v < PLLGPU_SCALE_THRESHOLD);
+              if (valid)
+              {
+                if (LTIP && RTIP)
+                  __builtin_nontemporal_store(v, dst + (size_t)i * 64); // a tip x tip launch is pure store traffic, far beyond the caches: 260 -> 251 us for C3's 32 ops
+                else
+                  dst[(size_t)i * 64] = v;
+              }
+            }
+        }
       }
-      if (paos && valid) // the padding lanes of the host layout stay zero
-        for (unsigned s = g.S; s < g.SP; ++s) out[(size_t)k * pks + s] = 0.0;
+      if (GATHER && paos && valid) // the padding lanes of the host layout stay zero
+        for (unsigned s = g.S; s < g.SP; ++s) out[(size_t)k * g.SP + s] = 0.0;
       if (mode == 2)
       {
         if (valid)
@@ -526,8 +578,8 @@ __global__ __launch_bounds__(256) void k_edge_tiled(const DevEdge e, const GenGe
     const unsigned espan = g.R * g.SP;
     const double *__restrict__ px = paos ? e.parent + (size_t)pe * espan : e.parent + tiled_base(pe, g.tile_sz);
     const double *__restrict__ cx = (CTIP || e.is_root) ? nullptr : caos ? e.child + (size_t)ce * espan : e.child + tiled_base(ce, g.tile_sz);
-    const unsigned pxs = paos ? 1u : 64u, cxs = caos ? 1u : 64u;
-    const size_t pks = paos ? g.SP : (size_t)g.S * 64, cks = caos ? g.SP : (size_t)g.S * 64;
+    const unsigned pxs = GATHER ? (paos ? 1u : 64u) : 64u; // without GATHER a compile-time constant
+    const size_t pks = (GATHER && paos) ? g.SP : (size_t)g.S * 64;
 
     unsigned scal;
     if (e.per_rate)
@@ -557,7 +609,12 @@ __global__ __launch_bounds__(256) void k_edge_tiled(const DevEdge e, const GenGe
           for (int i = 0; i < ICH; ++i) B[i] = 1.0;
         }
         else
-          contract<ICH, CTIP>(B, e.mat, k, c, g, CTIP ? nullptr : cx + (size_t)k * cks, cmask, cxs);
+        {
+          if (GATHER && caos) // wave-uniform
+            contract_aos<ICH>(B, e.mat, k, c, g, cx + (size_t)k * g.SP);
+          else
+            contract<ICH, CTIP>(B, e.mat, k, c, g, CTIP ? nullptr : cx + (size_t)k * g.S * 64, cmask);
+        }
         cdouble_p pi = as_const(e.freqs) + (size_t)fi * g.SP + c * ICH;
         const double *pk = px + (size_t)k * pks + (size_t)(c * ICH) * pxs;
 #pragma unroll
