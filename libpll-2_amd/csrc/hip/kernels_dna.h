@@ -116,8 +116,11 @@ __device__ __forceinline__ void dna_matvec(double (&r)[4], cdouble_p pt_k, const
 // lanes on distinct banks both when a lane writes its own entry and when it reads the dense order
 constexpr unsigned kAosRow = 18;
 
+#ifndef DNA_GATHER_WAVES
+#define DNA_GATHER_WAVES 3
+#endif
 template <bool LTIP, bool RTIP, bool GATHER>
-__global__ __launch_bounds__(256) void k_partials_dna(const OpPack pack, int scale_mode, unsigned tiles_per_wave)
+__global__ __launch_bounds__(256, GATHER ? DNA_GATHER_WAVES : 1) void k_partials_dna(const OpPack pack, int scale_mode, unsigned tiles_per_wave)
 {
   // entry-contiguous parents leave through LDS: a lane holds ITS entry's 128 bytes, but 64 lanes
   // writing 16 bytes each at a 128-byte stride reach only half the store bandwidth of dense 1 KB
@@ -152,42 +155,84 @@ __global__ __launch_bounds__(256) void k_partials_dna(const OpPack pack, int sca
 
     double v[4][4];
     bool small[4];
-    double cl[4][4], cr[4][4]; // entry-contiguous children (GATHER): all 16 values through the cooperative fetch
     if (GATHER)
     {
-      DnaCoop pl, pr;
+      // One child after the other: fetch (entry-contiguous: cooperatively, through LDS), contract, and only then
+      // touch the second child. With both children's 16 values and both fetches' pieces alive at once the kernel
+      // needed 246 registers = two waves per SIMD (the unified file: architected + accumulation registers), and a
+      // gather launch lives on the number of waves that wait for memory side by side.
       double *mine = transpose + (size_t)wave * 64 * kAosRow;
-      if (!LTIP && laos) dna_coop_issue(pl, op.left, le, lane, (op.layout & kStreamLeft) != 0);
-      if (!RTIP && raos) dna_coop_issue(pr, op.right, re, lane, (op.layout & kStreamRight) != 0);
-      if (!LTIP && laos) dna_coop_finish(pl, mine, lane, kAosRow, cl);
-      if (!RTIP && raos) dna_coop_finish(pr, mine, lane, kAosRow, cr);
+      double a[4][4];
+      {
+        double cl[4][4];
+        if (!LTIP && laos)
+        {
+          DnaCoop pl;
+          dna_coop_issue(pl, op.left, le, lane, (op.layout & kStreamLeft) != 0);
+          dna_coop_finish(pl, mine, lane, kAosRow, cl);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+          double xl[4];
+          if (!LTIP && laos)
+          {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xl[j] = cl[k][j];
+          }
+          else
+            dna_fetch<LTIP>(xl, lx, k, lcode);
+          dna_matvec(a[k], lm + k * 16, xl);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0); // the right child's fetch starts after the left child's values are dead
+      {
+        double cr[4][4];
+        if (!RTIP && raos)
+        {
+          DnaCoop pr;
+          dna_coop_issue(pr, op.right, re, lane, (op.layout & kStreamRight) != 0);
+          dna_coop_finish(pr, mine, lane, kAosRow, cr);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+          double xr[4], b[4];
+          if (!RTIP && raos)
+          {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xr[j] = cr[k][j];
+          }
+          else
+            dna_fetch<RTIP>(xr, rx, k, rcode);
+          dna_matvec(b, rm + k * 16, xr);
+          small[k] = true;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+          {
+            v[k][i] = a[k][i] * b[i];
+            small[k] = small[k] && (v[k][i] < PLLGPU_SCALE_THRESHOLD);
+          }
+        }
+      }
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
+    else
     {
-      double xl[4], xr[4], a[4], b[4];
-      if (GATHER && !LTIP && laos)
-      {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xl[j] = cl[k][j];
-      }
-      else
+      for (int k = 0; k < 4; ++k)
+      {
+        double xl[4], xr[4], a[4], b[4];
         dna_fetch<LTIP>(xl, lx, k, lcode);
-      if (GATHER && !RTIP && raos)
-      {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xr[j] = cr[k][j];
-      }
-      else
         dna_fetch<RTIP>(xr, rx, k, rcode);
-      dna_matvec(a, lm + k * 16, xl);
-      dna_matvec(b, rm + k * 16, xr);
-      small[k] = true;
+        dna_matvec(a, lm + k * 16, xl);
+        dna_matvec(b, rm + k * 16, xr);
+        small[k] = true;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-      {
-        v[k][i] = a[i] * b[i];
-        small[k] = small[k] && (v[k][i] < PLLGPU_SCALE_THRESHOLD);
+        for (int i = 0; i < 4; ++i)
+        {
+          v[k][i] = a[i] * b[i];
+          small[k] = small[k] && (v[k][i] < PLLGPU_SCALE_THRESHOLD);
+        }
       }
     }
     if (mode == 1)
