@@ -66,7 +66,7 @@ __device__ __forceinline__ void contract_aos(double (&acc)[ICH], const double *p
   {
     typedef double c_dbl2 __attribute__((ext_vector_type(2)));
     const c_dbl2 *x2 = reinterpret_cast<const c_dbl2 *>(x);
-#pragma unroll 2
+#pragma unroll 1
     for (unsigned jc = 0; jc < (g.S + 1u) / 2u; ++jc)
     {
       const unsigned j = 2u * jc;
@@ -146,7 +146,10 @@ __device__ __forceinline__ size_t tiled_base(unsigned e, unsigned tile_sz)
 // instantiation sits at 127 = four waves per SIMD; two more and it runs three (C3: 3.86 -> 3.52 G updates/s), and a
 // forced bound (__launch_bounds__(256, 4)) makes the compiler give up its prefetching instead (3.1 G). Hence the
 // entry-contiguous addressing below lives in branches of its own that only the GATHER instantiations contain.
-template <int ICH, bool LTIP, bool RTIP, bool GATHER>
+// LAY >= 0: the layout bits (kAosLeft | kAosRight | kAosParent) of every op of the launch, known at compile time - the
+// gathering 20-state instantiation that decides them at run time carries both addressings through its loops and
+// needs 147 registers (three waves per SIMD); -1: read them from the op.
+template <int ICH, bool LTIP, bool RTIP, bool GATHER, int LAY = -1>
 __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const GenGeo g,
                                                         const unsigned long long *__restrict__ tipmap, unsigned tip_lds,
                                                         unsigned tiles_per_block)
@@ -185,6 +188,9 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
     {
       gather_entries(op, nn, le, re);
     }
+    // per-site mode: the children's counts now, so that their entries need not stay in registers to the end
+    unsigned below = 0;
+    if (mode == 1 && wave == 0) below = (op.lscaler ? op.lscaler[le] : 0u) + (op.rscaler ? op.rscaler[re] : 0u);
     unsigned long long lmask = 0, rmask = 0;
     if (LTIP) lmask = tipmap ? tipmap[op.ltip[le]] : (unsigned long long)op.ltip[le];
     if (RTIP) rmask = tipmap ? tipmap[op.rtip[re]] : (unsigned long long)op.rtip[re];
@@ -194,19 +200,19 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
     // bytes instead of 20 pieces in 20 rows of a tile (C3 with site repeats: the launch that reads the compressed
     // level-2 nodes took 579 us - every 8-byte value its own cache line - against 60 us for the same ops without
     // repeats). xs / ks: distance between states / between rate categories of the lane's entry.
-    const bool laos = GATHER && !LTIP && (op.layout & kAosLeft), raos = GATHER && !RTIP && (op.layout & kAosRight),
-               paos = GATHER && (op.layout & kAosParent);
+    const unsigned lay = LAY >= 0 ? (unsigned)LAY : op.layout;
+    const bool laos = GATHER && !LTIP && (lay & kAosLeft), raos = GATHER && !RTIP && (lay & kAosRight), paos = GATHER && (lay & kAosParent);
     const unsigned espan = g.R * g.SP;
     const double *__restrict__ lx = LTIP ? nullptr : laos ? op.left + (size_t)le * espan : op.left + tiled_base(le, g.tile_sz);
     const double *__restrict__ rx = RTIP ? nullptr : raos ? op.right + (size_t)re * espan : op.right + tiled_base(re, g.tile_sz);
-    double *__restrict__ out = (GATHER && paos) ? op.parent + (size_t)n * espan : op.parent + (size_t)tile * g.tile_sz + lane;
+    double *__restrict__ out = op.parent + (size_t)tile * g.tile_sz + lane; // tiled parent (an entry-contiguous one is addressed where it is stored)
 
     auto rescale_rate = [&](unsigned k) {
       // this lane's stored column of rate k: same lane wrote it; order the accesses explicitly
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       if (GATHER && paos)
       {
-        double *col = out + (size_t)k * g.SP;
+        double *col = op.parent + ((size_t)n * g.R + k) * g.SP;
         for (unsigned s = 0; s < g.S; ++s) col[s] *= PLLGPU_SCALE_FACTOR;
         return;
       }
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
         }
         if (GATHER && paos) // wave-uniform: entry-contiguous parent
         {
-          double *dst = out + (size_t)k * g.SP + c * ICH;
+          double *dst = op.parent + ((size_t)n * g.R + k) * g.SP + c * ICH; // formed here: one pointer less across the contractions
 #pragma unroll
           for (int i = 0; i < ICH; ++i)
             if (c * ICH + i < g.S)
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
         }
       }
       if (GATHER && paos && valid) // the padding lanes of the host layout stay zero
-        for (unsigned s = g.S; s < g.SP; ++s) out[(size_t)k * g.SP + s] = 0.0;
+        for (unsigned s = g.S; s < g.SP; ++s) op.parent[((size_t)n * g.R + k) * g.SP + s] = 0.0;
       if (mode == 2)
       {
         if (valid)
@@ -307,9 +313,7 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
       {
         if (site_small)
           for (unsigned k = wave; k < g.R; k += nw) rescale_rate(k);
-        if (wave == 0)
-          op.pscaler[n] = (op.lscaler ? op.lscaler[le] : 0u) + (op.rscaler ? op.rscaler[re] : 0u) +
-                          (site_small ? 1u : 0u);
+        if (wave == 0) op.pscaler[n] = below + (site_small ? 1u : 0u);
       }
       __syncthreads(); // flags[] is reused by the next tile
     }

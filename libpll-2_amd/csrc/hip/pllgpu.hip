@@ -790,6 +790,29 @@ static void launch_generic(pllgpu_ctx *c, const OpPack &pack, unsigned nops, uns
   // tiles per workgroup and >= 4096 workgroups, 247 us with up to 16 and >= 2048, 268 us with 32 / 1024)
   if (stage) tpb = std::max(1u, std::min(16u, (unsigned)(((size_t)tiles * nops) / 2048u)));
   dim3 grid((tiles + tpb - 1) / tpb, nops), block(64u * nw);
+  if (gather && ICH == 20)
+  {
+    // the protein shape: when every op of the launch has the same CLV layouts (the rule: a level of a tree), the
+    // instantiation that knows them at compile time
+    const unsigned lay = pack.ops[0].layout & 7u;
+    bool same = true;
+    for (unsigned i = 1; i < nops; ++i) same = same && (pack.ops[i].layout & 7u) == lay;
+    if (same)
+    {
+#define GEN_LAY(LT, RT, L) \
+  case L: hipLaunchKernelGGL((k_partials_tiled<ICH == 20 ? 20 : ICH, LT, RT, true, ICH == 20 ? L : -1>), grid, block, lds, c->stream, pack, c->gg, tm, tip_lds, tpb); return;
+#define GEN_LAYS(LT, RT) \
+  switch (lay)             \
+  {                        \
+    GEN_LAY(LT, RT, 0) GEN_LAY(LT, RT, 1) GEN_LAY(LT, RT, 2) GEN_LAY(LT, RT, 3) GEN_LAY(LT, RT, 4) GEN_LAY(LT, RT, 5) GEN_LAY(LT, RT, 6) GEN_LAY(LT, RT, 7) \
+  }
+      if (kind == 0) { GEN_LAYS(false, false) }
+      else if (kind == 1) { GEN_LAYS(true, false) }
+      else { GEN_LAYS(true, true) }
+#undef GEN_LAYS
+#undef GEN_LAY
+    }
+  }
 #define GEN_LAUNCH(LT, RT, GA) \
   hipLaunchKernelGGL((k_partials_tiled<ICH, LT, RT, GA>), grid, block, lds, c->stream, pack, c->gg, tm, tip_lds, tpb)
   if (kind == 0)
