@@ -398,8 +398,21 @@ def roofline_leg(args, cfg, lib, api, runner, reps=20):
             ii_ops = low
         else:
             cc = False
+    # 17..32 states with tips as codes: the bottom two levels are ONE launch of (tip x tip, tip x tip -> inner x inner)
+    # groups on the matrix pipe (k_partials_mfma_cc) - half of the step; the leg re-runs exactly those ops
+    grouped = (17 <= cfg["states"] <= 32 and codes and not cfg.get("repeats") and not os.environ.get("PLL_AMD_NO_FUSE", "0").strip("0")
+               and os.environ.get("PLL_AMD_FUSE_GENERIC", "2") not in ("0", "1") and not os.environ.get("PLL_AMD_MFMA_MIN_STATES"))
+    if grouped:
+        depth = {t: 0 for t in range(case.tips)}
+        for op in all_ops:
+            depth[op[0]] = 1 + max(depth[op[2]], depth[op[5]])
+        low = [op for op in all_ops if depth[op[0]] <= 2]
+        if len(low) == 3 * (case.tips // 4):
+            ii_ops = low
+        else:
+            grouped = False
     if args.tree != "balanced":  # irregular levels: no single dominant launch shape - the leg is the whole traversal
-        ii_ops, cc = list(all_ops), False
+        ii_ops, cc, grouped = list(all_ops), False, False
     ii_arr = api.make_ops(ii_ops)
     for _ in range(3):
         lib.pll_update_partials_rep(sess.p, ii_arr, len(ii_ops), 0)
@@ -422,12 +435,10 @@ def roofline_leg(args, cfg, lib, api, runner, reps=20):
     if os.path.exists(tfile) and not args.pattern_tip and not args.sites and not args.taxa and args.tree == "balanced" and not args.tips:
         traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")  # PMC-derived HBM bytes per launch of the same command (profiles/README.md)
     mfma = cfg["states"] > 32 and not os.environ.get("PLL_AMD_NO_MFMA", "0").strip("0")
-    grouped20 = cfg["states"] == 20 and not cfg.get("repeats") and not os.environ.get("PLL_AMD_NO_FUSE", "0").strip("0")
     kernel = {4: "k_partials_dna_cc<5,5>%.0s" if cc else "k_partials_dna_fused<4,4>%.0s" if fused else "k_partials_dna<false,false,%s>",
-              20: "k_partials_tiled<20,false,false,%s>",
+              20: "k_partials_mfma_cc<5>%.0s" if grouped else "k_partials_tiled<20,false,false,%s>",
               61: "k_partials_mfma<false,false,%s>" if mfma else "k_partials_tiled<32,false,false,%s>"
               }[cfg["states"]] % ("true" if cfg.get("repeats") else "false")
-    del grouped20
     if args.tree != "balanced":
         kernel = "all update launches of the traversal"
     if mfma:

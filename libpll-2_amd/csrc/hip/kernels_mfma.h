@@ -356,86 +356,117 @@ __global__ __launch_bounds__(256) void k_mfma_scale_epilogue(const OpPack pack, 
 // ------------------------------------------------------------------------------------------------
 // (tip x tip, tip x tip -> inner x inner) groups on the matrix pipe (C3: 20 states, NG = 5): an op P whose two
 // children are cherries produced by the same call is evaluated together with them; nothing is read back from
-// HBM. A cherry entry for the lane's states j = 4 jg + row is a product of two tip columns (read from the
-// LDS-staged fragments, exactly what k_partials_mfma<.., true, true> stores) - and that register layout IS the
-// B operand of the next MFMA stage (D and B share their lane map), so P's contraction starts from registers:
-// D_left = P_left x_a, D_right = P_right x_b, 2 x NG x NG MFMAs per 16 sites with their coefficients from LDS.
-// (The FMA kernels feed every multiply-add a fresh coefficient through the scalar path and reach a third of the
-// fp64 rate: for 20 states that contraction takes as long as the group's 1.5 GB of stores, and the two did not
-// overlap - kernels_generic.h. Here the contraction is a fraction of the store time.)
+// HBM. A cherry entry for the lane's states j = 4 jg + row is a product of two tip columns (what
+// k_partials_mfma<.., true, true> stores) - and that register layout IS the B operand of the next MFMA stage (D
+// and B share their lane map), so P's contraction starts from registers: D_left = P_left x_a, D_right = P_right
+// x_b, 2 x NG x NG MFMAs per 16 sites. The launch is store traffic only (3 CLVs per group and site).
+//
+// What the kernel is built around: instruction count. The group's arithmetic per 32 sites and rate is 100 MFMAs
+// (1600 cycles of the matrix pipe) and a quarter of the store time; a first version spent 900 vector-ALU
+// instructions per item on addresses, masks and selects and ran at half the store rate. Here
+// * the six matrices sit in LDS exactly as the host stores them (PT[j][i], row stride 4 NG) plus one row of row
+//   sums: row j IS tip column j, so a tip's contribution is one LDS read at (column of the code) * stride + state
+//   with the state group as the instruction's immediate offset, and the same array serves the A operand
+//   (element (i, k) of block (ig, jg) at (4 jg + k) * stride + 4 ig + i);
+// * a code's column index (state, "row sums" for the full gap, or "ambiguous") and the cherries' scaling
+//   decisions (k_cherry_bits) are byte / halfword tables in LDS;
+// * a lane owns two ADJACENT sites (2 col, 2 col + 1 of the item's 32): tip codes come in as one halfword per
+//   tip, every CLV row goes out as one 16-byte store whose address is a wave-uniform base + a lane constant;
+// * the next item's tip codes are requested before the current item is worked on.
+// Items with an ambiguous code anywhere take the MFMA route with 0/1 operands for that tip, like the level kernel.
 // The arithmetic per op is that of k_partials_mfma, in the same order: bit-identical to the level-by-level
 // launches on this pipe. Scaling: the cherries' decisions come from k_cherry_bits (every rate's answer per pair of
 // tip codes) and are applied in registers before the parent is formed; the parent's own "all below 2^-256" bits
 // go to flagbuf per (group, rate, entry) and k_mfma_scale_epilogue applies them, as for any op of this pipe.
-// grid = (item blocks, groups, rate categories); LDS: fragments of a.l, a.r, b.l, b.r, p.l, p.r + the four tip
-// matrices' row sums.
+// grid = (item blocks, groups, rate categories).
+//
 // Which cherries are rescaled? A cherry entry depends on the two tip codes only, so "all S values of rate k
 // below 2^-256" is a property of (cherry, rate, code pair): bits[cherry][code_l * ncodes + code_r] has bit k set
 // when it holds. k_partials_mfma_cc runs one rate category per workgroup, but the per-site decision needs all of
 // them and has to be known BEFORE the parent's contraction (the parent is formed from the rescaled cherry);
 // with this small table every workgroup knows every rate's answer. Values as the kernels form them: ascending
-// sums over the set bits of each mask, then the product (src/core_partials.c:1166-1209). grid = cherries.
-struct CherryTips // by value: the tip matrices of up to 2 x kMaxGroups cherries
+// sums over the set bits of each mask, then the product (src/core_partials.c:1166-1209). A table is a function of
+// the cherry's two tip matrices and the code map: the host keeps kCherrySlots of them on the device and recomputes
+// one only when either matrix was written since (launch_mfma_cc).
+constexpr unsigned kCherrySlots = 512; // cherry tables kept on the device (one per pair of tip matrices)
+
+struct CherryTips // by value: tip matrices and table slots of the cherries whose tables are (re)computed
 {
   const double *lmat[2 * kMaxGroups];
   const double *rmat[2 * kMaxGroups];
+  unsigned short slot[2 * kMaxGroups];
 };
 
+// grid = (cherries, rate categories); out[slot][rate][code_l * ncodes + code_r] = 1 when all S values are below 2^-256
 __global__ __launch_bounds__(256) void k_cherry_bits(const CherryTips mats, const GenGeo g, const unsigned long long *__restrict__ tipmap,
-                                                      unsigned ncodes, unsigned short *__restrict__ bits)
+                                                      unsigned ncodes, unsigned char *__restrict__ out)
 {
-  extern __shared__ double cols[]; // [2][ncodes][S]
-  const unsigned c = blockIdx.x, S = g.S, npairs = ncodes * ncodes;
-  unsigned short mine[4] = {0, 0, 0, 0}; // pairs threadIdx.x + 256 q, q < 4 (ncodes <= 32)
-  for (unsigned k = 0; k < g.R; ++k)
+  extern __shared__ double sh[]; // ML[S][S], MR[S][S] (PT: [j][i]), CL[ncodes][S], CR[ncodes][S]
+  const unsigned c = blockIdx.x, k = blockIdx.y, S = g.S, npairs = ncodes * ncodes;
+  double *ML = sh, *MR = sh + S * S, *CL = sh + 2 * S * S, *CR = CL + ncodes * S;
+  const double *lm = mats.lmat[c] + (size_t)k * S * g.SPT, *rm = mats.rmat[c] + (size_t)k * S * g.SPT;
+  for (unsigned idx = threadIdx.x; idx < S * S; idx += 256u)
   {
-    const double *lm = mats.lmat[c] + (size_t)k * S * g.SPT, *rm = mats.rmat[c] + (size_t)k * S * g.SPT;
-    __syncthreads();
-    for (unsigned idx = threadIdx.x; idx < ncodes * S; idx += 256u)
-    {
-      const unsigned code = idx / S, i = idx % S;
-      const unsigned long long mask = tipmap ? tipmap[code] : (unsigned long long)code;
-      double a = 0.0, b = 0.0;
-      for (unsigned m = 0; m < S; ++m)
-        if ((mask >> m) & 1ull)
-        {
-          a += lm[(size_t)m * g.SPT + i];
-          b += rm[(size_t)m * g.SPT + i];
-        }
-      cols[idx] = a;
-      cols[ncodes * S + idx] = b;
-    }
-    __syncthreads();
-#pragma unroll
-    for (unsigned q = 0; q < 4; ++q)
-    {
-      const unsigned pr = threadIdx.x + 256u * q;
-      if (pr >= npairs) break;
-      const double *cl = cols + (pr / ncodes) * S, *cr = cols + ncodes * S + (pr % ncodes) * S;
-      bool small = true;
-      for (unsigned i = 0; i < S; ++i) small = small && (cl[i] * cr[i] < PLLGPU_SCALE_THRESHOLD);
-      if (small) mine[q] |= (unsigned short)(1u << k);
-    }
+    const unsigned j = idx / S, i = idx % S;
+    ML[idx] = lm[(size_t)j * g.SPT + i];
+    MR[idx] = rm[(size_t)j * g.SPT + i];
   }
-#pragma unroll
-  for (unsigned q = 0; q < 4; ++q)
+  __syncthreads();
+  for (unsigned idx = threadIdx.x; idx < ncodes * S; idx += 256u)
   {
-    const unsigned pr = threadIdx.x + 256u * q;
-    if (pr < npairs) bits[(size_t)c * npairs + pr] = mine[q];
+    const unsigned code = idx / S, i = idx % S;
+    const unsigned long long mask = tipmap ? tipmap[code] : (unsigned long long)code;
+    double a = 0.0, b = 0.0;
+    // ascending over the set bits; a clear bit adds +0.0, which changes nothing
+    for (unsigned m = 0; m < S; ++m)
+    {
+      const bool on = (mask >> m) & 1ull;
+      a += on ? ML[m * S + i] : 0.0;
+      b += on ? MR[m * S + i] : 0.0;
+    }
+    CL[idx] = a;
+    CR[idx] = b;
+  }
+  __syncthreads();
+  unsigned char *o = out + ((size_t)mats.slot[c] * g.R + k) * npairs;
+  for (unsigned pr = threadIdx.x; pr < npairs; pr += 256u)
+  {
+    const double *cl = CL + (pr / ncodes) * S, *cr = CR + (pr % ncodes) * S;
+    bool small = true;
+    for (unsigned i = 0; i < S; ++i) small = small && (cl[i] * cr[i] < PLLGPU_SCALE_THRESHOLD);
+    o[pr] = small ? 1 : 0;
   }
 }
+
+struct CherrySlots // by value: where the tables of a launch's cherries are (cherry 2 g: group g's left child, 2 g + 1: right)
+{
+  unsigned short s[2 * kMaxGroups];
+};
+
+constexpr unsigned kCcAmbiguous = 255u; // column index of a code that is neither one state nor the full gap
+
+template <int NG> struct CcGeo
+{
+  static constexpr unsigned LD = 4 * NG;              // row stride (doubles) of a staged matrix
+  static constexpr unsigned rows = 4 * NG + 1;        // PT rows j < S, zero rows up to 4 NG, then the row sums
+  static constexpr unsigned mat = rows * LD;          // doubles per matrix
+  static constexpr unsigned gap_col = 4 * NG;
+  static size_t lds_bytes(unsigned ncodes) { return (size_t)6 * mat * sizeof(double) + (size_t)2 * ncodes * ncodes * sizeof(unsigned short) + 256; }
+};
 
 template <int NG>
 __global__ __launch_bounds__(256, 4) void k_partials_mfma_cc(const FusePack pack, const GenGeo g, const unsigned long long *__restrict__ tipmap,
                                                              unsigned entries, unsigned items_per_wave, unsigned char *__restrict__ flagbuf,
-                                                             unsigned flag_stride, const unsigned short *__restrict__ bits, unsigned ncodes)
+                                                             unsigned flag_stride, const unsigned char *__restrict__ bits, const CherrySlots slots,
+                                                             unsigned ncodes)
 {
-  typedef MfmaGeo<NG> MG;
+  typedef CcGeo<NG> CG;
+  constexpr unsigned LD = CG::LD;
+  typedef double __attribute__((ext_vector_type(2))) double2v;
   extern __shared__ double lds[];
-  double *F[6];
-#pragma unroll
-  for (int m = 0; m < 6; ++m) F[m] = lds + (size_t)m * MG::frag_array; // a.l a.r b.l b.r p.l p.r
-  double *RS = lds + 6u * MG::frag_array;                               // [4][4 NG] row sums of the tip matrices
+  double *M = lds;                                                                  // [6][rows][LD]: a.l a.r b.l b.r p.l p.r
+  unsigned short *BITS = reinterpret_cast<unsigned short *>(lds + 6u * CG::mat);    // [2][ncodes * ncodes]
+  unsigned char *CIDX = reinterpret_cast<unsigned char *>(BITS + 2u * ncodes * ncodes); // [ncodes]
 
   const FGroup &grp = pack.g[blockIdx.y];
   const unsigned lane = threadIdx.x & 63u;
@@ -444,144 +475,150 @@ __global__ __launch_bounds__(256, 4) void k_partials_mfma_cc(const FusePack pack
   const unsigned S = g.S, k = blockIdx.z;
   const unsigned nitems = (entries + 31u) / 32u;
   if (blockIdx.x * 4u * items_per_wave >= nitems) return; // whole workgroup
-  const unsigned fragoff = row * 4u + (lane & 3u);
   const unsigned long long full = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
   {
     const double *src[6] = {grp.a.lmat, grp.a.rmat, grp.b.lmat, grp.b.rmat, grp.p.lmat, grp.p.rmat};
-    for (unsigned idx = threadIdx.x; idx < NG * NG * 16u; idx += 256)
+    for (unsigned idx = threadIdx.x; idx < (CG::rows - 1u) * LD; idx += 256u)
     {
-      const unsigned ii = idx & 3u, kk = (idx >> 2) & 3u, jg = (idx >> 4) % NG, ig = (idx >> 4) / NG;
-      const unsigned j = 4 * jg + kk, i = 4 * ig + ii;
-      const bool in = j < S && i < g.SPT;
+      const unsigned j = idx / LD, i = idx % LD;
+      const bool in = j < S && i < S;
       const size_t off = ((size_t)k * S + j) * g.SPT + i;
 #pragma unroll
-      for (int m = 0; m < 6; ++m) F[m][(idx >> 4) * kFrag + (idx & 15u)] = in ? src[m][off] : 0.0;
+      for (int m = 0; m < 6; ++m) M[m * CG::mat + idx] = in ? src[m][off] : 0.0;
+    }
+    const unsigned npairs = ncodes * ncodes;
+    for (unsigned idx = threadIdx.x; idx < 2u * npairs; idx += 256u)
+    {
+      const unsigned ch = idx >= npairs ? 1u : 0u, pr = idx - ch * npairs;
+      const unsigned char *t = bits + (size_t)slots.s[2u * blockIdx.y + ch] * g.R * npairs + pr;
+      unsigned v = 0;
+      for (unsigned kk = 0; kk < g.R; ++kk) v |= (unsigned)t[(size_t)kk * npairs] << kk;
+      BITS[idx] = (unsigned short)v;
+    }
+    if (threadIdx.x < ncodes)
+    {
+      const unsigned long long mk = tipmap[threadIdx.x];
+      CIDX[threadIdx.x] = (unsigned char)(mk == full ? CG::gap_col : __popcll(mk) == 1 ? (unsigned)__ffsll((long long)mk) - 1u : kCcAmbiguous);
     }
   }
   __syncthreads();
-  if (threadIdx.x < 16 * NG)
+  if (threadIdx.x < 4u * LD)
   {
     // row sums in ascending j like the reference's set-bit walk (core_partials.c:480-489)
-    const unsigned m = threadIdx.x / (4 * NG), i = threadIdx.x % (4 * NG);
+    const unsigned m = threadIdx.x / LD, i = threadIdx.x % LD;
     double s = 0.0;
-    for (unsigned j = 0; j < S; ++j) s += F[m][((i >> 2) * NG + (j >> 2)) * kFrag + (j & 3u) * 4 + (i & 3u)];
-    RS[threadIdx.x] = s;
+    for (unsigned j = 0; j < S; ++j) s += M[m * CG::mat + j * LD + i];
+    M[m * CG::mat + CG::gap_col * LD + i] = s;
   }
   __syncthreads();
   const int ma = grp.a.pscaler ? g.scale_mode : 0, mb = grp.b.pscaler ? g.scale_mode : 0, mp = grp.p.pscaler ? g.scale_mode : 0;
   const unsigned item0 = (blockIdx.x * 4u + wave) * items_per_wave;
   if (item0 >= nitems) return; // no barriers below
   const unsigned nmine = min(items_per_wave, nitems - item0);
+  const unsigned last_pair = (entries - 1u) & ~1u;
+  const unsigned allr = (1u << g.R) - 1u;
+  const unsigned char *tips[4] = {grp.a.ltip, grp.a.rtip, grp.b.ltip, grp.b.rtip};
+  const double *afrag = M + row * LD + (lane & 3u); // + m * mat + 4 jg * LD + 4 ig: element (i = lane & 3, k = row) of block (ig, jg)
+  const unsigned lane_off = row * 64u + 2u * col;    // the lane's place in a CLV tile row group (+ 256 per state group)
+
+  auto fetch_codes = [&](unsigned item, unsigned (&cw)[4]) {
+    const unsigned e0 = min(item * 32u + 2u * col, last_pair);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) cw[t] = *reinterpret_cast<const unsigned short *>(tips[t] + e0);
+  };
+  unsigned cw[4];
+  fetch_codes(item0, cw);
 
   for (unsigned it = 0; it < nmine; ++it)
   {
-    unsigned e[2];
-    bool valid[2];
-    unsigned long long m[4][2];
+    const unsigned item = item0 + it; // wave-uniform
+    unsigned nw[4] = {cw[0], cw[1], cw[2], cw[3]};
+    if (it + 1 < nmine) fetch_codes(item + 1u, nw);
+
+    const unsigned e0 = item * 32u + 2u * col;
+    const bool valid[2] = {e0 < entries, e0 + 1u < entries};
+    unsigned code[4][2], cx[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+    {
+      code[t][0] = cw[t] & 0xffu;
+      code[t][1] = (min(e0, last_pair) + 1u < entries) ? (cw[t] >> 8) : code[t][0];
+      cx[t][0] = CIDX[code[t][0]];
+      cx[t][1] = CIDX[code[t][1]];
+    }
     bool scale_a[2], scale_b[2]; // is the cherry entry rescaled (for this rate category)?
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg)
     {
-      e[sg] = (item0 + it) * 32u + sg * 16u + col;
-      valid[sg] = e[sg] < entries;
-      const unsigned nn = valid[sg] ? e[sg] : entries - 1;
-      const unsigned c0 = grp.a.ltip[nn], c1 = grp.a.rtip[nn], c2 = grp.b.ltip[nn], c3 = grp.b.rtip[nn];
-      {
-        const unsigned npairs = ncodes * ncodes, allr = (1u << g.R) - 1u;
-        const unsigned ba = bits[(size_t)(2u * blockIdx.y) * npairs + c0 * ncodes + c1];
-        const unsigned bb = bits[(size_t)(2u * blockIdx.y + 1u) * npairs + c2 * ncodes + c3];
-        scale_a[sg] = ma == 1 ? ba == allr : ma == 2 ? ((ba >> k) & 1u) != 0 : false;
-        scale_b[sg] = mb == 1 ? bb == allr : mb == 2 ? ((bb >> k) & 1u) != 0 : false;
-      }
-      m[0][sg] = tipmap ? tipmap[c0] : (unsigned long long)c0;
-      m[1][sg] = tipmap ? tipmap[c1] : (unsigned long long)c1;
-      m[2][sg] = tipmap ? tipmap[c2] : (unsigned long long)c2;
-      m[3][sg] = tipmap ? tipmap[c3] : (unsigned long long)c3;
+      const unsigned ba = BITS[code[0][sg] * ncodes + code[1][sg]];
+      const unsigned bb = BITS[ncodes * ncodes + code[2][sg] * ncodes + code[3][sg]];
+      scale_a[sg] = ma == 1 ? ba == allr : ma == 2 ? ((ba >> k) & 1u) != 0 : false;
+      scale_b[sg] = mb == 1 ? bb == allr : mb == 2 ? ((bb >> k) & 1u) != 0 : false;
     }
-    // a cherry in the lane's states j = 4 jg + row: (P_l x_l)_j (P_r x_r)_j, like k_partials_mfma<.., true, true>
-    auto cherry = [&](int t0, double (&x)[NG][2], bool (&small)[2]) {
-      const bool lsimple = mfma_simple_tips(m[t0], full), rsimple = mfma_simple_tips(m[t0 + 1], full);
-      double DLc[NG][2];
-      if (lsimple)
+    // (P_t x_t) for the lane's states 4 ig + row of both sites: a column of P_t (or its row sums), else MFMAs on 0/1 x
+    auto tip_side = [&](int t, double (&d)[NG][2]) {
+      const bool simple = __all(cx[t][0] != kCcAmbiguous && cx[t][1] != kCcAmbiguous);
+      if (simple)
       {
+        const double *c0 = M + t * CG::mat + cx[t][0] * LD + row, *c1 = M + t * CG::mat + cx[t][1] * LD + row;
 #pragma unroll
         for (int ig = 0; ig < NG; ++ig)
-#pragma unroll
-          for (int sg = 0; sg < 2; ++sg) DLc[ig][sg] = mfma_tip_column<NG>(F[t0], RS + t0 * 4 * NG, m[t0][sg], full, row, ig);
+        {
+          d[ig][0] = c0[4 * ig];
+          d[ig][1] = c1[4 * ig];
+        }
       }
       else
       {
+        const unsigned long long m0 = tipmap[code[t][0]], m1 = tipmap[code[t][1]];
 #pragma unroll
-        for (int ig = 0; ig < NG; ++ig) DLc[ig][0] = DLc[ig][1] = 0.0;
-#pragma unroll
-        for (int jg = 0; jg < NG; ++jg)
-        {
-          const double x0 = mfma_x<true>(nullptr, m[t0][0], S, 4 * jg + row), x1 = mfma_x<true>(nullptr, m[t0][1], S, 4 * jg + row);
-#pragma unroll
-          for (int ig = 0; ig < NG; ++ig)
-          {
-            const double a = F[t0][(ig * NG + jg) * kFrag + fragoff];
-            DLc[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x0, DLc[ig][0], 0, 0, 0);
-            DLc[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x1, DLc[ig][1], 0, 0, 0);
-          }
-        }
-      }
-      small[0] = small[1] = true;
-      if (rsimple)
-      {
-#pragma unroll
-        for (int ig = 0; ig < NG; ++ig)
-#pragma unroll
-          for (int sg = 0; sg < 2; ++sg)
-          {
-            x[ig][sg] = DLc[ig][sg] * mfma_tip_column<NG>(F[t0 + 1], RS + (t0 + 1) * 4 * NG, m[t0 + 1][sg], full, row, ig);
-            if (4 * ig + row < S) small[sg] = small[sg] && (x[ig][sg] < PLLGPU_SCALE_THRESHOLD);
-          }
-      }
-      else
-      {
-        double DRc[NG][2];
-#pragma unroll
-        for (int ig = 0; ig < NG; ++ig) DRc[ig][0] = DRc[ig][1] = 0.0;
+        for (int ig = 0; ig < NG; ++ig) d[ig][0] = d[ig][1] = 0.0;
 #pragma unroll
         for (int jg = 0; jg < NG; ++jg)
         {
-          const double x0 = mfma_x<true>(nullptr, m[t0 + 1][0], S, 4 * jg + row), x1 = mfma_x<true>(nullptr, m[t0 + 1][1], S, 4 * jg + row);
+          const double x0 = mfma_x<true>(nullptr, m0, S, 4 * jg + row), x1 = mfma_x<true>(nullptr, m1, S, 4 * jg + row);
 #pragma unroll
           for (int ig = 0; ig < NG; ++ig)
           {
-            const double a = F[t0 + 1][(ig * NG + jg) * kFrag + fragoff];
-            DRc[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x0, DRc[ig][0], 0, 0, 0);
-            DRc[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x1, DRc[ig][1], 0, 0, 0);
+            const double a = afrag[t * CG::mat + 4 * jg * LD + 4 * ig];
+            d[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x0, d[ig][0], 0, 0, 0);
+            d[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x1, d[ig][1], 0, 0, 0);
           }
         }
-#pragma unroll
-        for (int ig = 0; ig < NG; ++ig)
-#pragma unroll
-          for (int sg = 0; sg < 2; ++sg)
-          {
-            x[ig][sg] = DLc[ig][sg] * DRc[ig][sg];
-            if (4 * ig + row < S) small[sg] = small[sg] && (x[ig][sg] < PLLGPU_SCALE_THRESHOLD);
-          }
       }
     };
-    // store the lane's states of an op's CLV entry (both site groups)
-    auto put = [&](const FOp &op, const double (&v)[NG][2], bool stream) {
+    auto cherry = [&](int t0, double (&x)[NG][2]) {
+      double r[NG][2];
+      tip_side(t0, x);
+      tip_side(t0 + 1, r);
 #pragma unroll
-      for (int sg = 0; sg < 2; ++sg)
+      for (int ig = 0; ig < NG; ++ig)
       {
-        double *pb = op.parent + (size_t)(e[sg] >> 6) * g.tile_sz + (e[sg] & 63u) + (size_t)k * S * 64;
+        x[ig][0] *= r[ig][0];
+        x[ig][1] *= r[ig][1];
+      }
+    };
+    // one CLV row group of an op: states 4 ig + row of the lane's two sites, 16 bytes
+    auto put = [&](const FOp &op, const double (&v)[NG][2], bool stream) {
+      double *ub = op.parent + (size_t)(item >> 1) * g.tile_sz + (size_t)k * S * 64 + (item & 1u) * 32u; // wave-uniform
 #pragma unroll
-        for (int ig = 0; ig < NG; ++ig)
+      for (int ig = 0; ig < NG; ++ig)
+      {
+        if (4u * ig + row < S)
         {
-          const unsigned i = 4 * ig + row;
-          if (i < S && valid[sg])
+          double *q = ub + (lane_off + 256u * ig);
+          if (valid[1])
           {
+            double2v w;
+            w.x = v[ig][0];
+            w.y = v[ig][1];
             if (stream)
-              __builtin_nontemporal_store(v[ig][sg], pb + (size_t)i * 64);
+              __builtin_nontemporal_store(w, reinterpret_cast<double2v *>(q));
             else
-              pb[(size_t)i * 64] = v[ig][sg];
+              *reinterpret_cast<double2v *>(q) = w;
           }
+          else if (valid[0])
+            q[0] = v[ig][0];
         }
       }
     };
@@ -591,14 +628,13 @@ __global__ __launch_bounds__(256, 4) void k_partials_mfma_cc(const FusePack pack
       for (int sg = 0; sg < 2; ++sg)
         if (row == 0 && valid[sg])
         {
-          if (mode == 2) op.pscaler[(size_t)e[sg] * g.R + k] = scaled[sg] ? 1u : 0u;
-          if (mode == 1 && k == 0) op.pscaler[e[sg]] = scaled[sg] ? 1u : 0u;
+          if (mode == 2) op.pscaler[(size_t)(e0 + sg) * g.R + k] = scaled[sg] ? 1u : 0u;
+          if (mode == 1 && k == 0) op.pscaler[e0 + sg] = scaled[sg] ? 1u : 0u;
         }
     };
     double xa[NG][2], xb[NG][2];
-    bool sa[2], sb[2]; // this rate's own "all small" (the table says the same; only the table knows the other rates)
-    cherry(0, xa, sa);
-    cherry(2, xb, sb);
+    cherry(0, xa);
+    cherry(2, xb);
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg)
     {
@@ -613,6 +649,8 @@ __global__ __launch_bounds__(256, 4) void k_partials_mfma_cc(const FusePack pack
         for (int ig = 0; ig < NG; ++ig) xb[ig][sg] *= PLLGPU_SCALE_FACTOR;
       }
     }
+    put(grp.a, xa, true);
+    put(grp.b, xb, true);
     // the parent: both contractions from registers
     double DL[NG][2], DR[NG][2];
 #pragma unroll
@@ -623,7 +661,7 @@ __global__ __launch_bounds__(256, 4) void k_partials_mfma_cc(const FusePack pack
 #pragma unroll
       for (int ig = 0; ig < NG; ++ig)
       {
-        const double a = F[4][(ig * NG + jg) * kFrag + fragoff];
+        const double a = afrag[4 * CG::mat + 4 * jg * LD + 4 * ig];
         DL[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, xa[jg][0], DL[ig][0], 0, 0, 0);
         DL[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, xa[jg][1], DL[ig][1], 0, 0, 0);
       }
@@ -634,7 +672,7 @@ __global__ __launch_bounds__(256, 4) void k_partials_mfma_cc(const FusePack pack
 #pragma unroll
       for (int ig = 0; ig < NG; ++ig)
       {
-        const double a = F[5][(ig * NG + jg) * kFrag + fragoff];
+        const double a = afrag[5 * CG::mat + 4 * jg * LD + 4 * ig];
         DR[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, xb[jg][0], DR[ig][0], 0, 0, 0);
         DR[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, xb[jg][1], DR[ig][1], 0, 0, 0);
       }
@@ -648,8 +686,6 @@ __global__ __launch_bounds__(256, 4) void k_partials_mfma_cc(const FusePack pack
         DL[ig][sg] *= DR[ig][sg];
         if (4 * ig + row < S) sp[sg] = sp[sg] && (DL[ig][sg] < PLLGPU_SCALE_THRESHOLD);
       }
-    put(grp.a, xa, true);
-    put(grp.b, xb, true);
     put(grp.p, DL, false);
     if (ma) put_scaler(grp.a, ma, scale_a);
     if (mb) put_scaler(grp.b, mb, scale_b);
@@ -661,9 +697,11 @@ __global__ __launch_bounds__(256, 4) void k_partials_mfma_cc(const FusePack pack
         int sm = sp[sg] ? 1 : 0; // a site's states are spread over the four row groups of the wave
         sm &= __shfl_xor(sm, 16, 64);
         sm &= __shfl_xor(sm, 32, 64);
-        if (row == 0 && valid[sg]) flagbuf[((size_t)blockIdx.y * g.R + k) * flag_stride + e[sg]] = (unsigned char)sm;
+        if (row == 0 && valid[sg]) flagbuf[((size_t)blockIdx.y * g.R + k) * flag_stride + e0 + sg] = (unsigned char)sm;
       }
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) cw[t] = nw[t];
   }
 }
 

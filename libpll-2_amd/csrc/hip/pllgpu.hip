@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <vector>
 
 #include "kernels_common.h"
@@ -150,7 +151,14 @@ struct pllgpu_ctx
   unsigned long long plan_stamp = 0;
   bool plan_cache = true;           // PLL_AMD_NO_PLAN_CACHE=1 plans every call afresh
   int gather_stream = 0;            // PLL_AMD_GATHER_STREAM: 1 always streaming loads from compressed children, -1 never, 0 by size
-  DevBuf<unsigned short> cherry_bits; // k_cherry_bits: which cherry entries are rescaled, per pair of tip codes
+  DevBuf<unsigned char> cherry_bits; // k_cherry_bits: which cherry entries are rescaled, [slot][rate][pair of tip codes]
+  struct CherrySlot
+  {
+    unsigned long long lver = 0, rver = 0, maps = 0;
+  };
+  std::map<unsigned long long, unsigned> cherry_slot_of; // (left matrix, right matrix) -> slot
+  std::vector<CherrySlot> cherry_slot;                   // what the slot's table was computed from
+  std::vector<unsigned long long> pm_version;            // bumped whenever a device matrix is written
   DevBuf<double> cherry_tab;        // k_cherry_tables: [cherry][rate][code pair][state] of the launch being issued
   unsigned tip_ncodes = 0;          // codes in use: 1 + the highest code with a non-empty mask
   bool generic_aos = true;          // PLL_AMD_NO_GENERIC_AOS=1: compressed nodes of non-4x4 shapes stay tiled (A/B)
@@ -290,16 +298,22 @@ static void derive_geometry(pllgpu_ctx *c)
   }
   if (const char *v = getenv("PLL_AMD_NO_MFMA"))
     if (*v && *v != '0') c->use_mfma = false;
-  // any-state FMA path: cherry-cherry groups need one wave per rate category
-  // Both group kernels are OPT-IN (PLL_AMD_FUSE_GENERIC=1): bit-identical to the level-by-level launches and one
-  // launch shorter, but on C3 (20 states) neither beats them - same-box runs: level path 3.86-3.91 G updates/s,
-  // table-fed FMA groups 3.74-3.81, matrix-pipe groups 3.67-3.70 (profiles/README.md, round 2)
-  bool opt_in = false;
-  if (const char *v = getenv("PLL_AMD_FUSE_GENERIC")) opt_in = *v && *v != '0';
+  // (tip x tip, tip x tip -> inner x inner) groups of the shapes outside the 4x4 kernels:
+  // * 17..32 states: ON, on the matrix pipe (kernels_mfma.h: k_partials_mfma_cc), whatever pipe the level launches
+  //   use - C3 (20 states) 4.0 -> 5.1 G updates/s on the same box (profiles/README.md, round 2);
+  // * PLL_AMD_FUSE_GENERIC=1: the table-fed FMA groups instead (kernels_generic.h: k_partials_tiled_cc; any state
+  //   count, one wave per rate category) - bit-identical to the level launches, but not faster than them;
+  // * PLL_AMD_FUSE_GENERIC=0 or PLL_AMD_NO_FUSE=1: level launches only.
+  bool groups = true, fma_groups = false;
+  if (const char *v = getenv("PLL_AMD_FUSE_GENERIC"))
+  {
+    groups = *v && *v != '0';
+    fma_groups = *v == '1';
+  }
   if (const char *v = getenv("PLL_AMD_NO_FUSE"))
-    if (*v && *v != '0') opt_in = false;
-  c->fuse_generic = opt_in && !c->dna_fast && !c->use_mfma && g.rate_cats <= 4 && gg.nchunks == 1;
-  c->fuse_mfma = opt_in && c->use_mfma && c->mfma_ng <= 8;
+    if (*v && *v != '0') groups = false;
+  c->fuse_mfma = groups && g.states >= 17 && g.states <= 32 && g.rate_cats <= 16 && (c->use_mfma || !fma_groups);
+  c->fuse_generic = groups && fma_groups && !c->dna_fast && !c->use_mfma && g.rate_cats <= 4 && gg.nchunks == 1;
   c->pm_stride = (size_t)g.rate_cats * g.states * gg.SPT;
   c->span = g.rate_cats * g.states_padded;
 }
@@ -406,6 +420,7 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
     return nullptr;
   }
   (void)hipMemsetAsync(c->pmat.p, 0, c->pmat.cap * sizeof(double), c->stream);
+  c->pm_version.assign(geo->prob_matrices + 2, 1ull);
   (void)hipMemsetAsync(c->prop_invar.p, 0, c->prop_invar.cap * sizeof(double), c->stream);
   (void)hipMemsetAsync(c->counter.p, 0, c->counter.cap * sizeof(unsigned), c->stream);
   return c;
@@ -561,7 +576,7 @@ extern "C" int pllgpu_tipchars_upload(pllgpu_ctx_t *c, unsigned tip, const unsig
 {
   CHECK_CTX(c);
   if (tip >= c->geo.tips) return fail(PLLGPU_EINVAL, "tip %u out of range", tip);
-  if (int rc = c->tipchars[tip].ensure(count)) return rc;
+  if (int rc = c->tipchars[tip].ensure(((size_t)count + 65) & ~(size_t)63)) return rc; // kernels fetch two codes at a time
   HIP_TRY(hipMemcpyAsync(c->tipchars[tip].p, host, count, hipMemcpyHostToDevice, c->stream));
   return 0;
 }
@@ -606,6 +621,7 @@ static int upload_matrices(pllgpu_ctx *c, unsigned first, unsigned count, const 
       }
   HIP_TRY(hipMemcpyAsync(c->pmat.p + (size_t)first * c->pm_stride, c->stage.data(),
                          c->stage.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  for (unsigned m = first; m < first + count && m < c->pm_version.size(); ++m) ++c->pm_version[m];
   return 0;
 }
 
@@ -906,6 +922,7 @@ static int launch_mfma_t(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsig
   const unsigned want = NG > 8 ? 2048u : 4096u;
   unsigned ipw = (unsigned)(((size_t)items * nops * R + want - 1) / want);
   ipw = std::max(1u, std::min(ipw, NG > 8 ? ~0u : 8u));
+  if (const char *ev = getenv("PLL_AMD_MFMA_IPW")) ipw = std::max(1, atoi(ev));
   dim3 grid((items + 4 * ipw - 1) / (4 * ipw), nops, R), block(256);
   const size_t lds = MfmaGeo<NG>::lds_doubles * sizeof(double);
   const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
@@ -953,23 +970,56 @@ static int launch_mfma_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroup
   const unsigned items = (entries + 31) / 32;
   unsigned ipw = (unsigned)(((size_t)items * ngroups * R + 4095) / 4096);
   ipw = std::max(1u, std::min(ipw, 8u));
+  if (const char *ev = getenv("PLL_AMD_MFMA_IPW")) ipw = std::max(1, atoi(ev));
   dim3 grid((items + 4 * ipw - 1) / (4 * ipw), ngroups, R), block(256);
-  const size_t lds = (6u * MfmaGeo<NG>::frag_array + 16u * NG) * sizeof(double);
   const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
   const unsigned ncodes = c->tip_ncodes;
-  // which cherries are rescaled: per pair of tip codes, every rate's answer (k_cherry_bits)
-  if (int rc = c->cherry_bits.ensure((size_t)2 * kMaxGroups * ncodes * ncodes)) return rc;
-  CherryTips tips;
-  memset(&tips, 0, sizeof tips);
+  const size_t lds = CcGeo<NG>::lds_bytes(ncodes);
+  // which cherries are rescaled: per pair of tip codes, every rate's answer (k_cherry_bits) - a table per pair of
+  // tip matrices, kept on the device until one of the two is written again
+  if (int rc = c->cherry_bits.ensure((size_t)kCherrySlots * R * 32u * 32u)) return rc;
+  if (c->cherry_slot.size() != kCherrySlots) c->cherry_slot.assign(kCherrySlots, pllgpu_ctx::CherrySlot());
+  CherryTips stale;
+  memset(&stale, 0, sizeof stale);
+  unsigned nstale = 0;
+  CherrySlots slots;
+  memset(&slots, 0, sizeof slots);
   OpPack parents; // the group parents as plain ops: what the scaling epilogue works on
   memset(&parents, 0, sizeof parents);
   bool scaling = false;
+  if (c->cherry_slot_of.size() + 2 * ngroups > kCherrySlots)
+  {
+    // full: start over (launches already in the stream read their tables before any of them is overwritten)
+    c->cherry_slot_of.clear();
+    c->cherry_slot.assign(kCherrySlots, pllgpu_ctx::CherrySlot());
+  }
   for (unsigned i = 0; i < ngroups; ++i)
   {
-    tips.lmat[2 * i] = pack.g[i].a.lmat;
-    tips.rmat[2 * i] = pack.g[i].a.rmat;
-    tips.lmat[2 * i + 1] = pack.g[i].b.lmat;
-    tips.rmat[2 * i + 1] = pack.g[i].b.rmat;
+    for (unsigned ch = 0; ch < 2; ++ch)
+    {
+      const FOp &f = ch ? pack.g[i].b : pack.g[i].a;
+      const unsigned long long li = (unsigned long long)((f.lmat - c->pmat.p) / (ptrdiff_t)c->pm_stride),
+                               ri = (unsigned long long)((f.rmat - c->pmat.p) / (ptrdiff_t)c->pm_stride);
+      auto ins = c->cherry_slot_of.emplace((li << 32) | ri, (unsigned)c->cherry_slot_of.size());
+      const unsigned sl = ins.first->second;
+      pllgpu_ctx::CherrySlot &cs = c->cherry_slot[sl];
+      slots.s[2 * i + ch] = (unsigned short)sl;
+      if (cs.lver != c->pm_version[li] || cs.rver != c->pm_version[ri] || cs.maps != c->maps_epoch + 1ull)
+      {
+        cs.lver = c->pm_version[li];
+        cs.rver = c->pm_version[ri];
+        cs.maps = c->maps_epoch + 1ull;
+        bool listed = false; // the same pair of matrices twice in one launch: one table
+        for (unsigned q = 0; q < nstale; ++q) listed = listed || stale.slot[q] == sl;
+        if (!listed)
+        {
+          stale.lmat[nstale] = f.lmat;
+          stale.rmat[nstale] = f.rmat;
+          stale.slot[nstale] = (unsigned short)sl;
+          ++nstale;
+        }
+      }
+    }
     DevOp &d = parents.ops[i];
     d.parent = pack.g[i].p.parent;
     d.pscaler = pack.g[i].p.pscaler;
@@ -979,14 +1029,17 @@ static int launch_mfma_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroup
     scaling = scaling || d.pscaler != nullptr;
   }
   scaling = scaling && c->gg.scale_mode != 0;
-  const size_t bits_lds = (size_t)2 * ncodes * S * sizeof(double);
-  raise_lds_limit((const void *)k_cherry_bits, c->device, bits_lds);
-  hipLaunchKernelGGL(k_cherry_bits, dim3(2 * ngroups), dim3(256), bits_lds, c->stream, tips, c->gg, tm, ncodes, c->cherry_bits.p);
+  if (nstale)
+  {
+    const size_t bits_lds = ((size_t)2 * S * S + (size_t)2 * ncodes * S) * sizeof(double);
+    raise_lds_limit((const void *)k_cherry_bits, c->device, bits_lds);
+    hipLaunchKernelGGL(k_cherry_bits, dim3(nstale, R), dim3(256), bits_lds, c->stream, stale, c->gg, tm, ncodes, c->cherry_bits.p);
+  }
   const unsigned fstride = (entries + 63u) & ~63u;
   if (scaling && c->mfma_flags.ensure((size_t)kMaxOpsPerLaunch * R * fstride)) return PLLGPU_ENOMEM;
   raise_lds_limit((const void *)k_partials_mfma_cc<NG>, c->device, lds);
   hipLaunchKernelGGL((k_partials_mfma_cc<NG>), grid, block, lds, c->stream, pack, c->gg, tm, entries, ipw, c->mfma_flags.p, fstride,
-                     c->cherry_bits.p, ncodes);
+                     c->cherry_bits.p, slots, ncodes);
   if (scaling)
     hipLaunchKernelGGL((k_mfma_scale_epilogue<false>), dim3((entries + 255) / 256, ngroups), dim3(256), 0, c->stream, parents, c->gg,
                        c->mfma_flags.p, fstride);
@@ -1187,7 +1240,7 @@ static int plan_and_launch_levels(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigne
         unsigned n = 0, entries = 0;
         auto flush = [&]() -> int {
           if (!n) return 0;
-          if (c->use_mfma)
+          if (c->use_mfma || c->fuse_mfma)
             emit(c, [c, pack, n, entries]() {
               if (int rc = launch_mfma_cc(c, pack, n, entries)) c->launch_rc = rc;
             });
@@ -2176,6 +2229,7 @@ extern "C" int pllgpu_update_pmatrices(pllgpu_ctx_t *c, const unsigned *params_i
   // (ensure() frees synchronously), a reused one is overwritten in stream order
   if (int rc = c->mindex.ensure(count)) return rc;
   if (int rc = c->brlen.ensure(count)) return rc;
+  for (unsigned i = 0; i < count; ++i) ++c->pm_version[matrix_indices[i]];
   HIP_TRY(hipMemcpyAsync(c->mindex.p, matrix_indices, count * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->brlen.p, branch_lengths, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
   d.pmat = c->pmat.p;

@@ -340,7 +340,7 @@ def test_dna_without_fusion(amd_lib, kw, monkeypatch):
                                 dict(states=20, tips=16, sites=300, seed=308, rate_cats=2), dict(states=20, tips=16, sites=300, seed=309, rate_cats=1),
                                 dict(states=20, tips=24, sites=600, seed=310, tree="random"), dict(states=32, tips=16, sites=200, seed=311),
                                 dict(states=20, tips=16, sites=300, seed=312, scalers=False)], ids=_id)
-@pytest.mark.parametrize("pipe", ["fma", "mfma"])
+@pytest.mark.parametrize("pipe", ["fma", "mfma", "mixed"])
 def test_cherry_groups_of_fma_shapes_are_bit_identical(amd_lib, kw, pipe, monkeypatch):
     """any-state FMA path: an op over two cherries is evaluated together with them (k_partials_tiled_cc), its
     contraction fed from the staged tip matrices instead of HBM; PLL_AMD_NO_FUSE=1 launches level by level -
@@ -351,6 +351,10 @@ def test_cherry_groups_of_fma_shapes_are_bit_identical(amd_lib, kw, pipe, monkey
         if kw["states"] < 17:
             pytest.skip("the matrix-pipe kernels start at 17 states")
         monkeypatch.setenv("PLL_AMD_MFMA_MIN_STATES", "17")
+    if pipe == "mixed":  # the groups on the matrix pipe, every other launch on the FMA kernels: same numbers within the
+        if not 17 <= kw["states"] <= 32:  # tolerance (the two pipes sum a contraction in different orders), scaling decisions equal
+            pytest.skip("the matrix-pipe groups serve 17..32 states")
+        monkeypatch.setenv("PLL_AMD_FUSE_GENERIC", "2")
     tiny = kw.pop("tiny_p", None)
     case = W.make_case("ccg", **kw)
     if tiny:  # P = (1 - (s - 1) eps) on the diagonal, eps elsewhere (numpy's expm cannot produce such entries)
@@ -367,8 +371,13 @@ def test_cherry_groups_of_fma_shapes_are_bit_identical(amd_lib, kw, pipe, monkey
         npl = amd_lib.pll_gpu_last_launch_count(s.p)
     exp = O.run_case(case)
     assert_results_match(plain, exp, what=_id(kw))
-    if kw.get("tree", "balanced") == "balanced" and kw.get("rate_cats", 4) <= 4:
+    if kw.get("tree", "balanced") == "balanced" and kw.get("rate_cats", 4) <= 4 and pipe != "mixed":
         assert nf < npl, (nf, npl)  # the cherries' launch is gone
+    if pipe == "mixed":
+        assert_results_match(fused, exp, what=_id(kw))
+        for k in plain["scaler"]:
+            assert np.array_equal(fused["scaler"][k], plain["scaler"][k]), k
+        return
     assert fused["lnl"] == plain["lnl"]
     for k in plain["clv"]:
         assert np.array_equal(fused["clv"][k], plain["clv"][k]), k
@@ -377,6 +386,43 @@ def test_cherry_groups_of_fma_shapes_are_bit_identical(amd_lib, kw, pipe, monkey
     if tiny:
         cherries = [op[0] for op in case.op_batches[0] if op[2] < case.tips and op[5] < case.tips]
         assert sum(int(plain["scaler"][c].sum()) for c in cherries) > 0  # cherries were rescaled
+
+
+def test_cherry_tables_follow_the_matrices(amd_lib, monkeypatch):
+    """matrix-pipe groups keep a cherry's table of scaling decisions on the device for as long as its two tip
+    matrices stand: near-identity matrices (cherries of two different states are rescaled), then ordinary ones in
+    the same partition (nothing is), then the first set again - scalers and CLVs as the level launches give them"""
+    case = W.make_case("cct", states=20, tips=8, sites=500, seed=320)
+    normal = case.pmatrix.copy()
+    s_ = case.states
+    tiny = np.full((s_, s_), 1e-80) + np.eye(s_) * (1.0 - s_ * 1e-80)
+    cherries = [op[0] for op in case.op_batches[0] if op[2] < case.tips and op[5] < case.tips]
+    r, sp = case.rate_cats, None
+
+    def passes():
+        out = []
+        with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+            for mats in (tiny, normal, tiny):
+                for i in range(case.prob_matrices):
+                    dst = api.as_np(s.part.pmatrix[i], r * s_ * s.sp, np.float64).reshape(r, s_, s.sp)
+                    dst[:, :, :s_] = mats if mats is tiny else mats[i]
+                amd_lib.pll_gpu_invalidate(s.p, api.DIRTY_PMATRIX, -1)
+                s.update_partials()
+                lnl = s.edge_lnl(case.edges[0], persite=False)[0]
+                out.append((lnl, [s.read_scaler(c - case.tips, c) for c in cherries], s.read_clv(case.edges[0][0])))
+        return out
+
+    monkeypatch.setenv("PLL_AMD_FUSE_GENERIC", "2")
+    fused = passes()
+    monkeypatch.setenv("PLL_AMD_NO_FUSE", "1")
+    plain = passes()
+    assert sum(int(x.sum()) for x in plain[0][1]) > 0 and sum(int(x.sum()) for x in plain[1][1]) == 0
+    for f, p_ in zip(fused, plain):
+        assert abs(f[0] - p_[0]) <= RTOL * abs(p_[0])
+        for a, b in zip(f[1], p_[1]):
+            assert np.array_equal(a, b)
+        assert np.allclose(f[2], p_[2], rtol=1e-12, atol=0)
+    assert fused[0][0] == fused[2][0]
 
 
 def test_fusion_plan_on_a_balanced_tree(amd_lib, monkeypatch):
