@@ -67,7 +67,7 @@ __device__ __forceinline__ void contract_aos(double (&acc)[ICH], const double *p
     typedef double c_dbl2 __attribute__((ext_vector_type(2)));
     const c_dbl2 *x2 = reinterpret_cast<const c_dbl2 *>(x);
 #pragma unroll 1
-    for (unsigned jc = 0; jc < (g.S + 1u) / 2u; ++jc)
+    for (unsigned jc = 0; jc < (g.S + 1u) / 2u; ++jc) // (five requests in flight per wait: 156 registers, the launch 216 -> 289 us)
     {
       const unsigned j = 2u * jc;
       c_dbl2 v;
@@ -152,10 +152,11 @@ __device__ __forceinline__ size_t tiled_base(unsigned e, unsigned tile_sz)
 template <int ICH, bool LTIP, bool RTIP, bool GATHER, int LAY = -1>
 __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const GenGeo g,
                                                         const unsigned long long *__restrict__ tipmap, unsigned tip_lds,
-                                                        unsigned tiles_per_block)
+                                                        unsigned tiles_per_block, unsigned par_lds)
 {
   __shared__ unsigned char flags[kMaxRates][64];
-  extern __shared__ double tipmat[]; // tip_lds: [child][wave][(S + 1) x SPT] staged tip matrices + row sums
+  extern __shared__ double tipmat[]; // tip_lds: [child][wave][(S + 1) x SPT] staged tip matrices + row sums;
+                                     // par_lds: then [wave][64][SP + 2], the entries of an entry-contiguous parent on their way out
 
   const DevOp &op = pack.ops[blockIdx.y];
   const unsigned lane = threadIdx.x & 63u;
@@ -170,6 +171,15 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
   double *lstage = tipmat + (size_t)wave * slot, *rstage = tipmat + (size_t)(nw + wave) * slot;
   // one rate category per wave (R <= 4): the tip matrices are staged once for all tiles of the workgroup
   const bool stage_once = tip_lds && g.R <= nw && wave < g.R;
+  // An entry-contiguous parent (class-compressed node): lane = entry, so a store instruction of the plain path puts 8
+  // bytes into each of 64 different entries, SP x R x 8 bytes apart (C3 with site repeats: the 16 ops over compressed
+  // level-2 nodes wrote 160 MB in 182 us). Instead the wave parks its 64 entries of one rate in LDS ([entry][SP + 2]:
+  // 16-byte aligned rows, eight consecutive lanes on eight different bank groups) and writes them out 16 bytes per
+  // lane, SP / 2 lanes per entry: every store instruction covers whole (entry, rate) blocks.
+  const unsigned pst = g.SP + 2u, hp = ICH == 20 ? 10u : g.SP >> 1; // (the host sets par_lds for ICH == 20 only when SP == 20)
+  double *pstage = tipmat + (tip_lds ? (size_t)2 * nw * slot : 0) + (size_t)wave * 64u * pst;
+  const bool par_via_lds = GATHER && par_lds != 0;
+  const unsigned fl_sub = lane % (hp ? hp : 1u), fl_ent = lane / (hp ? hp : 1u), fl_per = 64u / (hp ? hp : 1u);
   if (stage_once)
   {
     if (LTIP) tip_stage(lstage, op.lmat, wave, g, lane);
@@ -207,6 +217,46 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
     const double *__restrict__ rx = RTIP ? nullptr : raos ? op.right + (size_t)re * espan : op.right + tiled_base(re, g.tile_sz);
     double *__restrict__ out = op.parent + (size_t)tile * g.tile_sz + lane; // tiled parent (an entry-contiguous one is addressed where it is stored)
 
+    // Entry-contiguous CHILDREN through the same LDS slot (one child at a time; ops of one chunk): SP / 2 consecutive
+    // lanes fetch the SP x 8 bytes of one (entry, rate) - every cache line requested once per wave. A lane fetching
+    // its own entry 16 bytes at a time puts 64 different lines into every request, ten requests long, and the
+    // vector cache (12 waves x 2 children x 64 entries) does not keep them from one request to the next: the
+    // launch over C3's compressed level-2 nodes asked L2 for 1.1 GB to read 0.3 GB.
+    const bool coop = GATHER && par_lds == 1u && g.nchunks == 1u; // par_lds == 2: the parent's way out only (A/B switch)
+    auto coop_fetch = [&](const double *__restrict__ base, unsigned my_entry, unsigned k) {
+      typedef double dbl2 __attribute__((ext_vector_type(2)));
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier(); // every lane is done with what the slot held
+      const double *src0 = base + (size_t)k * g.SP + 2u * fl_sub;
+      if (ICH == 20)
+      {
+        dbl2 w[11]; // all requests first
+#pragma unroll
+        for (int r = 0; r < 11; ++r)
+        {
+          const unsigned ent = 6u * r + fl_ent;
+          const unsigned src = __shfl(my_entry, ent & 63u, 64);
+          if (fl_ent < 6u && ent < 64u) w[r] = *reinterpret_cast<const dbl2 *>(src0 + (size_t)src * espan);
+        }
+#pragma unroll
+        for (int r = 0; r < 11; ++r)
+        {
+          const unsigned ent = 6u * r + fl_ent;
+          if (fl_ent < 6u && ent < 64u) *reinterpret_cast<dbl2 *>(pstage + ent * pst + 2u * fl_sub) = w[r];
+        }
+      }
+      else
+        for (unsigned e0 = 0; e0 < 64u; e0 += fl_per)
+        {
+          const unsigned ent = e0 + fl_ent;
+          const unsigned src = __shfl(my_entry, ent & 63u, 64);
+          if (fl_ent < fl_per && ent < 64u)
+            *reinterpret_cast<dbl2 *>(pstage + ent * pst + 2u * fl_sub) = *reinterpret_cast<const dbl2 *>(src0 + (size_t)src * espan);
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    };
+
     auto rescale_rate = [&](unsigned k) {
       // this lane's stored column of rate k: same lane wrote it; order the accesses explicitly
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -243,7 +293,12 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
           tip_columns<ICH>(A, lstage, c, g, lmask, full);
         else
         {
-          if (GATHER && laos) // wave-uniform
+          if (GATHER && laos && coop) // wave-uniform
+          {
+            coop_fetch(op.left, le, k);
+            contract_aos<ICH>(A, op.lmat, k, c, g, pstage + lane * pst);
+          }
+          else if (GATHER && laos)
             contract_aos<ICH>(A, op.lmat, k, c, g, lx + (size_t)k * g.SP);
           else
             contract<ICH, LTIP>(A, op.lmat, k, c, g, LTIP ? nullptr : lx + (size_t)k * g.S * 64, lmask);
@@ -252,12 +307,29 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
           tip_columns<ICH>(B, rstage, c, g, rmask, full);
         else
         {
-          if (GATHER && raos)
+          if (GATHER && raos && coop)
+          {
+            coop_fetch(op.right, re, k);
+            contract_aos<ICH>(B, op.rmat, k, c, g, pstage + lane * pst);
+          }
+          else if (GATHER && raos)
             contract_aos<ICH>(B, op.rmat, k, c, g, rx + (size_t)k * g.SP);
           else
             contract<ICH, RTIP>(B, op.rmat, k, c, g, RTIP ? nullptr : rx + (size_t)k * g.S * 64, rmask);
         }
-        if (GATHER && paos) // wave-uniform: entry-contiguous parent
+        if (GATHER && paos && par_via_lds) // wave-uniform: entry-contiguous parent, through LDS
+        {
+          double *dst = pstage + lane * pst + c * ICH;
+#pragma unroll
+          for (int i = 0; i < ICH; ++i)
+            if (c * ICH + i < g.S)
+            {
+              const double v = A[i] * B[i];
+              small = small && (v < PLLGPU_SCALE_THRESHOLD);
+              dst[i] = v;
+            }
+        }
+        else if (GATHER && paos) // wave-uniform: entry-contiguous parent
         {
           double *dst = op.parent + ((size_t)n * g.R + k) * g.SP + c * ICH; // formed here: one pointer less across the contractions
 #pragma unroll
@@ -288,7 +360,26 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
             }
         }
       }
-      if (GATHER && paos && valid) // the padding lanes of the host layout stay zero
+      if (GATHER && paos && par_via_lds)
+      {
+        typedef double dbl2 __attribute__((ext_vector_type(2)));
+        for (unsigned s = g.S; s < g.SP; ++s) pstage[lane * pst + s] = 0.0; // the padding lanes of the host layout stay zero
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (fl_ent < fl_per)
+          for (unsigned e0 = 0; e0 < 64u; e0 += fl_per)
+          {
+            const unsigned ent = e0 + fl_ent;
+            if (ent < 64u && tile * 64u + ent < op.entries)
+            {
+              const dbl2 w = *reinterpret_cast<const dbl2 *>(pstage + ent * pst + 2u * fl_sub);
+              *reinterpret_cast<dbl2 *>(op.parent + ((size_t)(tile * 64u + ent) * g.R + k) * g.SP + 2u * fl_sub) = w;
+            }
+          }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier(); // the slot is rewritten by the wave's next rate / tile
+      }
+      else if (GATHER && paos && valid) // the padding lanes of the host layout stay zero
         for (unsigned s = g.S; s < g.SP; ++s) op.parent[((size_t)n * g.R + k) * g.SP + s] = 0.0;
       if (mode == 2)
       {

@@ -21,6 +21,7 @@
 #include "kernels_generic.h"
 #include "kernels_deriv.h"
 #include "kernels_mfma.h"
+#include "kernels_lean.h"
 #include "kernels_repeats.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -131,6 +132,7 @@ struct pllgpu_ctx
   unsigned last_launches = 0;
   double last_bytes = 0.0;       // algorithmic HBM bytes of the last update_partials call
   bool no_tip_columns = false;   // PLL_AMD_NO_TIP_COLUMNS=1: tips always through the FMA contraction
+  bool no_par_lds = false;       // PLL_AMD_NO_PARENT_LDS=1 (A/B): entry-contiguous parents stored 8 bytes per lane
   size_t stream_parent_bytes = (size_t)256 << 20; // PLL_AMD_STREAM_PARENT_MB overrides (experiments)
   bool defer_tail = false;       // DNA: hold the traversal's last ops for one call (k_edge_dna_tail)
   std::vector<pllgpu_op_t> deferred; // ops accepted by pllgpu_update_partials and not launched yet
@@ -162,6 +164,8 @@ struct pllgpu_ctx
   DevBuf<double> cherry_tab;        // k_cherry_tables: [cherry][rate][code pair][state] of the launch being issued
   unsigned tip_ncodes = 0;          // codes in use: 1 + the highest code with a non-empty mask
   bool generic_aos = true;          // PLL_AMD_NO_GENERIC_AOS=1: compressed nodes of non-4x4 shapes stay tiled (A/B)
+  bool lean = false;                // 17..20 states, <= 4 rates: the level launches on the matrix pipe (kernels_lean.h)
+  bool lean_plain = false;          // ... also the ones that do not gather (PLL_AMD_LEAN_PLAIN=1)
   bool fuse_mfma = false;           // 17..32 states on the matrix pipe: the same groups (kernels_mfma.h: k_partials_mfma_cc)
   bool fuse_generic = false;        // FMA-path shapes: (tip x tip, tip x tip -> inner x inner) groups (kernels_generic.h: k_partials_tiled_cc)
   bool subtrees = false;            // DNA + site repeats: all-tip subtrees straight from the tip codes (subtree_plan.h)
@@ -267,6 +271,8 @@ static void derive_geometry(pllgpu_ctx *c)
     if (*v && *v != '0') c->fuse = false;
   if (const char *v = getenv("PLL_AMD_NO_TIP_COLUMNS"))
     if (*v && *v != '0') c->no_tip_columns = true;
+  if (const char *v = getenv("PLL_AMD_NO_PARENT_LDS"))
+    if (*v && *v != '0') c->no_par_lds = true;
   c->defer_tail = c->dna_fast;
   if (const char *v = getenv("PLL_AMD_NO_TAIL_FUSION"))
     if (*v && *v != '0') c->defer_tail = false;
@@ -314,6 +320,11 @@ static void derive_geometry(pllgpu_ctx *c)
     if (*v && *v != '0') groups = false;
   c->fuse_mfma = groups && g.states >= 17 && g.states <= 32 && g.rate_cats <= 16 && (c->use_mfma || !fma_groups);
   c->fuse_generic = groups && fma_groups && !c->dna_fast && !c->use_mfma && g.rate_cats <= 4 && gg.nchunks == 1;
+  c->lean = !c->dna_fast && !c->use_mfma && g.states >= 17 && g.states <= 20 && g.rate_cats <= 4;
+  if (const char *v = getenv("PLL_AMD_NO_LEAN")) // A/B switch: the scalar-fed FMA kernels for these shapes
+    if (*v && *v != '0') c->lean = false;
+  if (const char *v = getenv("PLL_AMD_LEAN_PLAIN"))
+    c->lean_plain = *v && *v != '0';
   c->pm_stride = (size_t)g.rate_cats * g.states * gg.SPT;
   c->span = g.rate_cats * g.states_padded;
 }
@@ -798,7 +809,15 @@ static void launch_generic(pllgpu_ctx *c, const OpPack &pack, unsigned nops, uns
   const unsigned nw = std::min(c->gg.R, 4u);
   const bool stage = kind != 0 && c->gg.S * c->gg.SPT <= 1024u && !c->no_tip_columns;
   const unsigned tip_lds = stage ? 1u : 0u;
-  const size_t lds = stage ? (size_t)2 * nw * (c->gg.S + 1u) * (c->gg.SPT | 1u) * sizeof(double) : 0;
+  size_t lds = stage ? (size_t)2 * nw * (c->gg.S + 1u) * (c->gg.SPT | 1u) * sizeof(double) : 0;
+  // entry-contiguous parents leave through LDS (kernels_generic.h): 16-byte rows need states_padded % 4 == 0
+  // and entry-contiguous children arrive through it, SP / 2 lanes per (entry, rate)
+  bool any_aos = false;
+  for (unsigned i = 0; i < nops; ++i) any_aos = any_aos || (pack.ops[i].layout & (kAosParent | kAosLeft | kAosRight));
+  static const bool no_coop = getenv("PLL_AMD_NO_COOP_FETCH") && atoi(getenv("PLL_AMD_NO_COOP_FETCH")) != 0;
+  const unsigned par_lds = (gather && any_aos && c->gg.SP % 4u == 0 && (ICH != 20 || c->gg.SP == 20u) && !c->no_par_lds) ? (no_coop ? 2u : 1u) : 0u;
+  if (par_lds) lds += (size_t)nw * 64u * (c->gg.SP + 2u) * sizeof(double);
+
   // staged tip matrices are shared by the tiles of a workgroup: several tiles each, as long as
   // ~2048 workgroups remain
   unsigned tpb = 1;
@@ -816,7 +835,8 @@ static void launch_generic(pllgpu_ctx *c, const OpPack &pack, unsigned nops, uns
     if (same)
     {
 #define GEN_LAY(LT, RT, L) \
-  case L: hipLaunchKernelGGL((k_partials_tiled<ICH == 20 ? 20 : ICH, LT, RT, true, ICH == 20 ? L : -1>), grid, block, lds, c->stream, pack, c->gg, tm, tip_lds, tpb); return;
+  case L: if (par_lds) raise_lds_limit((const void *)k_partials_tiled<ICH == 20 ? 20 : ICH, LT, RT, true, ICH == 20 ? L : -1>, c->device, lds); \
+    hipLaunchKernelGGL((k_partials_tiled<ICH == 20 ? 20 : ICH, LT, RT, true, ICH == 20 ? L : -1>), grid, block, lds, c->stream, pack, c->gg, tm, tip_lds, tpb, par_lds); return;
 #define GEN_LAYS(LT, RT) \
   switch (lay)             \
   {                        \
@@ -830,7 +850,8 @@ static void launch_generic(pllgpu_ctx *c, const OpPack &pack, unsigned nops, uns
     }
   }
 #define GEN_LAUNCH(LT, RT, GA) \
-  hipLaunchKernelGGL((k_partials_tiled<ICH, LT, RT, GA>), grid, block, lds, c->stream, pack, c->gg, tm, tip_lds, tpb)
+  do { if (par_lds) raise_lds_limit((const void *)k_partials_tiled<ICH, LT, RT, GA>, c->device, lds); \
+  hipLaunchKernelGGL((k_partials_tiled<ICH, LT, RT, GA>), grid, block, lds, c->stream, pack, c->gg, tm, tip_lds, tpb, par_lds); } while (0)
   if (kind == 0)
   {
     if (gather) GEN_LAUNCH(false, false, true); else GEN_LAUNCH(false, false, false);
@@ -1062,12 +1083,66 @@ static int launch_mfma(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigne
   }
 }
 
+// 17..20 states, up to four rate categories: every level launch on the matrix pipe (kernels_lean.h)
+static int launch_lean(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
+{
+  const unsigned R = c->gg.R;
+  const unsigned items = (maxent + 31) / 32;
+  // staging the workgroup's matrices costs about as much as two items: several items per workgroup, as long as
+  // a few thousand workgroups remain
+  unsigned ipb = (unsigned)(((size_t)items * nops) / 4096u);
+  ipb = std::max(2u, std::min(ipb, 16u));
+  if (const char *ev = getenv("PLL_AMD_LEAN_IPB")) ipb = std::max(1, atoi(ev));
+  dim3 grid((items + ipb - 1) / ipb, nops), block(64u * R);
+  const size_t lds = LeanGeo<5>::lds_bytes(R, gather);
+  if (gather)
+  {
+    raise_lds_limit((const void *)k_partials_lean<5, false, false, true>, c->device, lds);
+    raise_lds_limit((const void *)k_partials_lean<5, true, false, true>, c->device, lds);
+    raise_lds_limit((const void *)k_partials_lean<5, true, true, true>, c->device, lds);
+  }
+  const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
+  const unsigned ncodes = std::min(c->tip_ncodes, 256u);
+#define LEAN_LAUNCH(LT, RT, GA) hipLaunchKernelGGL((k_partials_lean<5, LT, RT, GA>), grid, block, lds, c->stream, pack, c->gg, tm, ipb, ncodes)
+  if (kind == 0)
+  {
+    if (gather) LEAN_LAUNCH(false, false, true); else LEAN_LAUNCH(false, false, false);
+  }
+  else if (kind == 1)
+  {
+    if (gather) LEAN_LAUNCH(true, false, true); else LEAN_LAUNCH(true, false, false);
+  }
+  else
+  {
+    if (gather) LEAN_LAUNCH(true, true, true); else LEAN_LAUNCH(true, true, false);
+  }
+#undef LEAN_LAUNCH
+  return 0;
+}
+
+// the matrix-pipe level kernel takes gathering launches (site repeats) whose inner children are entry-contiguous
+// (the rule unless PLL_AMD_NO_GENERIC_AOS=1), states_padded = 20
+static bool lean_serves(const pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned kind, bool gather)
+{
+  if (!gather) return c->lean_plain;
+  if (c->gg.SP != 20u) return false;
+  for (unsigned i = 0; i < nops; ++i)
+  {
+    const unsigned lay = pack.ops[i].layout;
+    if (kind == 0 && !(lay & kAosLeft)) return false;
+    if (kind != 2 && !(lay & kAosRight)) return false;
+  }
+  return true;
+}
+
 static int launch_partials(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
 {
   if (c->dna_fast)
     launch_dna(c, pack, nops, maxent, kind, gather);
   else if (c->use_mfma)
     return launch_mfma(c, pack, nops, maxent, kind, gather);
+  else if (c->lean && (kind == 0 || c->tipmap_set) && lean_serves(c, pack, nops, kind, gather))
+    return launch_lean(c, pack, nops, maxent, kind, gather);
   else
     switch (c->ich)
     {

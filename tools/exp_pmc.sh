@@ -1,0 +1,30 @@
+# usage: exp_pmc.sh <outdir-name> <kernel substring> -- bench args...
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+NAME=$1; KSUB=$2; shift 3
+O=$R/gpurun_out/$NAME; mkdir -p $O
+i=0
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_INST_CYCLES_SMEM" "TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_GATE_EN1_sum" "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_TC_DATA_READ_REQ SQ_IFETCH"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$i -- python3 $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu > $O/pmc_$i.log 2>&1 || echo "pmc set $i failed: $set"
+done
+KSUB="$KSUB" python3 - <<'PY'
+import csv,glob,os,collections
+O=os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/"+os.environ.get("NAME","")
+PY
+NAME=$NAME KSUB="$KSUB" python3 - <<'PY'
+import csv,glob,os,collections
+O=os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/"+os.environ["NAME"]
+ks=os.environ["KSUB"]
+acc=collections.defaultdict(lambda: collections.defaultdict(list))
+for d in sorted(glob.glob(O+"/pmc_*/")):
+    fs=glob.glob(d+"/**/*counter_collection.csv",recursive=True)
+    if not fs: continue
+    for r in csv.DictReader(open(fs[0])):
+        if ks not in r["Kernel_Name"]: continue
+        kn=r["Kernel_Name"][:52]+" g"+r["Grid_Size"]
+        acc[kn][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for kn,c in acc.items():
+    print(kn)
+    for k,v in c.items(): print("   %-42s %14.0f" % (k, sum(v)/len(v)))
+PY
