@@ -154,6 +154,7 @@ struct pllgpu_ctx
   bool plan_cache = true;           // PLL_AMD_NO_PLAN_CACHE=1 plans every call afresh
   int gather_stream = 0;            // PLL_AMD_GATHER_STREAM: 1 always streaming loads from compressed children, -1 never, 0 by size
   DevBuf<unsigned char> cherry_bits; // k_cherry_bits: which cherry entries are rescaled, [slot][rate][pair of tip codes]
+  DevBuf<double> cherry_rowsums;     // ... and the row sums of the slot's two tip matrices [slot][rate][2][64] (33..64 states)
   struct CherrySlot
   {
     unsigned long long lver = 0, rver = 0, maps = 0;
@@ -318,7 +319,14 @@ static void derive_geometry(pllgpu_ctx *c)
   }
   if (const char *v = getenv("PLL_AMD_NO_FUSE"))
     if (*v && *v != '0') groups = false;
-  c->fuse_mfma = groups && g.states >= 17 && g.states <= 32 && g.rate_cats <= 16 && (c->use_mfma || !fma_groups);
+  // 33..64 states: the same groups exist (k_partials_mfma_cc_big, bit-identical to the level launches) but are OPT-IN
+  // (PLL_AMD_FUSE_BIG=1): LDS has no room for the four tip matrices beside the parent's fragments, the tip columns come
+  // from L2 8 bytes per lane, and those 128 requests per item keep the address unit busier than the 1024 MFMAs keep the
+  // matrix pipe - C5: 470 us for the group launch against 183 + 234 us for the two level launches
+  bool big_groups = false;
+  if (const char *v = getenv("PLL_AMD_FUSE_BIG")) big_groups = *v && *v != '0';
+  c->fuse_mfma = groups && g.rate_cats <= 16 &&
+                 ((g.states >= 17 && g.states <= 32 && (c->use_mfma || !fma_groups)) || (big_groups && g.states > 32 && g.states <= 64 && c->use_mfma));
   c->fuse_generic = groups && fma_groups && !c->dna_fast && !c->use_mfma && g.rate_cats <= 4 && gg.nchunks == 1;
   c->lean = !c->dna_fast && !c->use_mfma && g.states >= 17 && g.states <= 20 && g.rate_cats <= 4;
   if (const char *v = getenv("PLL_AMD_NO_LEAN")) // A/B switch: the scalar-fed FMA kernels for these shapes
@@ -453,6 +461,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->sub_dev.release();
   c->cherry_tab.release();
   c->cherry_bits.release();
+  c->cherry_rowsums.release();
   for (auto &b : c->clv) b.release();
   for (auto &b : c->scaler) b.release();
   for (auto &b : c->tipchars) b.release();
@@ -989,17 +998,28 @@ static int launch_mfma_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroup
 {
   const unsigned R = c->gg.R, S = c->gg.S;
   const unsigned items = (entries + 31) / 32;
-  unsigned ipw = (unsigned)(((size_t)items * ngroups * R + 4095) / 4096);
-  ipw = std::max(1u, std::min(ipw, 8u));
+  // 17..32 states: store-bound, many small workgroups; 33..64: two workgroups (2 x 70 KB of fragments) on every CU, one round
+  const unsigned want = NG == 16 ? 2048u : 4096u;
+  unsigned ipw = (unsigned)(((size_t)items * ngroups * R + want - 1) / want);
+  ipw = std::max(1u, NG == 16 ? ipw : std::min(ipw, 8u));
   if (const char *ev = getenv("PLL_AMD_MFMA_IPW")) ipw = std::max(1, atoi(ev));
   dim3 grid((items + 4 * ipw - 1) / (4 * ipw), ngroups, R), block(256);
   const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
   const unsigned ncodes = c->tip_ncodes;
-  const size_t lds = CcGeo<NG>::lds_bytes(ncodes);
+  const size_t lds = NG == 16 ? (size_t)2 * MfmaGeo<16>::frag_array * sizeof(double) + 256u : CcGeo<NG == 16 ? 8 : NG>::lds_bytes(ncodes);
   // which cherries are rescaled: per pair of tip codes, every rate's answer (k_cherry_bits) - a table per pair of
   // tip matrices, kept on the device until one of the two is written again
-  if (int rc = c->cherry_bits.ensure((size_t)kCherrySlots * R * 32u * 32u)) return rc;
-  if (c->cherry_slot.size() != kCherrySlots) c->cherry_slot.assign(kCherrySlots, pllgpu_ctx::CherrySlot());
+  {
+    const unsigned char *before = c->cherry_bits.p;
+    if (int rc = c->cherry_bits.ensure((size_t)kCherrySlots * R * ncodes * ncodes)) return rc;
+    if (NG == 16)
+      if (int rc = c->cherry_rowsums.ensure((size_t)kCherrySlots * R * 2u * 64u)) return rc;
+    if (c->cherry_bits.p != before || c->cherry_slot.size() != kCherrySlots)
+    {
+      c->cherry_slot_of.clear(); // a fresh block: no table survives
+      c->cherry_slot.assign(kCherrySlots, pllgpu_ctx::CherrySlot());
+    }
+  }
   CherryTips stale;
   memset(&stale, 0, sizeof stale);
   unsigned nstale = 0;
@@ -1052,15 +1072,27 @@ static int launch_mfma_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroup
   scaling = scaling && c->gg.scale_mode != 0;
   if (nstale)
   {
-    const size_t bits_lds = ((size_t)2 * S * S + (size_t)2 * ncodes * S) * sizeof(double);
+    size_t bits_lds = ((size_t)2 * S * S + (size_t)2 * ncodes * S) * sizeof(double);
+    const unsigned staged = bits_lds <= 144u * 1024u ? 1u : 0u;
+    if (!staged) bits_lds = (size_t)2 * ncodes * S * sizeof(double);
     raise_lds_limit((const void *)k_cherry_bits, c->device, bits_lds);
-    hipLaunchKernelGGL(k_cherry_bits, dim3(nstale, R), dim3(256), bits_lds, c->stream, stale, c->gg, tm, ncodes, c->cherry_bits.p);
+    hipLaunchKernelGGL(k_cherry_bits, dim3(nstale, R), dim3(256), bits_lds, c->stream, stale, c->gg, tm, ncodes, c->cherry_bits.p,
+                       NG == 16 ? c->cherry_rowsums.p : nullptr, staged);
   }
   const unsigned fstride = (entries + 63u) & ~63u;
   if (scaling && c->mfma_flags.ensure((size_t)kMaxOpsPerLaunch * R * fstride)) return PLLGPU_ENOMEM;
-  raise_lds_limit((const void *)k_partials_mfma_cc<NG>, c->device, lds);
-  hipLaunchKernelGGL((k_partials_mfma_cc<NG>), grid, block, lds, c->stream, pack, c->gg, tm, entries, ipw, c->mfma_flags.p, fstride,
-                     c->cherry_bits.p, slots, ncodes);
+  if constexpr (NG == 16)
+  {
+    raise_lds_limit((const void *)k_partials_mfma_cc_big<16>, c->device, lds);
+    hipLaunchKernelGGL((k_partials_mfma_cc_big<16>), grid, block, lds, c->stream, pack, c->gg, tm, entries, ipw, c->mfma_flags.p, fstride,
+                       c->cherry_bits.p, c->cherry_rowsums.p, slots, ncodes);
+  }
+  else
+  {
+    raise_lds_limit((const void *)k_partials_mfma_cc<NG>, c->device, lds);
+    hipLaunchKernelGGL((k_partials_mfma_cc<NG>), grid, block, lds, c->stream, pack, c->gg, tm, entries, ipw, c->mfma_flags.p, fstride,
+                       c->cherry_bits.p, slots, ncodes);
+  }
   if (scaling)
     hipLaunchKernelGGL((k_mfma_scale_epilogue<false>), dim3((entries + 255) / 256, ngroups), dim3(256), 0, c->stream, parents, c->gg,
                        c->mfma_flags.p, fstride);
@@ -1070,6 +1102,7 @@ static int launch_mfma_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroup
 static int launch_mfma_cc(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries)
 {
   if (c->mfma_ng == 5) return launch_mfma_cc_t<5>(c, pack, ngroups, entries);
+  if (c->mfma_ng == 16) return launch_mfma_cc_t<16>(c, pack, ngroups, entries);
   return launch_mfma_cc_t<8>(c, pack, ngroups, entries);
 }
 
@@ -1194,7 +1227,7 @@ static int plan_and_launch_levels(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigne
   std::vector<int> role;
   std::vector<FusedGroup> groups;
   // FMA-path groups look their cherries up in a table over all pairs of tip codes: only for a sane number of codes
-  const bool generic_groups = (c->fuse_mfma && c->tipmap_set && c->tip_ncodes <= 32u) ||
+  const bool generic_groups = (c->fuse_mfma && c->tipmap_set && c->tip_ncodes <= (c->gg.S > 32u ? 128u : 32u)) ||
                               (c->fuse_generic && (c->tipmap_set ? c->tip_ncodes : (1u << std::min(c->gg.S, 8u))) <= 64u);
   plan_fusion(c->fuse || generic_groups, c->fuse_cc, c->geo.nodes, ops, count, role, groups);
   if (generic_groups)

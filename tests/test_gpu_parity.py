@@ -388,6 +388,46 @@ def test_cherry_groups_of_fma_shapes_are_bit_identical(amd_lib, kw, pipe, monkey
         assert sum(int(plain["scaler"][c].sum()) for c in cherries) > 0  # cherries were rescaled
 
 
+@pytest.mark.parametrize("kw", [dict(states=61, tips=16, sites=300, seed=330),
+                                dict(states=61, tips=8, sites=333, seed=331, ambiguity_pct=8, partial_pct=6),       # masks with several states: MFMA route, fragments from L2
+                                dict(states=61, tips=8, sites=200, seed=332, tiny_p=1e-80),                        # rescaled cherries
+                                dict(states=61, tips=8, sites=200, seed=333, tiny_p=1e-80, attributes=api.RATE_SCALERS),
+                                dict(states=40, tips=16, sites=129, seed=334, rate_cats=2),
+                                dict(states=61, tips=12, sites=257, seed=335, tree="random"),
+                                dict(states=64, tips=8, sites=100, seed=336, scalers=False)], ids=_id)
+def test_cherry_groups_of_the_matrix_pipe_shapes_are_bit_identical(amd_lib, kw, monkeypatch):
+    """33..64 states: an op over two cherries is evaluated together with them (k_partials_mfma_cc_big) - tip columns
+    read as rows of the stored matrices, the parent's contraction from registers; PLL_AMD_NO_FUSE=1 launches level
+    by level: the same numbers, bit for bit, including the cherries' and the parent's scaling decisions"""
+    kw = dict(kw)
+    monkeypatch.setenv("PLL_AMD_FUSE_BIG", "1")  # opt-in: slower than the level launches on C5 (the tip columns come from L2)
+    tiny = kw.pop("tiny_p", None)
+    case = W.make_case("ccb", **kw)
+    if tiny:
+        s_ = case.states
+        case.pmatrix[:] = np.full((s_, s_), tiny) + np.eye(s_) * (1.0 - s_ * tiny)
+    fused = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        nf = amd_lib.pll_gpu_last_launch_count(s.p)
+    monkeypatch.setenv("PLL_AMD_NO_FUSE", "1")
+    plain = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        npl = amd_lib.pll_gpu_last_launch_count(s.p)
+    assert_results_match(plain, O.run_case(case), what=_id(kw))
+    if kw.get("tree", "balanced") == "balanced":
+        assert nf < npl, (nf, npl)
+    assert fused["lnl"] == plain["lnl"]
+    for k in plain["clv"]:
+        assert np.array_equal(fused["clv"][k], plain["clv"][k]), k
+        if k in plain["scaler"]:
+            assert np.array_equal(fused["scaler"][k], plain["scaler"][k]), k
+    if tiny:
+        cherries = [op[0] for op in case.op_batches[0] if op[2] < case.tips and op[5] < case.tips]
+        assert sum(int(plain["scaler"][c].sum()) for c in cherries) > 0
+
+
 def test_cherry_tables_follow_the_matrices(amd_lib, monkeypatch):
     """matrix-pipe groups keep a cherry's table of scaling decisions on the device for as long as its two tip
     matrices stand: near-identity matrices (cherries of two different states are rescaled), then ordinary ones in
