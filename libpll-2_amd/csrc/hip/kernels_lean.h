@@ -69,12 +69,30 @@ __global__ __launch_bounds__(256) void k_partials_lean(const OpPack pack, const 
   {
     double *ML = M + (size_t)(2u * k) * LG::mat, *MR = ML + LG::mat;
     const double *sl = op.lmat + (size_t)k * S * g.SPT, *sr = op.rmat + (size_t)k * S * g.SPT;
-    for (unsigned idx = lane; idx < (LG::rows - 1u) * LD; idx += 64u)
     {
-      const unsigned j = idx / LD, i = idx % LD;
-      const bool in = j < S && i < S;
-      ML[idx] = in ? sl[(size_t)j * g.SPT + i] : 0.0;
-      MR[idx] = in ? sr[(size_t)j * g.SPT + i] : 0.0;
+      // all requests first: a load / wait / write loop made this seven L2 round trips per workgroup
+      constexpr unsigned N = (LG::rows - 1u) * LD, PER = (N + 63u) / 64u;
+      double vl[PER], vr[PER];
+#pragma unroll
+      for (unsigned q = 0; q < PER; ++q)
+      {
+        const unsigned idx = lane + 64u * q, j = idx / LD, i = idx % LD;
+        const bool in = idx < N && j < S && i < S;
+        const size_t off = in ? (size_t)j * g.SPT + i : 0;
+        const double a = sl[off], b = sr[off];
+        vl[q] = in ? a : 0.0;
+        vr[q] = in ? b : 0.0;
+      }
+#pragma unroll
+      for (unsigned q = 0; q < PER; ++q)
+      {
+        const unsigned idx = lane + 64u * q;
+        if (idx < N)
+        {
+          ML[idx] = vl[q];
+          MR[idx] = vr[q];
+        }
+      }
     }
     if (LTIP || RTIP)
       for (unsigned c0 = threadIdx.x; c0 < 256u; c0 += blockDim.x)

@@ -40,6 +40,41 @@
 // column reads of the tip route (address ~ state >> 2) over the banks; the MFMA operand reads (16
 // consecutive doubles of one fragment, broadcast to the four blocks) do not care
 constexpr unsigned kFrag = 17;
+// Staging NM transition matrices of one rate category (PT[j][i], row stride SPT) as MFMA fragments in LDS:
+// frag[ig][jg][kk][ii] = P[4 ig + ii][4 jg + kk] = PT[4 jg + kk][4 ig + ii], zero beyond S. Every thread of the
+// 256 issues ALL its requests (coalesced: thread t takes elements t, t + 256, ...) before the first LDS write - a
+// loop of load / wait / write made this 16 L2 round trips long, a fifth of a 61-state workgroup's time.
+template <int NG, int NM>
+__device__ __forceinline__ void mfma_stage(double *const (&dst)[NM], const double *const (&src)[NM], unsigned S, unsigned SPT)
+{
+  constexpr unsigned W = 4 * NG, N = W * W, PER = (N + 255u) / 256u;
+  double v[NM][PER];
+#pragma unroll
+  for (unsigned q = 0; q < PER; ++q)
+  {
+    const unsigned lin = threadIdx.x + 256u * q, j = lin / W, i = lin % W;
+    const bool in = lin < N && j < S && i < SPT;
+    const size_t off = in ? (size_t)j * SPT + i : 0;
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+    {
+      const double x = src[m][off];
+      v[m][q] = in ? x : 0.0;
+    }
+  }
+#pragma unroll
+  for (unsigned q = 0; q < PER; ++q)
+  {
+    const unsigned lin = threadIdx.x + 256u * q, j = lin / W, i = lin % W;
+    if (lin < N)
+    {
+      const unsigned pos = ((i >> 2) * NG + (j >> 2)) * kFrag + (j & 3u) * 4u + (i & 3u);
+#pragma unroll
+      for (int m = 0; m < NM; ++m) dst[m][pos] = v[m][q];
+    }
+  }
+}
+
 // NG = number of 4-state groups the kernels are compiled for: 16 (33..64 states), 8 (21..32), 5 (17..20: the
 // 20-state protein models - the coefficient delivery is what the matrix pipe is used for there too, the
 // scalar-load-fed FMA contraction of kernels_generic.h reaches a third of the fp64 rate)
@@ -142,18 +177,10 @@ __global__ __launch_bounds__(256, NG > 8 ? 2 : 4) void k_partials_mfma(const OpP
   const unsigned long long full = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
 
   // stage fragments: frag[ig][jg][kk][ii] = P[4ig+ii][4jg+kk] = PT[k][4jg+kk][4ig+ii]
-  for (unsigned idx = threadIdx.x; idx < NG * NG * 16u; idx += 256)
   {
-    const unsigned ii = idx & 3u, kk = (idx >> 2) & 3u, jg = (idx >> 4) % NG, ig = (idx >> 4) / NG;
-    const unsigned j = 4 * jg + kk, i = 4 * ig + ii;
-    double l = 0.0, r = 0.0;
-    if (j < S && i < g.SPT)
-    {
-      l = op.lmat[((size_t)k * S + j) * g.SPT + i];
-      r = op.rmat[((size_t)k * S + j) * g.SPT + i];
-    }
-    PL[(idx >> 4) * kFrag + (idx & 15u)] = l;
-    PR[(idx >> 4) * kFrag + (idx & 15u)] = r;
+    double *const dst[2] = {PL, PR};
+    const double *const src[2] = {op.lmat + (size_t)k * S * g.SPT, op.rmat + (size_t)k * S * g.SPT};
+    mfma_stage<NG, 2>(dst, src, S, g.SPT);
   }
   __syncthreads();
   if (LTIP || RTIP)
@@ -759,18 +786,10 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma_cc_big(const FusePack 
   const unsigned fragoff = row * 4u + (lane & 3u);
   const unsigned long long full = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
   constexpr unsigned kGap = 254u;
-  for (unsigned idx = threadIdx.x; idx < NG * NG * 16u; idx += 256)
   {
-    const unsigned ii = idx & 3u, kk = (idx >> 2) & 3u, jg = (idx >> 4) % NG, ig = (idx >> 4) / NG;
-    const unsigned j = 4 * jg + kk, i = 4 * ig + ii;
-    double l = 0.0, r = 0.0;
-    if (j < S && i < g.SPT)
-    {
-      l = grp.p.lmat[((size_t)k * S + j) * g.SPT + i];
-      r = grp.p.rmat[((size_t)k * S + j) * g.SPT + i];
-    }
-    PL[(idx >> 4) * kFrag + (idx & 15u)] = l;
-    PR[(idx >> 4) * kFrag + (idx & 15u)] = r;
+    double *const dst[2] = {PL, PR};
+    const double *const src[2] = {grp.p.lmat + (size_t)k * S * g.SPT, grp.p.rmat + (size_t)k * S * g.SPT};
+    mfma_stage<NG, 2>(dst, src, S, g.SPT);
   }
   {
     unsigned ci = kCcAmbiguous;
@@ -1031,194 +1050,203 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma_cc_big(const FusePack 
 
 // ------------------------------------------------------------------------------------------------
 // Edge log-likelihood for 33..64 states on the matrix pipe (src/core_likelihood.c:1388-1490 ii,
-// :812-915 ti, :1077-1183 repeats). Same fragments and lane maps as k_partials_mfma: per rate
-// category the workgroup stages the edge's transition matrix in LDS, every wave forms D = P x
-// (child side) for its items of 32 sites with MFMAs (or reads columns / row sums of P for simple
-// tips), dots it with parent_i * pi_i over the 16 parent states a lane owns, and keeps the
-// rate-weighted partial per (item, site group) in registers; after the last rate the four row
-// groups of a site meet through two shuffles and row group 0 finishes the site (scaling undone,
-// invariant share, log, pattern weight). A wave carries up to 4 items per round (their partials
-// wait in LDS between rate categories: the item loop stays rolled, one item's 128 fragment
-// registers at a time); more work per workgroup = more rounds, each re-staging the R matrices.
-constexpr int kEdgeItems = 4;
-
+// :812-915 ti, :1077-1183 repeats). Same fragments and lane maps as k_partials_mfma. One RATE CATEGORY per
+// workgroup (grid = item blocks x R, block b works on rate b % R of item block b / R): it stages the edge's
+// transition matrix of that rate once, every wave forms D = P x (child side) for its items of 32 sites with MFMAs
+// (or reads columns / row sums of P for simple tips), dots it with parent_i * pi_i over the 16 parent states a lane
+// owns and leaves the rate-weighted partial per (rate, row group, site) in HBM. The workgroup that finishes an item
+// block LAST (a ticket per item block) adds the partials up in a fixed order - rates ascending within a row
+// group, then (r0 + r1) + (r2 + r3) - and finishes the sites (scaling undone, invariant share, log, pattern weight).
+// (One workgroup walking all R rates of its items, re-staging the matrix for each, left C5's 20k sites with 157
+// workgroups on 256 CUs and took 65-71 us; the evaluation is 78 MB of reads and 8 us of MFMAs.)
 template <bool CTIP, bool GATHER>
 __global__ __launch_bounds__(256, 2) void k_edge_mfma(const DevEdge e, const GenGeo g,
-                                                      const unsigned long long *__restrict__ tipmap, unsigned rounds, unsigned ipw)
+                                                      const unsigned long long *__restrict__ tipmap, unsigned ipw,
+                                                      double *__restrict__ partials /* [R][4][pstride] */, unsigned pstride,
+                                                      unsigned *__restrict__ tickets /* [item blocks], zero between launches */)
 {
   extern __shared__ double lds[];
-  double *PM = lds;           // [16 ig][16 jg][4 k][4 i]
+  __shared__ unsigned finisher;
+  double *PM = lds;                 // [16 ig][16 jg][4 k][4 i]
   double *RS = lds + kFragArray;    // row sums [64]
-  double *TA = lds + kFragArray + 64 + (size_t)(threadIdx.x >> 6) * (kEdgeItems * 2 * 64) + (threadIdx.x & 63u); // [it][sg][lane] of this wave
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned row = lane >> 4, col = lane & 15u;
   const unsigned S = g.S, R = g.R;
+  const unsigned k = blockIdx.x % R, ib = blockIdx.x / R;
   const unsigned nitems = (e.sites + 31u) / 32u;
   const unsigned fragoff = row * 4u + (lane & 3u);
   const unsigned long long full = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
-  double acc = 0.0;
 
-  for (unsigned rd = 0; rd < rounds; ++rd)
   {
-    const unsigned item0 = ((blockIdx.x * rounds + rd) * 4u + wave) * ipw; // ipw <= kEdgeItems items per wave and round
-    for (int q = 0; q < kEdgeItems * 2; ++q) TA[q * 64] = 0.0;
-
-    for (unsigned k = 0; k < R; ++k)
+    double *const dst[1] = {PM};
+    const double *const src[1] = {e.mat + (size_t)k * S * g.SPT};
+    mfma_stage<16, 1>(dst, src, S, g.SPT);
+  }
+  __syncthreads();
+  if (CTIP)
+  {
+    if (threadIdx.x < 64)
     {
-      __syncthreads(); // the previous matrix is no longer read
-      for (unsigned idx = threadIdx.x; idx < 4096; idx += 256)
-      {
-        const unsigned ii = idx & 3u, kk = (idx >> 2) & 3u, jg = (idx >> 4) & 15u, ig = idx >> 8;
-        const unsigned j = 4 * jg + kk, i = 4 * ig + ii;
-        PM[(idx >> 4) * kFrag + (idx & 15u)] = (j < S && i < g.SPT) ? e.mat[((size_t)k * S + j) * g.SPT + i] : 0.0;
-      }
-      __syncthreads();
-      if (CTIP)
-      {
-        if (threadIdx.x < 64)
-        {
-          const unsigned i = threadIdx.x;
-          double s = 0.0;
-          for (unsigned j = 0; j < S; ++j) s += PM[((i >> 2) * 16 + (j >> 2)) * kFrag + (j & 3u) * 4 + (i & 3u)];
-          RS[i] = s;
-        }
-        __syncthreads();
-      }
-      const unsigned fi = e.fidx[k];
-      const double pinv = e.prop_invar ? e.prop_invar[fi] : 0.0;
-      const double wk = pinv > 0.0 ? e.rate_weights[k] * (1.0 - pinv) : e.rate_weights[k];
-      // pi_i of the 16 parent states this lane owns
-      double pif[16];
-#pragma unroll
-      for (int ig = 0; ig < 16; ++ig) pif[ig] = (4 * ig + row < S) ? e.freqs[(size_t)fi * g.SP + 4 * ig + row] : 0.0;
-
-#pragma unroll 1
-      for (unsigned it = 0; it < ipw; ++it)
-      {
-        const unsigned item = item0 + it;
-        if (item >= nitems) break; // wave-uniform
-        unsigned pe[2], ce[2];
-        unsigned long long cm[2] = {0, 0};
-        double ex[2];
-#pragma unroll
-        for (int sg = 0; sg < 2; ++sg)
-        {
-          const unsigned n = item * 32u + sg * 16u + col;
-          const unsigned nn = n < e.sites ? n : e.sites - 1;
-          pe[sg] = ce[sg] = nn;
-          if (GATHER)
-          {
-            pe[sg] = e.psid ? e.psid[nn] : nn;
-            ce[sg] = e.csid ? e.csid[nn] : nn;
-          }
-          if (CTIP) cm[sg] = tipmap ? tipmap[e.ctip[ce[sg]]] : (unsigned long long)e.ctip[ce[sg]];
-          ex[sg] = 1.0;
-          if (e.per_rate)
-          {
-            unsigned mn = 0xFFFFFFFFu, mine = 0;
-            for (unsigned q = 0; q < R; ++q)
-            {
-              const unsigned rs = (e.pscaler ? e.pscaler[(size_t)pe[sg] * R + q] : 0u) + (e.cscaler ? e.cscaler[(size_t)ce[sg] * R + q] : 0u);
-              mn = min(mn, rs);
-              if (q == k) mine = rs;
-            }
-            const unsigned d = min(mine - mn, PLLGPU_RATE_MAXDIFF);
-            if (d) ex[sg] = minlh(d);
-          }
-        }
-        double D[16][2];
-        const bool simple = CTIP && mfma_simple_tips(cm, full);
-        if (simple)
-        {
-#pragma unroll
-          for (int ig = 0; ig < 16; ++ig)
-#pragma unroll
-            for (int sg = 0; sg < 2; ++sg) D[ig][sg] = mfma_tip_column(PM, RS, cm[sg], full, row, ig);
-        }
-        else
-        {
-          double x[16][2];
-#pragma unroll
-          for (int jg = 0; jg < 16; ++jg)
-#pragma unroll
-            for (int sg = 0; sg < 2; ++sg)
-              x[jg][sg] = CTIP ? mfma_x<true>(nullptr, cm[sg], S, 4 * jg + row)
-                               : mfma_x<false>(e.child + tiled_base(ce[sg], g.tile_sz) + (size_t)k * S * 64, 0, S, 4 * jg + row);
-#pragma unroll
-          for (int ig = 0; ig < 16; ++ig) D[ig][0] = D[ig][1] = 0.0;
-#pragma unroll
-          for (int jg = 0; jg < 16; ++jg)
-          {
-#pragma unroll
-            for (int ig = 0; ig < 16; ++ig)
-            {
-              const double a = PM[(ig * 16 + jg) * kFrag + fragoff];
-              D[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][0], D[ig][0], 0, 0, 0);
-              D[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][1], D[ig][1], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-#pragma unroll
-        for (int sg = 0; sg < 2; ++sg)
-        {
-          const double *pb = e.parent + tiled_base(pe[sg], g.tile_sz) + (size_t)k * S * 64;
-          double tr = 0.0;
-#pragma unroll
-          for (int ig = 0; ig < 16; ++ig)
-          {
-            const unsigned i = 4 * ig + row;
-            const double pv = i < S ? __builtin_nontemporal_load(pb + (size_t)i * 64) : 0.0;
-            tr = fma(pv * pif[ig], D[ig][sg], tr);
-          }
-          TA[(it * 2 + sg) * 64] += wk * (tr * ex[sg]);
-        }
-      }
+      const unsigned i = threadIdx.x;
+      double s = 0.0;
+      for (unsigned j = 0; j < S; ++j) s += PM[((i >> 2) * 16 + (j >> 2)) * kFrag + (j & 3u) * 4 + (i & 3u)];
+      RS[i] = s;
     }
+    __syncthreads();
+  }
+  {
+    const unsigned fi = e.fidx[k];
+    const double pinv = e.prop_invar ? e.prop_invar[fi] : 0.0;
+    const double wk = pinv > 0.0 ? e.rate_weights[k] * (1.0 - pinv) : e.rate_weights[k];
+    // pi_i of the 16 parent states this lane owns
+    double pif[16];
+#pragma unroll
+    for (int ig = 0; ig < 16; ++ig) pif[ig] = (4 * ig + row < S) ? e.freqs[(size_t)fi * g.SP + 4 * ig + row] : 0.0;
+    const unsigned item0 = (ib * 4u + wave) * ipw;
+    double *mine = partials + ((size_t)k * 4u + row) * pstride;
 
-    // the four row groups of a site meet; row group 0 finishes the site
 #pragma unroll 1
     for (unsigned it = 0; it < ipw; ++it)
     {
       const unsigned item = item0 + it;
-      if (item >= nitems) break;
+      if (item >= nitems) break; // wave-uniform
+      unsigned pe[2], ce[2];
+      unsigned long long cm[2] = {0, 0};
+      double ex[2];
 #pragma unroll
       for (int sg = 0; sg < 2; ++sg)
       {
-        double t = TA[(it * 2 + sg) * 64];
-        t += __shfl_xor(t, 16, 64);
-        t += __shfl_xor(t, 32, 64);
         const unsigned n = item * 32u + sg * 16u + col;
-        if (row != 0 || n >= e.sites) continue;
-        unsigned pe = n, ce = n;
+        const unsigned nn = n < e.sites ? n : e.sites - 1;
+        pe[sg] = ce[sg] = nn;
         if (GATHER)
         {
-          pe = e.psid ? e.psid[n] : n;
-          ce = e.csid ? e.csid[n] : n;
+          pe[sg] = e.psid ? e.psid[nn] : nn;
+          ce[sg] = e.csid ? e.csid[nn] : nn;
         }
-        unsigned scal;
+        if (CTIP) cm[sg] = tipmap ? tipmap[e.ctip[ce[sg]]] : (unsigned long long)e.ctip[ce[sg]];
+        ex[sg] = 1.0;
         if (e.per_rate)
         {
-          scal = 0xFFFFFFFFu;
-          for (unsigned q = 0; q < R; ++q)
-            scal = min(scal, (e.pscaler ? e.pscaler[(size_t)pe * R + q] : 0u) + (e.cscaler ? e.cscaler[(size_t)ce * R + q] : 0u));
-        }
-        else
-          scal = (e.pscaler ? e.pscaler[pe] : 0u) + (e.cscaler ? e.cscaler[ce] : 0u);
-        double terminv = 0.0;
-        const int inv = e.invariant ? e.invariant[n] : -1;
-        if (inv >= 0 && e.prop_invar)
+          unsigned mn = 0xFFFFFFFFu, own = 0;
           for (unsigned q = 0; q < R; ++q)
           {
-            const unsigned fi = e.fidx[q];
-            const double pinv = e.prop_invar[fi];
-            if (pinv > 0.0) terminv += e.rate_weights[q] * e.freqs[(size_t)fi * g.SP + inv] * pinv;
+            const unsigned rs = (e.pscaler ? e.pscaler[(size_t)pe[sg] * R + q] : 0u) + (e.cscaler ? e.cscaler[(size_t)ce[sg] * R + q] : 0u);
+            mn = min(mn, rs);
+            if (q == k) own = rs;
           }
-        const double site = finish_site(t, terminv, scal, 0) * (double)e.pattern_weights[n];
-        if (e.persite) e.persite[n] = site;
-        acc += site;
+          const unsigned d = min(own - mn, PLLGPU_RATE_MAXDIFF);
+          if (d) ex[sg] = minlh(d);
+        }
       }
+      double D[16][2];
+      const bool simple = CTIP && mfma_simple_tips(cm, full);
+      if (simple)
+      {
+#pragma unroll
+        for (int ig = 0; ig < 16; ++ig)
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg) D[ig][sg] = mfma_tip_column(PM, RS, cm[sg], full, row, ig);
+      }
+      else
+      {
+        double x[16][2];
+#pragma unroll
+        for (int jg = 0; jg < 16; ++jg)
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg)
+            x[jg][sg] = CTIP ? mfma_x<true>(nullptr, cm[sg], S, 4 * jg + row)
+                             : mfma_x<false>(e.child + tiled_base(ce[sg], g.tile_sz) + (size_t)k * S * 64, 0, S, 4 * jg + row);
+#pragma unroll
+        for (int ig = 0; ig < 16; ++ig) D[ig][0] = D[ig][1] = 0.0;
+#pragma unroll
+        for (int jg = 0; jg < 16; ++jg)
+        {
+#pragma unroll
+          for (int ig = 0; ig < 16; ++ig)
+          {
+            const double a = PM[(ig * 16 + jg) * kFrag + fragoff];
+            D[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][0], D[ig][0], 0, 0, 0);
+            D[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][1], D[ig][1], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg)
+      {
+        const double *pb = e.parent + tiled_base(pe[sg], g.tile_sz) + (size_t)k * S * 64;
+        double tr = 0.0;
+#pragma unroll
+        for (int ig = 0; ig < 16; ++ig)
+        {
+          const unsigned i = 4 * ig + row;
+          const double pv = i < S ? __builtin_nontemporal_load(pb + (size_t)i * 64) : 0.0;
+          tr = fma(pv * pif[ig], D[ig][sg], tr);
+        }
+        const unsigned n = item * 32u + sg * 16u + col;
+        if (n < e.sites) mine[n] = wk * (tr * ex[sg]);
+      }
+    }
+  }
+  // ---- the last workgroup of this item block finishes its sites
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    __threadfence(); // this workgroup's partials before its ticket
+    const unsigned t = __hip_atomic_fetch_add(&tickets[ib], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    finisher = (t == R - 1u) ? 1u : 0u;
+    if (finisher)
+    {
+      __hip_atomic_store(&tickets[ib], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence(); // every workgroup's partials after the last ticket
+    }
+  }
+  __syncthreads();
+  double acc = 0.0;
+  if (finisher)
+  {
+    const unsigned n0 = ib * 4u * ipw * 32u, n1 = min(n0 + 4u * ipw * 32u, e.sites);
+    for (unsigned n = n0 + threadIdx.x; n < n1; n += 256u)
+    {
+      // rates ascending within a row group, then the row groups as the shuffles used to pair them
+      double tr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+      {
+        double t = 0.0;
+        for (unsigned q = 0; q < R; ++q) t += __hip_atomic_load(partials + ((size_t)q * 4u + r) * pstride + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // from L2: other CUs wrote them
+        tr[r] = t;
+      }
+      const double t = (tr[0] + tr[1]) + (tr[2] + tr[3]);
+      unsigned pe = n, ce = n;
+      if (GATHER)
+      {
+        pe = e.psid ? e.psid[n] : n;
+        ce = e.csid ? e.csid[n] : n;
+      }
+      unsigned scal;
+      if (e.per_rate)
+      {
+        scal = 0xFFFFFFFFu;
+        for (unsigned q = 0; q < R; ++q)
+          scal = min(scal, (e.pscaler ? e.pscaler[(size_t)pe * R + q] : 0u) + (e.cscaler ? e.cscaler[(size_t)ce * R + q] : 0u));
+      }
+      else
+        scal = (e.pscaler ? e.pscaler[pe] : 0u) + (e.cscaler ? e.cscaler[ce] : 0u);
+      double terminv = 0.0;
+      const int inv = e.invariant ? e.invariant[n] : -1;
+      if (inv >= 0 && e.prop_invar)
+        for (unsigned q = 0; q < R; ++q)
+        {
+          const unsigned fi = e.fidx[q];
+          const double pinv = e.prop_invar[fi];
+          if (pinv > 0.0) terminv += e.rate_weights[q] * e.freqs[(size_t)fi * g.SP + inv] * pinv;
+        }
+      const double site = finish_site(t, terminv, scal, 0) * (double)e.pattern_weights[n];
+      if (e.persite) e.persite[n] = site;
+      acc += site;
     }
   }
   publish_block_sum(e, wave_sum(acc), 4u);

@@ -110,6 +110,8 @@ struct pllgpu_ctx
   DevBuf<unsigned long long> tipmap;
   bool tipmap_set = false;
   DevBuf<double> pmat, freqs, rate_weights, prop_invar, persite, block_sums;
+  DevBuf<double> edge_partials;   // k_edge_mfma: [rate][row group][site] partial site likelihoods
+  DevBuf<unsigned> edge_tickets;  // ... and the ticket per item block (zero between launches)
   DevBuf<unsigned> counter;
   DevBuf<unsigned char> mfma_flags;      // [op in launch][rate][entry] scaling decisions (kernels_mfma.h)
   DevBuf<double> eigenvals, rates, diag; // derivatives: [rate_matrices][SP], [R], [R][S][4]
@@ -472,6 +474,8 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->tipmap.release();
   c->scratch.release();
   c->pmat.release();
+  c->edge_partials.release();
+  c->edge_tickets.release();
   c->freqs.release();
   c->rate_weights.release();
   c->prop_invar.release();
@@ -1619,18 +1623,26 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
   unsigned blocks, tpw;
   if (c->use_mfma && c->mfma_ng == 16 && !e.is_root)
   {
-    // 33..64 states: P x on the matrix pipe (kernels_mfma.h: k_edge_mfma); 16 items of 32 sites per
-    // workgroup and round
-    const unsigned items = (g.sites + 31) / 32;
-    // small inputs: one item per wave so that every CU gets work; large ones: up to kEdgeItems
-    const unsigned ipw = std::max(1u, std::min((unsigned)kEdgeItems, items / (4u * 512u)));
-    const unsigned per_round = 4u * ipw;
-    unsigned rounds = (items + per_round * 2048u - 1) / (per_round * 2048u);
-    rounds = std::max(1u, rounds);
-    blocks = (items + per_round * rounds - 1) / (per_round * rounds);
-    const size_t lds = (kFragArray + 64 + 4 * kEdgeItems * 2 * 64) * sizeof(double);
+    // 33..64 states: P x on the matrix pipe (kernels_mfma.h: k_edge_mfma), one rate category per workgroup
+    const unsigned items = (g.sites + 31) / 32, R = c->gg.R;
+    // a workgroup's life is a chain of round trips (matrix, child, parent, ticket, partials, block sum: ~30 us at C5's
+    // size) around 3 us of MFMAs per item, and two workgroups fit a CU: ONE round of at most 512 workgroups - C5's 625
+    // items as 628 workgroups of one item per wave took two rounds, 67 us; as 316 of two items per wave 3x us
+    const unsigned max_ib = std::max(1u, 512u / R);
+    const unsigned ipw = std::max(1u, (items + 4u * max_ib - 1) / (4u * max_ib));
+    const unsigned nib = (items + 4u * ipw - 1) / (4u * ipw);
+    blocks = nib * R;
+    const unsigned pstride = (g.sites + 63u) & ~63u;
+    if (c->block_sums.ensure(std::max<size_t>(4096, blocks)) || c->edge_partials.ensure((size_t)R * 4u * pstride)) return PLLGPU_ENOMEM;
+    if (c->edge_tickets.cap < nib)
+    {
+      if (c->edge_tickets.ensure(std::max(1024u, nib))) return PLLGPU_ENOMEM;
+      HIP_TRY(hipMemsetAsync(c->edge_tickets.p, 0, c->edge_tickets.cap * sizeof(unsigned), c->stream));
+    }
+    e.block_sums = c->block_sums.p;
+    const size_t lds = (kFragArray + 64) * sizeof(double);
     const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
-#define EM(CT, GA) hipLaunchKernelGGL((k_edge_mfma<CT, GA>), dim3(blocks), dim3(256), lds, c->stream, e, c->gg, tm, rounds, ipw)
+#define EM(CT, GA) hipLaunchKernelGGL((k_edge_mfma<CT, GA>), dim3(blocks), dim3(256), lds, c->stream, e, c->gg, tm, ipw, c->edge_partials.p, pstride, c->edge_tickets.p)
     if (ctip)
     {
       if (gather) EM(true, true); else EM(true, false);
