@@ -1,4 +1,4 @@
-# usage: exp_pmc2.sh <outdir-name> <kernel substring> -- bench args...   (each counter set under its own timeout)
+# usage: pmc_sets.sh <outdir-name> <kernel substring> -- bench args...   (each counter set under its own timeout)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 NAME=$1; KSUB=$2; shift 3

@@ -16,6 +16,12 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write" 
 find "$O/prof_c2" -name "*kernel_stats.csv" -exec cp {} "$O/c2_kernel_stats.csv" \;
 python3 "$R/tools/pmc_traffic.py" --fetch "$O/pmc_fetch" --write "$O/pmc_write" --kernel 'k_partials_dna_cc<5, 5>' \
   --algorithmic 745600000 --out "$O/traffic_c2.json" --trim "$O/c2_pmc" > /dev/null
+# C3: HBM bytes per launch of the group kernel (the dominant launch of the 20-state step)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc3_fetch" -- python3 "$R/bench.py" --config c3 --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc3_write" -- python3 "$R/bench.py" --config c3 --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1
+python3 "$R/tools/pmc_traffic.py" --fetch "$O/pmc3_fetch" --write "$O/pmc3_write" --kernel 'k_partials_mfma_cc<5>' \
+  --algorithmic 1548800000 --out "$O/traffic_c3.json" --trim "$O/c3_pmc" > /dev/null
+cp "$O/traffic_c3.json" "$R/profiles/traffic_c3.json"   # bench.py's c3 line reads it (only on this box: copy it home with the rest)
 for c in c3 c3r c4 c5; do
   python3 "$R/bench.py" --config $c --steps 10 > "$O/${c}_bench.json" 2> "$O/${c}_bench.err"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$c" -- python3 "$R/bench.py" --config $c --steps 10 --no-cpu > /dev/null 2>&1
@@ -23,5 +29,5 @@ for c in c3 c3r c4 c5; do
 done
 python3 "$R/bench.py" --config c5 --tips states --steps 10 --no-cpu > "$O/c5_codes_bench.json" 2>/dev/null
 python3 "$R/tools/c4_projection.py" --steps 20 > "$O/c4_projection.json" 2> "$O/c4_projection.err"
-rm -rf "$O"/prof_* "$O"/pmc_fetch "$O"/pmc_write
+rm -rf "$O"/prof_* "$O"/pmc_fetch "$O"/pmc_write "$O"/pmc3_fetch "$O"/pmc3_write
 ls -la "$O"
