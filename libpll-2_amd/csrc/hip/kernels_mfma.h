@@ -1186,21 +1186,22 @@ __global__ __launch_bounds__(256, 2) void k_edge_mfma(const DevEdge e, const Gen
           tr = fma(pv * pif[ig], D[ig][sg], tr);
         }
         const unsigned n = item * 32u + sg * 16u + col;
-        if (n < e.sites) mine[n] = wk * (tr * ex[sg]);
+        if (n < e.sites) partial_store(&mine[n], wk * (tr * ex[sg])); // at the coherent level, like the block sums (kernels_common.h)
       }
     }
   }
-  // ---- the last workgroup of this item block finishes its sites
+  // ---- the last workgroup of this item block finishes its sites. The hand-off follows publish_block_sum's rules:
+  // no fences (an agent-scope release writes back the XCD's L2), every wave waits for its own partial stores
+  handoff_before_ticket(e.fenced);
   __syncthreads();
   if (threadIdx.x == 0)
   {
-    __threadfence(); // this workgroup's partials before its ticket
     const unsigned t = __hip_atomic_fetch_add(&tickets[ib], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     finisher = (t == R - 1u) ? 1u : 0u;
     if (finisher)
     {
       __hip_atomic_store(&tickets[ib], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence(); // every workgroup's partials after the last ticket
+      handoff_after_last_ticket(e.fenced);
     }
   }
   __syncthreads();
@@ -1216,7 +1217,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_mfma(const DevEdge e, const Gen
       for (int r = 0; r < 4; ++r)
       {
         double t = 0.0;
-        for (unsigned q = 0; q < R; ++q) t += __hip_atomic_load(partials + ((size_t)q * 4u + r) * pstride + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // from L2: other CUs wrote them
+        for (unsigned q = 0; q < R; ++q) t += partial_load(partials + ((size_t)q * 4u + r) * pstride + n);
         tr[r] = t;
       }
       const double t = (tr[0] + tr[1]) + (tr[2] + tr[3]);
