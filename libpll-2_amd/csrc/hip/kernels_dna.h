@@ -705,6 +705,138 @@ __global__ __launch_bounds__(256) void k_partials_dna_fused(const FusePack pack,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Site repeats, where compression ends: a group = an op P (uncompressed, like its children) whose two children A, B
+// are GATHERING inner x inner ops - uncompressed parents over class-compressed, entry-contiguous children (C4: the 8
+// ops of level 4 over 16 compressed level-3 nodes, and the 4 ops above them). The wave fetches the four compressed
+// children's entries of its 64 sites cooperatively (k_partials_dna's gather path, one child after the other), forms
+// A and B in registers, stores them (streaming: nothing reads them back in this traversal) and forms P from the
+// registers: per site 4 x 128 B gathered + 3 CLVs written instead of 4 x 128 B gathered + 2 written, 2 read, 1 written.
+constexpr int CK_FGG = 6;
+
+struct GGroup
+{
+  DevOp a, b; // the gathering producers (maps, layouts and scalers as for a plain launch)
+  FOp p;      // the op over them; its memory-side fields are not read
+};
+
+constexpr int kMaxGGroups = 12; // 12 * (2 * 112 + 80) B = 3648 B of kernarg
+
+struct GGPack
+{
+  GGroup g[kMaxGGroups];
+};
+
+// one gathering inner x inner op for the lane's site n (clamped nn): its 16 values, scaled, and its scaler words
+__device__ __forceinline__ void dna_gather_op(const DevOp &op, unsigned nn, unsigned lane, double *mine, int scale_mode, double (&v)[4][4],
+                                              uint4 &sc)
+{
+  unsigned le = nn, re = nn;
+  gather_entries(op, nn, le, re);
+  cdouble_p lm = as_const(op.lmat), rm = as_const(op.rmat);
+  const int mode = op.pscaler ? scale_mode : 0;
+  double a[4][4];
+  {
+    double cl[4][4];
+    DnaCoop pl;
+    dna_coop_issue(pl, op.left, le, lane, (op.layout & kStreamLeft) != 0);
+    dna_coop_finish(pl, mine, lane, kAosRow, cl);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dna_matvec(a[k], lm + k * 16, cl[k]);
+  }
+  __builtin_amdgcn_sched_barrier(0); // the right child's fetch starts after the left child's values are dead
+  bool small[4];
+  {
+    double cr[4][4];
+    DnaCoop pr;
+    dna_coop_issue(pr, op.right, re, lane, (op.layout & kStreamRight) != 0);
+    dna_coop_finish(pr, mine, lane, kAosRow, cr);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      double b[4];
+      dna_matvec(b, rm + k * 16, cr[k]);
+      small[k] = true;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+      {
+        v[k][i] = a[k][i] * b[i];
+        small[k] = small[k] && (v[k][i] < PLLGPU_SCALE_THRESHOLD);
+      }
+    }
+  }
+  const uint4 lsc = dna_load_scaler(op.lscaler, le, scale_mode), rsc = dna_load_scaler(op.rscaler, re, scale_mode);
+  dna_scale(v, small, mode, lsc, rsc, sc);
+}
+
+#ifndef DNA_GG_WAVES
+#define DNA_GG_WAVES 2
+#endif
+__global__ __launch_bounds__(256, DNA_GG_WAVES) void k_partials_dna_gg(const GGPack pack, unsigned entries, int scale_mode, unsigned tiles_per_wave,
+                                                                       unsigned stream_parent)
+{
+  __shared__ double transpose[4 * 64 * kAosRow];
+  const GGroup &g = pack.g[blockIdx.y];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned ntiles = (entries + 63u) / 64u;
+  const int mode = g.p.pscaler ? scale_mode : 0;
+  cdouble_p lm = as_const(g.p.lmat), rm = as_const(g.p.rmat);
+  double *mine = transpose + (size_t)wave * 64 * kAosRow;
+
+  for (unsigned t = 0; t < tiles_per_wave; ++t)
+  {
+    const unsigned tile = (blockIdx.x * 4u + wave) * tiles_per_wave + t;
+    if (tile >= ntiles) break; // wave-uniform
+    const unsigned n0 = tile * 64u + lane;
+    const bool valid = n0 < entries;
+    const unsigned n = valid ? n0 : entries - 1;
+    const size_t off = (size_t)tile * kDnaTile + lane;
+    auto put = [&](double *parent, unsigned *pscaler, int m, const double (&x)[4][4], uint4 sc, bool stream) {
+      if (!valid) return;
+      if (m == 1) pscaler[n] = sc.x;
+      if (m == 2) reinterpret_cast<uint4 *>(pscaler)[n] = sc;
+      double *__restrict__ out = parent + off;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+          if (stream)
+            __builtin_nontemporal_store(x[k][i], out + (k * 4 + i) * 64);
+          else
+            out[(k * 4 + i) * 64] = x[k][i];
+        }
+    };
+    double va[4][4], v[4][4];
+    uint4 sca, scb, sc;
+    dna_gather_op(g.a, n, lane, mine, scale_mode, va, sca);
+    put(g.a.parent, g.a.pscaler, g.a.pscaler ? scale_mode : 0, va, sca, true);
+    bool small[4];
+    {
+      double vb[4][4];
+      dna_gather_op(g.b, n, lane, mine, scale_mode, vb, scb);
+      put(g.b.parent, g.b.pscaler, g.b.pscaler ? scale_mode : 0, vb, scb, true);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+      {
+        double a[4], b[4];
+        dna_matvec(a, lm + k * 16, va[k]);
+        dna_matvec(b, rm + k * 16, vb[k]);
+        small[k] = true;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+          v[k][i] = a[i] * b[i];
+          small[k] = small[k] && (v[k][i] < PLLGPU_SCALE_THRESHOLD);
+        }
+      }
+    }
+    dna_scale(v, small, mode, sca, scb, sc);
+    put(g.p.parent, g.p.pscaler, mode, v, sc, stream_parent != 0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Two levels of producers: a child of the group parent P may be an inner x inner op A whose own
 // children are both CHERRIES (tip x tip ops) of the level below - kind CK_FCC. The four tip codes are
 // all such a child needs from HBM; the two cherries and A are formed in registers and stored like

@@ -139,6 +139,7 @@ struct pllgpu_ctx
   bool defer_tail = false;       // DNA: hold the traversal's last ops for one call (k_edge_dna_tail)
   std::vector<pllgpu_op_t> deferred; // ops accepted by pllgpu_update_partials and not launched yet
   bool fuse_cc = false;          // DNA: also two producer levels under a group parent (cherry-cherry children)
+  bool fuse_gg = true;           // DNA + site repeats: groups over two gathering producers (PLL_AMD_NO_FUSE_GG=1: off)
   bool fuse = false;             // DNA: evaluate producer + consumer ops in one kernel (kernels_dna.h)
   bool chains = false;           // DNA: chain plans (k_partials_dna_chain) for dependency-only op lists
   bool any_aos = false;          // a class-compressed CLV exists (site repeats): no chain plans
@@ -293,6 +294,8 @@ static void derive_geometry(pllgpu_ctx *c)
     if (*v && *v != '0') c->fenced = 1;
   if (const char *v = getenv("PLL_AMD_NO_PLAN_CACHE"))
     if (*v && *v != '0') c->plan_cache = false;
+  if (const char *v = getenv("PLL_AMD_NO_FUSE_GG"))
+    if (*v && *v != '0') c->fuse_gg = false;
   c->subtrees = c->dna_fast;
   if (const char *v = getenv("PLL_AMD_NO_SUBTREES")) // A/B switch: the bottom levels under site repeats go level by level
     if (*v && *v != '0') c->subtrees = false;
@@ -945,6 +948,17 @@ static void launch_dna(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigne
 #undef DNA_LAUNCH
 }
 
+// site repeats: (gathering, gathering -> inner x inner) groups (kernels_dna.h: k_partials_dna_gg)
+static void launch_gg(pllgpu_ctx *c, const GGPack &pack, unsigned ngroups, unsigned entries)
+{
+  const unsigned tiles = (entries + 63) / 64;
+  unsigned tpw = (unsigned)(((size_t)tiles * ngroups + 4 * 4096 - 1) / (4 * 4096));
+  tpw = std::max(1u, std::min(tpw, 8u));
+  dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), ngroups), block(256);
+  const unsigned stream_parent = ((size_t)ngroups * entries * 128u > c->stream_parent_bytes) ? 1u : 0u;
+  hipLaunchKernelGGL(k_partials_dna_gg, grid, block, 0, c->stream, pack, entries, c->gg.scale_mode, tpw, stream_parent);
+}
+
 // fp64 MFMA 4x4x4 kernels, matrices staged in LDS (kernels_mfma.h): NG = number of 4-state groups
 template <int NG>
 static int launch_mfma_t(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
@@ -1249,6 +1263,58 @@ static int plan_and_launch_levels(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigne
       }
     groups.swap(keep);
   }
+  // site repeats (4x4 kernels): an uncompressed op over two GATHERING inner x inner ops of the level below, all four
+  // of their children class-compressed, is evaluated with them (kernels_dna.h: k_partials_dna_gg). Such an op may
+  // have been taken as a producer by the op above it; that group gives way (its parent is usually one of the last
+  // level's ops, which then wait for the edge evaluation).
+  if (c->dna_fast && c->fuse && c->fuse_gg)
+  {
+    std::vector<int> producer(c->geo.nodes, -1), pl(count, -1), pr(count, -1);
+    for (unsigned q = 0; q < count; ++q)
+    {
+      if (!(ops[q].flags & PLLGPU_OP_LEFT_TIP)) pl[q] = producer[ops[q].left_clv];
+      if (!(ops[q].flags & PLLGPU_OP_RIGHT_TIP)) pr[q] = producer[ops[q].right_clv];
+      producer[ops[q].parent_clv] = (int)q;
+    }
+    auto gathering = [&](int x, int pscal, const pllgpu_op_t &P, unsigned L) {
+      if (x < 0 || role[x] != 0) return false;
+      const pllgpu_op_t &o = ops[x];
+      return o.level == L && (o.flags & PLLGPU_OP_GATHER) && !(o.flags & (PLLGPU_OP_LEFT_TIP | PLLGPU_OP_RIGHT_TIP)) &&
+             o.parent_entries == P.parent_entries && o.parent_entries == c->geo.sites_alloc && o.parent_scaler == pscal &&
+             c->ids[o.left_clv] && c->ids[o.right_clv];
+    };
+    for (unsigned q = 0; q < count; ++q)
+    {
+      const pllgpu_op_t &P = ops[q];
+      if ((P.flags & (PLLGPU_OP_GATHER | PLLGPU_OP_LEFT_TIP | PLLGPU_OP_RIGHT_TIP)) || P.level == 0 || role[q] == 1) continue;
+      const unsigned L = P.level - 1;
+      if (P.war_level >= (int)L || pl[q] == pr[q]) continue;
+      if (!gathering(pl[q], P.left_scaler, P, L) || !gathering(pr[q], P.right_scaler, P, L)) continue;
+      if (role[q] == 2)
+      {
+        // dissolve the group that took P as a producer
+        for (size_t gi = 0; gi < groups.size(); ++gi)
+          if (groups[gi].a == (int)q || groups[gi].b == (int)q)
+          {
+            role[groups[gi].p] = 0;
+            if (groups[gi].a >= 0) role[groups[gi].a] = 0;
+            if (groups[gi].b >= 0) role[groups[gi].b] = 0;
+            groups.erase(groups.begin() + gi);
+            break;
+          }
+        if (role[q] != 0) continue; // (a cherry-cherry side: leave it)
+      }
+      FusedGroup gq;
+      gq.p = q;
+      gq.a = pl[q];
+      gq.b = pr[q];
+      gq.lk = gq.rk = CK_FGG;
+      gq.level = L;
+      role[q] = 1;
+      role[gq.a] = role[gq.b] = 2;
+      groups.push_back(gq);
+    }
+  }
   // tail fusion: the plain ops of the last level (at most two: the ends of the edge a caller evaluates
   // next) are accepted but not launched yet - role 3
   if (c->defer_tail && count)
@@ -1345,6 +1411,39 @@ static int plan_and_launch_levels(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigne
         ++c->last_launches;
       }
     }
+    // groups over two gathering producers (site repeats)
+    {
+      GGPack gp;
+      unsigned n = 0, entries = 0;
+      auto flushg = [&]() -> int {
+        if (!n) return 0;
+        emit(c, [c, gp, n, entries]() { launch_gg(c, gp, n, entries); });
+        ++c->last_launches;
+        n = 0;
+        return c->launch_rc;
+      };
+      for (size_t gi = g0; gi < gi_sorted; ++gi)
+      {
+        const FusedGroup &gq = groups[gi];
+        if (gq.lk != CK_FGG) continue;
+        const pllgpu_op_t &P = ops[gq.p];
+        if (P.parent_entries == 0) continue;
+        if (n && P.parent_entries != entries)
+          if (int rc = flushg()) return rc;
+        entries = P.parent_entries;
+        GGroup &gg = gp.g[n];
+        memset(&gg, 0, sizeof gg);
+        DevOp d;
+        if (int rc = resolve_op(c, ops[gq.a], gg.a)) return rc;
+        if (int rc = resolve_op(c, ops[gq.b], gg.b)) return rc;
+        if (int rc = resolve_op(c, P, d)) return rc;
+        to_fop(d, gg.p);
+        c->last_bytes += op_traffic(c, ops[gq.a], true, true) + op_traffic(c, ops[gq.b], true, true) + op_traffic(c, P, false, false);
+        if (++n == (unsigned)kMaxGGroups)
+          if (int rc = flushg()) return rc;
+      }
+      if (int rc = flushg()) return rc;
+    }
     for (int lk = 0; lk <= CK_FII; ++lk)
       for (int rk = lk; rk <= CK_FII; ++rk)
       {
@@ -1372,7 +1471,7 @@ static int plan_and_launch_levels(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigne
         for (size_t gi = g0; gi < gi_sorted; ++gi)
         {
           FusedGroup g = groups[gi];
-          if (g.lk == CK_FCC || g.rk == CK_FCC) continue; // launched above
+          if (g.lk == CK_FCC || g.rk == CK_FCC || g.lk == CK_FGG) continue; // launched above
           const bool swap = g.lk > g.rk; // canonical order: the "smaller" kind on the left
           if ((swap ? g.rk : g.lk) != lk || (swap ? g.lk : g.rk) != rk) continue;
           const pllgpu_op_t &P = ops[g.p];
