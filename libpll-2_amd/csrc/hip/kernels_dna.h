@@ -769,7 +769,7 @@ __device__ __forceinline__ void dna_gather_op(const DevOp &op, unsigned nn, unsi
 }
 
 #ifndef DNA_GG_WAVES
-#define DNA_GG_WAVES 2
+#define DNA_GG_WAVES 3
 #endif
 __global__ __launch_bounds__(256, DNA_GG_WAVES) void k_partials_dna_gg(const GGPack pack, unsigned entries, int scale_mode, unsigned tiles_per_wave,
                                                                        unsigned stream_parent)

@@ -136,3 +136,40 @@ def test_tip_rooted_subtrees_are_bit_identical(amd_lib, monkeypatch, kw):
         if k in plain["scaler"]:
             assert np.array_equal(fast["scaler"][k], plain["scaler"][k]), k
     assert_results_match(fast, O.run_case(case), what="subtrees")
+
+
+@pytest.mark.parametrize("kw", [dict(tips=128, sites=20000, mutate_pct=30, seed=41),                                   # C4's shape: levels 4+5 in groups, level 6 inside the edge kernel
+                                dict(tips=64, sites=3000, mutate_pct=40, seed=42, attributes=api.RATE_SCALERS),
+                                dict(tips=48, sites=2500, tree="random", mutate_pct=35, seed=43),
+                                dict(tips=300, sites=900, tree="caterpillar", mutate_pct=20, seed=44, brlen_scale=4),    # scaling above the groups
+                                dict(tips=32, sites=1111, mutate_pct=50, seed=45, ambiguity_pct=10)],
+                         ids=lambda k: "t%d-n%d-%s" % (k["tips"], k["sites"], k.get("tree", "balanced")))
+def test_groups_over_gathering_producers_are_bit_identical(amd_lib, monkeypatch, kw):
+    """site repeats, where compression ends: an uncompressed op over two gathering inner x inner ops is evaluated with
+    them (k_partials_dna_gg) - every CLV, scaler vector and the log-likelihood equal, bit for bit, what the launches
+    per level give (PLL_AMD_NO_FUSE_GG=1), and agree with the oracle"""
+    from compare import assert_results_match
+    from oracle import oracle as O
+    kw = dict(kw)
+    attrs = api.SITE_REPEATS | kw.pop("attributes", 0)
+    case = W.make_case("gg", 4, attributes=attrs, **kw)
+    fused = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        nf = amd_lib.pll_gpu_last_launch_count(s.p)
+        s.update_partials(update_repeats=0)                 # the cached plan
+        again = s.edge_lnl(case.edges[0], persite=False)[0]
+    monkeypatch.setenv("PLL_AMD_NO_FUSE_GG", "1")
+    plain = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        npl = amd_lib.pll_gpu_last_launch_count(s.p)
+    assert nf <= npl
+    if kw["tips"] == 128:
+        assert nf < npl
+    assert fused["lnl"] == plain["lnl"] and again == plain["lnl"][0]
+    for k in plain["clv"]:
+        assert np.array_equal(fused["clv"][k], plain["clv"][k]), k
+        if k in plain["scaler"]:
+            assert np.array_equal(fused["scaler"][k], plain["scaler"][k]), k
+    assert_results_match(fused, O.run_case(case), what="gather groups")
