@@ -150,6 +150,26 @@ __device__ __forceinline__ double mfma_tip_column(const double *__restrict__ fra
   return *p;
 }
 
+// The same with the address formed ONCE per (tip, site): where the lane's column starts in the fragment array; state
+// group ig is then NG * kFrag doubles further on - an immediate offset. The row sums a full gap stands for sit in the
+// fragments' padding slots ((ig, jg = row) slot 16: mfma_rowsums_into_padding), so both cases share that stride.
+// (With the column / row-sum choice and the address arithmetic inside the loops over ig the tip x tip launch of C5
+// issued 1270 vector-ALU instructions per item of 32 sites and was bound by instruction issue, not by its stores.)
+template <int NG>
+__device__ __forceinline__ const double *mfma_tip_column_base(const double *__restrict__ frag, unsigned long long m, unsigned long long full,
+                                                              unsigned row)
+{
+  const unsigned code = (unsigned)__ffsll((long long)m) - 1u;
+  return m == full ? frag + row * kFrag + 16u : frag + (code >> 2) * kFrag + (code & 3u) * 4u + row;
+}
+
+template <int NG>
+__device__ __forceinline__ void mfma_rowsums_into_padding(double *__restrict__ frag, const double *__restrict__ rowsum)
+{
+  // frag[(ig * NG + r) * kFrag + 16] = rowsum[4 ig + r]
+  for (unsigned t = threadIdx.x; t < 4u * NG; t += 256u) frag[((t >> 2) * NG + (t & 3u)) * kFrag + 16u] = rowsum[t];
+}
+
 template <int NG, bool LTIP, bool RTIP, bool GATHER>
 __global__ __launch_bounds__(256, NG > 8 ? 2 : 4) void k_partials_mfma(const OpPack pack, const GenGeo g,
                                                           const unsigned long long *__restrict__ tipmap,
@@ -195,6 +215,9 @@ __global__ __launch_bounds__(256, NG > 8 ? 2 : 4) void k_partials_mfma(const OpP
       RS[threadIdx.x] = s;
     }
     __syncthreads();
+    mfma_rowsums_into_padding<NG>(PL, RS);
+    mfma_rowsums_into_padding<NG>(PR, RS + 4 * NG);
+    __syncthreads();
   }
 
   const unsigned item0 = (blockIdx.x * 4u + wave) * items_per_wave;
@@ -224,10 +247,13 @@ __global__ __launch_bounds__(256, NG > 8 ? 2 : 4) void k_partials_mfma(const OpP
     const bool lsimple = LTIP && mfma_simple_tips(cur.lm, full);
     if (lsimple)
     {
+      const double *c0 = mfma_tip_column_base<NG>(PL, cur.lm[0], full, row), *c1 = mfma_tip_column_base<NG>(PL, cur.lm[1], full, row);
 #pragma unroll
       for (int ig = 0; ig < NG; ++ig)
-#pragma unroll
-        for (int sg = 0; sg < 2; ++sg) DL[ig][sg] = mfma_tip_column<NG>(PL, RS, cur.lm[sg], full, row, ig);
+      {
+        DL[ig][0] = c0[ig * NG * kFrag];
+        DL[ig][1] = c1[ig * NG * kFrag];
+      }
     }
     else
     {
@@ -264,6 +290,7 @@ __global__ __launch_bounds__(256, NG > 8 ? 2 : 4) void k_partials_mfma(const OpP
       pb[sg] = op.parent + (size_t)(cur.e[sg] >> 6) * g.tile_sz + (cur.e[sg] & 63u) + (size_t)k * S * 64;
     if (rsimple)
     {
+      const double *rc[2] = {mfma_tip_column_base<NG>(PR, cur.rm[0], full, row), mfma_tip_column_base<NG>(PR, cur.rm[1], full, row)};
 #pragma unroll
       for (int ig = 0; ig < NG; ++ig)
       {
@@ -273,7 +300,7 @@ __global__ __launch_bounds__(256, NG > 8 ? 2 : 4) void k_partials_mfma(const OpP
 #pragma unroll
           for (int sg = 0; sg < 2; ++sg)
           {
-            const double v = DL[ig][sg] * mfma_tip_column<NG>(PR, RS + 4 * NG, cur.rm[sg], full, row, ig);
+            const double v = DL[ig][sg] * rc[sg][ig * NG * kFrag];
             small[sg] = small[sg] && (v < PLLGPU_SCALE_THRESHOLD);
             if (cur.valid[sg]) pb[sg][(size_t)i * 64] = v;
           }
@@ -1094,6 +1121,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_mfma(const DevEdge e, const Gen
       RS[i] = s;
     }
     __syncthreads();
+    mfma_rowsums_into_padding<16>(PM, RS);
+    __syncthreads();
   }
   {
     const unsigned fi = e.fidx[k];
@@ -1144,10 +1173,13 @@ __global__ __launch_bounds__(256, 2) void k_edge_mfma(const DevEdge e, const Gen
       const bool simple = CTIP && mfma_simple_tips(cm, full);
       if (simple)
       {
+        const double *c0 = mfma_tip_column_base<16>(PM, cm[0], full, row), *c1 = mfma_tip_column_base<16>(PM, cm[1], full, row);
 #pragma unroll
         for (int ig = 0; ig < 16; ++ig)
-#pragma unroll
-          for (int sg = 0; sg < 2; ++sg) D[ig][sg] = mfma_tip_column(PM, RS, cm[sg], full, row, ig);
+        {
+          D[ig][0] = c0[ig * 16 * kFrag];
+          D[ig][1] = c1[ig * 16 * kFrag];
+        }
       }
       else
       {
