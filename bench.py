@@ -435,7 +435,9 @@ def roofline_leg(args, cfg, lib, api, runner, reps=20):
     if os.path.exists(tfile) and not args.pattern_tip and not args.sites and not args.taxa and args.tree == "balanced" and not args.tips:
         traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")  # PMC-derived HBM bytes per launch of the same command (profiles/README.md)
     mfma = cfg["states"] > 32 and not os.environ.get("PLL_AMD_NO_MFMA", "0").strip("0")
-    kernel = {4: "k_partials_dna_cc<5,5>%.0s" if cc else "k_partials_dna_fused<4,4>%.0s" if fused else "k_partials_dna<false,false,%s>",
+    gg = cfg["states"] == 4 and cfg.get("repeats") and not os.environ.get("PLL_AMD_NO_FUSE_GG", "0").strip("0")
+    kernel = {4: "k_partials_dna_cc<5,5>%.0s" if cc else "k_partials_dna_fused<4,4>%.0s" if fused else
+                 "k_partials_dna<false,false,true>%.0s (compressed levels) + k_partials_dna_gg (where compression ends)" if gg else "k_partials_dna<false,false,%s>",
               20: "k_partials_mfma_cc<5>%.0s" if grouped else
                   ("k_partials_lean<5,false,false,true>%.0s (gathering launches) + k_partials_tiled<20,false,false,false>"
                    if cfg.get("repeats") and not os.environ.get("PLL_AMD_NO_LEAN", "0").strip("0") else "k_partials_tiled<20,false,false,%s>"),
