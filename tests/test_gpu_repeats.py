@@ -173,3 +173,33 @@ def test_groups_over_gathering_producers_are_bit_identical(amd_lib, monkeypatch,
         if k in plain["scaler"]:
             assert np.array_equal(fused["scaler"][k], plain["scaler"][k]), k
     assert_results_match(fused, O.run_case(case), what="gather groups")
+
+
+@pytest.mark.parametrize("kw", [dict(states=20, tips=32, sites=2000, mutate_pct=3, seed=51),
+                                dict(states=20, tips=32, sites=1999, mutate_pct=3, seed=52, rate_cats=1),
+                                dict(states=20, tips=16, sites=777, mutate_pct=5, seed=53, rate_cats=2, attributes=api.RATE_SCALERS),
+                                dict(states=20, tips=24, sites=1500, mutate_pct=4, seed=54, rate_cats=3, tree="random"),
+                                dict(states=17, tips=16, sites=900, mutate_pct=4, seed=55),
+                                dict(states=19, tips=16, sites=333, mutate_pct=6, seed=56, ambiguity_pct=10, partial_pct=5),
+                                dict(states=20, tips=150, sites=400, mutate_pct=30, seed=57, tree="caterpillar", brlen_scale=6),  # scaling, per site: the LDS exchange
+                                dict(states=20, tips=150, sites=400, mutate_pct=30, seed=58, tree="caterpillar", brlen_scale=6, attributes=api.RATE_SCALERS)],
+                         ids=lambda k: "s%d-t%d-n%d-r%d" % (k["states"], k["tips"], k["sites"], k.get("rate_cats", 4)))
+def test_matrix_pipe_gather_kernel_against_the_fma_kernel(amd_lib, monkeypatch, kw):
+    """17..20 states under site repeats: the gathering launches run on the matrix pipe (k_partials_lean) - class maps
+    and scaler vectors equal those of the FMA kernels (PLL_AMD_NO_LEAN=1), CLVs and log-likelihood agree within the
+    tolerance (the two pipes sum a contraction in different orders) and with the oracle"""
+    from compare import assert_results_match
+    from oracle import oracle as O
+    kw = dict(kw)
+    attrs = api.SITE_REPEATS | kw.pop("attributes", 0)
+    case = W.make_case("lean", attributes=attrs, **kw)
+    lean = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    monkeypatch.setenv("PLL_AMD_NO_LEAN", "1")
+    fma = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    exp = O.run_case(case)
+    assert_results_match(lean, exp, what="lean")
+    assert_results_match(fma, exp, what="fma")
+    for k in fma["scaler"]:
+        assert np.array_equal(lean["scaler"][k], fma["scaler"][k]), k
+    if "caterpillar" == kw.get("tree"):
+        assert sum(int(v.sum()) for v in fma["scaler"].values()) > 0  # the case does rescale
