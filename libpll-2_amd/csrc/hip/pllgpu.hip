@@ -135,6 +135,7 @@ struct pllgpu_ctx
   double last_bytes = 0.0;       // algorithmic HBM bytes of the last update_partials call
   bool no_tip_columns = false;   // PLL_AMD_NO_TIP_COLUMNS=1: tips always through the FMA contraction
   bool no_par_lds = false;       // PLL_AMD_NO_PARENT_LDS=1 (A/B): entry-contiguous parents stored 8 bytes per lane
+  bool no_coop_fetch = false;    // PLL_AMD_NO_COOP_FETCH=1 (A/B): the FMA kernels' entry-contiguous children fetched per lane
   size_t stream_parent_bytes = (size_t)256 << 20; // PLL_AMD_STREAM_PARENT_MB overrides (experiments)
   bool defer_tail = false;       // DNA: hold the traversal's last ops for one call (k_edge_dna_tail)
   std::vector<pllgpu_op_t> deferred; // ops accepted by pllgpu_update_partials and not launched yet
@@ -277,6 +278,8 @@ static void derive_geometry(pllgpu_ctx *c)
     if (*v && *v != '0') c->no_tip_columns = true;
   if (const char *v = getenv("PLL_AMD_NO_PARENT_LDS"))
     if (*v && *v != '0') c->no_par_lds = true;
+  if (const char *v = getenv("PLL_AMD_NO_COOP_FETCH"))
+    if (*v && *v != '0') c->no_coop_fetch = true;
   c->defer_tail = c->dna_fast;
   if (const char *v = getenv("PLL_AMD_NO_TAIL_FUSION"))
     if (*v && *v != '0') c->defer_tail = false;
@@ -830,8 +833,7 @@ static void launch_generic(pllgpu_ctx *c, const OpPack &pack, unsigned nops, uns
   // and entry-contiguous children arrive through it, SP / 2 lanes per (entry, rate)
   bool any_aos = false;
   for (unsigned i = 0; i < nops; ++i) any_aos = any_aos || (pack.ops[i].layout & (kAosParent | kAosLeft | kAosRight));
-  static const bool no_coop = getenv("PLL_AMD_NO_COOP_FETCH") && atoi(getenv("PLL_AMD_NO_COOP_FETCH")) != 0;
-  const unsigned par_lds = (gather && any_aos && c->gg.SP % 4u == 0 && (ICH != 20 || c->gg.SP == 20u) && !c->no_par_lds) ? (no_coop ? 2u : 1u) : 0u;
+  const unsigned par_lds = (gather && any_aos && c->gg.SP % 4u == 0 && (ICH != 20 || c->gg.SP == 20u) && !c->no_par_lds) ? (c->no_coop_fetch ? 2u : 1u) : 0u;
   if (par_lds) lds += (size_t)nw * 64u * (c->gg.SP + 2u) * sizeof(double);
 
   // staged tip matrices are shared by the tiles of a workgroup: several tiles each, as long as
