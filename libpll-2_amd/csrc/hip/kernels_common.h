@@ -75,6 +75,15 @@ struct GenGeo
   int scale_mode;     // 0 none, 1 per site, 2 per rate
 };
 
+// Workgroup barrier for an exchange through LDS in the middle of a kernel's loop: wait for the wave's own LDS
+// accesses, then s_barrier. __syncthreads() carries workgroup-scope release / acquire semantics for GLOBAL memory
+// too, i.e. s_waitcnt vmcnt(0): every such barrier drained the wave's prefetched loads and its stores in flight -
+// three per item in k_partials_lean3 made an item 19 us long around 2 us of MFMAs.
+__device__ __forceinline__ void lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // one edge / root evaluation
 struct DevEdge
 {

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
 
     if (mode == 1)
     {
-      __syncthreads();
+      lds_barrier(); // the flags only: the tile's stores stay in flight
       bool site_small = true;
       for (unsigned k = 0; k < g.R; ++k) site_small = site_small && flags[k][lane];
       if (valid)
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
           for (unsigned k = wave; k < g.R; k += nw) rescale_rate(k);
         if (wave == 0) op.pscaler[n] = below + (site_small ? 1u : 0u);
       }
-      __syncthreads(); // flags[] is reused by the next tile
+      lds_barrier(); // flags[] is reused by the next tile
     }
   }
 }

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void k_partials_lean(const OpPack pack, const 
           fl[k * 32u + 2u * col] = scale[0] ? 1 : 0;
           fl[k * 32u + 2u * col + 1u] = scale[1] ? 1 : 0;
         }
-        __syncthreads();
+        lds_barrier(); // (not __syncthreads(): that would wait for the loads and stores in flight as well)
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg)
         {
@@ -415,5 +415,237 @@ __global__ __launch_bounds__(256) void k_partials_lean(const OpPack pack, const 
     cur = nxt;
     nxt = nn2;
     if (has_next) oc = on;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (inner x inner, inner x inner -> inner x inner) groups of the same shapes: an op P whose two children A, B are
+// produced by the same call is evaluated with them - four CLVs read, three written per site instead of six and three.
+// What kept such groups from the 17..32-state kernels so far: P is formed from the RESCALED A and B, and whether an
+// entry of A is rescaled depends on every rate category - here all rates of an item sit in one workgroup and meet in
+// LDS (one barrier per op). D and B operands share their lane map, so A and B go from the accumulators straight into
+// P's MFMAs. LDS: six matrices x R rates as stored (20 x 20), 77 KB for four rates: two workgroups per CU.
+template <int NG>
+__global__ __launch_bounds__(256, 2) void k_partials_lean3(const FusePack pack, const GenGeo g, unsigned entries, unsigned items_per_block)
+{
+  constexpr unsigned LD = 4 * NG, MAT = LD * LD;
+  typedef double __attribute__((ext_vector_type(2))) double2v;
+  extern __shared__ double lds[];
+  const unsigned R = g.R, S = g.S;
+  double *M = lds;                                                                  // [R][6][LD][LD]: a.l a.r b.l b.r p.l p.r
+  unsigned char *FL = reinterpret_cast<unsigned char *>(lds + (size_t)R * 6u * MAT); // [3 ops][2][R][32]
+
+  const FGroup &grp = pack.g[blockIdx.y];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave = rate category
+  const unsigned row = lane >> 4, col = lane & 15u;
+  const unsigned nitems = (entries + 31u) / 32u;
+  const unsigned item_first = blockIdx.x * items_per_block;
+  if (item_first >= nitems) return; // whole workgroup
+  const unsigned item_end = min(item_first + items_per_block, nitems);
+  {
+    const double *src[6] = {grp.a.lmat, grp.a.rmat, grp.b.lmat, grp.b.rmat, grp.p.lmat, grp.p.rmat};
+    constexpr unsigned PER = (MAT + 63u) / 64u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) // three matrices at a time: all their requests first
+    {
+      double v[3][PER];
+#pragma unroll
+      for (unsigned q = 0; q < PER; ++q)
+      {
+        const unsigned idx = lane + 64u * q, j = idx / LD, i = idx % LD;
+        const bool in = idx < MAT && j < S && i < S;
+        const size_t off = in ? ((size_t)k * S + j) * g.SPT + i : 0;
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+        {
+          const double x = src[3 * h + m][off];
+          v[m][q] = in ? x : 0.0;
+        }
+      }
+#pragma unroll
+      for (unsigned q = 0; q < PER; ++q)
+      {
+        const unsigned idx = lane + 64u * q;
+        if (idx < MAT)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) M[((size_t)k * 6u + 3 * h + m) * MAT + idx] = v[m][q];
+      }
+    }
+  }
+  __syncthreads();
+  const double *Mk = M + (size_t)k * 6u * MAT;
+  const unsigned afrag = row * LD + (lane & 3u);
+  const unsigned lane_off = row * 64u + 2u * col;
+  const FOp *fo[3] = {&grp.a, &grp.b, &grp.p};
+  int mode[3];
+#pragma unroll
+  for (int o = 0; o < 3; ++o) mode[o] = fo[o]->pscaler ? g.scale_mode : 0;
+
+  struct Kids
+  {
+    double x[4][NG][2]; // a.left a.right b.left b.right: the lane's states of its two entries
+    unsigned below[2][2]; // [a, b][entry]: the scaler entries of the producers' children, summed
+  };
+  // Requested one item ahead, scaler entries first: waits for vector memory are in issue order, so a scaler word
+  // fetched after the next item's 20 CLV requests would make its user wait for all of them - no prefetch at all.
+  auto request = [&](unsigned item, Kids &kd) {
+    {
+      const unsigned f0 = min(item * 32u + 2u * col, entries - 1u), f1 = min(item * 32u + 2u * col + 1u, entries - 1u);
+      const unsigned fe[2] = {f0, f1};
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+      {
+        const FOp &op = o ? grp.b : grp.a;
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+        {
+          unsigned b = 0u;
+          if (mode[o] == 1) b = (op.lscaler ? op.lscaler[fe[sg]] : 0u) + (op.rscaler ? op.rscaler[fe[sg]] : 0u);
+          if (mode[o] == 2) b = (op.lscaler ? op.lscaler[(size_t)fe[sg] * R + k] : 0u) + (op.rscaler ? op.rscaler[(size_t)fe[sg] * R + k] : 0u);
+          kd.below[o][sg] = b;
+        }
+      }
+    }
+    const double *cl[4] = {grp.a.left, grp.a.right, grp.b.left, grp.b.right};
+    const size_t uo = (size_t)(item >> 1) * g.tile_sz + (size_t)k * S * 64 + (item & 1u) * 32u + 2u * col;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int jg = 0; jg < NG; ++jg)
+      {
+        const unsigned j = min(4u * jg + row, S - 1u);
+        const double2v w = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(cl[c] + uo + (size_t)j * 64u));
+        kd.x[c][jg][0] = w.x;
+        kd.x[c][jg][1] = w.y;
+      }
+  };
+  auto contract = [&](const double *Mx, const double (&x)[NG][2], double (&d)[NG][2]) {
+#pragma unroll
+    for (int ig = 0; ig < NG; ++ig) d[ig][0] = d[ig][1] = 0.0;
+#pragma unroll
+    for (int jg = 0; jg < NG; ++jg)
+#pragma unroll
+      for (int ig = 0; ig < NG; ++ig)
+      {
+        const double a = Mx[afrag + 4 * jg * LD + 4 * ig];
+        d[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][0], d[ig][0], 0, 0, 0);
+        d[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][1], d[ig][1], 0, 0, 0);
+      }
+  };
+
+  Kids cur;
+  request(item_first, cur);
+  unsigned buf = 0;
+  for (unsigned item = item_first; item < item_end; ++item)
+  {
+    const bool has_next = item + 1u < item_end;
+    Kids nxt;
+    if (has_next) request(item + 1u, nxt);
+    const unsigned e0 = item * 32u + 2u * col;
+    const bool valid[2] = {e0 < entries, e0 + 1u < entries};
+    unsigned count[2][2] = {{0u, 0u}, {0u, 0u}}; // [a, b][entry]: the producers' scaler entries, what P's build on
+
+    // one op: v = D_left o D_right, the scaling decision (all rates, through LDS), the scaler entry, the store
+    auto finish = [&](int o, double (&v)[NG][2], const double (&dr)[NG][2], const unsigned (&below)[2], unsigned (&out)[2], bool stream) {
+      bool small[2] = {true, true};
+#pragma unroll
+      for (int ig = 0; ig < NG; ++ig)
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+        {
+          v[ig][sg] *= dr[ig][sg];
+          if (4u * ig + row < S) small[sg] = small[sg] && (v[ig][sg] < PLLGPU_SCALE_THRESHOLD);
+        }
+      const FOp &op = *fo[o];
+      out[0] = out[1] = 0u;
+      if (mode[o])
+      {
+        bool scale[2];
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+        {
+          int sm = small[sg] ? 1 : 0; // an entry's states are spread over the four row groups of the wave
+          sm &= __shfl_xor(sm, 16, 64);
+          sm &= __shfl_xor(sm, 32, 64);
+          scale[sg] = sm != 0;
+        }
+        if (mode[o] == 1)
+        {
+          unsigned char *fl = FL + ((size_t)o * 2u + buf) * R * 32u;
+          if (row == 0)
+          {
+            fl[k * 32u + 2u * col] = scale[0] ? 1 : 0;
+            fl[k * 32u + 2u * col + 1u] = scale[1] ? 1 : 0;
+          }
+          lds_barrier(); // (not __syncthreads(): that would wait for the loads and stores in flight as well)
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg)
+          {
+            bool all = true;
+            for (unsigned kk = 0; kk < R; ++kk) all = all && fl[kk * 32u + 2u * col + sg];
+            scale[sg] = all;
+            out[sg] = below[sg] + (all ? 1u : 0u);
+          }
+          if (k == 0 && row == 0)
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg)
+              if (valid[sg]) op.pscaler[e0 + sg] = out[sg];
+        }
+        else
+        {
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg) out[sg] = below[sg] + (scale[sg] ? 1u : 0u);
+          if (row == 0)
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg)
+              if (valid[sg]) op.pscaler[(size_t)(e0 + sg) * R + k] = out[sg];
+        }
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+          if (scale[sg])
+          {
+#pragma unroll
+            for (int ig = 0; ig < NG; ++ig) v[ig][sg] *= PLLGPU_SCALE_FACTOR;
+          }
+      }
+      double *ub = op.parent + (size_t)(item >> 1) * g.tile_sz + (size_t)k * S * 64 + (item & 1u) * 32u; // wave-uniform
+#pragma unroll
+      for (int ig = 0; ig < NG; ++ig)
+        if (4u * ig + row < S)
+        {
+          double *q = ub + (lane_off + 256u * ig);
+          if (valid[1])
+          {
+            double2v w;
+            w.x = v[ig][0];
+            w.y = v[ig][1];
+            if (stream)
+              __builtin_nontemporal_store(w, reinterpret_cast<double2v *>(q));
+            else
+              *reinterpret_cast<double2v *>(q) = w;
+          }
+          else if (valid[0])
+            q[0] = v[ig][0];
+        }
+    };
+    const unsigned ba[2] = {cur.below[0][0], cur.below[0][1]}, bb[2] = {cur.below[1][0], cur.below[1][1]};
+
+    double va[NG][2], vb[NG][2], dr[NG][2];
+    contract(Mk + 0 * MAT, cur.x[0], va);
+    contract(Mk + 1 * MAT, cur.x[1], dr);
+    finish(0, va, dr, ba, count[0], true);
+    contract(Mk + 2 * MAT, cur.x[2], vb);
+    contract(Mk + 3 * MAT, cur.x[3], dr);
+    finish(1, vb, dr, bb, count[1], true);
+    // P from the registers; its children's scaler entries are the producers' (a producer without a scaler buffer: 0)
+    unsigned bp[2] = {(mode[0] ? count[0][0] : 0u) + (mode[1] ? count[1][0] : 0u), (mode[0] ? count[0][1] : 0u) + (mode[1] ? count[1][1] : 0u)};
+    double vp[NG][2];
+    contract(Mk + 4 * MAT, va, vp);
+    contract(Mk + 5 * MAT, vb, dr);
+    unsigned cp[2];
+    finish(2, vp, dr, bp, cp, false);
+    buf ^= 1u;
+    if (has_next) cur = nxt;
   }
 }

@@ -171,6 +171,7 @@ struct pllgpu_ctx
   bool generic_aos = true;          // PLL_AMD_NO_GENERIC_AOS=1: compressed nodes of non-4x4 shapes stay tiled (A/B)
   bool lean = false;                // 17..20 states, <= 4 rates: the level launches on the matrix pipe (kernels_lean.h)
   bool lean_plain = false;          // ... also the ones that do not gather (PLL_AMD_LEAN_PLAIN=1)
+  bool lean_groups = false;         // ... and (inner x inner, inner x inner -> inner x inner) groups (k_partials_lean3; opt-in)
   bool fuse_mfma = false;           // 17..32 states on the matrix pipe: the same groups (kernels_mfma.h: k_partials_mfma_cc)
   bool fuse_generic = false;        // FMA-path shapes: (tip x tip, tip x tip -> inner x inner) groups (kernels_generic.h: k_partials_tiled_cc)
   bool subtrees = false;            // DNA + site repeats: all-tip subtrees straight from the tip codes (subtree_plan.h)
@@ -341,6 +342,12 @@ static void derive_geometry(pllgpu_ctx *c)
     if (*v && *v != '0') c->lean = false;
   if (const char *v = getenv("PLL_AMD_LEAN_PLAIN"))
     c->lean_plain = *v && *v != '0';
+  // OPT-IN (PLL_AMD_LEAN_GROUPS=1): bit-compatible scaling decisions and one launch less, but slower than the two level
+  // launches it replaces (C3 levels 3 + 4: 290 us against 221) - 77 KB of matrices leave room for two workgroups per CU,
+  // whose four waves load, multiply and store in lockstep (a barrier per op): reads and writes take turns
+  c->lean_groups = false;
+  if (const char *v = getenv("PLL_AMD_LEAN_GROUPS"))
+    c->lean_groups = c->lean && groups && *v && *v != '0';
   c->pm_stride = (size_t)g.rate_cats * g.states * gg.SPT;
   c->span = g.rate_cats * g.states_padded;
 }
@@ -1188,6 +1195,21 @@ static bool lean_serves(const pllgpu_ctx *c, const OpPack &pack, unsigned nops, 
   return true;
 }
 
+// (inner x inner, inner x inner -> inner x inner) groups of the 17..20-state shapes (kernels_lean.h: k_partials_lean3)
+static int launch_lean3(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries)
+{
+  const unsigned R = c->gg.R;
+  const unsigned items = (entries + 31) / 32;
+  unsigned ipb = (unsigned)(((size_t)items * ngroups) / 2048u);
+  ipb = std::max(2u, std::min(ipb, 16u));
+  if (const char *ev = getenv("PLL_AMD_LEAN_IPB")) ipb = std::max(1, atoi(ev));
+  dim3 grid((items + ipb - 1) / ipb, ngroups), block(64u * R);
+  const size_t lds = (size_t)R * 6u * 400u * sizeof(double) + 3u * 2u * R * 32u;
+  raise_lds_limit((const void *)k_partials_lean3<5>, c->device, lds);
+  hipLaunchKernelGGL((k_partials_lean3<5>), grid, block, lds, c->stream, pack, c->gg, entries, ipb);
+  return 0;
+}
+
 static int launch_partials(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
 {
   if (c->dna_fast)
@@ -1247,15 +1269,18 @@ static int plan_and_launch_levels(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigne
   std::vector<int> role;
   std::vector<FusedGroup> groups;
   // FMA-path groups look their cherries up in a table over all pairs of tip codes: only for a sane number of codes
-  const bool generic_groups = (c->fuse_mfma && c->tipmap_set && c->tip_ncodes <= (c->gg.S > 32u ? 128u : 32u)) ||
-                              (c->fuse_generic && (c->tipmap_set ? c->tip_ncodes : (1u << std::min(c->gg.S, 8u))) <= 64u);
+  const bool cherry_groups = (c->fuse_mfma && c->tipmap_set && c->tip_ncodes <= (c->gg.S > 32u ? 128u : 32u)) ||
+                             (c->fuse_generic && (c->tipmap_set ? c->tip_ncodes : (1u << std::min(c->gg.S, 8u))) <= 64u);
+  const bool generic_groups = cherry_groups || c->lean_groups;
   plan_fusion(c->fuse || generic_groups, c->fuse_cc, c->geo.nodes, ops, count, role, groups);
   if (generic_groups)
   {
-    // of the groups the 4x4 planner knows, the FMA-path kernels have one: both children cherries
+    // of the groups the 4x4 planner knows, the other shapes have two: both children cherries, or (17..20 states) both
+    // children inner x inner ops over CLVs in memory
     std::vector<FusedGroup> keep;
     for (const FusedGroup &gq : groups)
-      if (gq.lk == CK_FTT && gq.rk == CK_FTT && gq.a >= 0 && gq.b >= 0)
+      if ((cherry_groups && gq.lk == CK_FTT && gq.rk == CK_FTT && gq.a >= 0 && gq.b >= 0) ||
+          (c->lean_groups && gq.lk == CK_FII && gq.rk == CK_FII && gq.a >= 0 && gq.b >= 0))
         keep.push_back(gq);
       else
       {
@@ -1453,7 +1478,11 @@ static int plan_and_launch_levels(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigne
         unsigned n = 0, entries = 0;
         auto flush = [&]() -> int {
           if (!n) return 0;
-          if (c->use_mfma || c->fuse_mfma)
+          if (!c->dna_fast && lk == CK_FII)
+            emit(c, [c, pack, n, entries]() {
+              if (int rc = launch_lean3(c, pack, n, entries)) c->launch_rc = rc;
+            });
+          else if (c->use_mfma || c->fuse_mfma)
             emit(c, [c, pack, n, entries]() {
               if (int rc = launch_mfma_cc(c, pack, n, entries)) c->launch_rc = rc;
             });

@@ -428,6 +428,38 @@ def test_cherry_groups_of_the_matrix_pipe_shapes_are_bit_identical(amd_lib, kw, 
         assert sum(int(plain["scaler"][c].sum()) for c in cherries) > 0
 
 
+@pytest.mark.parametrize("kw", [dict(states=20, tips=32, sites=1500, seed=340), dict(states=20, tips=32, sites=333, seed=341, attributes=api.RATE_SCALERS),
+                                dict(states=20, tips=150, sites=300, seed=342, tree="caterpillar", brlen_scale=6),      # rescaling inside the groups
+                                dict(states=20, tips=40, sites=700, seed=343, tree="random", rate_cats=2), dict(states=18, tips=16, sites=200, seed=344, rate_cats=3),
+                                dict(states=20, tips=16, sites=500, seed=345, tiny_p=1e-80)], ids=_id)
+def test_inner_groups_of_the_protein_shapes(amd_lib, kw, monkeypatch):
+    """17..20 states, opt-in (PLL_AMD_LEAN_GROUPS=1): an op over two inner x inner ops of the same call is evaluated
+    with them on the matrix pipe (k_partials_lean3), the per-site scaling decisions of all three meeting in LDS -
+    scaler vectors equal those of the level launches, CLVs and log-likelihood within the tolerance, oracle parity"""
+    kw = dict(kw)
+    tiny = kw.pop("tiny_p", None)
+    case = W.make_case("l3", **kw)
+    if tiny:
+        s_ = case.states
+        case.pmatrix[:] = np.full((s_, s_), tiny) + np.eye(s_) * (1.0 - s_ * tiny)
+    plain = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        npl = amd_lib.pll_gpu_last_launch_count(s.p)
+    monkeypatch.setenv("PLL_AMD_LEAN_GROUPS", "1")
+    fused = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        nf = amd_lib.pll_gpu_last_launch_count(s.p)
+    exp = O.run_case(case)
+    assert_results_match(fused, exp, what=_id(kw))
+    assert_results_match(plain, exp, what=_id(kw))
+    if kw.get("tree", "balanced") == "balanced" and kw["tips"] >= 32:
+        assert nf < npl, (nf, npl)
+    for k in plain["scaler"]:
+        assert np.array_equal(fused["scaler"][k], plain["scaler"][k]), k
+
+
 def test_cherry_tables_follow_the_matrices(amd_lib, monkeypatch):
     """matrix-pipe groups keep a cherry's table of scaling decisions on the device for as long as its two tip
     matrices stand: near-identity matrices (cherries of two different states are rescaled), then ordinary ones in
