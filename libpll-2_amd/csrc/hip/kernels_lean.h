@@ -649,3 +649,260 @@ __global__ __launch_bounds__(256, 2) void k_partials_lean3(const FusePack pack, 
     if (has_next) cur = nxt;
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// The same groups with ONE rate category per workgroup (as the cherry groups, k_partials_mfma_cc): 19 KB of LDS, no
+// barrier, every wave on items of its own - three workgroups per CU by registers, their phases independent. The
+// per-site scaling decision (every rate below 2^-256?) is not available to such a workgroup, so in that mode the
+// kernel works SPECULATIVELY: A, B and P are formed and stored unscaled, each (op, rate, entry) leaves its "all below"
+// bit in a byte buffer, and k_iii_epilogue finishes the entries: scaler words; an op whose every rate says "below" is
+// rescaled in place; and when a PRODUCER was rescaled - P was then formed from the wrong A or B - that entry of P is
+// recomputed from the rescaled producers with plain multiply-adds (rare beyond counting on real data; exact up to the
+// summation order of that entry). Per-rate scalers need no speculation: the decision is the workgroup's own.
+// grid = (item blocks, groups, rate categories); flag buffer: [group][a, b, p][rate][entry].
+template <int NG>
+__global__ __launch_bounds__(256, 3) void k_partials_mfma_iii(const FusePack pack, const GenGeo g, unsigned entries, unsigned items_per_wave,
+                                                              unsigned char *__restrict__ flagbuf, unsigned flag_stride)
+{
+  constexpr unsigned LD = 4 * NG, MAT = LD * LD;
+  typedef double __attribute__((ext_vector_type(2))) double2v;
+  extern __shared__ double lds[];
+  double *M = lds; // [6][LD][LD] as stored (PT[j][i]), zero beyond S: a.l a.r b.l b.r p.l p.r
+  const unsigned R = g.R, S = g.S, k = blockIdx.z;
+  const FGroup &grp = pack.g[blockIdx.y];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned row = lane >> 4, col = lane & 15u;
+  const unsigned nitems = (entries + 31u) / 32u;
+  if (blockIdx.x * 4u * items_per_wave >= nitems) return; // whole workgroup
+  {
+    const double *src[6] = {grp.a.lmat, grp.a.rmat, grp.b.lmat, grp.b.rmat, grp.p.lmat, grp.p.rmat};
+    constexpr unsigned PER = (MAT + 255u) / 256u;
+    double v[6][PER];
+#pragma unroll
+    for (unsigned q = 0; q < PER; ++q)
+    {
+      const unsigned idx = threadIdx.x + 256u * q, j = idx / LD, i = idx % LD;
+      const bool in = idx < MAT && j < S && i < S;
+      const size_t off = in ? ((size_t)k * S + j) * g.SPT + i : 0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m)
+      {
+        const double x = src[m][off];
+        v[m][q] = in ? x : 0.0;
+      }
+    }
+#pragma unroll
+    for (unsigned q = 0; q < PER; ++q)
+    {
+      const unsigned idx = threadIdx.x + 256u * q;
+      if (idx < MAT)
+#pragma unroll
+        for (int m = 0; m < 6; ++m) M[(size_t)m * MAT + idx] = v[m][q];
+    }
+  }
+  __syncthreads();
+  const unsigned item0 = (blockIdx.x * 4u + wave) * items_per_wave;
+  if (item0 >= nitems) return; // no barriers below
+  const unsigned item_end = min(item0 + items_per_wave, nitems);
+  const unsigned afrag = row * LD + (lane & 3u);
+  const unsigned lane_off = row * 64u + 2u * col;
+  const FOp *fo[3] = {&grp.a, &grp.b, &grp.p};
+  int mode[3];
+#pragma unroll
+  for (int o = 0; o < 3; ++o) mode[o] = fo[o]->pscaler ? g.scale_mode : 0;
+  unsigned char *flags = flagbuf + (size_t)blockIdx.y * 3u * R * flag_stride + (size_t)k * flag_stride; // + o * R * flag_stride + entry
+
+  struct Kids
+  {
+    double x[4][NG][2];
+  };
+  // wave-uniform base + a 32-bit lane offset per state group: the address form that needs no 64-bit registers per request
+  unsigned loff[NG];
+#pragma unroll
+  for (int jg = 0; jg < NG; ++jg) loff[jg] = min(4u * jg + row, S - 1u) * 64u + 2u * col;
+  auto request = [&](unsigned item, Kids &kd) {
+    const double *cl[4] = {grp.a.left, grp.a.right, grp.b.left, grp.b.right};
+    const size_t uo = (size_t)(item >> 1) * g.tile_sz + (size_t)k * S * 64 + (item & 1u) * 32u; // wave-uniform
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+    {
+      const double *ub = cl[c] + uo;
+#pragma unroll
+      for (int jg = 0; jg < NG; ++jg)
+      {
+        const double2v w = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(ub + loff[jg]));
+        kd.x[c][jg][0] = w.x;
+        kd.x[c][jg][1] = w.y;
+      }
+    }
+  };
+  auto contract = [&](const double *Mx, const double (&x)[NG][2], double (&d)[NG][2]) {
+#pragma unroll
+    for (int ig = 0; ig < NG; ++ig) d[ig][0] = d[ig][1] = 0.0;
+#pragma unroll
+    for (int jg = 0; jg < NG; ++jg)
+    {
+#pragma unroll
+      for (int ig = 0; ig < NG; ++ig)
+      {
+        const double a = Mx[afrag + 4 * jg * LD + 4 * ig];
+        d[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][0], d[ig][0], 0, 0, 0);
+        d[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][1], d[ig][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0); // keep the fragment look-ahead bounded (the six contractions' 150 LDS reads otherwise all move up front)
+    }
+  };
+
+  Kids cur;
+  request(item0, cur);
+  for (unsigned item = item0; item < item_end; ++item)
+  {
+    const unsigned e0 = item * 32u + 2u * col;
+    const bool valid[2] = {e0 < entries, e0 + 1u < entries};
+    const unsigned ec[2] = {min(e0, entries - 1u), min(e0 + 1u, entries - 1u)};
+    // v = D_left o D_right of op o; its decision: per rate - applied here; per site - left to the epilogue; store
+    auto finish = [&](int o, double (&v)[NG][2], const double (&dr)[NG][2], unsigned (&count)[2], const unsigned (&below)[2], bool stream) {
+      bool small[2] = {true, true};
+#pragma unroll
+      for (int ig = 0; ig < NG; ++ig)
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+        {
+          v[ig][sg] *= dr[ig][sg];
+          if (4u * ig + row < S) small[sg] = small[sg] && (v[ig][sg] < PLLGPU_SCALE_THRESHOLD);
+        }
+      const FOp &op = *fo[o];
+      count[0] = count[1] = 0u;
+      if (mode[o])
+      {
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+        {
+          int sm = small[sg] ? 1 : 0; // an entry's states are spread over the four row groups of the wave
+          sm &= __shfl_xor(sm, 16, 64);
+          sm &= __shfl_xor(sm, 32, 64);
+          if (mode[o] == 1)
+          {
+            if (row == 0 && valid[sg]) flags[(size_t)o * R * flag_stride + e0 + sg] = (unsigned char)sm;
+          }
+          else
+          {
+            count[sg] = below[sg] + (sm ? 1u : 0u);
+            if (row == 0 && valid[sg]) op.pscaler[(size_t)(e0 + sg) * R + k] = count[sg];
+            if (sm)
+            {
+#pragma unroll
+              for (int ig = 0; ig < NG; ++ig) v[ig][sg] *= PLLGPU_SCALE_FACTOR;
+            }
+          }
+        }
+      }
+      double *ub = op.parent + (size_t)(item >> 1) * g.tile_sz + (size_t)k * S * 64 + (item & 1u) * 32u; // wave-uniform
+#pragma unroll
+      for (int ig = 0; ig < NG; ++ig)
+        if (4u * ig + row < S)
+        {
+          double *q = ub + (lane_off + 256u * ig);
+          if (valid[1])
+          {
+            double2v w;
+            w.x = v[ig][0];
+            w.y = v[ig][1];
+            if (stream)
+              __builtin_nontemporal_store(w, reinterpret_cast<double2v *>(q));
+            else
+              *reinterpret_cast<double2v *>(q) = w;
+          }
+          else if (valid[0])
+            q[0] = v[ig][0];
+        }
+    };
+    auto below_rate = [&](const FOp &op, int m, unsigned (&b)[2]) {
+      b[0] = b[1] = 0u;
+      if (m == 2)
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+          b[sg] = (op.lscaler ? op.lscaler[(size_t)ec[sg] * R + k] : 0u) + (op.rscaler ? op.rscaler[(size_t)ec[sg] * R + k] : 0u);
+    };
+    unsigned ba[2], bb[2], ca[2], cb[2], cp[2];
+    below_rate(grp.a, mode[0], ba);
+    below_rate(grp.b, mode[1], bb);
+    double va[NG][2], vb[NG][2], dr[NG][2];
+    contract(M + 0 * MAT, cur.x[0], va);
+    contract(M + 1 * MAT, cur.x[1], dr);
+    finish(0, va, dr, ca, ba, true);
+    contract(M + 2 * MAT, cur.x[2], vb);
+    contract(M + 3 * MAT, cur.x[3], dr);
+    // the operands are dead: the next item's requests go out in front of P's MFMAs and the stores
+    if (item + 1u < item_end) request(item + 1u, cur);
+    finish(1, vb, dr, cb, bb, true);
+    const unsigned bp[2] = {ca[0] + cb[0], ca[1] + cb[1]};
+    double vp[NG][2];
+    contract(M + 4 * MAT, va, vp);
+    contract(M + 5 * MAT, vb, dr);
+    finish(2, vp, dr, cp, bp, false);
+  }
+}
+
+// per-site mode: finishes what k_partials_mfma_iii left open - one thread per entry of a group
+__global__ __launch_bounds__(256) void k_iii_epilogue(const FusePack pack, const GenGeo g, unsigned entries, const unsigned char *__restrict__ flagbuf,
+                                                      unsigned flag_stride)
+{
+  if (g.scale_mode != 1) return;
+  const FGroup &grp = pack.g[blockIdx.y];
+  const unsigned n = blockIdx.x * 256u + threadIdx.x;
+  if (n >= entries) return;
+  const unsigned S = g.S, R = g.R;
+  const unsigned char *fl = flagbuf + (size_t)blockIdx.y * 3u * R * flag_stride + n;
+  const FOp *fo[3] = {&grp.a, &grp.b, &grp.p};
+  bool f[3];
+#pragma unroll
+  for (int o = 0; o < 3; ++o)
+  {
+    f[o] = fo[o]->pscaler != nullptr;
+    if (f[o])
+      for (unsigned kk = 0; kk < R; ++kk) f[o] = f[o] && fl[((size_t)o * R + kk) * flag_stride];
+  }
+  auto base = [&](const FOp &op) { return op.parent + (size_t)(n >> 6) * g.tile_sz + (n & 63u); };
+  auto rescale = [&](const FOp &op) {
+    double *b = base(op);
+    for (unsigned q = 0; q < R * S; ++q) b[(size_t)q * 64] *= PLLGPU_SCALE_FACTOR;
+  };
+  unsigned cnt[2] = {0u, 0u};
+#pragma unroll
+  for (int o = 0; o < 2; ++o)
+  {
+    const FOp &op = *fo[o];
+    if (!op.pscaler) continue;
+    if (f[o]) rescale(op);
+    cnt[o] = (op.lscaler ? op.lscaler[n] : 0u) + (op.rscaler ? op.rscaler[n] : 0u) + (f[o] ? 1u : 0u);
+    op.pscaler[n] = cnt[o];
+  }
+  if (f[0] || f[1])
+  {
+    // P was formed from a producer that has been rescaled since: this entry again, from what is in memory now
+    const double *A = base(grp.a), *B = base(grp.b);
+    double *P = base(grp.p);
+    bool all = true;
+    for (unsigned kk = 0; kk < R; ++kk)
+      for (unsigned i = 0; i < S; ++i)
+      {
+        double l = 0.0, r = 0.0;
+        for (unsigned j = 0; j < S; ++j)
+        {
+          l = fma(grp.p.lmat[((size_t)kk * S + j) * g.SPT + i], A[((size_t)kk * S + j) * 64], l);
+          r = fma(grp.p.rmat[((size_t)kk * S + j) * g.SPT + i], B[((size_t)kk * S + j) * 64], r);
+        }
+        const double v = l * r;
+        all = all && (v < PLLGPU_SCALE_THRESHOLD);
+        P[((size_t)kk * S + i) * 64] = v;
+      }
+    f[2] = grp.p.pscaler != nullptr && all;
+  }
+  if (grp.p.pscaler)
+  {
+    if (f[2]) rescale(grp.p);
+    grp.p.pscaler[n] = cnt[0] + cnt[1] + (f[2] ? 1u : 0u);
+  }
+}

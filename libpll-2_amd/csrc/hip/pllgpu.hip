@@ -171,7 +171,7 @@ struct pllgpu_ctx
   bool generic_aos = true;          // PLL_AMD_NO_GENERIC_AOS=1: compressed nodes of non-4x4 shapes stay tiled (A/B)
   bool lean = false;                // 17..20 states, <= 4 rates: the level launches on the matrix pipe (kernels_lean.h)
   bool lean_plain = false;          // ... also the ones that do not gather (PLL_AMD_LEAN_PLAIN=1)
-  bool lean_groups = false;         // ... and (inner x inner, inner x inner -> inner x inner) groups (k_partials_lean3; opt-in)
+  int lean_groups = 0;              // ... and (inner x inner, inner x inner -> inner x inner) groups: 1 = k_partials_lean3, 2 = k_partials_mfma_iii
   bool fuse_mfma = false;           // 17..32 states on the matrix pipe: the same groups (kernels_mfma.h: k_partials_mfma_cc)
   bool fuse_generic = false;        // FMA-path shapes: (tip x tip, tip x tip -> inner x inner) groups (kernels_generic.h: k_partials_tiled_cc)
   bool subtrees = false;            // DNA + site repeats: all-tip subtrees straight from the tip codes (subtree_plan.h)
@@ -345,9 +345,9 @@ static void derive_geometry(pllgpu_ctx *c)
   // OPT-IN (PLL_AMD_LEAN_GROUPS=1): bit-compatible scaling decisions and one launch less, but slower than the two level
   // launches it replaces (C3 levels 3 + 4: 290 us against 221) - 77 KB of matrices leave room for two workgroups per CU,
   // whose four waves load, multiply and store in lockstep (a barrier per op): reads and writes take turns
-  c->lean_groups = false;
+  c->lean_groups = 0;
   if (const char *v = getenv("PLL_AMD_LEAN_GROUPS"))
-    c->lean_groups = c->lean && groups && *v && *v != '0';
+    c->lean_groups = (c->lean && groups) ? atoi(v) : 0;
   c->pm_stride = (size_t)g.rate_cats * g.states * gg.SPT;
   c->span = g.rate_cats * g.states_padded;
 }
@@ -1196,8 +1196,31 @@ static bool lean_serves(const pllgpu_ctx *c, const OpPack &pack, unsigned nops, 
 }
 
 // (inner x inner, inner x inner -> inner x inner) groups of the 17..20-state shapes (kernels_lean.h: k_partials_lean3)
+// ... one rate category per workgroup, per-site scaling finished by an epilogue (k_partials_mfma_iii)
+static int launch_mfma_iii(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries)
+{
+  const unsigned R = c->gg.R;
+  const unsigned items = (entries + 31) / 32;
+  unsigned ipw = (unsigned)(((size_t)items * ngroups * R + 8191) / 8192);
+  ipw = std::max(1u, std::min(ipw, 8u));
+  if (const char *ev = getenv("PLL_AMD_MFMA_IPW")) ipw = std::max(1, atoi(ev));
+  dim3 grid((items + 4 * ipw - 1) / (4 * ipw), ngroups, R), block(256);
+  const size_t lds = (size_t)6u * 400u * sizeof(double);
+  const unsigned fstride = (entries + 63u) & ~63u;
+  bool scaling = false;
+  for (unsigned i = 0; i < ngroups; ++i) scaling = scaling || pack.g[i].a.pscaler || pack.g[i].b.pscaler || pack.g[i].p.pscaler;
+  scaling = scaling && c->gg.scale_mode == 1;
+  if (scaling && c->mfma_flags.ensure((size_t)3 * kMaxGroups * R * fstride)) return PLLGPU_ENOMEM;
+  raise_lds_limit((const void *)k_partials_mfma_iii<5>, c->device, lds);
+  hipLaunchKernelGGL((k_partials_mfma_iii<5>), grid, block, lds, c->stream, pack, c->gg, entries, ipw, c->mfma_flags.p, fstride);
+  if (scaling)
+    hipLaunchKernelGGL(k_iii_epilogue, dim3((entries + 255) / 256, ngroups), dim3(256), 0, c->stream, pack, c->gg, entries, c->mfma_flags.p, fstride);
+  return 0;
+}
+
 static int launch_lean3(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries)
 {
+  if (c->lean_groups == 2) return launch_mfma_iii(c, pack, ngroups, entries);
   const unsigned R = c->gg.R;
   const unsigned items = (entries + 31) / 32;
   unsigned ipb = (unsigned)(((size_t)items * ngroups) / 2048u);

@@ -432,7 +432,8 @@ def test_cherry_groups_of_the_matrix_pipe_shapes_are_bit_identical(amd_lib, kw, 
                                 dict(states=20, tips=150, sites=300, seed=342, tree="caterpillar", brlen_scale=6),      # rescaling inside the groups
                                 dict(states=20, tips=40, sites=700, seed=343, tree="random", rate_cats=2), dict(states=18, tips=16, sites=200, seed=344, rate_cats=3),
                                 dict(states=20, tips=16, sites=500, seed=345, tiny_p=1e-80)], ids=_id)
-def test_inner_groups_of_the_protein_shapes(amd_lib, kw, monkeypatch):
+@pytest.mark.parametrize("form", ["1", "2"], ids=["all-rates-per-workgroup", "speculative"])
+def test_inner_groups_of_the_protein_shapes(amd_lib, kw, form, monkeypatch):
     """17..20 states, opt-in (PLL_AMD_LEAN_GROUPS=1): an op over two inner x inner ops of the same call is evaluated
     with them on the matrix pipe (k_partials_lean3), the per-site scaling decisions of all three meeting in LDS -
     scaler vectors equal those of the level launches, CLVs and log-likelihood within the tolerance, oracle parity"""
@@ -446,7 +447,7 @@ def test_inner_groups_of_the_protein_shapes(amd_lib, kw, monkeypatch):
     with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
         s.update_partials()
         npl = amd_lib.pll_gpu_last_launch_count(s.p)
-    monkeypatch.setenv("PLL_AMD_LEAN_GROUPS", "1")
+    monkeypatch.setenv("PLL_AMD_LEAN_GROUPS", form)
     fused = driver.run_case(amd_lib, case, api.ARCH_AVX2)
     with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
         s.update_partials()
