@@ -211,6 +211,51 @@ __device__ __forceinline__ void handoff_before_sequence(int fenced)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// The same when only SOME workgroups hold a value and which ones is decided at run time (k_edge_mfma: the workgroup
+// that finishes an item block last): the value goes to the slot of the ITEM BLOCK, not of the workgroup, so that the
+// final sum adds the same numbers in the same places whichever workgroup produced them - with one slot per
+// workgroup the non-zero entries moved between threads of the last workgroup from run to run and the total with
+// them, by an ulp or two.
+__device__ __forceinline__ void publish_block_sum_slot(const DevEdge &e, double wave_value, unsigned nsum_waves, bool has_value, unsigned slot,
+                                                       unsigned nslots)
+{
+  __shared__ double ws[4];
+  __shared__ unsigned last;
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) ws[wave] = wave < nsum_waves ? wave_value : 0.0;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    if (has_value)
+    {
+      double s = ws[0];
+      for (unsigned w = 1; w < nw; ++w) s += ws[w];
+      partial_store(&e.block_sums[slot], s);
+    }
+    handoff_before_ticket(e.fenced);
+    const unsigned ticket = __hip_atomic_fetch_add(e.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (ticket == gridDim.x - 1) ? 1u : 0u;
+    if (last) handoff_after_last_ticket(e.fenced);
+  }
+  __syncthreads();
+  if (!last) return;
+  double a = 0.0;
+  for (unsigned i = threadIdx.x; i < nslots; i += blockDim.x) a += partial_load(&e.block_sums[i]);
+  a = wave_sum(a);
+  __syncthreads();
+  if (lane == 0) ws[wave] = a;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    double s = ws[0];
+    for (unsigned w = 1; w < nw; ++w) s += ws[w];
+    __hip_atomic_store(e.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(e.result, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    handoff_before_sequence(e.fenced);
+    __hip_atomic_store(e.result + 1, e.sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 __device__ __forceinline__ void publish_block_sum(const DevEdge &e, double wave_value, unsigned nsum_waves)
 {
   __shared__ double ws[4];

@@ -1282,5 +1282,5 @@ __global__ __launch_bounds__(256, 2) void k_edge_mfma(const DevEdge e, const Gen
       acc += site;
     }
   }
-  publish_block_sum(e, wave_sum(acc), 4u);
+  publish_block_sum_slot(e, wave_sum(acc), 4u, finisher != 0u, ib, (nitems + 4u * ipw - 1u) / (4u * ipw));
 }

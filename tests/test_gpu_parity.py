@@ -461,6 +461,26 @@ def test_inner_groups_of_the_protein_shapes(amd_lib, kw, form, monkeypatch):
         assert np.array_equal(fused["scaler"][k], plain["scaler"][k]), k
 
 
+@pytest.mark.parametrize("kw", [dict(states=61, tips=8, sites=3000, seed=350), dict(states=61, tips=16, sites=20000, seed=351),
+                                dict(states=20, tips=16, sites=5000, seed=352), dict(states=4, tips=32, sites=30000, seed=353),
+                                dict(states=40, tips=8, sites=4000, seed=354, attributes=api.PATTERN_TIP)], ids=_id)
+def test_results_are_reproducible_run_to_run(amd_lib, kw):
+    """the reductions add in a fixed order: 60 evaluations of the same partition give the same double, bit for bit
+    (the 61-state edge kernel hands an item block to whichever workgroup finishes it last - its sum must not depend
+    on which one that was)"""
+    case = W.make_case("rep", **kw)
+    e = case.edges[0]
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        ref = s.edge_lnl(e, persite=False)[0]
+        root = s.root_lnl((e[0], e[1]), persite=False)[0]
+        for _ in range(60):
+            s.update_partials()
+            assert s.edge_lnl(e, persite=False)[0] == ref
+        for _ in range(20):
+            assert s.root_lnl((e[0], e[1]), persite=False)[0] == root
+
+
 def test_cherry_tables_follow_the_matrices(amd_lib, monkeypatch):
     """matrix-pipe groups keep a cherry's table of scaling decisions on the device for as long as its two tip
     matrices stand: near-identity matrices (cherries of two different states are rescaled), then ordinary ones in

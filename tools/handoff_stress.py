@@ -13,7 +13,9 @@ from pllamd import api, driver, workload as W  # noqa: E402
 lib = api.PllLib()
 bad = 0
 for states, taxa, sites, tree, reps in ((4, 64, 100000, "balanced", 3000), (4, 64, 100000, "random", 2000), (4, 32, 250000, "caterpillar", 500),
-                                        (4, 16, 1000, "balanced", 5000), (20, 16, 20000, "balanced", 500), (4, 64, 100000, "nochains", 1500)):
+                                        (4, 16, 1000, "balanced", 5000), (20, 16, 20000, "balanced", 500), (4, 64, 100000, "nochains", 1500),
+                                        # 61 states: k_edge_mfma's per-rate partials and the ticket per item block (round 2)
+                                        (61, 32, 20000, "balanced", 1500), (61, 8, 3000, "balanced", 3000), (40, 8, 70000, "balanced", 300)):
     if tree == "nochains":
         os.environ["PLL_AMD_NO_CHAINS"] = "1"
         tree = "balanced"
