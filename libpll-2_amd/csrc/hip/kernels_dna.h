@@ -1009,6 +1009,7 @@ struct SubItem // 384 bytes, read through the scalar path from a device array
   unsigned scaler_mask; // bit p: the op at position p has a scaler (its scaling decision is taken)
   unsigned flags;       // kSubAos
   unsigned pad;
+  unsigned long long *packed; // [entries]: the 4-bit code of position p in bits 4 p .. 4 p + 3, written by k_sub_pack
 };
 constexpr unsigned kSubAos = 4u; // the parent is class-compressed: entry-contiguous [entry][16]
 typedef const SubItem __attribute__((address_space(4))) *csubitem_p;
@@ -1057,7 +1058,7 @@ __device__ __forceinline__ void dna_sub_level(csubitem_p it, unsigned node_mask,
       for (int j = 0; j < 4; ++j) out[i][j] = (code[pos] >> j) & 1u ? 1.0 : 0.0;
     }
   }
-  if (SM == 1) __syncthreads(); // workgroup-uniform: every wave of the tile walks the same positions
+  if (SM == 1) lds_barrier(); // workgroup-uniform: every wave of the tile walks the same positions (the ballots only: no wait for memory)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
   {
@@ -1088,6 +1089,67 @@ struct SubTiles
   unsigned first[kSubItemsPerLaunch + 1];
 };
 
+// what a tile needs before any arithmetic: its item, the entry of every position (a chain of dependent map look-ups,
+// level by level) and the codes of the tips
+struct SubFetch
+{
+  csubitem_p it;
+  unsigned tile, n;
+  bool valid;
+  unsigned long long codes; // the 4-bit code of position p in bits 4 p .. 4 p + 3
+};
+
+__device__ __forceinline__ void dna_sub_fetch(const SubItem *items, const SubTiles &tiles, unsigned nitems, unsigned gtile, unsigned lane, SubFetch &f)
+{
+  unsigned lo = 0, hi = nitems; // first[lo] <= gtile < first[hi]
+  while (hi - lo > 1u)
+  {
+    const unsigned mid = (lo + hi) >> 1;
+    if (tiles.first[mid] <= gtile) lo = mid; else hi = mid;
+  }
+  csubitem_p it = (csubitem_p)(uintptr_t)items + lo;
+  f.it = it;
+  f.tile = gtile - tiles.first[lo];
+  const unsigned entries = it->entries;
+  const unsigned n0 = f.tile * 64u + lane;
+  f.valid = n0 < entries;
+  f.n = f.valid ? n0 : entries - 1;
+  const unsigned node_mask = it->node_mask, tip_mask = it->tip_mask;
+  // breadth-first: the entry of every position, then the codes of the tips
+  unsigned e[15];
+  e[0] = f.n;
+#pragma unroll
+  for (int p = 0; p < 7; ++p)
+  {
+    e[2 * p + 1] = e[2 * p + 2] = 0u;
+    if ((node_mask >> p) & 1u)
+    {
+      const unsigned *lent = it->node[p].lent, *rent = it->node[p].rent;
+      e[2 * p + 1] = lent ? lent[e[p]] : e[p];
+      e[2 * p + 2] = rent ? rent[e[p]] : e[p];
+    }
+  }
+  unsigned long long codes = 0ull;
+#pragma unroll
+  for (int p = 1; p < 15; ++p)
+    if ((tip_mask >> p) & 1u) codes |= (unsigned long long)(it->tip[p - 1][e[p]] & 15u) << (4 * p);
+  f.codes = codes;
+}
+
+// The look-ups of an entry - maps level by level, then the tip codes: three or four DEPENDENT loads - do not change
+// from one traversal to the next as long as class maps and tip data stand: k_sub_pack does them once and leaves the
+// entry's tip codes as one 64-bit word (launched by the host when maps, tips or descriptors changed); the evaluation
+// then starts from one coalesced load. (C4's shard: a workgroup lived 12 us, 60 % of it waiting in that chain; the
+// launch 35 us for 30 MB of output. Two tiles per workgroup with the second tile's chain in flight was slower: 44 us.)
+__global__ __launch_bounds__(256) void k_sub_pack(const SubItem *items, const SubTiles tiles, unsigned nitems, unsigned total_tiles)
+{
+  const unsigned gtile = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (gtile >= total_tiles) return;
+  SubFetch f;
+  dna_sub_fetch(items, tiles, nitems, gtile, threadIdx.x & 63u, f);
+  if (f.valid) f.it->packed[f.n] = f.codes;
+}
+
 template <int SM>
 __global__ __launch_bounds__(256) void k_partials_dna_sub(const SubItem *items, const SubTiles tiles, unsigned nitems)
 {
@@ -1103,32 +1165,14 @@ __global__ __launch_bounds__(256) void k_partials_dna_sub(const SubItem *items, 
   const unsigned lane = threadIdx.x & 63u;
   const unsigned rate = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned tile = blockIdx.x - tiles.first[lo];
-  const unsigned node_mask = it->node_mask, tip_mask = it->tip_mask, scaler_mask = it->scaler_mask, flags = it->flags;
+  const unsigned node_mask = it->node_mask, scaler_mask = it->scaler_mask, flags = it->flags;
   const unsigned n0 = tile * 64u + lane;
   const bool valid = n0 < entries;
   const unsigned n = valid ? n0 : entries - 1;
-  // breadth-first: the entry of every position, then the codes of the tips
-  unsigned e[15];
-  e[0] = n;
-#pragma unroll
-  for (int p = 0; p < 7; ++p)
-  {
-    e[2 * p + 1] = e[2 * p + 2] = 0u;
-    if ((node_mask >> p) & 1u)
-    {
-      const unsigned *lent = it->node[p].lent, *rent = it->node[p].rent;
-      e[2 * p + 1] = lent ? lent[e[p]] : e[p];
-      e[2 * p + 2] = rent ? rent[e[p]] : e[p];
-    }
-  }
+  const unsigned long long codes = it->packed[n];
   unsigned code[15];
-  code[0] = 0u;
 #pragma unroll
-  for (int p = 1; p < 15; ++p)
-  {
-    code[p] = 0u;
-    if ((tip_mask >> p) & 1u) code[p] = it->tip[p - 1][e[p]];
-  }
+  for (int p = 0; p < 15; ++p) code[p] = (unsigned)(codes >> (4 * p)) & 15u;
   // bottom-up, level by level
   double v3[8][4], v2[4][4], v1[2][4], v0[1][4];
   unsigned s3[8], s2[4], s1[2], s0[1];
@@ -1153,13 +1197,13 @@ __global__ __launch_bounds__(256) void k_partials_dna_sub(const SubItem *items, 
   if (flags & kSubAos)
   {
     dbl2 *w = reinterpret_cast<dbl2 *>(parent + (size_t)n * 16 + rate * 4u);
-    dbl2 lo, hi;
-    lo.x = v0[0][0];
-    lo.y = v0[0][1];
-    hi.x = v0[0][2];
-    hi.y = v0[0][3];
-    w[0] = lo;
-    w[1] = hi;
+    dbl2 lo2, hi2;
+    lo2.x = v0[0][0];
+    lo2.y = v0[0][1];
+    hi2.x = v0[0][2];
+    hi2.y = v0[0][3];
+    w[0] = lo2;
+    w[1] = hi2;
   }
   else
   {

@@ -178,6 +178,9 @@ struct pllgpu_ctx
   DevBuf<unsigned char> sub_dev;    // their descriptors on the device ...
   std::vector<SubItem> sub_cache, sub_build; // ... and what that array holds / the list being planned
   unsigned long long sub_epoch = 0;
+  DevBuf<unsigned long long> sub_packed; // k_sub_pack: per sub-tree op and entry, the tip codes below it
+  bool sub_pack_valid = false;           // ... formed for the descriptors on the device, the class maps (maps_epoch) ...
+  unsigned long long sub_pack_maps = 0, sub_pack_tips = 0, tips_epoch = 1; // ... and the tip data (tips_epoch) of now
 };
 
 // what pllgpu_update_partials did for one op list through the level scheduler: its launches, in order, with
@@ -474,6 +477,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->level_plans.clear();
   c->chain_dev.release();
   c->sub_dev.release();
+  c->sub_packed.release();
   c->cherry_tab.release();
   c->cherry_bits.release();
   c->cherry_rowsums.release();
@@ -615,6 +619,7 @@ extern "C" int pllgpu_tipchars_upload(pllgpu_ctx_t *c, unsigned tip, const unsig
   if (tip >= c->geo.tips) return fail(PLLGPU_EINVAL, "tip %u out of range", tip);
   if (int rc = c->tipchars[tip].ensure(((size_t)count + 65) & ~(size_t)63)) return rc; // kernels fetch two codes at a time
   HIP_TRY(hipMemcpyAsync(c->tipchars[tip].p, host, count, hipMemcpyHostToDevice, c->stream));
+  ++c->tips_epoch;
   return 0;
 }
 

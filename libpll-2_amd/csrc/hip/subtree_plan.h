@@ -107,7 +107,20 @@ static int plan_subtrees(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count, 
                                          (double)(1u << (d + 1)) + 8.0);
   }
   nsub = (unsigned)sub.size();
-  if (nsub) c->last_bytes += bytes;
+  if (nsub)
+  {
+    c->last_bytes += bytes;
+    // where k_sub_pack leaves each op's packed tip codes
+    size_t total = 0;
+    for (const SubItem &it : sub) total += ((size_t)it.entries + 63u) & ~(size_t)63u;
+    if (int rc = c->sub_packed.ensure(total)) return rc;
+    size_t off = 0;
+    for (SubItem &it : sub)
+    {
+      it.packed = c->sub_packed.p + off;
+      off += ((size_t)it.entries + 63u) & ~(size_t)63u;
+    }
+  }
   return 0;
 }
 
@@ -120,6 +133,7 @@ static int upload_subtrees(pllgpu_ctx *c, const std::vector<SubItem> &items)
   if (int rc = c->sub_dev.ensure(nbytes)) return rc;
   // pageable source: staged before hipMemcpyAsync returns; ordered behind the kernels that read the old array
   HIP_TRY(hipMemcpyAsync(c->sub_dev.p, items.data(), nbytes, hipMemcpyHostToDevice, c->stream));
+  c->sub_pack_valid = false; // other descriptors: their packed codes have to be formed
   c->sub_cache = items;
   c->sub_epoch = g_alloc_epoch.load(std::memory_order_relaxed);
   return 0;
@@ -130,6 +144,7 @@ static unsigned launch_subtrees(pllgpu_ctx *c, unsigned nsub)
 {
   const SubItem *items = reinterpret_cast<const SubItem *>(c->sub_dev.p);
   unsigned launches = 0;
+  const bool stale = !c->sub_pack_valid || c->sub_pack_maps != c->maps_epoch || c->sub_pack_tips != c->tips_epoch;
   for (unsigned first = 0; first < nsub; first += (unsigned)kSubItemsPerLaunch, ++launches)
   {
     const unsigned n = std::min(nsub - first, (unsigned)kSubItemsPerLaunch);
@@ -142,10 +157,15 @@ static unsigned launch_subtrees(pllgpu_ctx *c, unsigned nsub)
     }
     for (unsigned i = n; i <= (unsigned)kSubItemsPerLaunch; ++i) tiles.first[i] = t;
     dim3 grid(t), block(256);
+    // the entries' tip codes, packed: once per set of class maps, tip data and descriptors (kernels_dna.h: k_sub_pack)
+    if (stale) hipLaunchKernelGGL(k_sub_pack, dim3((t + 3u) / 4u), block, 0, c->stream, items + first, tiles, n, t);
     if (c->gg.scale_mode == 2)
       hipLaunchKernelGGL(k_partials_dna_sub<2>, grid, block, 0, c->stream, items + first, tiles, n);
     else
       hipLaunchKernelGGL(k_partials_dna_sub<1>, grid, block, 0, c->stream, items + first, tiles, n);
   }
+  c->sub_pack_valid = true;
+  c->sub_pack_maps = c->maps_epoch;
+  c->sub_pack_tips = c->tips_epoch;
   return launches;
 }

@@ -203,3 +203,31 @@ def test_matrix_pipe_gather_kernel_against_the_fma_kernel(amd_lib, monkeypatch, 
         assert np.array_equal(lean["scaler"][k], fma["scaler"][k]), k
     if "caterpillar" == kw.get("tree"):
         assert sum(int(v.sum()) for v in fma["scaler"].values()) > 0  # the case does rescale
+
+
+def test_packed_subtree_lookups_follow_maps_and_tips(amd_lib):
+    """the all-tip subtrees are evaluated from per-entry words of packed tip codes that k_sub_pack forms once per set
+    of class maps, tip data and descriptors: new tip sequences in a living partition (class maps recomputed) must give
+    what a fresh partition gives, and so must going back"""
+    import ctypes
+    case_a = W.make_case("pk", 4, tips=32, sites=4000, attributes=api.SITE_REPEATS, mutate_pct=4, seed=61)
+    case_b = W.make_case("pk", 4, tips=32, sites=4000, attributes=api.SITE_REPEATS, mutate_pct=4, seed=62)
+    case_b.pmatrix, case_b.freqs = case_a.pmatrix, case_a.freqs  # the same model and tree, other sequences
+    fresh = {}
+    for tag, c in (("a", case_a), ("b", case_b)):
+        c2 = W.make_case("pk", 4, tips=32, sites=4000, attributes=api.SITE_REPEATS, mutate_pct=4, seed=61)
+        c2.sequences = c.sequences
+        with driver.Session(amd_lib, c2, api.ARCH_AVX2) as s:
+            s.update_partials()
+            fresh[tag] = (s.edge_lnl(c2.edges[0], persite=False)[0], s.read_clv(c2.edges[0][0]))
+    with driver.Session(amd_lib, case_a, api.ARCH_AVX2) as s:
+        cmap = (ctypes.c_ulonglong * 256)(*[int(x) for x in case_a.charmap])
+        for tag, c in (("a", case_a), ("b", case_b), ("a", case_a)):
+            for t, seq in enumerate(c.sequences):
+                assert amd_lib.pll_set_tip_states(s.p, t, cmap, seq)
+            s.update_partials(update_repeats=1)
+            v = s.edge_lnl(case_a.edges[0], persite=False)[0]
+            assert v == fresh[tag][0], tag
+            assert np.array_equal(s.read_clv(case_a.edges[0][0]), fresh[tag][1]), tag
+            s.update_partials(update_repeats=0)  # the cached plan and the packed words as they are
+            assert s.edge_lnl(case_a.edges[0], persite=False)[0] == v
