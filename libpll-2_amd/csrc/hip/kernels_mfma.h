@@ -533,7 +533,7 @@ template <int NG>
 __global__ __launch_bounds__(256, 4) void k_partials_mfma_cc(const FusePack pack, const GenGeo g, const unsigned long long *__restrict__ tipmap,
                                                              unsigned entries, unsigned items_per_wave, unsigned char *__restrict__ flagbuf,
                                                              unsigned flag_stride, const unsigned char *__restrict__ bits, const CherrySlots slots,
-                                                             unsigned ncodes)
+                                                             unsigned ncodes, unsigned stream_parent)
 {
   typedef CcGeo<NG> CG;
   constexpr unsigned LD = CG::LD;
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256, 4) void k_partials_mfma_cc(const FusePack pack
         DL[ig][sg] *= DR[ig][sg];
         if (4 * ig + row < S) sp[sg] = sp[sg] && (DL[ig][sg] < PLLGPU_SCALE_THRESHOLD);
       }
-    put(grp.p, DL, false);
+    put(grp.p, DL, stream_parent != 0u);
     if (ma) put_scaler(grp.a, ma, scale_a);
     if (mb) put_scaler(grp.b, mb, scale_b);
     if (mp)

@@ -1122,8 +1122,11 @@ static int launch_mfma_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroup
   else
   {
     raise_lds_limit((const void *)k_partials_mfma_cc<NG>, c->device, lds);
+    // parents beyond what the Infinity Cache keeps for the next level: streamed out like the cherries (as the 4x4 groups do)
+    unsigned stream_parent = ((size_t)ngroups * entries * S * R * 8u > c->stream_parent_bytes) ? 1u : 0u;
+    if (const char *ev = getenv("PLL_AMD_CC_STREAM_PARENT")) stream_parent = atoi(ev) != 0;
     hipLaunchKernelGGL((k_partials_mfma_cc<NG>), grid, block, lds, c->stream, pack, c->gg, tm, entries, ipw, c->mfma_flags.p, fstride,
-                       c->cherry_bits.p, slots, ncodes);
+                       c->cherry_bits.p, slots, ncodes, stream_parent);
   }
   if (scaling)
     hipLaunchKernelGGL((k_mfma_scale_epilogue<false>), dim3((entries + 255) / 256, ngroups), dim3(256), 0, c->stream, parents, c->gg,
