@@ -87,7 +87,8 @@ def tips_are_codes(case, api):
     compact form of an indicator CLV) unless PLL_AMD_NO_TIP_CODES=1 forces dense tip CLVs"""
     if case.attributes & api.PATTERN_TIP:
         return True
-    return case.sequences is not None and os.environ.get("PLL_AMD_NO_TIP_CODES", "0") in ("", "0")
+    # (tip CLVs that are indicator vectors - what --tips clv feeds - are recognised as state masks by pll_set_tip_clv)
+    return os.environ.get("PLL_AMD_NO_TIP_CODES", "0") in ("", "0") and not (case.attributes & api.SITE_REPEATS and case.sequences is None)
 
 
 def op_bytes(case, api, ops, entries=None):
@@ -477,8 +478,10 @@ def roofline_leg(args, cfg, lib, api, runner, reps=20):
 def tip_note(case, api, args):
     if args.pattern_tip:
         return ", PLL_ATTRIB_PATTERN_TIP"
+    if case.sequences is None and tips_are_codes(case, api):
+        return ", tips as one-hot CLVs through pll_set_tip_clv (recognised as indicator vectors: the device reads 1-byte codes, tip x tip / tip x inner kernels at the leaves; PLL_AMD_NO_TIP_CODES=1 keeps them dense)"
     if case.sequences is None:
-        return ", tips as one-hot CLVs through pll_set_tip_clv (every update inner x inner)"
+        return ", tips as one-hot CLVs through pll_set_tip_clv, kept dense (every update inner x inner)"
     if tips_are_codes(case, api):
         return ", tips set with pll_set_tip_states (device reads 1-byte codes: tip x tip / tip x inner kernels at the leaves)"
     return ", tips as dense 0/1 CLVs (every update inner x inner)"

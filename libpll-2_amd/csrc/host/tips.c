@@ -288,7 +288,48 @@ int pll_set_tip_clv(pll_partition_t *p, unsigned int tip, const double *clv, int
   if (x)
   {
     x->clv_side[tip] = SIDE_HOST;
-    x->tip_compact[tip] = 0; /* arbitrary values: a dense CLV on the device */
+    /* An INDICATOR vector per site - every value exactly 0 or 1, at least one 1: what a caller gets from one-hot
+     * encoding its sequences itself (SURVEY 8d's C5) - is a state mask in CLV form: the device then reads one-byte
+     * codes and runs the tip kernels, as it does for pll_set_tip_states without PLL_ATTRIB_PATTERN_TIP. The dense CLV
+     * stays in the host mirror for whoever reads or edits it (pll_tip_densify). Anything else: a dense CLV. */
+    int compact = !x->no_tip_codes && !rep && p->states <= 8 * sizeof(pll_state_t);
+    if (compact)
+    {
+      free(x->tipcodes[tip]);
+      x->tipcodes[tip] = (unsigned char *)malloc((size_t)n + p->states);
+      compact = x->tipcodes[tip] != NULL;
+    }
+    for (i = 0; compact && i < n; ++i)
+    {
+      const double *src = clv + (size_t)i * in_stride;
+      pll_state_t m = 0;
+      unsigned int j;
+      for (j = 0; j < p->states; ++j)
+      {
+        if (src[j] == 1.0) m |= (pll_state_t)1 << j;
+        else if (src[j] != 0.0) compact = 0;
+      }
+      if (!m) compact = 0;
+      if (compact)
+      {
+        const int code = compact_code(p, x, m);
+        if (code < 0) compact = 0;
+        else x->tipcodes[tip][i] = (unsigned char)code;
+      }
+    }
+    if (p->asc_bias_alloc)
+      for (i = 0; compact && i < p->states; ++i)
+      {
+        const int code = compact_code(p, x, (pll_state_t)1 << i);
+        if (code < 0) compact = 0;
+        else x->tipcodes[tip][n + i] = (unsigned char)code;
+      }
+    x->tip_compact[tip] = (unsigned char)compact;
+    if (compact)
+    {
+      x->tipchars_dirty[tip] = 1;
+      x->tipmap_dirty = 1;
+    }
   }
   return PLL_SUCCESS;
 }

@@ -226,6 +226,46 @@ def test_compact_tips_become_dense_when_needed(amd_lib):
         assert abs((v1 - v0) - 200 * np.log(0.5)) < 1e-8
 
 
+@pytest.mark.parametrize("kw", [dict(states=4, tips=16, sites=777, seed=360), dict(states=20, tips=16, sites=500, seed=361),
+                                dict(states=61, tips=8, sites=200, seed=362), dict(states=4, tips=16, sites=300, seed=363, asc_type=1),
+                                dict(states=20, tips=8, sites=300, seed=364, attributes=api.RATE_SCALERS)], ids=_id)
+def test_indicator_tip_clvs_are_recognised(amd_lib, kw, monkeypatch):
+    """pll_set_tip_clv with one-hot vectors (a caller that encodes its sequences itself: SURVEY 8d's C5): the device
+    reads one-byte codes and runs the tip kernels - fewer launches of the inner x inner kind, the same numbers as with
+    the CLVs kept dense (PLL_AMD_NO_TIP_CODES=1) and as the oracle; a CLV with any other value stays dense; a host
+    edit of a recognised tip's CLV is seen by the next traversal"""
+    case = W.make_case("ind", tips_as="clv", **kw)
+    exp = O.run_case(case)
+    got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    assert_results_match(got, exp, what=_id(kw))
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        v0, _ = s.edge_lnl(case.edges[0], persite=False)
+        # fractional values in one tip: that tip is dense again, the others keep their codes
+        t = 1
+        frac = np.ascontiguousarray(np.asarray(case.tip_clvs[t]) * 0.5)
+        assert amd_lib.pll_set_tip_clv(s.p, t, api.dptr(frac), 0)
+        s.update_partials()
+        v1, _ = s.edge_lnl(case.edges[0], persite=False)
+        assert abs((v1 - v0) - case.sites * np.log(0.5)) <= 1e-9 * abs(v0)
+        # back to the indicator vectors, then a host edit of the mirror
+        one = np.ascontiguousarray(case.tip_clvs[t], dtype=np.float64)
+        assert amd_lib.pll_set_tip_clv(s.p, t, api.dptr(one), 0)
+        s.update_partials()
+        assert s.edge_lnl(case.edges[0], persite=False)[0] == v0
+        span = case.rate_cats * s.sp
+        a = api.as_np(s.part.clv[0], case.sites * span, np.float64)
+        a *= 0.25
+        amd_lib.pll_gpu_invalidate(s.p, api.DIRTY_CLV, 0)
+        s.update_partials()
+        v2, _ = s.edge_lnl(case.edges[0], persite=False)
+        assert abs((v2 - v0) - case.sites * np.log(0.25)) <= 1e-9 * abs(v0)
+    monkeypatch.setenv("PLL_AMD_NO_TIP_CODES", "1")
+    dense = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    assert_results_match(dense, exp, what=_id(kw))
+    assert scalers_equal(got, dense)
+
+
 @pytest.mark.parametrize("kw", [k for k in ORACLE_CASES if k["states"] == 4 and k.get("rate_cats", 4) == 4], ids=_id)
 def test_dna_through_generic_kernels(amd_lib, kw, monkeypatch):
     """the 4x4 shape also has to be right in the any-shape kernels (PLL_AMD_GENERIC_ONLY=1)"""
