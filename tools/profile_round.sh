@@ -28,6 +28,7 @@ for c in c3 c3r c4 c5; do
   find "$O/prof_$c" -name "*kernel_stats.csv" -exec cp {} "$O/${c}_kernel_stats.csv" \;
 done
 python3 "$R/bench.py" --config c5 --tips states --steps 10 --no-cpu > "$O/c5_codes_bench.json" 2>/dev/null
+PLL_AMD_NO_TIP_CODES=1 python3 "$R/bench.py" --config c5 --steps 10 --no-cpu > "$O/c5_dense_bench.json" 2>/dev/null   # one-hot tip CLVs NOT recognised: 30 inner x inner ops
 python3 "$R/tools/c4_projection.py" --steps 20 > "$O/c4_projection.json" 2> "$O/c4_projection.err"
 rm -rf "$O"/prof_* "$O"/pmc_fetch "$O"/pmc_write "$O"/pmc3_fetch "$O"/pmc3_write
 ls -la "$O"
