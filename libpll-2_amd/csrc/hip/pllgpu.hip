@@ -1352,7 +1352,7 @@ static int plan_and_launch_levels(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigne
       {
         // dissolve the group that took P as a producer
         for (size_t gi = 0; gi < groups.size(); ++gi)
-          if (groups[gi].a == (int)q || groups[gi].b == (int)q)
+          if ((groups[gi].a == (int)q || groups[gi].b == (int)q) && groups[gi].lk != CK_FCC && groups[gi].rk != CK_FCC)
           {
             role[groups[gi].p] = 0;
             if (groups[gi].a >= 0) role[groups[gi].a] = 0;
