@@ -295,12 +295,15 @@ class Runner:
             # the path's one exchange: sum of the shards' log-likelihoods (word 0); word 1 = every rank's
             # call sequence number, so its sum tells the host which evaluation the pair belongs to
             h.dist.all_reduce(self.red)
-            self.pinned[0:1].copy_(self.red[0:1], non_blocking=True)
-            self.pinned[1:2].copy_(self.red[1:2], non_blocking=True)  # stream-ordered behind the value
+            # one 16-byte copy of {value, sequence} (two stream-ordered 8-byte copies cost ~5 us more per step); the host
+            # reads the value only after it has seen the sequence word twice
+            self.pinned.copy_(self.red, non_blocking=True)
             if self.expected is not None:
                 self.expected += h.world
                 t_spin = time.perf_counter()
-                while self.pview[1] != self.expected:
+                seen = 0
+                while seen < 2:
+                    seen = seen + 1 if self.pview[1] == self.expected else 0
                     if time.perf_counter() - t_spin > 0.02:
                         self.expected = None
                         break
