@@ -1160,6 +1160,9 @@ static int launch_lean(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigne
   // a few thousand workgroups remain
   unsigned ipb = (unsigned)(((size_t)items * nops) / 4096u);
   ipb = std::max(2u, std::min(ipb, 16u));
+  // a tip x tip item is two dozen LDS reads and five stores: staging has to be spread over more of them (C3's 32 cherries:
+  // 295 / 240 / 205 / 204 / 254 us with 2 / 8 / 16 / 32 / 64 items per workgroup)
+  if (kind == 2 && !gather) ipb = std::max(2u, std::min((unsigned)(((size_t)items * nops) / 1536u), 32u));
   if (const char *ev = getenv("PLL_AMD_LEAN_IPB")) ipb = std::max(1, atoi(ev));
   dim3 grid((items + ipb - 1) / ipb, nops), block(64u * R);
   const size_t lds = LeanGeo<5>::lds_bytes(R, gather);
@@ -1192,7 +1195,7 @@ static int launch_lean(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigne
 // (the rule unless PLL_AMD_NO_GENERIC_AOS=1), states_padded = 20
 static bool lean_serves(const pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned kind, bool gather)
 {
-  if (!gather) return c->lean_plain;
+  if (!gather) return c->lean_plain || kind == 2; // tip x tip: 204 us against the FMA kernel's 251 for C3's 32 cherries (same box)
   if (c->gg.SP != 20u) return false;
   for (unsigned i = 0; i < nops; ++i)
   {
