@@ -906,3 +906,249 @@ __global__ __launch_bounds__(256) void k_iii_epilogue(const FusePack pack, const
     grp.p.pscaler[n] = cnt[0] + cnt[1] + (f[2] ? 1u : 0u);
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Edge / root log-likelihood for 17..20 states on the matrix pipe (src/core_likelihood.c:1388-1490 ii, :812-915 ti,
+// :163-207 root): workgroup = R waves, wave = rate category, items of 32 sites as above. Per item a wave forms
+// D = P x (child side) with 25 MFMAs per 16 sites (or reads the tip's column), dots it with parent_i * pi_i over the
+// lane's states, the four row groups of a site meet through two shuffles; the rates' terms meet in LDS and wave 0
+// finishes the site (scaling undone, invariant share, log, pattern weight). The scalar-fed FMA kernel spent its life
+// waiting for 20 matrix rows one after the other: C3's 50k sites 33 us for 64 MB, one round of 782 workgroups.
+template <int NG, bool CTIP>
+__global__ __launch_bounds__(256) void k_edge_lean(const DevEdge e, const GenGeo g, const unsigned long long *__restrict__ tipmap,
+                                                   unsigned items_per_block, unsigned ncodes)
+{
+  typedef LeanGeo<NG> LG;
+  constexpr unsigned LD = LG::LD;
+  typedef double __attribute__((ext_vector_type(2))) double2v;
+  extern __shared__ double lds[];
+  const unsigned R = g.R, S = g.S;
+  double *M = lds;                             // [R][rows][LD]
+  double *PART = lds + (size_t)R * LG::mat;    // [2 buffers][2: terma, terminv][R][32]
+  unsigned char *CIDX = reinterpret_cast<unsigned char *>(PART + 2u * 2u * R * 32u); // [256]
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned row = lane >> 4, col = lane & 15u;
+  const unsigned nitems = (e.sites + 31u) / 32u;
+  const unsigned item_first = blockIdx.x * items_per_block;
+  const unsigned item_end = min(item_first + items_per_block, nitems);
+  const unsigned long long full = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
+  double *Mk = M + (size_t)k * LG::mat;
+  if (!e.is_root)
+  {
+    constexpr unsigned N = (LG::rows - 1u) * LD, PER = (N + 63u) / 64u;
+    const double *src = e.mat + (size_t)k * S * g.SPT;
+    double v[PER];
+#pragma unroll
+    for (unsigned q = 0; q < PER; ++q)
+    {
+      const unsigned idx = lane + 64u * q, j = idx / LD, i = idx % LD;
+      const bool in = idx < N && j < S && i < S;
+      const double x = src[in ? (size_t)j * g.SPT + i : 0];
+      v[q] = in ? x : 0.0;
+    }
+#pragma unroll
+    for (unsigned q = 0; q < PER; ++q)
+      if (lane + 64u * q < N) Mk[lane + 64u * q] = v[q];
+    if (CTIP)
+    {
+      for (unsigned c0 = threadIdx.x; c0 < 256u; c0 += blockDim.x)
+      {
+        unsigned ci = kCcAmbiguous;
+        if (c0 < ncodes)
+        {
+          const unsigned long long mk = tipmap[c0];
+          ci = mk == full ? LG::gap_col : __popcll(mk) == 1 ? (unsigned)__ffsll((long long)mk) - 1u : kCcAmbiguous;
+        }
+        CIDX[c0] = (unsigned char)ci;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < LD)
+      {
+        double sum = 0.0; // ascending j like the reference's set-bit walk
+        for (unsigned j = 0; j < S; ++j) sum += Mk[j * LD + lane];
+        Mk[LG::gap_col * LD + lane] = sum;
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned fi = e.fidx[k];
+  const double pinv = e.prop_invar ? e.prop_invar[fi] : 0.0;
+  const double wk = e.rate_weights[k];
+  double pif[NG]; // pi_i of the lane's states
+#pragma unroll
+  for (int ig = 0; ig < NG; ++ig) pif[ig] = (4u * ig + row < S) ? e.freqs[(size_t)fi * g.SP + 4u * ig + row] : 0.0;
+  unsigned loff[NG];
+#pragma unroll
+  for (int jg = 0; jg < NG; ++jg) loff[jg] = min(4u * jg + row, S - 1u) * 64u + 2u * col;
+  const unsigned afrag = row * LD + (lane & 3u);
+  double acc = 0.0;
+  unsigned buf = 0;
+
+  struct Ops
+  {
+    double x[NG][2], p[NG][2];
+    unsigned code[2];
+  };
+  auto request = [&](unsigned item, Ops &o) {
+    const size_t uo = (size_t)(item >> 1) * g.tile_sz + (size_t)k * S * 64 + (item & 1u) * 32u; // wave-uniform
+    const double *pb = e.parent + uo;
+#pragma unroll
+    for (int jg = 0; jg < NG; ++jg)
+    {
+      const double2v w = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(pb + loff[jg]));
+      o.p[jg][0] = w.x;
+      o.p[jg][1] = w.y;
+    }
+    if (CTIP)
+    {
+      const unsigned e0 = min(item * 32u + 2u * col, e.sites - 1u), e1 = min(item * 32u + 2u * col + 1u, e.sites - 1u);
+      o.code[0] = e.ctip[e0];
+      o.code[1] = e.ctip[e1];
+    }
+    else if (!e.is_root)
+    {
+      const double *cb = e.child + uo;
+#pragma unroll
+      for (int jg = 0; jg < NG; ++jg)
+      {
+        const double2v w = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(cb + loff[jg]));
+        o.x[jg][0] = w.x;
+        o.x[jg][1] = w.y;
+      }
+    }
+  };
+  Ops cur;
+  if (item_first < item_end) request(item_first, cur);
+  for (unsigned item = item_first; item < item_end; ++item)
+  {
+    Ops nxt;
+    const bool has_next = item + 1u < item_end;
+    if (has_next) request(item + 1u, nxt);
+    const unsigned n0 = item * 32u + 2u * col;
+    const unsigned nc[2] = {min(n0, e.sites - 1u), min(n0 + 1u, e.sites - 1u)};
+    double D[NG][2];
+    if (e.is_root)
+    {
+#pragma unroll
+      for (int ig = 0; ig < NG; ++ig) D[ig][0] = D[ig][1] = 1.0;
+    }
+    else if (CTIP)
+    {
+      const unsigned c0 = CIDX[cur.code[0]], c1 = CIDX[cur.code[1]];
+      if (__all(c0 != kCcAmbiguous && c1 != kCcAmbiguous))
+      {
+        const double *p0 = Mk + c0 * LD + row, *p1 = Mk + c1 * LD + row;
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig)
+        {
+          D[ig][0] = p0[4 * ig];
+          D[ig][1] = p1[4 * ig];
+        }
+      }
+      else
+      {
+        const unsigned long long m0 = tipmap[cur.code[0]], m1 = tipmap[cur.code[1]];
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig) D[ig][0] = D[ig][1] = 0.0;
+#pragma unroll
+        for (int jg = 0; jg < NG; ++jg)
+        {
+          const double x0 = mfma_x<true>(nullptr, m0, S, 4 * jg + row), x1 = mfma_x<true>(nullptr, m1, S, 4 * jg + row);
+#pragma unroll
+          for (int ig = 0; ig < NG; ++ig)
+          {
+            const double a = Mk[afrag + 4 * jg * LD + 4 * ig];
+            D[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x0, D[ig][0], 0, 0, 0);
+            D[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x1, D[ig][1], 0, 0, 0);
+          }
+        }
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int ig = 0; ig < NG; ++ig) D[ig][0] = D[ig][1] = 0.0;
+#pragma unroll
+      for (int jg = 0; jg < NG; ++jg)
+      {
+#pragma unroll
+        for (int ig = 0; ig < NG; ++ig)
+        {
+          const double a = Mk[afrag + 4 * jg * LD + 4 * ig];
+          D[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, cur.x[jg][0], D[ig][0], 0, 0, 0);
+          D[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, cur.x[jg][1], D[ig][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    double *part = PART + (size_t)buf * 2u * R * 32u;
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg)
+    {
+      double tr = 0.0;
+#pragma unroll
+      for (int ig = 0; ig < NG; ++ig) tr = fma(cur.p[ig][sg] * pif[ig], D[ig][sg], tr);
+      tr += __shfl_xor(tr, 16, 64);
+      tr += __shfl_xor(tr, 32, 64);
+      if (row == 0)
+      {
+        if (e.per_rate)
+        {
+          unsigned mn = 0xFFFFFFFFu, own = 0;
+          for (unsigned q = 0; q < R; ++q)
+          {
+            const unsigned rs = (e.pscaler ? e.pscaler[(size_t)nc[sg] * R + q] : 0u) + (e.cscaler ? e.cscaler[(size_t)nc[sg] * R + q] : 0u);
+            mn = min(mn, rs);
+            if (q == k) own = rs;
+          }
+          const unsigned ex = min(own - mn, PLLGPU_RATE_MAXDIFF);
+          if (ex) tr *= minlh(ex);
+        }
+        double ta, ti = 0.0;
+        if (pinv > 0.0)
+        {
+          ta = wk * tr * (1.0 - pinv);
+          const int inv = e.invariant ? e.invariant[nc[sg]] : -1;
+          if (inv >= 0) ti = wk * e.freqs[(size_t)fi * g.SP + inv] * pinv;
+        }
+        else
+          ta = tr * wk;
+        part[(0u * R + k) * 32u + 2u * col + sg] = ta;
+        part[(1u * R + k) * 32u + 2u * col + sg] = ti;
+      }
+    }
+    lds_barrier();
+    if (k == 0 && row == 0)
+    {
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg)
+      {
+        const unsigned n = n0 + sg;
+        if (n >= e.sites) continue;
+        double ta = part[(0u * R) * 32u + 2u * col + sg], ti = part[(1u * R) * 32u + 2u * col + sg];
+        for (unsigned q = 1; q < R; ++q)
+        {
+          ta += part[(0u * R + q) * 32u + 2u * col + sg];
+          ti += part[(1u * R + q) * 32u + 2u * col + sg];
+        }
+        unsigned scal;
+        if (e.per_rate)
+        {
+          scal = 0xFFFFFFFFu;
+          for (unsigned q = 0; q < R; ++q)
+            scal = min(scal, (e.pscaler ? e.pscaler[(size_t)n * R + q] : 0u) + (e.cscaler ? e.cscaler[(size_t)n * R + q] : 0u));
+        }
+        else
+          scal = (e.pscaler ? e.pscaler[n] : 0u) + (e.cscaler ? e.cscaler[n] : 0u);
+        const double site = finish_site(ta, ti, scal, e.is_root) * (double)e.pattern_weights[n];
+        if (e.persite) e.persite[n] = site;
+        acc += site;
+      }
+    }
+    buf ^= 1u;
+    if (has_next) cur = nxt;
+  }
+  publish_block_sum(e, k == 0 ? wave_sum(acc) : 0.0, 1u);
+}

@@ -171,6 +171,7 @@ struct pllgpu_ctx
   bool generic_aos = true;          // PLL_AMD_NO_GENERIC_AOS=1: compressed nodes of non-4x4 shapes stay tiled (A/B)
   bool lean = false;                // 17..20 states, <= 4 rates: the level launches on the matrix pipe (kernels_lean.h)
   bool lean_plain = false;          // ... also the ones that do not gather (PLL_AMD_LEAN_PLAIN=1)
+  bool lean_edge = false;           // PLL_AMD_LEAN_EDGE=1: edge log-likelihoods of these shapes on the matrix pipe (k_edge_lean: 37 us against the FMA kernel's 33 at C3's size - both are a chain of round trips around microseconds of arithmetic)
   int lean_groups = 0;              // ... and (inner x inner, inner x inner -> inner x inner) groups: 1 = k_partials_lean3, 2 = k_partials_mfma_iii
   bool fuse_mfma = false;           // 17..32 states on the matrix pipe: the same groups (kernels_mfma.h: k_partials_mfma_cc)
   bool fuse_generic = false;        // FMA-path shapes: (tip x tip, tip x tip -> inner x inner) groups (kernels_generic.h: k_partials_tiled_cc)
@@ -345,6 +346,8 @@ static void derive_geometry(pllgpu_ctx *c)
     if (*v && *v != '0') c->lean = false;
   if (const char *v = getenv("PLL_AMD_LEAN_PLAIN"))
     c->lean_plain = *v && *v != '0';
+  if (const char *v = getenv("PLL_AMD_LEAN_EDGE"))
+    c->lean_edge = *v && *v != '0';
   // OPT-IN (PLL_AMD_LEAN_GROUPS=1): bit-compatible scaling decisions and one launch less, but slower than the two level
   // launches it replaces (C3 levels 3 + 4: 290 us against 221) - 77 KB of matrices leave room for two workgroups per CU,
   // whose four waves load, multiply and store in lockstep (a barrier per op): reads and writes take turns
@@ -1850,6 +1853,21 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
     // one tile per workgroup pass (the waves split its rate categories), tpw tiles per workgroup
     tpw = (tiles + max_blocks - 1) / max_blocks;
     blocks = (tiles + tpw - 1) / tpw;
+    if (c->lean && c->lean_edge && !gather && (!ctip || c->tipmap_set) && c->gg.S >= 17 && c->gg.S <= 20)
+    {
+      // 17..20 states, both ends in the tiled layout: the matrix-pipe form (kernels_lean.h: k_edge_lean)
+      const unsigned items = (g.sites + 31) / 32, R = c->gg.R;
+      const unsigned ipb = std::max(1u, (items + 1023u) / 1024u);
+      const unsigned nb = (items + ipb - 1) / ipb;
+      const size_t lds = (size_t)R * LeanGeo<5>::mat * sizeof(double) + (size_t)2 * 2 * R * 32 * sizeof(double) + 256u;
+      const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
+      const unsigned ncodes = std::min(c->tip_ncodes, 256u);
+      if (ctip)
+        hipLaunchKernelGGL((k_edge_lean<5, true>), dim3(nb), dim3(64u * R), lds, c->stream, e, c->gg, tm, ipb, ncodes);
+      else
+        hipLaunchKernelGGL((k_edge_lean<5, false>), dim3(nb), dim3(64u * R), lds, c->stream, e, c->gg, tm, ipb, ncodes);
+    }
+    else
     switch (c->ich)
     {
       case 4: launch_edge_generic<4>(c, e, blocks, tpw, ctip, gather); break;

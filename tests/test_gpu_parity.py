@@ -521,6 +521,24 @@ def test_results_are_reproducible_run_to_run(amd_lib, kw):
             assert s.root_lnl((e[0], e[1]), persite=False)[0] == root
 
 
+@pytest.mark.parametrize("kw", [dict(states=20, tips=16, sites=1500, seed=370), dict(states=20, tips=16, sites=333, seed=371, attributes=api.RATE_SCALERS, rate_cats=3),
+                                dict(states=18, tips=8, sites=200, seed=372, attributes=api.PATTERN_TIP, ambiguity_pct=10), dict(states=20, tips=150, sites=300, seed=373, tree="caterpillar", brlen_scale=6),
+                                dict(states=20, tips=8, sites=500, seed=374, pinv=0.2)], ids=_id)
+def test_matrix_pipe_edge_kernel_of_the_protein_shapes(amd_lib, kw, monkeypatch):
+    """17..20 states, opt-in (PLL_AMD_LEAN_EDGE=1): edge and root log-likelihoods on the matrix pipe (k_edge_lean) against
+    the oracle, per-site values included; reproducible run to run"""
+    monkeypatch.setenv("PLL_AMD_LEAN_EDGE", "1")
+    case = W.make_case("el", **kw)
+    exp = O.run_case(case)
+    got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    assert_results_match(got, exp, what=_id(kw))
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        v = s.edge_lnl(case.edges[0], persite=False)[0]
+        for _ in range(20):
+            assert s.edge_lnl(case.edges[0], persite=False)[0] == v
+
+
 def test_cherry_tables_follow_the_matrices(amd_lib, monkeypatch):
     """matrix-pipe groups keep a cherry's table of scaling decisions on the device for as long as its two tip
     matrices stand: near-identity matrices (cherries of two different states are rescaled), then ordinary ones in
