@@ -211,6 +211,29 @@ __device__ __forceinline__ void handoff_before_sequence(int fenced)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// the last workgroup's share of the partials: thread t adds slots t, t + blockDim, ... in that order. All requests of a
+// batch of 16 first, then the additions: the loads are agent-scope atomics (each a trip to the coherent level, ~2 us
+// under load), and a loop of load / add made the tail of every evaluation as many trips long as a thread had slots.
+__device__ __forceinline__ double sum_partials_strided(const double *block_sums, unsigned n)
+{
+  double a = 0.0;
+  const unsigned stride = blockDim.x;
+  for (unsigned base = 0; base < n; base += 16u * stride)
+  {
+    double v[16];
+#pragma unroll
+    for (unsigned q = 0; q < 16u; ++q)
+    {
+      const unsigned i = base + q * stride + threadIdx.x;
+      v[q] = i < n ? partial_load(&block_sums[i]) : 0.0;
+    }
+#pragma unroll
+    for (unsigned q = 0; q < 16u; ++q)
+      if (base + q * stride + threadIdx.x < n) a += v[q];
+  }
+  return a;
+}
+
 // The same when only SOME workgroups hold a value and which ones is decided at run time (k_edge_mfma: the workgroup
 // that finishes an item block last): the value goes to the slot of the ITEM BLOCK, not of the workgroup, so that the
 // final sum adds the same numbers in the same places whichever workgroup produced them - with one slot per
@@ -239,8 +262,7 @@ __device__ __forceinline__ void publish_block_sum_slot(const DevEdge &e, double 
   }
   __syncthreads();
   if (!last) return;
-  double a = 0.0;
-  for (unsigned i = threadIdx.x; i < nslots; i += blockDim.x) a += partial_load(&e.block_sums[i]);
+  double a = sum_partials_strided(e.block_sums, nslots);
   a = wave_sum(a);
   __syncthreads();
   if (lane == 0) ws[wave] = a;
@@ -275,8 +297,7 @@ __device__ __forceinline__ void publish_block_sum(const DevEdge &e, double wave_
   }
   __syncthreads();
   if (!last) return;
-  double a = 0.0;
-  for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) a += partial_load(&e.block_sums[i]);
+  double a = sum_partials_strided(e.block_sums, gridDim.x);
   a = wave_sum(a);
   __syncthreads();
   if (lane == 0) ws[wave] = a;

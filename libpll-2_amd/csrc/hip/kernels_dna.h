@@ -1732,12 +1732,25 @@ __device__ __forceinline__ void chain_edge_body(const DevEdge &e, const SRC src,
   const unsigned wave = threadIdx.x >> 6;
   const unsigned site_tiles = (e.sites + 63u) / 64u, nblocks = (site_tiles + 3u) / 4u;
   double a = 0.0;
-  for (unsigned i = threadIdx.x; i < nblocks; i += blockDim.x)
+  for (unsigned base = 0; base < nblocks; base += 4u * blockDim.x) // all requests of a batch first (sum_partials_strided)
   {
-    double sblk = partial_load(&e.block_sums[4u * i]);
+    double v[4][4];
 #pragma unroll
-    for (unsigned w = 1; w < 4u; ++w) sblk += (4u * i + w < site_tiles) ? partial_load(&e.block_sums[4u * i + w]) : 0.0;
-    a += sblk;
+    for (unsigned q = 0; q < 4u; ++q)
+    {
+      const unsigned i = base + q * blockDim.x + threadIdx.x;
+#pragma unroll
+      for (unsigned w = 0; w < 4u; ++w) v[q][w] = (i < nblocks && 4u * i + w < site_tiles) ? partial_load(&e.block_sums[4u * i + w]) : 0.0;
+    }
+#pragma unroll
+    for (unsigned q = 0; q < 4u; ++q)
+      if (base + q * blockDim.x + threadIdx.x < nblocks)
+      {
+        double sblk = v[q][0];
+#pragma unroll
+        for (unsigned w = 1; w < 4u; ++w) sblk += v[q][w];
+        a += sblk;
+      }
   }
   a = wave_sum(a);
   if (lane == 0) ws[wave] = a;
