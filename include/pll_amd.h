@@ -512,6 +512,53 @@ int pll_gpu_edge_loglikelihood_async(pll_partition_t *partition, unsigned int pa
                                      int parent_scaler_index, unsigned int child_clv_index,
                                      int child_scaler_index, unsigned int matrix_index,
                                      const unsigned int *freqs_indices, double *device_result);
+/* ---- the ONE exchange of a site-sharded run (SURVEY section 8 row e) --------------------------
+ * Sites are independent through every CLV update; the only cross-site operation of the path is the sum
+ * of the per-site log-likelihoods (src/core_likelihood.c:1489, the sequential `logl += site_lk`). A run
+ * that gives every GPU its own partition over a contiguous site range therefore needs exactly one
+ * exchange per evaluation: the sum of one double per rank. Two forms, both plain C:
+ *
+ * (1) ranks of ONE node, fixed order - pll_gpu_group_*. The ranks (processes or threads) meet in a named
+ *     POSIX shared-memory segment with two alternating slots per rank; every rank leaves {value, step}
+ *     in its slot and adds the slots of all ranks IN RANK ORDER, so every rank returns the same bits and
+ *     the sum is reproducible run to run whatever the arrival order (an all-reduce tree is not). Cost:
+ *     a cache-line hand-off between host cores behind the result the device has already written to host
+ *     memory - no kernel, no collective library. `name` must be unique per run and start with '/'.
+ * (2) any communicator - pll_gpu_allreduce_lnl / pll_gpu_edge_loglikelihood_allreduce: one
+ *     ncclAllReduce(sum, ncclDouble) on the partition's stream. librccl is opened with dlopen() at the
+ *     first call (PLL_AMD_RCCL_LIB overrides the name), so the library loads and works without RCCL;
+ *     the caller creates the ncclComm_t (ncclCommInitRank) and passes it as void *. */
+typedef struct pll_gpu_group pll_gpu_group_t;
+/* join (and, whoever comes first, create) the segment `name` as rank `rank` of `size`; waits until all
+ * `size` ranks have joined (timeout_ms <= 0: 60 s). NULL + pll_errno on failure. */
+pll_gpu_group_t *pll_gpu_group_join(const char *name, unsigned int rank, unsigned int size, int timeout_ms);
+void pll_gpu_group_leave(pll_gpu_group_t *group);
+unsigned int pll_gpu_group_rank(const pll_gpu_group_t *group);
+unsigned int pll_gpu_group_size(const pll_gpu_group_t *group);
+/* global[i] = local[i] of rank 0 + rank 1 + ... + rank size-1, in that order, i < count <= 6. Every
+ * rank must call it the same number of times. PLL_FAILURE (pll_errno PLL_ERROR_GPU_RUNTIME) when a rank
+ * does not arrive within the group's timeout. */
+int pll_gpu_group_sum(pll_gpu_group_t *group, const double *local, unsigned int count, double *global);
+/* pll_compute_edge_loglikelihood (src/pll.h:790-797) on this rank's partition followed by the exchange:
+ * the log-likelihood of the WHOLE alignment on every rank (-inf on every rank if any rank failed).
+ * persite_lnl, if given, receives this rank's sites only (per-site values stay sharded). */
+double pll_gpu_group_edge_loglikelihood(pll_partition_t *partition, pll_gpu_group_t *group,
+                                        unsigned int parent_clv_index, int parent_scaler_index,
+                                        unsigned int child_clv_index, int child_scaler_index,
+                                        unsigned int matrix_index, const unsigned int *freqs_indices,
+                                        double *persite_lnl);
+/* enqueue ncclAllReduce(device_values, device_values, count, ncclDouble, ncclSum, comm) on the
+ * partition's stream (count doubles of DEVICE memory, e.g. what pll_gpu_edge_loglikelihood_async left) */
+int pll_gpu_allreduce_lnl(pll_partition_t *partition, void *nccl_comm, double *device_values, unsigned int count);
+/* the whole step without a host round trip before the exchange: the shard's log-likelihood stays in
+ * device memory, is all-reduced there and only the sum comes back. Collective: every rank of the
+ * communicator calls it, the same number of times. Returns the sum, -inf on failure. */
+double pll_gpu_edge_loglikelihood_allreduce(pll_partition_t *partition, void *nccl_comm,
+                                            unsigned int parent_clv_index, int parent_scaler_index,
+                                            unsigned int child_clv_index, int child_scaler_index,
+                                            unsigned int matrix_index, const unsigned int *freqs_indices);
+/* 1 if a RCCL library could be opened (pll_gpu_allreduce_* usable), 0 otherwise */
+int pll_gpu_rccl_available(void);
 /* HIP-event stopwatch on the partition's stream (bench.py's roofline leg): start .. stop
  * brackets whatever was enqueued in between; returns elapsed milliseconds from stop(). */
 int pll_gpu_timer_start(pll_partition_t *partition);

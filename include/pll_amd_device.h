@@ -77,6 +77,9 @@ typedef struct pllgpu_edge
                                          the kernel leaves {lnL, call sequence number} there and the
                                          call returns without waiting (multi-GPU: the sum over shards
                                          is reduced on the device, pll_gpu_edge_loglikelihood_async) */
+  double sequence;                    /* 0: the context numbers the call itself. Otherwise the sequence word the
+                                         kernel leaves next to the value (ranks of a collective number their
+                                         evaluations in step, so that the reduced word identifies the step) */
 } pllgpu_edge_t;
 
 int pllgpu_device_count(void);
@@ -214,6 +217,14 @@ int pllgpu_compress_patterns(const unsigned char *encoded, unsigned int count, u
                              unsigned char *compressed, unsigned int *weights,
                              unsigned int *site_pattern_map, unsigned int *patterns_out, int device);
 const char *pllgpu_compress_last_error(void);
+
+/* ---- the exchange of a site-sharded run (pll_gpu_edge_loglikelihood_allreduce) ---------------- */
+/* two doubles of device memory owned by the context: {lnL, sequence}, the operand of the all-reduce */
+double *pllgpu_reduce_buffer(pllgpu_ctx_t *ctx);
+/* after the collective has been enqueued on the context's stream: a one-lane kernel copies the reduced
+ * pair to mapped host memory (value first, sequence word behind it) and the call polls for
+ * expected_sequence (= ranks x the sequence every rank used). Synchronises only on time-out. */
+int pllgpu_reduce_fetch(pllgpu_ctx_t *ctx, double expected_sequence, double *value_out);
 
 /* ---- stream / timing ---------------------------------------------------------------------- */
 int pllgpu_set_stream(pllgpu_ctx_t *ctx, void *hip_stream);

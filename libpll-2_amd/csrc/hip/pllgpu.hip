@@ -130,6 +130,8 @@ struct pllgpu_ctx
   unsigned rep_seq = 0;
   double *result_host = nullptr; // pinned + mapped: [0] lnL, [1] sequence of the call that wrote it
   double seq = 0.0;
+  double seq_override = 0.0;     // pllgpu_edge_t.sequence of the evaluation being issued (0: number it here)
+  DevBuf<double> reduce;         // {lnL, sequence}: the operand of a caller's all-reduce (pllgpu_reduce_buffer)
   std::vector<double> stage;     // host staging for the P-matrix re-layout
   unsigned last_launches = 0;
   double last_bytes = 0.0;       // algorithmic HBM bytes of the last update_partials call
@@ -438,7 +440,7 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
     return nullptr;
   }
   c->own_stream = true;
-  c->result_host[0] = c->result_host[1] = 0.0;
+  memset(c->result_host, 0, 8 * sizeof(double));
   memset(c->rep_host, 0, (kRepOps + 2) * sizeof(unsigned));
   c->clv.resize(geo->nodes);
   c->clv_aos.assign(geo->nodes, 0);
@@ -501,6 +503,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->prop_invar.release();
   c->persite.release();
   c->block_sums.release();
+  c->reduce.release();
   c->counter.release();
   c->mfma_flags.release();
   c->eigenvals.release();
@@ -1777,10 +1780,15 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
   e.block_sums = c->block_sums.p;
   e.counter = c->counter.p;
   e.result = device_result ? device_result : c->result_dev;
-  c->seq += 1.0;
-  e.sequence = c->seq;
+  if (c->seq_override != 0.0)
+    e.sequence = c->seq_override; // a collective's step number: only meaningful in device_result
+  else
+  {
+    c->seq += 1.0;
+    e.sequence = c->seq;
+  }
   unsigned long long seq_bits;
-  memcpy(&seq_bits, &c->seq, sizeof seq_bits);
+  memcpy(&seq_bits, &e.sequence, sizeof seq_bits);
   e.sites = g.sites;
   e.per_rate = g.per_rate_scalers ? 1 : 0;
   e.fenced = c->fenced;
@@ -1960,6 +1968,13 @@ extern "C" int pllgpu_edge_loglikelihood(pllgpu_ctx_t *c, const pllgpu_edge_t *e
   if (ed->parent_scaler >= (int)g.scale_buffers || ed->child_scaler >= (int)g.scale_buffers)
     return fail(PLLGPU_EINVAL, "edge references a scale buffer out of range");
   if (ed->device_result && persite_host) return fail(PLLGPU_EINVAL, "per-site values are not available from an asynchronous evaluation");
+  if (ed->sequence != 0.0 && !ed->device_result) return fail(PLLGPU_EINVAL, "a caller-numbered evaluation needs device_result");
+  struct SeqScope
+  {
+    pllgpu_ctx *c;
+    ~SeqScope() { c->seq_override = 0.0; }
+  } seq_scope_{c};
+  c->seq_override = ed->sequence;
   if (ed->child_is_tip && (ed->child_clv >= g.tips || !c->tipchars[ed->child_clv].p))
     return fail(PLLGPU_EINVAL, "tip %u has no codes on the device", ed->child_clv);
   for (unsigned k = 0; k < g.rate_cats; ++k)
@@ -2176,6 +2191,48 @@ extern "C" int pllgpu_root_loglikelihood(pllgpu_ctx_t *c, unsigned clv, int scal
   if (e.layout && !gather) return fail(PLLGPU_EINVAL, "a class-compressed CLV met an evaluation without the gather flag");
   e.is_root = 1;
   return run_lnl(c, e, false, gather != 0, freqs_indices, persite_host, lnl_out);
+}
+
+// ---- the exchange of a site-sharded run ---------------------------------------------------------
+extern "C" double *pllgpu_reduce_buffer(pllgpu_ctx_t *c)
+{
+  if (!c) return nullptr;
+  DeviceScope device_scope_(c);
+  if (device_scope_.rc || c->reduce.ensure(2)) return nullptr;
+  return c->reduce.p;
+}
+
+// value, then - once the value has been performed - the sequence word: the order the host's poll relies on
+__global__ void k_publish_pair(const double *__restrict__ pair, double *__restrict__ host)
+{
+  const double v = pair[0], q = pair[1];
+  __hip_atomic_store(host, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __hip_atomic_store(host + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" int pllgpu_reduce_fetch(pllgpu_ctx_t *c, double expected_sequence, double *value_out)
+{
+  CHECK_CTX(c);
+  if (!c->reduce.p) return fail(PLLGPU_EINVAL, "no reduce buffer");
+  // words 4 and 5 of the mapped result block (0..2 belong to the synchronous evaluations and the derivatives)
+  hipLaunchKernelGGL(k_publish_pair, dim3(1), dim3(1), 0, c->stream, c->reduce.p, c->result_dev + 4);
+  HIP_TRY(hipGetLastError());
+  unsigned long long want;
+  memcpy(&want, &expected_sequence, sizeof want);
+  volatile double *res = c->result_host;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (__atomic_load_n((const unsigned long long *)&res[5], __ATOMIC_ACQUIRE) != want)
+    if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2000))
+    {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (__atomic_load_n((const unsigned long long *)&res[5], __ATOMIC_ACQUIRE) != want)
+        return fail(PLLGPU_ERUNTIME, "the reduced sequence word is %.17g, expected %.17g: the ranks are out of step", (double)res[5], expected_sequence);
+      break;
+    }
+  *value_out = c->result_host[4];
+  return 0;
 }
 
 // ---- stream / timing ---------------------------------------------------------------------------

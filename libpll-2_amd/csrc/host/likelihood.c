@@ -76,23 +76,29 @@ static int prepare_end(pll_partition_t *p, pll_amd_ext_t *x, unsigned int clv, i
  * (src/likelihood.c:612-624); compact indicator tips are this library's own device format, so for
  * them the swap must not change the value: sum_i p_i pi_i sum_j P_ij c_j is symmetric in (p, c) iff
  * pi_i P_ij = pi_j P_ji for the frequency set of every rate category. That is known to hold when
- * pll_update_prob_matrices formed the matrix from the eigensystem of the very parameter set whose
- * frequencies the caller names in freqs_indices, and that eigensystem is still valid (setting new
- * frequencies or rates invalidates it). A matrix the caller wrote, or other frequency sets: the tip
- * is given a dense CLV and the caller's orientation is evaluated as is. */
+ * pll_update_prob_matrices formed the matrix from an eigensystem this library computed for the very
+ * parameter set whose frequencies the caller names in freqs_indices, and neither the frequencies nor
+ * the substitution parameters of that set have changed since: every set carries a version counter
+ * (pll_set_frequencies, pll_set_subst_params, pll_gpu_invalidate FREQS / EIGEN move it) and the matrix
+ * remembers the version it was formed at. The CURRENT eigen_decomp_valid flag says nothing about
+ * that: it is set again by any later pll_update_prob_matrices / pll_update_sumtable on the new
+ * frequencies, and a caller who writes p->frequencies and invalidates never clears it. A matrix the
+ * caller wrote, an eigensystem the caller wrote, or other frequency sets: the tip is given a dense
+ * CLV and the caller's orientation is evaluated as is. */
 static int swap_is_exact(const pll_partition_t *p, const pll_amd_ext_t *x, unsigned int matrix_index,
                          const unsigned int *freqs_indices)
 {
   unsigned int k;
   const unsigned char *formed = x->pmatrix_params + (size_t)matrix_index * p->rate_cats;
+  const unsigned int *version = x->pmatrix_version + (size_t)matrix_index * p->rate_cats;
   for (k = 0; k < p->rate_cats; ++k)
-    if (formed[k] == 0xFFu || formed[k] != freqs_indices[k] || !p->eigen_decomp_valid[formed[k]]) return 0;
+    if (formed[k] == 0xFFu || formed[k] != freqs_indices[k] || version[k] != x->model_version[formed[k]]) return 0;
   return 1;
 }
 
 static double edge_lnl(pll_partition_t *p, unsigned int parent_clv_index, int parent_scaler_index,
                        unsigned int child_clv_index, int child_scaler_index, unsigned int matrix_index,
-                       const unsigned int *freqs_indices, double *persite_lnl, double *device_result)
+                       const unsigned int *freqs_indices, double *persite_lnl, double *device_result, double sequence)
 {
   pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
   if (!x || !x->ctx)
@@ -140,6 +146,7 @@ static double edge_lnl(pll_partition_t *p, unsigned int parent_clv_index, int pa
   e.freqs_indices = freqs_indices;
   e.want_persite = persite_lnl != NULL;
   e.device_result = device_result;
+  e.sequence = sequence;
   if (device_result && (p->attributes & PLL_ATTRIB_AB_MASK))
   {
     pll_set_error(PLL_ERROR_GPU_UNSUPPORTED, "the ascertainment-bias correction needs the synchronous call");
@@ -161,7 +168,7 @@ double pll_compute_edge_loglikelihood(pll_partition_t *p, unsigned int parent_cl
                                       const unsigned int *freqs_indices, double *persite_lnl)
 {
   return edge_lnl(p, parent_clv_index, parent_scaler_index, child_clv_index, child_scaler_index, matrix_index,
-                  freqs_indices, persite_lnl, NULL);
+                  freqs_indices, persite_lnl, NULL, 0.0);
 }
 
 int pll_gpu_edge_loglikelihood_async(pll_partition_t *p, unsigned int parent_clv_index, int parent_scaler_index,
@@ -175,8 +182,17 @@ int pll_gpu_edge_loglikelihood_async(pll_partition_t *p, unsigned int parent_clv
     return PLL_FAILURE;
   }
   const double v = edge_lnl(p, parent_clv_index, parent_scaler_index, child_clv_index, child_scaler_index,
-                            matrix_index, freqs_indices, NULL, device_result);
+                            matrix_index, freqs_indices, NULL, device_result, 0.0);
   return v == 0.0 ? PLL_SUCCESS : PLL_FAILURE; /* 0 = enqueued; failures come back as -inf */
+}
+
+int pll_gpu_edge_loglikelihood_numbered(pll_partition_t *p, unsigned int parent_clv_index, int parent_scaler_index,
+                                        unsigned int child_clv_index, int child_scaler_index, unsigned int matrix_index,
+                                        const unsigned int *freqs_indices, double *device_result, double sequence)
+{
+  const double v = edge_lnl(p, parent_clv_index, parent_scaler_index, child_clv_index, child_scaler_index,
+                            matrix_index, freqs_indices, NULL, device_result, sequence);
+  return v == 0.0 ? PLL_SUCCESS : PLL_FAILURE;
 }
 
 double pll_compute_root_loglikelihood(pll_partition_t *p, unsigned int clv_index, int scaler_index,

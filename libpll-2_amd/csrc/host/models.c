@@ -233,6 +233,7 @@ int pll_update_eigen(pll_partition_t *p, unsigned int idx)
     {
       x->eigen_dirty[idx] = 1;
       x->eigen_version++;
+      x->model_foreign[idx] = 0; /* computed here from this set's own rates and frequencies */
     }
   }
   free(keep); free(a); free(v); free(d); free(full);
@@ -281,8 +282,11 @@ int pll_update_prob_matrices(pll_partition_t *p, const unsigned int *params_indi
     x->pmatrix_dirty[matrix_indices[b]] = 0;
     x->pmatrix_stale[matrix_indices[b]] = 1;
     for (n = 0; n < p->rate_cats; ++n)
-      x->pmatrix_params[(size_t)matrix_indices[b] * p->rate_cats + n] =
-          params_indices[n] < 0xFFu ? (unsigned char)params_indices[n] : 0xFFu;
+    {
+      const size_t at = (size_t)matrix_indices[b] * p->rate_cats + n;
+      x->pmatrix_params[at] = (params_indices[n] < 0xFFu && !x->model_foreign[params_indices[n]]) ? (unsigned char)params_indices[n] : 0xFFu;
+      x->pmatrix_version[at] = x->model_version[params_indices[n]];
+    }
   }
   if (x->eager_mirror) return pll_gpu_sync_pmatrix(p, -1);
   return PLL_SUCCESS;

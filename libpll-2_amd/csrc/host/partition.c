@@ -92,6 +92,9 @@ static void free_ext(pll_amd_ext_t *x)
   free(x->eigen_dirty);
   free(x->pmatrix_stale);
   free(x->pmatrix_params);
+  free(x->model_version);
+  free(x->model_foreign);
+  free(x->pmatrix_version);
   free(x->repeats_stale);
   free(x->repeats_count);
   free(x->aux_params);
@@ -347,6 +350,10 @@ pll_partition_t *pll_partition_create(unsigned int tips, unsigned int clv_buffer
   x->pmatrix_params = (unsigned char *)malloc((size_t)(prob_matrices ? prob_matrices : 1) * rate_cats);
   NEED(x->pmatrix_params);
   memset(x->pmatrix_params, 0xFF, (size_t)(prob_matrices ? prob_matrices : 1) * rate_cats);
+  x->model_version = (unsigned int *)calloc(rate_matrices ? rate_matrices : 1, sizeof(unsigned int));
+  x->model_foreign = (unsigned char *)calloc(rate_matrices ? rate_matrices : 1, 1);
+  x->pmatrix_version = (unsigned int *)calloc((size_t)(prob_matrices ? prob_matrices : 1) * rate_cats, sizeof(unsigned int));
+  NEED(x->model_version && x->model_foreign && x->pmatrix_version);
   x->repeats_stale = (unsigned char *)calloc(p->nodes ? p->nodes : 1, 1);
   x->repeats_count = (unsigned int *)calloc(p->nodes ? p->nodes : 1, sizeof(unsigned int));
   NEED(x->repeats_stale && x->repeats_count);
@@ -484,6 +491,7 @@ void pll_set_frequencies(pll_partition_t *p, unsigned int idx, const double *f)
   {
     x->freqs_dirty[idx] = 1;
     x->eigen_version++;
+    x->model_version[idx]++;
   }
 }
 
@@ -491,6 +499,8 @@ void pll_set_subst_params(pll_partition_t *p, unsigned int idx, const double *pa
 {
   memcpy(p->subst_params[idx], params, (size_t)p->states * (p->states - 1) / 2 * sizeof(double));
   p->eigen_decomp_valid[idx] = 0;
+  pll_amd_ext_t *x = pll_ext(p);
+  if (x) x->model_version[idx]++;
 }
 
 void pll_set_category_rates(pll_partition_t *p, const double *rates)
@@ -796,7 +806,12 @@ void pll_gpu_invalidate(pll_partition_t *p, unsigned int what, int index)
     for (i = 0; i < p->prob_matrices; ++i)    /* ... and nothing is known about how it was formed */
       if (index < 0 || i == (unsigned int)index) memset(x->pmatrix_params + (size_t)i * p->rate_cats, 0xFF, p->rate_cats);
   }
-  if (what & PLL_GPU_DIRTY_FREQS) MARK(freqs_dirty, p->rate_matrices, 1);
+  if (what & PLL_GPU_DIRTY_FREQS)
+  {
+    MARK(freqs_dirty, p->rate_matrices, 1);
+    for (i = 0; i < p->rate_matrices; ++i) /* matrices formed with the old frequencies are not reversible for the new */
+      if (index < 0 || i == (unsigned int)index) x->model_version[i]++;
+  }
   if (what & PLL_GPU_DIRTY_RATE_WEIGHTS) x->rate_weights_dirty = x->prop_invar_dirty = 1;
   if (what & PLL_GPU_DIRTY_PATTERN_WEIGHTS) x->pattern_weights_dirty = 1;
   if (what & PLL_GPU_DIRTY_INVARIANT) x->invariant_dirty = x->prop_invar_dirty = 1;
@@ -815,6 +830,9 @@ void pll_gpu_invalidate(pll_partition_t *p, unsigned int what, int index)
   if (what & PLL_GPU_DIRTY_EIGEN)
   {
     MARK(eigen_dirty, p->rate_matrices, 1);
+    MARK(model_foreign, p->rate_matrices, 1); /* the caller's own eigensystem: nothing is known about it */
+    for (i = 0; i < p->rate_matrices; ++i)
+      if (index < 0 || i == (unsigned int)index) x->model_version[i]++;
     x->eigen_version++;
     x->rates_dirty = 1;
   }

@@ -56,6 +56,13 @@ typedef struct pll_amd_ext
   unsigned char *pmatrix_stale; /* [prob_matrices] computed on the device, host mirror not refreshed */
   unsigned char *pmatrix_params; /* [prob_matrices][rate_cats] params_indices pll_update_prob_matrices formed the
                                     matrix with; 0xFF = unknown (written by the caller) */
+  /* reversibility bookkeeping for swap_is_exact() (likelihood.c): model_version[set] moves whenever the
+   * frequencies or substitution parameters of a set change (setters, pll_gpu_invalidate FREQS / EIGEN);
+   * model_foreign[set] = the eigensystem was written by the caller, not computed here from (rates, pi);
+   * pmatrix_version = model_version of each category's set at the moment the matrix was formed */
+  unsigned int *model_version;   /* [rate_matrices] */
+  unsigned char *model_foreign;  /* [rate_matrices] */
+  unsigned int *pmatrix_version; /* [prob_matrices][rate_cats] */
   unsigned char *repeats_stale; /* [nodes] class maps computed on the device, host mirror not refreshed */
   unsigned int *repeats_count;  /* [nodes] classes the device found (kept even when the node stays uncompressed) */
   int rates_dirty;
@@ -69,6 +76,7 @@ typedef struct pll_amd_ext
    * upload the caller's (never written) buffer */
   const double *sumtable_evicted[PLLGPU_SUMTABLE_SLOTS];
   unsigned int sumtable_evicted_next;
+  double reduce_step;           /* collective evaluations issued so far (group.c: the ranks count in step) */
   /* scheduler scratch (grown on demand) */
   pllgpu_op_t *gops;
   unsigned int gops_cap;
@@ -103,6 +111,11 @@ int pll_is_pattern_tip(const pll_partition_t *p, unsigned int clv_index);
 int pll_tip_by_codes(const pll_partition_t *p, unsigned int clv_index);
 /* give a compact tip a dense device CLV again (someone needs it as an ordinary CLV) */
 void pll_tip_densify(pll_partition_t *p, unsigned int clv_index);
+
+/* pll_gpu_edge_loglikelihood_async with the sequence word chosen by the caller (group.c) */
+int pll_gpu_edge_loglikelihood_numbered(pll_partition_t *p, unsigned int parent_clv_index, int parent_scaler_index,
+                                        unsigned int child_clv_index, int child_scaler_index, unsigned int matrix_index,
+                                        const unsigned int *freqs_indices, double *device_result, double sequence);
 
 #pragma GCC visibility pop
 

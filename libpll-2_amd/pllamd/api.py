@@ -174,6 +174,17 @@ _GPU_PROTOS = {
     "pll_gpu_timer_start": (C.c_int, [PartitionP]),
     "pll_gpu_timer_stop": (C.c_double, [PartitionP]),
     "pll_gpu_last_launch_count": (C.c_uint, [PartitionP]),
+    "pll_gpu_group_join": (C.c_void_p, [C.c_char_p, C.c_uint, C.c_uint, C.c_int]),
+    "pll_gpu_group_leave": (None, [C.c_void_p]),
+    "pll_gpu_group_rank": (C.c_uint, [C.c_void_p]),
+    "pll_gpu_group_size": (C.c_uint, [C.c_void_p]),
+    "pll_gpu_group_sum": (C.c_int, [C.c_void_p, c_double_p, C.c_uint, c_double_p]),
+    "pll_gpu_group_edge_loglikelihood": (
+        C.c_double, [PartitionP, C.c_void_p, C.c_uint, C.c_int, C.c_uint, C.c_int, C.c_uint, c_uint_p, c_double_p]),
+    "pll_gpu_allreduce_lnl": (C.c_int, [PartitionP, C.c_void_p, C.c_void_p, C.c_uint]),
+    "pll_gpu_edge_loglikelihood_allreduce": (
+        C.c_double, [PartitionP, C.c_void_p, C.c_uint, C.c_int, C.c_uint, C.c_int, C.c_uint, c_uint_p]),
+    "pll_gpu_rccl_available": (C.c_int, []),
     "pll_gpu_device_count": (C.c_int, []),
     "pll_gpu_available": (C.c_int, []),
 }

@@ -99,3 +99,43 @@ def test_host_written_matrix_overrides_device_one(amd_lib):
         amd_lib.pll_gpu_invalidate(s.p, api.DIRTY_PMATRIX, mi)
         v2, _ = s.edge_lnl(case.edges[0], persite=False)
         assert abs(v2 - ref0) <= 1e-12 * abs(ref0)
+
+
+@pytest.mark.parametrize("how", ["setter", "direct-write"])
+def test_stale_matrix_with_a_revalidated_eigensystem_keeps_the_orientation(amd_lib, ref_lib, how):
+    """a matrix formed by pll_update_prob_matrices with frequencies A, then the frequencies of the
+    same set become B and the eigensystem is valid again (another matrix was formed, or the caller wrote
+    p->frequencies and invalidated - which never clears eigen_decomp_valid). The stale matrix is reversible
+    for A, the evaluation weighs with B: swapping the ends of a tip-parent edge would change the value, so the
+    caller's orientation must be evaluated (src/likelihood.c:626-634 - the reference never swaps without
+    PLL_ATTRIB_PATTERN_TIP). The set's version counter, not the current eigen_decomp_valid flag, decides."""
+    case = W.make_case("orient-stale", 4, 12, 500, tree="caterpillar", seed=62, ambiguity_pct=5)
+    p, ps, c, cs, m = case.edges[0]
+    assert c < case.tips  # the child end of the caterpillar's root edge is a tip
+    tip_parent = (c, cs, p, ps, m)
+    nmat = case.prob_matrices
+    brl = np.ascontiguousarray(W.branch_lengths(nmat))
+    fb = np.array([0.05, 0.45, 0.1, 0.4])
+    vals = {}
+    for lib in (ref_lib, amd_lib):
+        with driver.Session(lib, case, api.ARCH_AVX2) as s:
+            s.set_model(case.model["exch"], case.freqs, case.model["rates"])
+            pi = np.zeros(case.rate_cats, dtype=np.uint32)
+            mi = np.arange(nmat, dtype=np.uint32)
+            assert lib.pll_update_prob_matrices(s.p, api.uptr(pi), api.uptr(mi), api.dptr(brl), nmat)
+            s.update_partials()
+            before = s.edge_lnl(tip_parent, persite=False)[0]
+            if how == "setter":
+                lib.pll_set_frequencies(s.p, 0, api.dptr(fb))
+                other = np.array([(m + 1) % nmat], dtype=np.uint32)  # revalidates the eigensystem; matrix m stays stale
+                assert lib.pll_update_prob_matrices(s.p, api.uptr(pi), api.uptr(other), api.dptr(np.array([0.3])), 1)
+                assert s.part.eigen_decomp_valid[0] == 1
+            else:
+                api.as_np(s.part.frequencies[0], 4, np.float64)[:] = fb
+                if lib.is_amd:
+                    lib.pll_gpu_invalidate(s.p, api.DIRTY_FREQS, 0)
+            vals[lib.is_amd] = (before, s.edge_lnl(tip_parent, persite=False)[0], s.edge_lnl((p, ps, c, cs, m), persite=False)[0])
+    (b0, g_tp, g_usual), (r0, e_tp, e_usual) = vals[True], vals[False]
+    assert abs(b0 - r0) <= 1e-10 * abs(r0)
+    assert abs(e_tp - e_usual) > 1e-6 * abs(e_usual)  # the orientation matters for the stale matrix
+    assert abs(g_tp - e_tp) <= 1e-10 * abs(e_tp) and abs(g_usual - e_usual) <= 1e-10 * abs(e_usual)
