@@ -14,11 +14,27 @@ pll_compute_edge_loglikelihood at the root edge, which synchronises and returns 
     --gpus N > 1         BASELINE configs[3] "C4", STRONG scaling: ONE alignment - 4-state DNA, 128 taxa,
                          1M sites, PLL_ATTRIB_SITE_REPEATS, the same bytes on every rank - is pattern-sorted
                          (pll_compress_site_patterns, as applications do before they shard) and cut into N
-                         contiguous site ranges; rank r owns an independent partition over range r and the
-                         only exchange is ONE all-reduce of the shard log-likelihoods per step (RCCL on the
-                         device). value = 1M sites * 126 ops * steps / max-over-ranks
+                         contiguous site ranges of equal COST (pllamd/sharding.py: balanced_bounds; --cut equal
+                         for equal site counts); rank r owns an independent partition over range r and the
+                         only exchange is ONE sum of the shard log-likelihoods per step (SURVEY.md section 8e;
+                         the sum it stands for: src/core_likelihood.c:1489):
+                           --reduce peer (default)  fixed rank order through shared host memory
+                                                    (pll_gpu_group_edge_loglikelihood, csrc/host/group.c):
+                                                    reproducible bits, ~0.6 us at 8 ranks
+                           --reduce rccl            one RCCL all-reduce of the value where the kernel left it
+                         With peer and the nccl backend the same steps are timed again with rccl and both
+                         appear in the line (exchange.*). value = 1M sites * 126 ops * steps / max-over-ranks
                          time. Rank 0 afterwards times the UN-sharded alignment on its own GPU so that the
                          line carries t1_ms, tN_ms and speedup = t1 / tN.
+                         Started WITHOUT a launcher (WORLD_SIZE unset) the process starts its own N ranks
+                         (one child per GPU, 127.0.0.1 rendezvous) and relays rank 0's line; under
+                         torch.distributed.run it is one of the ranks. --gpus N with another WORLD_SIZE is
+                         an error.
+
+The timed region is `blocks` (default 5) blocks of exactly `steps` steps, each bracketed by a barrier and a
+device synchronise on both sides, max over ranks per block; ms_per_step / value come from the MEDIAN block,
+ms_per_step_min / _max give the spread. The steps themselves are issued by a C loop over the library's two
+C-ABI calls (csrc/workload/step_loop.c, --driver python for the ctypes loop): an application is C / C++.
 
 Inputs are SURVEY.md section 8d to the letter (xorshift64 alignment, seed 88172645463325252, balanced
 tree, branch lengths 0.05 + 0.01 (i mod 10), GTR / LG / 61-state stand-in, Gamma(0.5) x 4 mean rates).
@@ -129,28 +145,45 @@ def sub_case(case, driver, lo, hi, name):
     return driver.Case(**kw)
 
 
-def cpu_baseline(case, api, driver, budget_s=12.0):
-    """reference AVX2 path on the host cores: T threads, each its own partition over sites/T
-    contiguous sites (how applications parallelise libpll), traversal repeated to fill ~budget_s
-    of CPU work. Falls back to the scalar restatement (kind 'port', 1 core, small sample)."""
+def cpu_baseline(case, api, driver, budget_s=4.0):
+    """reference AVX2 path on the host cores (SURVEY 8d "CPU baseline plan"): T threads, each its own partition
+    over sites/T contiguous sites (how applications parallelise libpll). Three legs, each a bounded sample:
+      value        T = all host cores (<= 16), PLL_ATTRIB_ARCH_AVX2          median of 3 samples
+      pattern_tip  the same with | PLL_ATTRIB_PATTERN_TIP (the reference's faster tip kernels,
+                   src/core_partials_avx.c:1310-1506; only where tips are sequences)   median of 3
+      one_core     T = 1, plain AVX2                                          one sample
+    Falls back to the scalar restatement (kind 'port', 1 core, small sample) without the reference library."""
     import numpy as np
     from oracle import oracle as O
     ops = len(case.op_batches[0])
     total_sites = int(np.asarray(case.pattern_weights, dtype=np.uint64).sum())
-    if os.path.exists(O.REF_LIB):
-        ref = api.PllLib(O.REF_LIB)
-        cores = max(1, min(len(os.sched_getaffinity(0)), 16))
-        bounds = np.linspace(0, case.sites, cores + 1).astype(int)
-        shards = [driver.Session(ref, sub_case(case, driver, int(bounds[t]), int(bounds[t + 1]), f"shard{t}"), api.ARCH_AVX2)
+    if not os.path.exists(O.REF_LIB):
+        # no reference library on this host: time the scalar restatement on a small slice
+        n = min(case.sites, 2000)
+        sub = sub_case(case, driver, 0, n, "slice")
+        t0 = time.perf_counter()
+        O.run_case(sub)
+        dt = time.perf_counter() - t0
+        return dict(value=n * ops / dt / 1e6, unit="M site-CLV-updates/s", cores=1, kind="port",
+                    sample=f"one traversal of the first {n} sites with the scalar C restatement (oracle/pll_oracle.c)"), None
+    ref = api.PllLib(O.REF_LIB)
+    rep_mode = bool(case.attributes & api.SITE_REPEATS)
+
+    def leg(cores, extra_attr, samples, budget):
+        c2 = case
+        if extra_attr:
+            kw = {f: getattr(case, f) for f in case.__dataclass_fields__}
+            kw["attributes"] = case.attributes | extra_attr
+            c2 = driver.Case(**kw)
+        bounds = np.linspace(0, c2.sites, cores + 1).astype(int)
+        shards = [driver.Session(ref, sub_case(c2, driver, int(bounds[t]), int(bounds[t + 1]), f"shard{t}"), api.ARCH_AVX2)
                   for t in range(cores)]
         # one traversal to size the sample, then reps traversals timed
         t0 = time.perf_counter()
         shards[0].update_partials()
-        one = (time.perf_counter() - t0) * cores  # core-seconds per full traversal (approx.)
-        reps = int(max(2, min(200, budget_s / max(one, 1e-4))))
+        one = (time.perf_counter() - t0)  # wall seconds per traversal of one thread's share
+        reps = int(max(2, min(200, budget / max(one, 1e-4))))
         lnls = [0.0] * cores
-
-        rep_mode = bool(case.attributes & api.SITE_REPEATS)
         if rep_mode:  # class maps once, outside the timed region (same policy as the GPU leg)
             for sh in shards:
                 sh.update_partials(update_repeats=1)
@@ -158,32 +191,84 @@ def cpu_baseline(case, api, driver, budget_s=12.0):
         def work(i):
             for _ in range(reps):
                 shards[i].update_partials(update_repeats=0 if rep_mode else 1)
-            lnls[i] = shards[i].edge_lnl(case.edges[0], persite=False)[0]
+            lnls[i] = shards[i].edge_lnl(c2.edges[0], persite=False)[0]
 
-        th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
-        t0 = time.perf_counter()
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
-        dt = time.perf_counter() - t0
+        vals, walls = [], []
+        for _ in range(samples):
+            th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+            t0 = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            dt = time.perf_counter() - t0
+            walls.append(dt)
+            vals.append(total_sites * ops * reps / dt / 1e6)
         for sh in shards:
             sh.close()
-        return dict(value=total_sites * ops * reps / dt / 1e6, unit="M site-CLV-updates/s", cores=cores, kind="reference",
-                    sample=f"{reps} full traversals ({ops} ops) of the same {total_sites}-site alignment, reference "
-                           f"PLL_ATTRIB_ARCH_AVX2 path, {cores} threads x sites/{cores} partitions, {dt:.1f} s wall"), float(sum(lnls))
-    # no reference library on this host: time the scalar restatement on a small slice
-    n = min(case.sites, 2000)
-    sub = sub_case(case, driver, 0, n, "slice")
-    t0 = time.perf_counter()
-    O.run_case(sub)
-    dt = time.perf_counter() - t0
-    return dict(value=n * ops / dt / 1e6, unit="M site-CLV-updates/s", cores=1, kind="port",
-                sample=f"one traversal of the first {n} sites with the scalar C restatement (oracle/pll_oracle.c)"), None
+        return vals, reps, sum(walls), float(sum(lnls))
+
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    vals, reps, wall, lnl = leg(cores, 0, 3, budget_s)
+    out = dict(value=round(float(np.median(vals)), 2), unit="M site-CLV-updates/s", cores=cores, kind="reference",
+               samples=[round(v, 2) for v in vals],
+               sample=f"median of 3 samples of {reps} full traversals ({ops} ops) of the same {total_sites}-site alignment, reference "
+                      f"PLL_ATTRIB_ARCH_AVX2 path, {cores} threads x sites/{cores} partitions, {wall:.1f} s wall in all")
+    if case.sequences is not None and not rep_mode:
+        v2, r2, w2, _ = leg(cores, api.PATTERN_TIP, 3, budget_s * 0.75)
+        out["pattern_tip"] = dict(value=round(float(np.median(v2)), 2), cores=cores, samples=[round(v, 2) for v in v2],
+                                  sample=f"the same with | PLL_ATTRIB_PATTERN_TIP, {r2} traversals per sample, {w2:.1f} s wall")
+    v1, r1, w1, _ = leg(1, 0, 1, budget_s)
+    out["one_core"] = dict(value=round(v1[0], 3), cores=1, sample=f"{r1} traversals of the whole alignment on one thread, {w1:.1f} s wall")
+    return out, lnl
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """--gpus N > 1 without a launcher: this process becomes the launcher. It starts N children of this very
+    command line (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous), relays rank 0's stdout
+    - the one JSON line - and returns the worst exit code. It never touches the GPU (nor imports torch)."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    worst, line = 0, None
+    pending = set(range(args.gpus))
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if r == 0:
+                line = procs[0].stdout.read().decode()
+            if rc != 0:
+                worst = worst or rc
+                print(f"bench.py: rank {r} exited with {rc}; stopping the others", file=sys.stderr)
+                for q in pending:  # exactly the children started here, by pid
+                    procs[q].terminate()
+        time.sleep(0.05)
+    if line:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return worst
 
 
 class Harness:
-    """torch.distributed plumbing (only when WORLD_SIZE > 1 or PLL_BENCH_FORCE_DIST=1)"""
+    """torch.distributed plumbing (only when WORLD_SIZE > 1 or PLL_BENCH_FORCE_DIST=1): rendezvous, the barrier and
+    the max over ranks around the timed blocks. The path's own exchange is csrc/host/group.c (--reduce peer) or one
+    all-reduce on the device (--reduce rccl)."""
 
     def __init__(self, args):
         self.rank = int(os.environ.get("RANK", "0"))
@@ -195,6 +280,8 @@ class Harness:
         self.torch = None
         self.backend = args.backend
         self.real_stdout = None
+        self.group = None
+        self.group_lib = None
         if self.world > 1 or os.environ.get("PLL_BENCH_FORCE_DIST") == "1":
             import torch
             import torch.distributed as dist
@@ -218,6 +305,19 @@ class Harness:
         if self.on_device:
             self.tstream = self.torch.cuda.Stream()
             self.torch.cuda.set_stream(self.tstream)
+
+    def join_group(self, lib):
+        """the shared-memory segment of --reduce peer: rank 0 picks a name that is unique to this run"""
+        if not self.dist or self.group:
+            return self.group
+        import uuid
+        name = ["/pllamd-%s" % uuid.uuid4().hex[:16] if self.rank == 0 else None]
+        self.dist.broadcast_object_list(name, src=0)
+        g = lib.pll_gpu_group_join(name[0].encode(), self.rank, self.world, 120000)
+        if not g:
+            raise SystemExit(f"pll_gpu_group_join: [{lib.errno()}] {lib.errmsg()}")
+        self.group, self.group_lib = g, lib
+        return g
 
     def tsync(self):
         if self.on_device:
@@ -246,6 +346,9 @@ class Harness:
         return [[int(x) for x in o.tolist()] for o in out]
 
     def finish(self):
+        if self.group:
+            self.group_lib.pll_gpu_group_leave(self.group)
+            self.group = None
         if self.dist:
             self.dist.barrier()
             self.dist.destroy_process_group()
@@ -254,10 +357,30 @@ class Harness:
             os.dup2(self.real_stdout, 1)
 
 
-class Runner:
-    """one partition + the step the benchmark times"""
+_STEP_LOOP = None
 
-    def __init__(self, h, lib, api, driver, case, repeats, collective=True):
+
+def step_loop_fn():
+    """csrc/workload/step_loop.c: the caller side of the timed region in C (the library's entry points come in as
+    function pointers)"""
+    global _STEP_LOOP
+    if _STEP_LOOP is None:
+        import ctypes as C
+        dll = C.CDLL(os.path.join(ROOT, "libpll-2_amd", "csrc", "libpll_workload.so"))
+        fn = dll.pllwl_step_loop
+        fn.restype = C.c_double
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint,
+                       C.POINTER(C.c_int), C.POINTER(C.c_uint), C.c_uint, C.POINTER(C.c_double)]
+        _STEP_LOOP = fn
+    return _STEP_LOOP
+
+
+class Runner:
+    """one partition + the step the benchmark times. reduce: None (one partition is the whole job), 'peer' (fixed
+    rank order through shared host memory) or 'rccl' (all-reduce on the device)."""
+
+    def __init__(self, h, lib, api, driver, case, repeats, reduce=None, c_driver=True):
+        import ctypes as C
         import numpy as np
         self.h, self.lib, self.api, self.case = h, lib, api, case
         self.sess = driver.Session(lib, case, api.ARCH_AVX2)  # uploads happen on first use (warm-up)
@@ -265,8 +388,19 @@ class Runner:
         self.repeats = repeats
         self.upd = 1  # site repeats: class maps are computed by the first step and re-used, as applications do
         #               between topology changes: pll_update_partials_rep(..., update_repeats = 0)
-        self.collective = collective and bool(h.dist)
-        self.device_path = self.collective and h.on_device
+        self.reduce = reduce if h.dist else None
+        self.c_driver = c_driver
+        self.fi = np.ascontiguousarray(case.freqs_indices, dtype=np.uint32)
+        self.edge_c = (C.c_int * 5)(*[int(v) for v in self.edge])
+        self.device_path = False
+        if self.reduce == "peer":
+            self.group = h.join_group(lib)
+        elif self.reduce == "rccl":
+            self.setup_rccl()
+
+    def setup_rccl(self):
+        h, lib = self.h, self.lib
+        self.device_path = h.on_device
         if self.device_path:
             torch = h.torch
             # the partition works on torch's stream, the shard's lnL stays in HBM ({lnL, sequence} in `red`)
@@ -274,13 +408,12 @@ class Runner:
             if not lib.pll_gpu_set_stream(self.sess.p, h.tstream.cuda_stream):
                 raise SystemExit(f"pll_gpu_set_stream: [{lib.errno()}] {lib.errmsg()}")
             self.red = torch.zeros(2, dtype=torch.float64, device=h.tdev)
-            self.fi = np.ascontiguousarray(case.freqs_indices, dtype=np.uint32)
-            # the reduced {lnL, sequence} pair comes back through pinned host memory that the host polls,
-            # like the single-GPU path does (a stream synchronise costs more than the copy)
+            # the reduced {lnL, sequence} pair comes back through pinned host memory that the host polls: two
+            # stream-ordered 8-byte copies, the value first - when the sequence word has arrived the value is there
             self.pinned = torch.zeros(2, dtype=torch.float64).pin_memory()
             self.pview = self.pinned.numpy()
             self.expected = None
-        elif self.collective:
+        else:
             self.red = h.torch.zeros(1, dtype=h.torch.float64)
 
     def step(self):
@@ -288,6 +421,8 @@ class Runner:
         sess.update_partials(update_repeats=self.upd)
         if self.repeats:
             self.upd = 0
+        if self.reduce == "peer":
+            return lib.pll_gpu_group_edge_loglikelihood(sess.p, self.group, e[0], e[1], e[2], e[3], e[4], self.api.uptr(self.fi), None)
         if self.device_path:
             if not lib.pll_gpu_edge_loglikelihood_async(sess.p, e[0], e[1], e[2], e[3], e[4], self.api.uptr(self.fi),
                                                         self.red.data_ptr()):
@@ -295,15 +430,12 @@ class Runner:
             # the path's one exchange: sum of the shards' log-likelihoods (word 0); word 1 = every rank's
             # call sequence number, so its sum tells the host which evaluation the pair belongs to
             h.dist.all_reduce(self.red)
-            # one 16-byte copy of {value, sequence} (two stream-ordered 8-byte copies cost ~5 us more per step); the host
-            # reads the value only after it has seen the sequence word twice
-            self.pinned.copy_(self.red, non_blocking=True)
+            self.pinned[0:1].copy_(self.red[0:1], non_blocking=True)
+            self.pinned[1:2].copy_(self.red[1:2], non_blocking=True)
             if self.expected is not None:
                 self.expected += h.world
                 t_spin = time.perf_counter()
-                seen = 0
-                while seen < 2:
-                    seen = seen + 1 if self.pview[1] == self.expected else 0
+                while self.pview[1] != self.expected:
                     if time.perf_counter() - t_spin > 0.02:
                         self.expected = None
                         break
@@ -312,31 +444,52 @@ class Runner:
                 self.expected = float(self.pview[1])
             return float(self.pview[0])
         v, _ = sess.edge_lnl(e, persite=False)
-        if self.collective:
+        if self.reduce == "rccl":
             self.red[0] = v
             h.dist.all_reduce(self.red)
             v = float(self.red[0].item())
         return v
 
+    def steps(self, n):
+        """n steps; returns the last log-likelihood. The C loop serves every mode whose step is two C-ABI calls."""
+        if n <= 0:
+            return None
+        if self.c_driver and self.reduce in (None, "peer") and len(self.case.op_batches) == 1:
+            import ctypes as C
+            lib, sess = self.lib, self.sess
+            fp = lambda f: C.cast(f, C.c_void_p)
+            lnl = C.c_double(0.0)
+            grp = self.group if self.reduce == "peer" else None
+            step_loop_fn()(fp(lib.pll_update_partials_rep), fp(lib.pll_compute_edge_loglikelihood),
+                           fp(lib.pll_gpu_group_edge_loglikelihood), C.cast(sess.p, C.c_void_p), grp,
+                           C.cast(sess._op_arrays[0], C.c_void_p), len(self.case.op_batches[0]), self.upd, self.edge_c,
+                           self.api.uptr(self.fi), n, C.byref(lnl))
+            if self.repeats:
+                self.upd = 0
+            return lnl.value
+        v = None
+        for _ in range(n):
+            v = self.step()
+        return v
+
     def fence(self):
         self.lib.pll_gpu_synchronize(self.sess.p)
-        if self.collective:
+        if self.h.dist:
             self.h.barrier()
 
-    def timed(self, warmup, steps):
-        """`warmup` untimed steps, then exactly `steps` steps between two fences; max over ranks"""
-        lnl = None
-        for _ in range(warmup):
-            lnl = self.step()
-        self.fence()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            lnl = self.step()
-        self.fence()
-        dt = time.perf_counter() - t0
-        if self.collective:
-            dt = self.h.max_over_ranks(dt)
-        return dt, lnl
+    def timed(self, warmup, steps, blocks=1):
+        """`warmup` untimed steps, then `blocks` blocks of exactly `steps` steps, each between two fences, max over
+        ranks per block. Returns (block times, last lnL)."""
+        lnl = self.steps(warmup)
+        out = []
+        for _ in range(blocks):
+            self.fence()
+            t0 = time.perf_counter()
+            lnl = self.steps(steps)
+            self.fence()
+            dt = time.perf_counter() - t0
+            out.append(self.h.max_over_ranks(dt) if self.h.dist else dt)
+        return out, lnl
 
     def repeats_update_ms(self, reps=5):
         """what the class maps cost when the topology changed: a full pll_update_partials_rep(.., 1) minus the
@@ -365,6 +518,13 @@ class Runner:
 
     def close(self):
         self.sess.close()
+
+
+def block_stats(block_s, steps):
+    """median block -> ms per step; min / max for the spread"""
+    import numpy as np
+    ms = sorted(b / steps * 1e3 for b in block_s)
+    return float(np.median(ms)), ms[0], ms[-1]
 
 
 def roofline_leg(args, cfg, lib, api, runner, reps=20):
@@ -434,10 +594,16 @@ def roofline_leg(args, cfg, lib, api, runner, reps=20):
     per_launch_bytes = trav_bytes / launches
     per_launch_ms = ms / reps / launches
     achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
     if os.path.exists(tfile) and not args.pattern_tip and not args.sites and not args.taxa and args.tree == "balanced" and not args.tips:
-        traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")  # PMC-derived HBM bytes per launch of the same command (profiles/README.md)
+        # PMC-derived HBM bytes per launch of the same command: NOT measured in this run (counters need rocprofv3
+        # around the process) but read from the committed summary of the round's PMC passes - and only when that
+        # summary is about the kernel this leg launches
+        tj = json.load(open(tfile))
+        traffic, traffic_source = tj.get("hbm_bytes_per_launch"), dict(
+            file="profiles/" + os.path.basename(tfile), kernel=tj.get("kernel"), measured_at=tj.get("commit", "round 2 PMC passes"),
+            note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/profile_round.sh), not this run")
     mfma = cfg["states"] > 32 and not os.environ.get("PLL_AMD_NO_MFMA", "0").strip("0")
     gg = cfg["states"] == 4 and cfg.get("repeats") and not os.environ.get("PLL_AMD_NO_FUSE_GG", "0").strip("0")
     kernel = {4: "k_partials_dna_cc<5,5>%.0s" if cc else "k_partials_dna_fused<4,4>%.0s" if fused else
@@ -449,6 +615,8 @@ def roofline_leg(args, cfg, lib, api, runner, reps=20):
               }[cfg["states"]] % ("true" if cfg.get("repeats") else "false")
     if args.tree != "balanced":
         kernel = "all update launches of the traversal"
+    if traffic_source and (traffic_source["kernel"] or "").replace(" ", "") not in kernel.replace(" ", ""):
+        traffic, traffic_source = None, None  # the summary belongs to another kernel (a stale file): say nothing
     if mfma:
         # 33..64 states sit past the fp64 ridge: the bounding line is the fp64 matrix pipe.
         # Algorithmic flop per update = the reference's own arithmetic: 2 children x S x S multiply-adds
@@ -464,7 +632,7 @@ def roofline_leg(args, cfg, lib, api, runner, reps=20):
                         hbm_GBps=round(achieved, 1))
     else:
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, kernel=kernel,
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source, kernel=kernel,
                         launches=launches, ops_in_those_launches=len(ii_ops), avg_launch_ms=round(per_launch_ms, 5),
                         algorithmic_bytes_per_launch=int(per_launch_bytes))
     roofline["unfused_equivalent"] = dict(
@@ -511,20 +679,24 @@ def main_single(args, h):
     if cfg.get("sort"):  # the 1M-site alignment as applications hand it over: pattern-sorted, weights attached
         case = sharding.sort_columns(lib, case)
     nops = len(case.op_batches[0])
-    runner = Runner(h, lib, api, driver, case, cfg.get("repeats"), collective=bool(h.dist))
-    dt, lnl = runner.timed(args.warmup, args.steps)
+    runner = Runner(h, lib, api, driver, case, cfg.get("repeats"), reduce="rccl" if h.dist else None, c_driver=args.driver == "c")
+    blocks_s, lnl = runner.timed(args.warmup, args.steps, args.blocks)
     if not np.isfinite(lnl):
         raise SystemExit(f"hot path failed: lnL = {lnl} [{lib.errno()}] {lib.errmsg()}")
-    value = total_sites * nops * args.steps / dt / 1e6
+    ms, ms_min, ms_max = block_stats(blocks_s, args.steps)
+    value = total_sites * nops / (ms * 1e-3) / 1e6
     roofline, codes = roofline_leg(args, cfg, lib, api, runner)
     out = {
         "metric": "M site-CLV-updates/s", "value": round(value, 1), "unit": "M site-CLV-updates/s",
-        "n_gpus": h.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "n_gpus": h.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+        "blocks": args.blocks, "ms_per_step_min": round(ms_min, 4), "ms_per_step_max": round(ms_max, 4),
+        "higher_is_better": True, "scaling": None, "vs_baseline": None, "dtype": "f64",
         "data": "synthetic (SURVEY 8d: xorshift64 alignment, seed 88172645463325252)",
         "config": {"workload": cfg["desc"] + tip_note(case, api, args),
                    "sites_per_gpu": total_sites, "ops_per_traversal": nops, "states": cfg["states"], "rate_cats": 4,
                    "taxa": cfg["tips"], "step": "pll_update_partials(full traversal) + pll_compute_edge_loglikelihood",
+                   "timed": f"median of {args.blocks} blocks of {args.steps} steps, each block between two device synchronises",
+                   "driver": "C loop over the two C-ABI calls (csrc/workload/step_loop.c)" if args.driver == "c" and not h.dist else "Python ctypes loop",
                    "parallelism": "1 GPU"},
         "lnl": lnl, "roofline": roofline,
     }
@@ -561,13 +733,35 @@ def main_strong(args, h):
     full = build_case(cfg, total_sites, api.SITE_REPEATS)
     full = sharding.sort_columns(lib, full)  # unique columns in lexicographic order + weights (device radix sort)
     nops = len(full.op_batches[0])
-    mine = sharding.shard_case(full, h.rank, h.world)
-    runner = Runner(h, lib, api, driver, mine, True)
-    dt, lnl = runner.timed(args.warmup, args.steps)
+    # every rank computes the same cuts from the same alignment
+    bounds = sharding.balanced_bounds(full, h.world) if args.cut == "balanced" else sharding.shard_bounds(full.sites, h.world)
+    mine = sharding.shard_case(full, h.rank, h.world, bounds)
+    reduce = args.reduce
+    runner = Runner(h, lib, api, driver, mine, True, reduce=reduce, c_driver=args.driver == "c")
+    blocks_s, lnl = runner.timed(args.warmup, args.steps, args.blocks)
     if not np.isfinite(lnl):
         raise SystemExit(f"hot path failed: lnL = {lnl} [{lib.errno()}] {lib.errmsg()}")
-    value = total_sites * nops * args.steps / dt / 1e6
-    tN_ms = dt / args.steps * 1e3
+    tN_ms, tN_min, tN_max = block_stats(blocks_s, args.steps)
+    value = total_sites * nops / (tN_ms * 1e-3) / 1e6
+    exchange = {"reduce": reduce, reduce + "_ms_per_step": round(tN_ms, 4)}
+    # the same steps with the other exchange, for the record (both in one line): RCCL needs the nccl backend
+    if reduce == "peer" and h.on_device:
+        runner.reduce = "rccl"
+        runner.setup_rccl()
+        b2, lnl2 = runner.timed(args.warmup, args.steps, args.blocks)
+        exchange["rccl_ms_per_step"] = round(block_stats(b2, args.steps)[0], 4)
+        exchange["rccl_lnl_rel_diff"] = abs(lnl2 - lnl) / abs(lnl)
+        runner.reduce, runner.device_path = "peer", False
+    # what the exchange adds behind a result that is already in host memory: the group sum alone, all ranks in step
+    if reduce == "peer":
+        v = np.array([1.0])
+        o = np.zeros(1)
+        h.barrier()
+        t0 = time.perf_counter()
+        for _ in range(2000):
+            lib.pll_gpu_group_sum(runner.group, api.dptr(v), 1, api.dptr(o))
+        exchange["peer_exchange_alone_us"] = round(h.max_over_ranks((time.perf_counter() - t0) / 2000 * 1e6), 3)
+        exchange["peer_exchange_alone_note"] = "2000 group sums back to back through ctypes (~1-2 us of that is the Python call); tools/group_latency.c measures the C call"
     rep_extra, rep_full = runner.repeats_update_ms()
     rep_extra = h.max_over_ranks(rep_extra)
     shard_levels = h.gather_ints(runner.level_entries())
@@ -580,9 +774,9 @@ def main_strong(args, h):
     out = None
     if h.rank == 0:
         # t1: the un-sharded alignment on ONE GPU, same step, same K/W, nothing else running on the node
-        solo = Runner(h, lib, api, driver, full, True, collective=False)
-        dt1, lnl1 = solo.timed(args.warmup, args.steps)
-        t1_ms = dt1 / args.steps * 1e3
+        solo = Runner(h, lib, api, driver, full, True, reduce=None, c_driver=args.driver == "c")
+        b1, lnl1 = solo.timed(args.warmup, args.steps, args.blocks)
+        t1_ms = block_stats(b1, args.steps)[0]
         global_levels = solo.level_entries()
         rep1_extra, _ = solo.repeats_update_ms(reps=3)
         solo.close()
@@ -590,17 +784,22 @@ def main_strong(args, h):
         out = {
             "metric": "M site-CLV-updates/s", "value": round(value, 1), "unit": "M site-CLV-updates/s",
             "n_gpus": h.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tN_ms, 4),
+            "blocks": args.blocks, "ms_per_step_min": round(tN_min, 4), "ms_per_step_max": round(tN_max, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (SURVEY 8d: xorshift64 alignment, seed 88172645463325252; the same alignment on every rank)",
             "config": {"workload": cfg["desc"] + f", pattern-sorted (pll_compress_site_patterns) and cut into {h.world} contiguous site ranges"
+                       + (" of equal cost (sites + 0.19 x class entries of the tip-only subtrees)" if args.cut == "balanced" else " of equal site count")
                        + tip_note(full, api, args),
                        "total_sites": total_sites, "patterns": full.sites, "sites_per_gpu": [s[0] for s in shard_sites],
                        "ops_per_traversal": nops, "states": 4, "rate_cats": 4, "taxa": cfg["tips"],
-                       "step": "pll_update_partials(full traversal) + edge log-likelihood on the device + all-reduce(lnL)",
-                       "parallelism": f"sites sharded x{h.world}, one all-reduce of one double per step ({h.backend})"},
+                       "step": "pll_update_partials(full traversal) + edge log-likelihood + the one exchange: sum of the shard lnLs"
+                               + (" in rank order through shared host memory (pll_gpu_group_edge_loglikelihood)" if reduce == "peer" else " by one RCCL all-reduce on the device"),
+                       "timed": f"median of {args.blocks} blocks of {args.steps} steps, each block between two barriers + device synchronises, max over ranks per block",
+                       "driver": "C loop over the two C-ABI calls (csrc/workload/step_loop.c)" if args.driver == "c" and reduce == "peer" else "Python ctypes loop",
+                       "parallelism": f"sites sharded x{h.world}, one sum of one double per step ({reduce}; control plane {h.backend})"},
             "lnl": lnl, "t1_ms": round(t1_ms, 4), "tN_ms": round(tN_ms, 4), "speedup": round(t1_ms / tN_ms, 3),
             "t1_value": round(total_sites * nops / (t1_ms * 1e-3) / 1e6, 1), "lnl_unsharded": lnl1,
-            "lnl_rel_err_vs_unsharded": abs(lnl - lnl1) / abs(lnl1),
+            "lnl_rel_err_vs_unsharded": abs(lnl - lnl1) / abs(lnl1), "exchange": exchange,
             "repeats_update_ms": round(rep_extra, 4), "repeats_update_ms_unsharded": round(rep1_extra, 4),
             "entries_per_level": {"unsharded": global_levels, "shards": shard_levels,
                                   "sum_over_shards_div_unsharded": round(sum(sum(s) for s in shard_levels) / max(sum(global_levels), 1), 4)},
@@ -617,6 +816,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of `steps` steps each; the line reports the median block")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--sites", type=int, default=0, help="override the number of sites (N > 1: of the whole alignment)")
     ap.add_argument("--pattern-tip", action="store_true", help="PLL_ATTRIB_PATTERN_TIP variant")
@@ -627,10 +827,24 @@ def main():
     ap.add_argument("--taxa", type=int, default=0, help="override the number of taxa")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="collective backend; gloo + PLL_BENCH_SAME_DEVICE=1 rehearses the N>1 flow on a one-GPU box")
+                    help="torch.distributed backend of the control plane (barriers, max over ranks) and of --reduce rccl; "
+                         "gloo + PLL_BENCH_SAME_DEVICE=1 rehearses the N>1 flow on a one-GPU box")
+    ap.add_argument("--reduce", default="peer", choices=["peer", "rccl"],
+                    help="N > 1: how the shard log-likelihoods are summed (see the docstring)")
+    ap.add_argument("--cut", default="balanced", choices=["balanced", "equal"], help="N > 1: shards of equal cost or of equal site count")
+    ap.add_argument("--driver", default="c", choices=["c", "python"], help="who issues the steps of the timed region")
     args = ap.parse_args()
+    if args.gpus < 1 or args.blocks < 1 or args.steps < 1:
+        ap.error("--gpus, --steps and --blocks must be positive")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # no launcher: become one (before anything touches the GPU or imports torch)
+        sys.exit(spawn_ranks(args))
+    if env_world is not None and int(env_world) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: refusing to run another configuration than the one asked for",
+              file=sys.stderr)
+        sys.exit(2)
     h = Harness(args)
-    assert h.world == args.gpus or h.world == 1, f"--gpus {args.gpus} but WORLD_SIZE={h.world}"
     out = main_strong(args, h) if h.world > 1 else main_single(args, h)
     h.finish()
     if h.rank == 0:

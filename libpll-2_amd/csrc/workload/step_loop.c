@@ -1,0 +1,40 @@
+/* step_loop.c - the CALLER side of bench.py's timed region, in C: K times
+ *     pll_update_partials_rep(partition, ops, count, update_repeats);
+ *     lnL = pll_compute_edge_loglikelihood(partition, edge...)      (or the group form of a sharded run)
+ * which is how an application (RAxML-NG, ModelTest-NG: C / C++) drives the library. Nothing here is on the
+ * product path and nothing is computed here: the two entry points are passed in as function pointers from
+ * the loaded libpll_amd.so (this file links against nothing), so the loop measures the library's C ABI without
+ * the ~4 us per call that Python's ctypes adds between the result of one step and the launches of the next.
+ */
+#include <time.h>
+
+typedef void (*update_fn)(void *partition, const void *ops, unsigned int count, unsigned int update_repeats);
+typedef double (*edge_fn)(void *partition, unsigned int parent_clv, int parent_scaler, unsigned int child_clv,
+                          int child_scaler, unsigned int matrix, const unsigned int *freqs_indices, double *persite);
+typedef double (*group_edge_fn)(void *partition, void *group, unsigned int parent_clv, int parent_scaler,
+                                unsigned int child_clv, int child_scaler, unsigned int matrix,
+                                const unsigned int *freqs_indices, double *persite);
+
+/* edge = {parent_clv, parent_scaler, child_clv, child_scaler, matrix}; group == NULL: the plain evaluation.
+ * first_update_repeats applies to the first step only (class maps of a site-repeats partition are formed once
+ * and re-used, update_repeats = 0, until the topology changes). Returns the seconds the K steps took on the
+ * calling thread; *lnl = the last step's value. */
+double pllwl_step_loop(update_fn update, edge_fn edge_lnl, group_edge_fn group_edge_lnl, void *partition, void *group,
+                       const void *ops, unsigned int count, unsigned int first_update_repeats, const int *edge,
+                       const unsigned int *freqs_indices, unsigned int steps, double *lnl)
+{
+  struct timespec a, b;
+  double v = 0.0;
+  unsigned int k, ur = first_update_repeats;
+  clock_gettime(CLOCK_MONOTONIC, &a);
+  for (k = 0; k < steps; ++k)
+  {
+    update(partition, ops, count, ur);
+    ur = first_update_repeats ? 0u : ur; /* 1 -> 0 after the first step; 0 stays 0 */
+    v = group ? group_edge_lnl(partition, group, (unsigned int)edge[0], edge[1], (unsigned int)edge[2], edge[3], (unsigned int)edge[4], freqs_indices, 0)
+              : edge_lnl(partition, (unsigned int)edge[0], edge[1], (unsigned int)edge[2], edge[3], (unsigned int)edge[4], freqs_indices, 0);
+  }
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  *lnl = v;
+  return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+}

@@ -16,8 +16,64 @@ def shard_bounds(sites, world, align=64):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def shard_case(case: Case, rank, world):
-    lo, hi = shard_bounds(case.sites, world)[rank]
+# what a shard's step costs, relative: one site of the alignment against one class entry of the ops whose
+# subtrees are tips only (the compressing levels of a site-repeats traversal). From profiles/r2_c4_projection.json:
+# shards of equal site count took 0.114 .. 0.124 ms with 127k .. 234k such entries (0.09 us per 1000 entries) and
+# about 0.48 us per 1000 sites above the fixed part of a step.
+ENTRY_COST_PER_SITE_COST = 0.19
+
+
+def _tip_subtree_keys(case: Case):
+    """for every op whose subtree holds tips only and at most 8 of them: one 64-bit word per site that is
+    equal for two sites iff all tips below the op agree there (its site-repeat class, src/repeats.c:299-382)"""
+    tips_below = {t: [t] for t in range(case.tips)}
+    keys = []
+    seqs = [np.frombuffer(bytes(sq), dtype=np.uint8) for sq in case.sequences]
+    for op in case.op_batches[0]:
+        l, r = tips_below.get(op[2]), tips_below.get(op[5])
+        if l is None or r is None or len(l) + len(r) > 8:
+            continue
+        tips_below[op[0]] = l + r
+        k = np.zeros(case.sites, dtype=np.uint64)
+        for i, t in enumerate(tips_below[op[0]]):
+            k |= seqs[t].astype(np.uint64) << np.uint64(8 * i)
+        keys.append(k)
+    return keys
+
+
+def balanced_bounds(case: Case, world, align=64, rounds=6):
+    """Cuts that equalise the COST of the shards rather than their site counts. With site repeats a shard
+    computes one entry per class below the level where compression ends, and a contiguous range of the
+    pattern-sorted alignment holds very different class counts depending on where it lies (the first and last
+    eighth of the sorted 1M-site alignment: 127k entries at the 8-tip level, the second: 234k). cost(range) =
+    sites + ENTRY_COST_PER_SITE_COST x sum over tip-only subtrees of the distinct columns in the range; the cuts
+    move until the costs agree. Every rank computes the same cuts from the same alignment: nothing is exchanged."""
+    if world == 1 or case.sequences is None or not case.op_batches:
+        return shard_bounds(case.sites, world, align)
+    keys = _tip_subtree_keys(case)
+
+    def cost(lo, hi):
+        return (hi - lo) + ENTRY_COST_PER_SITE_COST * sum(len(np.unique(k[lo:hi])) for k in keys)
+
+    cuts = [b[0] for b in shard_bounds(case.sites, world, align)] + [case.sites]
+    for _ in range(rounds):
+        costs = [cost(cuts[r], cuts[r + 1]) for r in range(world)]
+        target = sum(costs) / world
+        # piecewise-linear cumulative cost over the current cuts; new cut r where it reaches r x target
+        cum = np.concatenate([[0.0], np.cumsum(costs)])
+        new = [0]
+        for r in range(1, world):
+            c = int(round(np.interp(r * target, cum, cuts) / align)) * align
+            new.append(min(max(c, new[-1] + align), case.sites - (world - r) * align))
+        new.append(case.sites)
+        if new == cuts:
+            break
+        cuts = new
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def shard_case(case: Case, rank, world, bounds=None):
+    lo, hi = (bounds or shard_bounds(case.sites, world))[rank]
     kw = dict(name=f"{case.name}[{lo}:{hi}]", states=case.states, rate_cats=case.rate_cats, tips=case.tips,
               sites=hi - lo, pmatrix=case.pmatrix, freqs=case.freqs, op_batches=case.op_batches, edges=case.edges,
               roots=case.roots, attributes=case.attributes, clv_buffers=case.clv_buffers,

@@ -1,0 +1,50 @@
+"""GPU: bench.py's own flows as the driver runs them (nothing ran main_strong; `--gpus N` did not
+start N ranks). Rehearsed on ONE device: two ranks share GPU 0 (PLL_BENCH_SAME_DEVICE=1), gloo as the control
+plane, the path's exchange through the library's shared-memory group."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*argv, env=None, timeout=900):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=e, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout  # ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("cut", ["balanced", "equal"])
+def test_gpus_2_starts_two_ranks_and_runs_the_strong_scaling_flow(cut):
+    out = run_bench("--gpus", "2", "--backend", "gloo", "--sites", "200000", "--steps", "3", "--blocks", "2", "--warmup", "2", "--cut", cut,
+                    env={"PLL_BENCH_SAME_DEVICE": "1"})
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 3
+    assert out["lnl_rel_err_vs_unsharded"] <= 1e-12
+    assert out["exchange"]["reduce"] == "peer" and out["exchange"]["peer_exchange_alone_us"] < 100
+    assert len(out["config"]["sites_per_gpu"]) == 2 and sum(out["config"]["sites_per_gpu"]) == out["config"]["patterns"]
+    assert out["value"] > 0 and out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
+    assert "roofline" in out and out["t1_ms"] > 0
+
+
+def test_default_line_carries_the_contract_fields():
+    out = run_bench("--steps", "5", "--blocks", "3", "--warmup", "2")
+    assert out["n_gpus"] == 1 and out["scaling"] is None and out["blocks"] == 3 and out["dtype"] == "f64"
+    assert out["lnl_rel_err_pinned"] <= 1e-10 and out["lnl_rel_err"] <= 1e-10
+    rf, cb = out["roofline"], out["cpu_baseline"]
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and rf["achieved"] > 0
+    assert (rf["traffic"] is None) == (rf["traffic_source"] is None)
+    assert cb["kind"] == "reference" and len(cb["samples"]) == 3 and cb["one_core"]["cores"] == 1 and cb["pattern_tip"]["value"] > 0
+
+
+def test_python_and_c_drivers_give_the_same_bits():
+    a = run_bench("--steps", "3", "--blocks", "1", "--no-cpu", "--driver", "c", "--sites", "20000")
+    b = run_bench("--steps", "3", "--blocks", "1", "--no-cpu", "--driver", "python", "--sites", "20000")
+    assert a["lnl"] == b["lnl"]
