@@ -389,6 +389,7 @@ class Runner:
         self.upd = 1  # site repeats: class maps are computed by the first step and re-used, as applications do
         #               between topology changes: pll_update_partials_rep(..., update_repeats = 0)
         self.reduce = reduce if h.dist else None
+        self.collective = self.reduce is not None  # this runner's steps are steps of ALL ranks (barriers, max over ranks)
         self.c_driver = c_driver
         self.fi = np.ascontiguousarray(case.freqs_indices, dtype=np.uint32)
         self.edge_c = (C.c_int * 5)(*[int(v) for v in self.edge])
@@ -474,7 +475,7 @@ class Runner:
 
     def fence(self):
         self.lib.pll_gpu_synchronize(self.sess.p)
-        if self.h.dist:
+        if self.collective:
             self.h.barrier()
 
     def timed(self, warmup, steps, blocks=1):
@@ -488,7 +489,7 @@ class Runner:
             lnl = self.steps(steps)
             self.fence()
             dt = time.perf_counter() - t0
-            out.append(self.h.max_over_ranks(dt) if self.h.dist else dt)
+            out.append(self.h.max_over_ranks(dt) if self.collective else dt)
         return out, lnl
 
     def repeats_update_ms(self, reps=5):

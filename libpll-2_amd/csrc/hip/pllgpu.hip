@@ -21,6 +21,7 @@
 #include "kernels_generic.h"
 #include "kernels_deriv.h"
 #include "kernels_mfma.h"
+#include "kernels_mfma_wide.h"
 #include "kernels_lean.h"
 #include "kernels_repeats.h"
 
@@ -94,6 +95,8 @@ struct pllgpu_ctx
   bool dna_fast = false;
   bool use_mfma = false;
   int mfma_ng = 16;         // 4-state groups the MFMA kernels run with: 16 (33..64 states), 8 (21..32), 5 (17..20)
+  unsigned mfma_wide = 4;   // 33..64 states, inner x inner: k_partials_mfma_wide with whole-tile items and one wave per SIMD (4), half-tile items and two (2), or k_partials_mfma (0) - PLL_AMD_MFMA_WIDE, A/B
+  bool mfma_pad = false;    // PLL_AMD_MFMA_PAD=1 (A/B): 61 states through the padded 64-state contraction
   bool tiled = false;       // generic shapes keep CLVs in the tiled sites-contiguous layout
   DevBuf<double> scratch;   // host-layout staging for mirror copies of tiled CLVs
   size_t pm_stride = 0; // doubles per matrix in PT layout
@@ -320,6 +323,8 @@ static void derive_geometry(pllgpu_ctx *c)
   }
   if (const char *v = getenv("PLL_AMD_NO_MFMA"))
     if (*v && *v != '0') c->use_mfma = false;
+  if (const char *v = getenv("PLL_AMD_MFMA_WIDE")) c->mfma_wide = (atoi(v) == 4 || atoi(v) == 2) ? (unsigned)atoi(v) : 0u;
+  if (const char *v = getenv("PLL_AMD_MFMA_PAD")) c->mfma_pad = *v && *v != '0';
   // (tip x tip, tip x tip -> inner x inner) groups of the shapes outside the 4x4 kernels:
   // * 17..32 states: ON, on the matrix pipe (kernels_mfma.h: k_partials_mfma_cc), whatever pipe the level launches
   //   use - C3 (20 states) 4.0 -> 5.1 G updates/s on the same box (profiles/README.md, round 2);
@@ -985,6 +990,47 @@ static int launch_mfma_t(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsig
 {
   const unsigned R = c->gg.R;
   const unsigned items = (maxent + 31) / 32; // 32 sites per item
+  if (NG == 16 && kind == 0 && !gather && c->mfma_wide)
+  {
+    // 33..64 states, inner x inner, tiled CLVs: the second-generation kernel (kernels_mfma_wide.h). Work is dealt in
+    // half tiles: every SIMD gets one wave (whole-tile items, 1 wave per SIMD) or two (half-tile items) and the same
+    // number of half tiles, give or take one; ONE round of workgroups (70 KB of fragments each).
+    const unsigned main_sg = c->mfma_wide;
+    const unsigned max_wgs = 256u * (main_sg == 4 ? 1u : 2u);
+    const size_t total = (size_t)items * nops * R;
+    unsigned hpw = (unsigned)std::max<size_t>(1, (total + 4u * max_wgs - 1) / (4u * max_wgs));
+    while ((size_t)((items + 4u * hpw - 1) / (4u * hpw)) * nops * R > max_wgs) ++hpw;
+    dim3 grid((items + 4 * hpw - 1) / (4 * hpw), nops, R), block(256);
+    const size_t lds = MfmaGeo<16>::lds_doubles * sizeof(double);
+    bool scaling = false;
+    for (unsigned i = 0; i < nops; ++i) scaling = scaling || pack.ops[i].pscaler != nullptr;
+    scaling = scaling && c->gg.scale_mode != 0;
+    const unsigned fstride = (maxent + 63u) & ~63u;
+    if (scaling && c->mfma_flags.ensure((size_t)kMaxOpsPerLaunch * R * fstride)) return PLLGPU_ENOMEM;
+    unsigned char *fb = c->mfma_flags.p;
+    const bool exact61 = c->gg.S == 61 && !c->mfma_pad;
+#define MW_LAUNCH(NGJ, TAIL, MSG)                                                                                  \
+  do                                                                                                               \
+  {                                                                                                                \
+    raise_lds_limit((const void *)k_partials_mfma_wide<NGJ, TAIL, MSG>, c->device, lds);                           \
+    hipLaunchKernelGGL((k_partials_mfma_wide<NGJ, TAIL, MSG>), grid, block, lds, c->stream, pack, c->gg, hpw, fb, fstride); \
+  } while (0)
+    if (main_sg == 4)
+    {
+      if (exact61) MW_LAUNCH(15, 1, 4); else MW_LAUNCH(16, 0, 4);
+    }
+    else
+    {
+      if (exact61) MW_LAUNCH(15, 1, 2); else MW_LAUNCH(16, 0, 2);
+    }
+#undef MW_LAUNCH
+    if (scaling)
+    {
+      dim3 eg((maxent + 255) / 256, nops);
+      hipLaunchKernelGGL((k_mfma_scale_epilogue<false>), eg, dim3(256), 0, c->stream, pack, c->gg, fb, fstride);
+    }
+    return 0;
+  }
   // aim at two workgroups of four waves on every CU (2048 waves) - four where the small shapes leave room;
   // more work -> more items per wave
   const unsigned want = NG > 8 ? 2048u : 4096u;

@@ -20,6 +20,34 @@ def test_c_caller_reproduces_the_reference_kat(tmp_path):
     assert abs(float(lines["lnl"].split()[0]) - (-58.887310)) < 5.1e-7
 
 
+def _build_sharded(tmp_path):
+    exe = str(tmp_path / "sharded")
+    libdir = os.path.join(ROOT, "libpll-2_amd", "csrc")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_caller", "sharded.c"),
+                           "-L" + libdir, "-lpll_amd", "-ldl", "-lm", "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_c_caller_sharded_over_the_fixed_order_exchange(tmp_path, world):
+    """the 12-site KAT cut into `world` ranges, one process and partition per range, summed by
+    pll_gpu_group_edge_loglikelihood: every rank reports the reference's value, the same bits in all 50 steps"""
+    out = subprocess.run([_build_sharded(tmp_path), "peer", str(world)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    vals = [ln.split()[-1] for ln in out.stdout.strip().splitlines()]
+    assert len(vals) == world and len(set(vals)) == 1  # the same bits (%a) on every rank
+
+
+def test_c_caller_all_reduces_through_rccl_without_python(tmp_path):
+    """the north_star's "single RCCL all-reduce" reachable from C - a real communicator of one
+    rank handed to pll_gpu_edge_loglikelihood_allreduce (librccl bound by the library with dlopen)"""
+    out = subprocess.run([_build_sharded(tmp_path), "rccl"], capture_output=True, text=True, timeout=600)
+    if out.returncode == 77:
+        pytest.skip("no RCCL library on this host")
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rccl lnl -58.88731" in out.stdout
+
+
 def _captured(fn):
     """what a C-level printf writes to stdout while fn() runs"""
     import ctypes as C

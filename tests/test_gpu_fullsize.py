@@ -146,3 +146,51 @@ def test_c2_intermediate_clvs_at_full_size(amd_lib, reference):
         assert err <= RTOL, (c, err)
         assert np.array_equal(g_clv[c][1], r_clv[c][1])
     assert abs(g_lnl - r_lnl) <= RTOL * abs(r_lnl)
+
+
+def _check_nodes(cfg_sites, span, case, nodes, reference, amd_lib):
+    r_lnl, _, r_clv, r_ids = run(reference, case, clvs=nodes)
+    g_lnl, _, g_clv, g_ids = run(amd_lib, case, clvs=nodes)
+    for c in nodes:
+        assert g_clv[c][0].shape == (cfg_sites,) + span
+        err = driver.rel_err_normalised(g_clv[c][0], g_clv[c][1], r_clv[c][0], r_clv[c][1])
+        assert err <= RTOL, (c, err)
+        assert np.array_equal(g_clv[c][1], r_clv[c][1]), c  # scaler vectors: exact
+    assert abs(g_lnl - r_lnl) <= RTOL * abs(r_lnl)
+    assert g_ids == r_ids
+
+
+def test_c3_intermediate_clvs_at_full_size(amd_lib, reference):
+    """C3 as bench.py runs it: the bottom two levels are ONE launch of (tip x tip, tip x tip -> inner x inner)
+    groups on the matrix pipe (k_partials_mfma_cc<5>: 48 CLVs per launch, kernels_mfma.h) whose cherries nobody in
+    the traversal reads back; the small cases stop at a few hundred entries. Whole CLVs and scalers of the
+    first / middle / last node of every level at 50k sites against the reference."""
+    b = _bench()
+    cfg = b.CONFIGS["c3"]
+    case = b.build_case(cfg, cfg["sites"], 0)
+    T = case.tips
+    nodes = (T, T + 15, T + 31,          # cherries
+             T + 32, T + 40, T + 47,     # level 2: the groups' parents
+             T + 48, T + 51, T + 55, T + 56, T + 59, T + 60, T + 61)
+    _check_nodes(cfg["sites"], (4, 20), case, nodes, reference, amd_lib)
+
+
+def test_c4_shard_intermediate_clvs_at_full_size(amd_lib, reference):
+    """One 125k-site shard of configs[3] as bench.py --gpus 8 runs it (pattern-sorted alignment, site repeats):
+    levels 1-3 come out of ONE launch over packed sub-tree look-ups (k_partials_dna_sub), levels 4 + 5 out of
+    groups over gathering producers (k_partials_dna_gg: the producers A / B leave through streaming stores and are
+    not read back), level 6 inside the edge kernel. Nodes of every level incl. both producers and the parent of a
+    group, expanded through the class maps, CLVs <= 1e-10 and scalers exact against the reference; class counts
+    exact. The small cases of tests/test_gpu_repeats.py stop at 700 entries."""
+    b = _bench()
+    from pllamd import sharding
+    cfg = b.CONFIGS["c4"]
+    full = sharding.sort_columns(amd_lib, b.build_case(cfg, cfg["sites"], api.SITE_REPEATS))
+    case = sharding.shard_case(full, 1, 8, sharding.balanced_bounds(full, 8))  # the shard with the most classes
+    T = case.tips
+    # level 1: T .. T+63, 2: T+64 .. T+95, 3: T+96 .. T+111, 4: T+112 .. T+119, 5: T+120 .. T+123, 6: T+124, T+125
+    nodes = (T, T + 63, T + 64, T + 95, T + 96, T + 103, T + 111,
+             T + 112, T + 113, T + 120,   # producers A, B and the parent P of the first group
+             T + 118, T + 119, T + 123,   # ... and of the last
+             T + 124, T + 125)
+    _check_nodes(case.sites, (4, 4), case, nodes, reference, amd_lib)

@@ -895,6 +895,41 @@ def test_matrix_pipe_kernels_for_all_group_counts(amd_lib, kw, monkeypatch):
         assert scalers_equal(got, exp)
 
 
+@pytest.mark.parametrize("kw", [dict(states=61, tips=8, sites=300, seed=421),                                   # half-tile items only
+                                dict(states=61, tips=8, sites=5001, seed=422, tips_as="clv_dense"),             # whole tiles + a ragged last one
+                                dict(states=61, tips=8, sites=9007, seed=423),                                   # odd shares: leading / trailing half tiles
+                                dict(states=61, tips=64, sites=260, seed=424, tree="caterpillar", brlen_scale=8),  # deep: per-site rescaling
+                                dict(states=61, tips=64, sites=260, seed=425, tree="caterpillar", brlen_scale=8, attributes=api.RATE_SCALERS),
+                                dict(states=64, tips=8, sites=4100, seed=426), dict(states=48, tips=8, sites=4100, seed=427),
+                                dict(states=33, tips=16, sites=700, seed=428)], ids=_id)
+def test_wide_matrix_pipe_kernel(amd_lib, kw, monkeypatch):
+    """k_partials_mfma_wide (kernels_mfma_wide.h), the inner x inner kernel of 33..64 states: lanes own adjacent sites
+    (16-byte loads and stores), items are whole tiles (one wave per SIMD) or half tiles, and 61 states contract over 15
+    full groups on the matrix pipe with the 61st column as the chains' initial value. Against the oracle (CLVs, scalers,
+    lnL) in every form; the padded forms (64-state contraction) are bit-identical to the first-generation kernel."""
+    kw = dict(kw)
+    tips_as = kw.pop("tips_as", None)
+    case = W.make_case("wide", **kw)
+    if tips_as == "clv_dense":
+        monkeypatch.setenv("PLL_AMD_NO_TIP_CODES", "1")  # every op inner x inner, also the bottom level
+    exp = O.run_case(case)
+    deep = kw.get("brlen_scale", 1) > 1
+    got = {}
+    for wide, pad in (("4", "0"), ("2", "0"), ("4", "1"), ("2", "1"), ("0", "0")):
+        monkeypatch.setenv("PLL_AMD_MFMA_WIDE", wide)
+        monkeypatch.setenv("PLL_AMD_MFMA_PAD", pad)
+        got[wide, pad] = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+        assert_results_match(got[wide, pad], exp, what=f"{_id(kw)} wide={wide} pad={pad}")
+        if deep:
+            assert sum(int(v.sum()) for v in got[wide, pad]["scaler"].values()) > 0
+            assert scalers_equal(got[wide, pad], exp)
+    old = got["0", "0"]
+    for key in (("4", "1"), ("2", "1")) + ((("4", "0"), ("2", "0")) if case.states != 61 else ()):
+        assert got[key]["lnl"] == old["lnl"], key
+        for c in old["clv"]:
+            assert np.array_equal(got[key]["clv"][c], old["clv"][c]), (key, c)
+
+
 def test_partitions_in_concurrent_threads(amd_lib):
     """distinct partitions may be driven from distinct threads (no internal threads, no
     global state): four threads, each with its own partition, stream and shape, interleave freely"""
