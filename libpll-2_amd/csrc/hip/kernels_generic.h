@@ -412,228 +412,6 @@ __global__ __launch_bounds__(256) void k_partials_tiled(const OpPack pack, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// (tip x tip, tip x tip -> inner x inner) groups for the FMA-path shapes (C3: 20 states): an op P whose two
-// children are CHERRIES produced by the same call is evaluated together with them, and nothing is read back
-// from HBM: the three CLVs and scalers are written exactly as three launches would write them (C3's bottom two
-// levels: 1.54 GB written instead of 2.56 GB moved).
-//
-// A cherry entry depends on the two tip codes only - x_i = (P_L x_l)_i (P_R x_r)_i, the table of
-// pll_core_create_lookup (src/core_partials.c:1073-1210) - so k_cherry_tables first forms that table for every
-// cherry of the launch, rate category and pair of codes (a few hundred KB per cherry: it lives in L2), with the
-// reference's arithmetic: ascending sums over the set bits of each mask, then the product. The contraction loop
-// of P is then the one of `contract` above - dynamic in j, coefficients through the scalar path - with x_j
-// gathered from the lane's table row instead of streamed from a CLV, and stored to the cherry's CLV on the way.
-// Two earlier forms lost to the level-by-level launches they were meant to replace: both children's 80 values
-// per lane in registers with the contraction unrolled over them (round 1: drowned in scalar loads), and x_j from
-// LDS-staged tip matrices (LDS reads and scalar loads share one completion counter, and the scalar ones return
-// out of order: every wait became a wait for everything; 56 KB of LDS per workgroup on top).
-// Scaling: a cherry's decision is known only after its loop, so P's sums are formed from the unscaled x_j and
-// multiplied by 2^256 afterwards when the cherry was rescaled - exact (a power of two; neither side can
-// underflow: the terms are products of at most three transition probabilities).
-struct CherryMats // by value: the tip matrices of up to 32 cherries
-{
-  const double *lmat[2 * kMaxGroups];
-  const double *rmat[2 * kMaxGroups];
-};
-
-// even row stride of a table row (16-byte loads)
-__host__ __device__ __forceinline__ unsigned cherry_row(unsigned S) { return (S + 1u) & ~1u; }
-
-// table[cherry][rate][code_l * ncodes + code_r][i]; grid (cherries, rates)
-__global__ __launch_bounds__(256) void k_cherry_tables(const CherryMats mats, const GenGeo g, const unsigned long long *__restrict__ tipmap,
-                                                        unsigned ncodes, double *__restrict__ table)
-{
-  extern __shared__ double cols[]; // [2][ncodes][S]: (P x)_i of every code for the left / right tip
-  const unsigned c = blockIdx.x, k = blockIdx.y, S = g.S;
-  const double *lm = mats.lmat[c] + (size_t)k * S * g.SPT, *rm = mats.rmat[c] + (size_t)k * S * g.SPT;
-  for (unsigned idx = threadIdx.x; idx < ncodes * S; idx += 256u)
-  {
-    const unsigned code = idx / S, i = idx % S;
-    const unsigned long long mask = tipmap ? tipmap[code] : (unsigned long long)code;
-    double a = 0.0, b = 0.0; // the set-bit walk of the FMA route (contract<.., true>): ascending sums
-    for (unsigned m = 0; m < S; ++m)
-      if ((mask >> m) & 1ull)
-      {
-        a += lm[(size_t)m * g.SPT + i];
-        b += rm[(size_t)m * g.SPT + i];
-      }
-    cols[idx] = a;
-    cols[ncodes * S + idx] = b;
-  }
-  __syncthreads();
-  const unsigned SR = cherry_row(S), npairs = ncodes * ncodes;
-  double *out = table + ((size_t)c * g.R + k) * npairs * SR;
-  for (unsigned idx = threadIdx.x; idx < npairs * SR; idx += 256u)
-  {
-    const unsigned i = idx % SR, pr = idx / SR;
-    out[idx] = i < S ? cols[(pr / ncodes) * S + i] * cols[ncodes * S + (pr % ncodes) * S + i] : 0.0;
-  }
-}
-
-typedef double gen_dbl2 __attribute__((ext_vector_type(2)));
-
-// the cherry's CLV column of this (entry, rate): the lane's table row, copied in one burst of stores (stores that
-// trickle out of the contraction loop one row at a time reached 3.1 TB/s on C3, a pure copy like this one 4+)
-template <int ICH>
-__device__ __forceinline__ void cherry_store(const double *__restrict__ row, unsigned S, double *__restrict__ out, bool valid, bool &small)
-{
-  const gen_dbl2 *r2 = reinterpret_cast<const gen_dbl2 *>(row);
-  gen_dbl2 v[(ICH + 1) / 2];
-#pragma unroll
-  for (int jc = 0; jc < (ICH + 1) / 2; ++jc) v[jc] = 2 * jc < (int)S ? r2[jc] : gen_dbl2{0.0, 0.0};
-  small = true;
-#pragma unroll
-  for (int jc = 0; jc < (ICH + 1) / 2; ++jc)
-  {
-    if (2 * jc < (int)S)
-    {
-      small = small && (v[jc].x < PLLGPU_SCALE_THRESHOLD);
-      if (valid) __builtin_nontemporal_store(v[jc].x, out + (size_t)(2 * jc) * 64);
-    }
-    if (2 * jc + 1 < (int)S)
-    {
-      small = small && (v[jc].y < PLLGPU_SCALE_THRESHOLD);
-      if (valid) __builtin_nontemporal_store(v[jc].y, out + (size_t)(2 * jc + 1) * 64);
-    }
-  }
-}
-
-// acc[i] = sum_j PT[k][j][i] x_j with x = the lane's table row (second read: from the vector cache)
-template <int ICH>
-__device__ __forceinline__ void cherry_contract(double (&acc)[ICH], const double *__restrict__ row, const double *pt, unsigned k, const GenGeo &g)
-{
-  cdouble_p p = as_const(pt) + ((size_t)k * g.S) * g.SPT;
-#pragma unroll
-  for (int i = 0; i < ICH; ++i) acc[i] = 0.0;
-  const gen_dbl2 *r2 = reinterpret_cast<const gen_dbl2 *>(row);
-  const unsigned half = cherry_row(g.S) / 2u;
-#pragma unroll 2
-  for (unsigned jc = 0; jc < half; ++jc)
-  {
-    const gen_dbl2 v = r2[jc];
-    const unsigned j = 2u * jc;
-    {
-      cdouble_p pj = p + (size_t)j * g.SPT;
-#pragma unroll
-      for (int i = 0; i < ICH; ++i) acc[i] = fma(pj[i], v.x, acc[i]);
-    }
-    if (j + 1u < g.S)
-    {
-      cdouble_p pj = p + (size_t)(j + 1u) * g.SPT;
-#pragma unroll
-      for (int i = 0; i < ICH; ++i) acc[i] = fma(pj[i], v.y, acc[i]);
-    }
-  }
-}
-
-// workgroup = one 64-entry tile at a time, wave k = rate category k (R <= 4)
-template <int ICH>
-__global__ __launch_bounds__(256) void k_partials_tiled_cc(const FusePack pack, const GenGeo g, const double *__restrict__ table, unsigned ncodes,
-                                                            unsigned entries, unsigned tiles_per_block)
-{
-  __shared__ unsigned char flags[3][4][64]; // [cherry a, cherry b, parent][rate][lane]
-  const FGroup &grp = pack.g[blockIdx.y];
-  const unsigned lane = threadIdx.x & 63u;
-  const unsigned k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave = rate category
-  const unsigned ntiles = (entries + 63u) / 64u;
-  const int ma = grp.a.pscaler ? g.scale_mode : 0, mb = grp.b.pscaler ? g.scale_mode : 0, mp = grp.p.pscaler ? g.scale_mode : 0;
-  const size_t col = (size_t)k * g.S * 64;
-  const unsigned SR = cherry_row(g.S), npairs = ncodes * ncodes;
-  const double *ta = table + ((size_t)(2u * blockIdx.y) * g.R + k) * npairs * SR;
-  const double *tb = table + ((size_t)(2u * blockIdx.y + 1u) * g.R + k) * npairs * SR;
-
-  for (unsigned t = 0; t < tiles_per_block; ++t)
-  {
-    const unsigned tile = blockIdx.x * tiles_per_block + t;
-    if (tile >= ntiles) break; // whole workgroup
-    const unsigned n = tile * 64u + lane;
-    const bool valid = n < entries;
-    const unsigned nn = valid ? n : entries - 1;
-    const unsigned pa = (unsigned)grp.a.ltip[nn] * ncodes + grp.a.rtip[nn], pb = (unsigned)grp.b.ltip[nn] * ncodes + grp.b.rtip[nn];
-    const size_t base = (size_t)tile * g.tile_sz + lane + col;
-    double *__restrict__ outa = grp.a.parent + base, *__restrict__ outb = grp.b.parent + base, *__restrict__ outp = grp.p.parent + base;
-
-    double A[ICH], B[ICH];
-    bool sa, sb;
-    cherry_store<ICH>(ta + (size_t)pa * SR, g.S, outa, valid, sa);
-    cherry_store<ICH>(tb + (size_t)pb * SR, g.S, outb, valid, sb);
-    cherry_contract<ICH>(A, ta + (size_t)pa * SR, grp.p.lmat, k, g);
-    cherry_contract<ICH>(B, tb + (size_t)pb * SR, grp.p.rmat, k, g);
-    sa = sa && ma != 0;
-    sb = sb && mb != 0;
-    // the cherries' scaling decisions: per rate they are this wave's own, per site the rates meet in LDS
-    if (g.scale_mode == 1 && (ma || mb)) // workgroup-uniform
-    {
-      flags[0][k][lane] = sa ? 1 : 0;
-      flags[1][k][lane] = sb ? 1 : 0;
-      __syncthreads();
-      sa = sb = true;
-      for (unsigned q = 0; q < g.R; ++q)
-      {
-        sa = sa && flags[0][q][lane];
-        sb = sb && flags[1][q][lane];
-      }
-      sa = sa && ma != 0;
-      sb = sb && mb != 0;
-    }
-    auto rescale_stored = [&](double *colp) { // rare: the entry's stored column of this rate, written by this lane
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      for (unsigned s = 0; s < g.S; ++s)
-      {
-        const double v = __builtin_nontemporal_load(colp + (size_t)s * 64);
-        __builtin_nontemporal_store(v * PLLGPU_SCALE_FACTOR, colp + (size_t)s * 64);
-      }
-    };
-    if (sa)
-    {
-      if (valid) rescale_stored(outa);
-#pragma unroll
-      for (int i = 0; i < ICH; ++i) A[i] *= PLLGPU_SCALE_FACTOR;
-    }
-    if (sb)
-    {
-      if (valid) rescale_stored(outb);
-#pragma unroll
-      for (int i = 0; i < ICH; ++i) B[i] *= PLLGPU_SCALE_FACTOR;
-    }
-    if (valid)
-    {
-      if (ma == 2) grp.a.pscaler[(size_t)n * g.R + k] = sa ? 1u : 0u;
-      if (mb == 2) grp.b.pscaler[(size_t)n * g.R + k] = sb ? 1u : 0u;
-      if (k == 0 && ma == 1) grp.a.pscaler[n] = sa ? 1u : 0u;
-      if (k == 0 && mb == 1) grp.b.pscaler[n] = sb ? 1u : 0u;
-    }
-    // the parent
-    bool sp = mp != 0;
-#pragma unroll
-    for (int i = 0; i < ICH; ++i)
-      if (i < (int)g.S)
-      {
-        A[i] *= B[i];
-        sp = sp && (A[i] < PLLGPU_SCALE_THRESHOLD);
-      }
-    if (mp == 1)
-    {
-      flags[2][k][lane] = sp ? 1 : 0;
-      __syncthreads();
-      sp = true;
-      for (unsigned q = 0; q < g.R; ++q) sp = sp && flags[2][q][lane];
-    }
-    if (valid)
-    {
-#pragma unroll
-      for (int i = 0; i < ICH; ++i)
-        if (i < (int)g.S) outp[(size_t)i * 64] = sp ? A[i] * PLLGPU_SCALE_FACTOR : A[i];
-      // the parent's children are the cherries: their counts are what was decided above (0 without a scaler)
-      const unsigned below = ((ma && sa) ? 1u : 0u) + ((mb && sb) ? 1u : 0u);
-      if (mp == 2) grp.p.pscaler[(size_t)n * g.R + k] = below + (sp ? 1u : 0u);
-      if (mp == 1 && k == 0) grp.p.pscaler[n] = below + (sp ? 1u : 0u);
-    }
-    if (g.scale_mode == 1 && (ma || mb || mp)) __syncthreads(); // flags[] is reused by the next tile
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // edge / root log-likelihood, any states/rates, tiled layout. Workgroup = one tile at a time; wave
 // w of min(R,4) owns the rate categories w, w+nw, ... : it forms (P c)_i in chunks exactly like the
 // update kernel, dots it with p_i * pi_i, applies the per-rate scaler excess, the rate weight and

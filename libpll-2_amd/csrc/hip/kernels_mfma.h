@@ -781,301 +781,6 @@ __global__ __launch_bounds__(256, 4) void k_partials_mfma_cc(const FusePack pack
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same groups for 33..64 states (C5: 61-state codon models, NG = 16). Here the parent's contraction IS the
-// launch: 2 x 256 MFMAs per 16 sites and rate, more than the stores of the three CLVs take - so the cherries come for
-// free, and the tip x tip launch (pure store traffic, 0.47 of HBM) and the read-back of its output disappear.
-// LDS holds the parent's two matrices as MFMA fragments (as k_partials_mfma); there is no room for the four tip
-// matrices, and none is needed: a tip column is a ROW of the matrix as the host stores it (PT[code][i]), 16 loads of
-// the lane's states 4 ig + row - the four row groups of an entry read one contiguous 488-byte row from L2 - and
-// the row sums a full gap stands for lie beside the cherry's table (k_cherry_bits). Ambiguous codes take the MFMA
-// route with 0/1 operands and fragments fetched from L2 (rare, slow, exact). Register plan: x of one cherry (64) ->
-// its store -> D_left of the parent (64) -> x of the other cherry in the same registers -> D_right four state groups
-// at a time. Arithmetic and order per op are those of k_partials_mfma<16, ...>: bit-identical to the level launches.
-template <int NG>
-__global__ __launch_bounds__(256, 2) void k_partials_mfma_cc_big(const FusePack pack, const GenGeo g, const unsigned long long *__restrict__ tipmap,
-                                                                 unsigned entries, unsigned items_per_wave, unsigned char *__restrict__ flagbuf,
-                                                                 unsigned flag_stride, const unsigned char *__restrict__ bits,
-                                                                 const double *__restrict__ rowsums, const CherrySlots slots, unsigned ncodes)
-{
-  typedef MfmaGeo<NG> MG;
-  typedef double __attribute__((ext_vector_type(2))) double2v;
-  extern __shared__ double lds[];
-  double *PL = lds, *PR = lds + MG::frag_array;
-  unsigned char *CIDX = reinterpret_cast<unsigned char *>(lds + 2u * MG::frag_array); // [256]
-
-  const FGroup &grp = pack.g[blockIdx.y];
-  const unsigned lane = threadIdx.x & 63u;
-  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const unsigned row = lane >> 4, col = lane & 15u;
-  const unsigned S = g.S, k = blockIdx.z, R = g.R;
-  const unsigned nitems = (entries + 31u) / 32u;
-  if (blockIdx.x * 4u * items_per_wave >= nitems) return; // whole workgroup
-  const unsigned fragoff = row * 4u + (lane & 3u);
-  const unsigned long long full = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
-  constexpr unsigned kGap = 254u;
-  {
-    double *const dst[2] = {PL, PR};
-    const double *const src[2] = {grp.p.lmat + (size_t)k * S * g.SPT, grp.p.rmat + (size_t)k * S * g.SPT};
-    mfma_stage<NG, 2>(dst, src, S, g.SPT);
-  }
-  {
-    unsigned ci = kCcAmbiguous;
-    if (threadIdx.x < ncodes)
-    {
-      const unsigned long long mk = tipmap[threadIdx.x];
-      ci = mk == full ? kGap : __popcll(mk) == 1 ? (unsigned)__ffsll((long long)mk) - 1u : kCcAmbiguous;
-    }
-    CIDX[threadIdx.x] = (unsigned char)ci;
-  }
-  __syncthreads();
-  const int ma = grp.a.pscaler ? g.scale_mode : 0, mb = grp.b.pscaler ? g.scale_mode : 0, mp = grp.p.pscaler ? g.scale_mode : 0;
-  const unsigned item0 = (blockIdx.x * 4u + wave) * items_per_wave;
-  if (item0 >= nitems) return; // no barriers below
-  const unsigned nmine = min(items_per_wave, nitems - item0);
-  const unsigned last_pair = (entries - 1u) & ~1u;
-  const unsigned allr = (1u << R) - 1u, npairs = ncodes * ncodes;
-  const unsigned char *tips[4] = {grp.a.ltip, grp.a.rtip, grp.b.ltip, grp.b.rtip};
-  const double *mats[4] = {grp.a.lmat + (size_t)k * S * g.SPT, grp.a.rmat + (size_t)k * S * g.SPT, grp.b.lmat + (size_t)k * S * g.SPT,
-                           grp.b.rmat + (size_t)k * S * g.SPT}; // PT[k]: row = tip column
-  const double *rsum[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) rsum[t] = rowsums + (((size_t)slots.s[2u * blockIdx.y + (t >> 1)] * R + k) * 2u + (t & 1)) * 64u;
-  const unsigned char *tab[2] = {bits + (size_t)slots.s[2u * blockIdx.y] * R * npairs, bits + (size_t)slots.s[2u * blockIdx.y + 1u] * R * npairs};
-  const unsigned lane_off = row * 64u + 2u * col;
-
-  auto fetch_codes = [&](unsigned item, unsigned (&cw)[4]) {
-    const unsigned e0 = min(item * 32u + 2u * col, last_pair);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) cw[t] = *reinterpret_cast<const unsigned short *>(tips[t] + e0);
-  };
-  unsigned cw[4];
-  fetch_codes(item0, cw);
-
-  for (unsigned it = 0; it < nmine; ++it)
-  {
-    const unsigned item = item0 + it; // wave-uniform
-    unsigned nw[4] = {cw[0], cw[1], cw[2], cw[3]};
-    if (it + 1 < nmine) fetch_codes(item + 1u, nw);
-    const unsigned e0 = item * 32u + 2u * col;
-    const bool valid[2] = {e0 < entries, e0 + 1u < entries};
-    unsigned code[4][2], cx[4][2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-    {
-      code[t][0] = cw[t] & 0xffu;
-      code[t][1] = (min(e0, last_pair) + 1u < entries) ? (cw[t] >> 8) : code[t][0];
-      cx[t][0] = CIDX[code[t][0]];
-      cx[t][1] = CIDX[code[t][1]];
-    }
-    bool scale_c[2][2]; // [cherry][entry]: is the cherry entry rescaled (for this rate category)?
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-      for (int sg = 0; sg < 2; ++sg)
-      {
-        const int mch = ch ? mb : ma;
-        unsigned bv = 0;
-        if (mch)
-        {
-          const unsigned pr = code[2 * ch][sg] * ncodes + code[2 * ch + 1][sg];
-          for (unsigned kk = 0; kk < R; ++kk) bv |= (unsigned)tab[ch][(size_t)kk * npairs + pr] << kk;
-        }
-        scale_c[ch][sg] = mch == 1 ? bv == allr : mch == 2 ? ((bv >> k) & 1u) != 0 : false;
-      }
-    // where the lane's tip column of entry sg starts: a row of PT[k], or the row sums
-    auto column = [&](int t, int sg) -> const double * {
-      const unsigned c = cx[t][sg];
-      return (c == kGap ? rsum[t] : mats[t] + (size_t)(c < S ? c : 0u) * g.SPT) + row;
-    };
-    // fragment element of tip matrix t for block (ig, jg), from L2 (ambiguous codes only)
-    auto afrag_global = [&](int t, int ig, int jg) -> double {
-      const unsigned j = 4u * jg + row, i = 4u * ig + (lane & 3u);
-      return (j < S && i < g.SPT) ? mats[t][(size_t)j * g.SPT + i] : 0.0;
-    };
-    // a cherry in the lane's states 4 ig + row of both entries: x = (P_l x_l) o (P_r x_r), scaled, stored
-    auto cherry = [&](int ch, const FOp &fo, double (&x)[NG][2]) {
-      const int t0 = 2 * ch;
-      const bool lsimple = __all(cx[t0][0] != kCcAmbiguous && cx[t0][1] != kCcAmbiguous);
-      const bool rsimple = __all(cx[t0 + 1][0] != kCcAmbiguous && cx[t0 + 1][1] != kCcAmbiguous);
-      if (lsimple)
-      {
-        const double *c0 = column(t0, 0), *c1 = column(t0, 1);
-#pragma unroll
-        for (int ig = 0; ig < NG; ++ig)
-        {
-          x[ig][0] = c0[4 * ig];
-          x[ig][1] = c1[4 * ig];
-        }
-      }
-      else
-      {
-        const unsigned long long m0 = tipmap[code[t0][0]], m1 = tipmap[code[t0][1]];
-#pragma unroll
-        for (int ig = 0; ig < NG; ++ig) x[ig][0] = x[ig][1] = 0.0;
-#pragma unroll 1
-        for (int jg = 0; jg < NG; ++jg)
-        {
-          const double x0 = mfma_x<true>(nullptr, m0, S, 4 * jg + row), x1 = mfma_x<true>(nullptr, m1, S, 4 * jg + row);
-#pragma unroll
-          for (int ig = 0; ig < NG; ++ig)
-          {
-            const double a = afrag_global(t0, ig, jg);
-            x[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x0, x[ig][0], 0, 0, 0);
-            x[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x1, x[ig][1], 0, 0, 0);
-          }
-        }
-      }
-      if (rsimple)
-      {
-        const double *c0 = column(t0 + 1, 0), *c1 = column(t0 + 1, 1);
-#pragma unroll
-        for (int ig = 0; ig < NG; ++ig)
-        {
-          x[ig][0] *= c0[4 * ig];
-          x[ig][1] *= c1[4 * ig];
-        }
-      }
-      else
-      {
-        const unsigned long long m0 = tipmap[code[t0 + 1][0]], m1 = tipmap[code[t0 + 1][1]];
-#pragma unroll
-        for (int c4 = 0; c4 < NG / 4; ++c4)
-        {
-          double dr[4][2];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) dr[q][0] = dr[q][1] = 0.0;
-#pragma unroll 1
-          for (int jg = 0; jg < NG; ++jg)
-          {
-            const double x0 = mfma_x<true>(nullptr, m0, S, 4 * jg + row), x1 = mfma_x<true>(nullptr, m1, S, 4 * jg + row);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-            {
-              const double a = afrag_global(t0 + 1, 4 * c4 + q, jg);
-              dr[q][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x0, dr[q][0], 0, 0, 0);
-              dr[q][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x1, dr[q][1], 0, 0, 0);
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-          {
-            x[4 * c4 + q][0] *= dr[q][0];
-            x[4 * c4 + q][1] *= dr[q][1];
-          }
-        }
-      }
-      const int mch = ch ? mb : ma;
-#pragma unroll
-      for (int sg = 0; sg < 2; ++sg)
-        if (scale_c[ch][sg])
-        {
-#pragma unroll
-          for (int ig = 0; ig < NG; ++ig) x[ig][sg] *= PLLGPU_SCALE_FACTOR;
-        }
-      // store (streaming: nothing reads a cherry back in this traversal)
-      double *ub = fo.parent + (size_t)(item >> 1) * g.tile_sz + (size_t)k * S * 64 + (item & 1u) * 32u; // wave-uniform
-#pragma unroll
-      for (int ig = 0; ig < NG; ++ig)
-        if (4u * ig + row < S)
-        {
-          double *q = ub + (lane_off + 256u * ig);
-          if (valid[1])
-          {
-            double2v w;
-            w.x = x[ig][0];
-            w.y = x[ig][1];
-            __builtin_nontemporal_store(w, reinterpret_cast<double2v *>(q));
-          }
-          else if (valid[0])
-            q[0] = x[ig][0];
-        }
-      if (mch && row == 0)
-#pragma unroll
-        for (int sg = 0; sg < 2; ++sg)
-          if (valid[sg])
-          {
-            if (mch == 2) fo.pscaler[(size_t)(e0 + sg) * R + k] = scale_c[ch][sg] ? 1u : 0u;
-            if (mch == 1 && k == 0) fo.pscaler[e0 + sg] = scale_c[ch][sg] ? 1u : 0u;
-          }
-    };
-
-    double x[NG][2], DL[NG][2];
-    cherry(0, grp.a, x);
-#pragma unroll
-    for (int ig = 0; ig < NG; ++ig) DL[ig][0] = DL[ig][1] = 0.0;
-#pragma unroll
-    for (int jg = 0; jg < NG; ++jg)
-    {
-#pragma unroll
-      for (int ig = 0; ig < NG; ++ig)
-      {
-        const double a = PL[(ig * NG + jg) * kFrag + fragoff];
-        DL[ig][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][0], DL[ig][0], 0, 0, 0);
-        DL[ig][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][1], DL[ig][1], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0); // keep the fragment look-ahead bounded
-    }
-    cherry(1, grp.b, x);
-    bool sp[2] = {true, true};
-    double *ub = grp.p.parent + (size_t)(item >> 1) * g.tile_sz + (size_t)k * S * 64 + (item & 1u) * 32u;
-#pragma unroll
-    for (int c4 = 0; c4 < NG / 4; ++c4)
-    {
-      double DR[4][2];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) DR[q][0] = DR[q][1] = 0.0;
-#pragma unroll
-      for (int jg = 0; jg < NG; ++jg)
-      {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-        {
-          const double a = PR[((c4 * 4 + q) * NG + jg) * kFrag + fragoff];
-          DR[q][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][0], DR[q][0], 0, 0, 0);
-          DR[q][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x[jg][1], DR[q][1], 0, 0, 0);
-        }
-        if ((jg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-      {
-        const int ig = c4 * 4 + q;
-        const unsigned i = 4u * ig + row;
-        if (i < S)
-        {
-          const double v0 = DL[ig][0] * DR[q][0], v1 = DL[ig][1] * DR[q][1];
-          sp[0] = sp[0] && (v0 < PLLGPU_SCALE_THRESHOLD);
-          sp[1] = sp[1] && (v1 < PLLGPU_SCALE_THRESHOLD);
-          double *qd = ub + (lane_off + 256u * ig);
-          if (valid[1])
-          {
-            double2v w;
-            w.x = v0;
-            w.y = v1;
-            *reinterpret_cast<double2v *>(qd) = w;
-          }
-          else if (valid[0])
-            qd[0] = v0;
-        }
-      }
-    }
-    if (mp)
-    {
-#pragma unroll
-      for (int sg = 0; sg < 2; ++sg)
-      {
-        int sm = sp[sg] ? 1 : 0; // a site's states are spread over the four row groups of the wave
-        sm &= __shfl_xor(sm, 16, 64);
-        sm &= __shfl_xor(sm, 32, 64);
-        if (row == 0 && valid[sg]) flagbuf[((size_t)blockIdx.y * R + k) * flag_stride + e0 + sg] = (unsigned char)sm;
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) cw[t] = nw[t];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Edge log-likelihood for 33..64 states on the matrix pipe (src/core_likelihood.c:1388-1490 ii,
 // :812-915 ti, :1077-1183 repeats). Same fragments and lane maps as k_partials_mfma. One RATE CATEGORY per
 // workgroup (grid = item blocks x R, block b works on rate b % R of item block b / R): it stages the edge's

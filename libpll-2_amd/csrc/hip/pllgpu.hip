@@ -95,7 +95,7 @@ struct pllgpu_ctx
   bool dna_fast = false;
   bool use_mfma = false;
   int mfma_ng = 16;         // 4-state groups the MFMA kernels run with: 16 (33..64 states), 8 (21..32), 5 (17..20)
-  unsigned mfma_wide = 4;   // 33..64 states, inner x inner: k_partials_mfma_wide with whole-tile items and one wave per SIMD (4), half-tile items and two (2), or k_partials_mfma (0) - PLL_AMD_MFMA_WIDE, A/B
+  unsigned mfma_wide = 1;   // 33..64 states, inner x inner: k_partials_mfma_wide (kernels_mfma_wide.h); PLL_AMD_MFMA_WIDE=0 (A/B, parity tests): k_partials_mfma
   bool mfma_pad = false;    // PLL_AMD_MFMA_PAD=1 (A/B): 61 states through the padded 64-state contraction
   bool tiled = false;       // generic shapes keep CLVs in the tiled sites-contiguous layout
   DevBuf<double> scratch;   // host-layout staging for mirror copies of tiled CLVs
@@ -163,7 +163,6 @@ struct pllgpu_ctx
   bool plan_cache = true;           // PLL_AMD_NO_PLAN_CACHE=1 plans every call afresh
   int gather_stream = 0;            // PLL_AMD_GATHER_STREAM: 1 always streaming loads from compressed children, -1 never, 0 by size
   DevBuf<unsigned char> cherry_bits; // k_cherry_bits: which cherry entries are rescaled, [slot][rate][pair of tip codes]
-  DevBuf<double> cherry_rowsums;     // ... and the row sums of the slot's two tip matrices [slot][rate][2][64] (33..64 states)
   struct CherrySlot
   {
     unsigned long long lver = 0, rver = 0, maps = 0;
@@ -171,15 +170,11 @@ struct pllgpu_ctx
   std::map<unsigned long long, unsigned> cherry_slot_of; // (left matrix, right matrix) -> slot
   std::vector<CherrySlot> cherry_slot;                   // what the slot's table was computed from
   std::vector<unsigned long long> pm_version;            // bumped whenever a device matrix is written
-  DevBuf<double> cherry_tab;        // k_cherry_tables: [cherry][rate][code pair][state] of the launch being issued
   unsigned tip_ncodes = 0;          // codes in use: 1 + the highest code with a non-empty mask
   bool generic_aos = true;          // PLL_AMD_NO_GENERIC_AOS=1: compressed nodes of non-4x4 shapes stay tiled (A/B)
   bool lean = false;                // 17..20 states, <= 4 rates: the level launches on the matrix pipe (kernels_lean.h)
   bool lean_plain = false;          // ... also the ones that do not gather (PLL_AMD_LEAN_PLAIN=1)
-  bool lean_edge = false;           // PLL_AMD_LEAN_EDGE=1: edge log-likelihoods of these shapes on the matrix pipe (k_edge_lean: 37 us against the FMA kernel's 33 at C3's size - both are a chain of round trips around microseconds of arithmetic)
-  int lean_groups = 0;              // ... and (inner x inner, inner x inner -> inner x inner) groups: 1 = k_partials_lean3, 2 = k_partials_mfma_iii
   bool fuse_mfma = false;           // 17..32 states on the matrix pipe: the same groups (kernels_mfma.h: k_partials_mfma_cc)
-  bool fuse_generic = false;        // FMA-path shapes: (tip x tip, tip x tip -> inner x inner) groups (kernels_generic.h: k_partials_tiled_cc)
   bool subtrees = false;            // DNA + site repeats: all-tip subtrees straight from the tip codes (subtree_plan.h)
   DevBuf<unsigned char> sub_dev;    // their descriptors on the device ...
   std::vector<SubItem> sub_cache, sub_build; // ... and what that array holds / the list being planned
@@ -323,44 +318,23 @@ static void derive_geometry(pllgpu_ctx *c)
   }
   if (const char *v = getenv("PLL_AMD_NO_MFMA"))
     if (*v && *v != '0') c->use_mfma = false;
-  if (const char *v = getenv("PLL_AMD_MFMA_WIDE")) c->mfma_wide = (atoi(v) == 4 || atoi(v) == 2) ? (unsigned)atoi(v) : 0u;
+  if (const char *v = getenv("PLL_AMD_MFMA_WIDE")) c->mfma_wide = atoi(v) != 0 ? 1u : 0u;
   if (const char *v = getenv("PLL_AMD_MFMA_PAD")) c->mfma_pad = *v && *v != '0';
-  // (tip x tip, tip x tip -> inner x inner) groups of the shapes outside the 4x4 kernels:
-  // * 17..32 states: ON, on the matrix pipe (kernels_mfma.h: k_partials_mfma_cc), whatever pipe the level launches
-  //   use - C3 (20 states) 4.0 -> 5.1 G updates/s on the same box (profiles/README.md, round 2);
-  // * PLL_AMD_FUSE_GENERIC=1: the table-fed FMA groups instead (kernels_generic.h: k_partials_tiled_cc; any state
-  //   count, one wave per rate category) - bit-identical to the level launches, but not faster than them;
-  // * PLL_AMD_FUSE_GENERIC=0 or PLL_AMD_NO_FUSE=1: level launches only.
-  bool groups = true, fma_groups = false;
-  if (const char *v = getenv("PLL_AMD_FUSE_GENERIC"))
-  {
-    groups = *v && *v != '0';
-    fma_groups = *v == '1';
-  }
+  // (tip x tip, tip x tip -> inner x inner) groups of 17..32 states: on the matrix pipe (kernels_mfma.h:
+  // k_partials_mfma_cc), whatever pipe the level launches use - C3 (20 states) 4.0 -> 5.1 G updates/s on the same box
+  // (profiles/README.md, round 2). PLL_AMD_FUSE_GENERIC=0 or PLL_AMD_NO_FUSE=1: level launches only (A/B, parity tests).
+  // (The table-fed FMA groups, the 33..64-state groups and the inner x inner groups of rounds 1-2 measured slower than
+  // the launches they replaced and are gone; their numbers stay in profiles/README.md.)
+  bool groups = true;
+  if (const char *v = getenv("PLL_AMD_FUSE_GENERIC")) groups = *v && *v != '0';
   if (const char *v = getenv("PLL_AMD_NO_FUSE"))
     if (*v && *v != '0') groups = false;
-  // 33..64 states: the same groups exist (k_partials_mfma_cc_big, bit-identical to the level launches) but are OPT-IN
-  // (PLL_AMD_FUSE_BIG=1): LDS has no room for the four tip matrices beside the parent's fragments, the tip columns come
-  // from L2 8 bytes per lane, and those 128 requests per item keep the address unit busier than the 1024 MFMAs keep the
-  // matrix pipe - C5: 470 us for the group launch against 183 + 234 us for the two level launches
-  bool big_groups = false;
-  if (const char *v = getenv("PLL_AMD_FUSE_BIG")) big_groups = *v && *v != '0';
-  c->fuse_mfma = groups && g.rate_cats <= 16 &&
-                 ((g.states >= 17 && g.states <= 32 && (c->use_mfma || !fma_groups)) || (big_groups && g.states > 32 && g.states <= 64 && c->use_mfma));
-  c->fuse_generic = groups && fma_groups && !c->dna_fast && !c->use_mfma && g.rate_cats <= 4 && gg.nchunks == 1;
+  c->fuse_mfma = groups && g.rate_cats <= 16 && g.states >= 17 && g.states <= 32;
   c->lean = !c->dna_fast && !c->use_mfma && g.states >= 17 && g.states <= 20 && g.rate_cats <= 4;
   if (const char *v = getenv("PLL_AMD_NO_LEAN")) // A/B switch: the scalar-fed FMA kernels for these shapes
     if (*v && *v != '0') c->lean = false;
   if (const char *v = getenv("PLL_AMD_LEAN_PLAIN"))
     c->lean_plain = *v && *v != '0';
-  if (const char *v = getenv("PLL_AMD_LEAN_EDGE"))
-    c->lean_edge = *v && *v != '0';
-  // OPT-IN (PLL_AMD_LEAN_GROUPS=1): bit-compatible scaling decisions and one launch less, but slower than the two level
-  // launches it replaces (C3 levels 3 + 4: 290 us against 221) - 77 KB of matrices leave room for two workgroups per CU,
-  // whose four waves load, multiply and store in lockstep (a barrier per op): reads and writes take turns
-  c->lean_groups = 0;
-  if (const char *v = getenv("PLL_AMD_LEAN_GROUPS"))
-    c->lean_groups = (c->lean && groups) ? atoi(v) : 0;
   c->pm_stride = (size_t)g.rate_cats * g.states * gg.SPT;
   c->span = g.rate_cats * g.states_padded;
 }
@@ -488,9 +462,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->chain_dev.release();
   c->sub_dev.release();
   c->sub_packed.release();
-  c->cherry_tab.release();
   c->cherry_bits.release();
-  c->cherry_rowsums.release();
   for (auto &b : c->clv) b.release();
   for (auto &b : c->scaler) b.release();
   for (auto &b : c->tipchars) b.release();
@@ -908,46 +880,6 @@ static void launch_generic(pllgpu_ctx *c, const OpPack &pack, unsigned nops, uns
 #undef GEN_LAUNCH
 }
 
-// (tip x tip, tip x tip -> inner x inner) groups of an FMA-path shape: workgroup = tile(s), wave = rate category
-template <int ICH>
-static int launch_tiled_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries)
-{
-  const unsigned tiles = (entries + 63) / 64, R = c->gg.R, S = c->gg.S;
-  const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
-  const unsigned ncodes = c->tipmap_set ? c->tip_ncodes : (1u << S); // without a map a code is its own mask (S <= 4 then)
-  const size_t per_cherry = (size_t)R * ncodes * ncodes * cherry_row(S);
-  if (int rc = c->cherry_tab.ensure(per_cherry * 2 * ngroups)) return rc;
-  CherryMats mats;
-  memset(&mats, 0, sizeof mats);
-  for (unsigned i = 0; i < ngroups; ++i)
-  {
-    mats.lmat[2 * i] = pack.g[i].a.lmat;
-    mats.rmat[2 * i] = pack.g[i].a.rmat;
-    mats.lmat[2 * i + 1] = pack.g[i].b.lmat;
-    mats.rmat[2 * i + 1] = pack.g[i].b.rmat;
-  }
-  const size_t tab_lds = (size_t)2 * ncodes * S * sizeof(double);
-  raise_lds_limit((const void *)k_cherry_tables, c->device, tab_lds);
-  hipLaunchKernelGGL(k_cherry_tables, dim3(2 * ngroups, R), dim3(256), tab_lds, c->stream, mats, c->gg, tm, ncodes, c->cherry_tab.p);
-  // workgroup = tile, wave = rate category; a few tiles per workgroup so that ~4096 workgroups exist
-  const unsigned tpb = std::max(1u, std::min(8u, (unsigned)(((size_t)tiles * ngroups) / 4096u)));
-  dim3 grid((tiles + tpb - 1) / tpb, ngroups), block(64u * R);
-  hipLaunchKernelGGL((k_partials_tiled_cc<ICH>), grid, block, 0, c->stream, pack, c->gg, c->cherry_tab.p, ncodes, entries, tpb);
-  return 0;
-}
-
-static int launch_tiled_cc(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries)
-{
-  switch (c->ich)
-  {
-    case 4: return launch_tiled_cc_t<4>(c, pack, ngroups, entries);
-    case 8: return launch_tiled_cc_t<8>(c, pack, ngroups, entries);
-    case 16: return launch_tiled_cc_t<16>(c, pack, ngroups, entries);
-    case 20: return launch_tiled_cc_t<20>(c, pack, ngroups, entries);
-    default: return launch_tiled_cc_t<32>(c, pack, ngroups, entries);
-  }
-}
-
 static void launch_dna(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
 {
   // one wave per 64-site tile; a wave takes tpw consecutive tiles so that ~4096 workgroups exist
@@ -985,18 +917,34 @@ static void launch_gg(pllgpu_ctx *c, const GGPack &pack, unsigned ngroups, unsig
 }
 
 // fp64 MFMA 4x4x4 kernels, matrices staged in LDS (kernels_mfma.h): NG = number of 4-state groups
+// k_partials_mfma_wide counts its own vector-memory operations (kernels_mfma_wide.h): a register spilled to scratch
+// would be one the count does not know about. The build is checked once per process; a compiler that spills sends the
+// shape back to the first-generation kernel (and says so).
+static bool wide_kernel_is_sound(bool exact61)
+{
+  static int state[2] = {-1, -1};
+  int &st = state[exact61 ? 1 : 0];
+  if (st < 0)
+  {
+    hipFuncAttributes at;
+    const void *fn = exact61 ? (const void *)k_partials_mfma_wide<15, 1> : (const void *)k_partials_mfma_wide<16, 0>;
+    st = (hipFuncGetAttributes(&at, fn) == hipSuccess && at.localSizeBytes == 0) ? 1 : 0;
+    if (!st) fprintf(stderr, "libpll_amd: k_partials_mfma_wide was built with scratch memory; using k_partials_mfma instead\n");
+  }
+  return st == 1;
+}
+
 template <int NG>
 static int launch_mfma_t(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
 {
   const unsigned R = c->gg.R;
   const unsigned items = (maxent + 31) / 32; // 32 sites per item
-  if (NG == 16 && kind == 0 && !gather && c->mfma_wide)
+  if (NG == 16 && kind == 0 && !gather && c->mfma_wide && wide_kernel_is_sound(c->gg.S == 61 && !c->mfma_pad))
   {
     // 33..64 states, inner x inner, tiled CLVs: the second-generation kernel (kernels_mfma_wide.h). Work is dealt in
-    // half tiles: every SIMD gets one wave (whole-tile items, 1 wave per SIMD) or two (half-tile items) and the same
-    // number of half tiles, give or take one; ONE round of workgroups (70 KB of fragments each).
-    const unsigned main_sg = c->mfma_wide;
-    const unsigned max_wgs = 256u * (main_sg == 4 ? 1u : 2u);
+    // half tiles: every SIMD gets two waves and every wave the same number of half tiles, give or take one; ONE round
+    // of workgroups (two per CU: 70 KB of fragments each).
+    const unsigned max_wgs = 512u;
     const size_t total = (size_t)items * nops * R;
     unsigned hpw = (unsigned)std::max<size_t>(1, (total + 4u * max_wgs - 1) / (4u * max_wgs));
     while ((size_t)((items + 4u * hpw - 1) / (4u * hpw)) * nops * R > max_wgs) ++hpw;
@@ -1006,24 +954,18 @@ static int launch_mfma_t(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsig
     for (unsigned i = 0; i < nops; ++i) scaling = scaling || pack.ops[i].pscaler != nullptr;
     scaling = scaling && c->gg.scale_mode != 0;
     const unsigned fstride = (maxent + 63u) & ~63u;
-    if (scaling && c->mfma_flags.ensure((size_t)kMaxOpsPerLaunch * R * fstride)) return PLLGPU_ENOMEM;
+    if (c->mfma_flags.ensure(std::max<size_t>(64, scaling ? (size_t)kMaxOpsPerLaunch * R * fstride : 0))) return PLLGPU_ENOMEM;
     unsigned char *fb = c->mfma_flags.p;
-    const bool exact61 = c->gg.S == 61 && !c->mfma_pad;
-#define MW_LAUNCH(NGJ, TAIL, MSG)                                                                                  \
-  do                                                                                                               \
-  {                                                                                                                \
-    raise_lds_limit((const void *)k_partials_mfma_wide<NGJ, TAIL, MSG>, c->device, lds);                           \
-    hipLaunchKernelGGL((k_partials_mfma_wide<NGJ, TAIL, MSG>), grid, block, lds, c->stream, pack, c->gg, hpw, fb, fstride); \
-  } while (0)
-    if (main_sg == 4)
+    if (c->gg.S == 61 && !c->mfma_pad)
     {
-      if (exact61) MW_LAUNCH(15, 1, 4); else MW_LAUNCH(16, 0, 4);
+      raise_lds_limit((const void *)k_partials_mfma_wide<15, 1>, c->device, lds);
+      hipLaunchKernelGGL((k_partials_mfma_wide<15, 1>), grid, block, lds, c->stream, pack, c->gg, hpw, fb, fstride);
     }
     else
     {
-      if (exact61) MW_LAUNCH(15, 1, 2); else MW_LAUNCH(16, 0, 2);
+      raise_lds_limit((const void *)k_partials_mfma_wide<16, 0>, c->device, lds);
+      hipLaunchKernelGGL((k_partials_mfma_wide<16, 0>), grid, block, lds, c->stream, pack, c->gg, hpw, fb, fstride);
     }
-#undef MW_LAUNCH
     if (scaling)
     {
       dim3 eg((maxent + 255) / 256, nops);
@@ -1082,22 +1024,20 @@ static int launch_mfma_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroup
 {
   const unsigned R = c->gg.R, S = c->gg.S;
   const unsigned items = (entries + 31) / 32;
-  // 17..32 states: store-bound, many small workgroups; 33..64: two workgroups (2 x 70 KB of fragments) on every CU, one round
-  const unsigned want = NG == 16 ? 2048u : 4096u;
+  // store-bound: many small workgroups
+  const unsigned want = 4096u;
   unsigned ipw = (unsigned)(((size_t)items * ngroups * R + want - 1) / want);
-  ipw = std::max(1u, NG == 16 ? ipw : std::min(ipw, 8u));
+  ipw = std::max(1u, std::min(ipw, 8u));
   if (const char *ev = getenv("PLL_AMD_MFMA_IPW")) ipw = std::max(1, atoi(ev));
   dim3 grid((items + 4 * ipw - 1) / (4 * ipw), ngroups, R), block(256);
   const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
   const unsigned ncodes = c->tip_ncodes;
-  const size_t lds = NG == 16 ? (size_t)2 * MfmaGeo<16>::frag_array * sizeof(double) + 256u : CcGeo<NG == 16 ? 8 : NG>::lds_bytes(ncodes);
+  const size_t lds = CcGeo<NG>::lds_bytes(ncodes);
   // which cherries are rescaled: per pair of tip codes, every rate's answer (k_cherry_bits) - a table per pair of
   // tip matrices, kept on the device until one of the two is written again
   {
     const unsigned char *before = c->cherry_bits.p;
     if (int rc = c->cherry_bits.ensure((size_t)kCherrySlots * R * ncodes * ncodes)) return rc;
-    if (NG == 16)
-      if (int rc = c->cherry_rowsums.ensure((size_t)kCherrySlots * R * 2u * 64u)) return rc;
     if (c->cherry_bits.p != before || c->cherry_slot.size() != kCherrySlots)
     {
       c->cherry_slot_of.clear(); // a fresh block: no table survives
@@ -1161,25 +1101,16 @@ static int launch_mfma_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroup
     if (!staged) bits_lds = (size_t)2 * ncodes * S * sizeof(double);
     raise_lds_limit((const void *)k_cherry_bits, c->device, bits_lds);
     hipLaunchKernelGGL(k_cherry_bits, dim3(nstale, R), dim3(256), bits_lds, c->stream, stale, c->gg, tm, ncodes, c->cherry_bits.p,
-                       NG == 16 ? c->cherry_rowsums.p : nullptr, staged);
+                       nullptr, staged);
   }
   const unsigned fstride = (entries + 63u) & ~63u;
   if (scaling && c->mfma_flags.ensure((size_t)kMaxOpsPerLaunch * R * fstride)) return PLLGPU_ENOMEM;
-  if constexpr (NG == 16)
-  {
-    raise_lds_limit((const void *)k_partials_mfma_cc_big<16>, c->device, lds);
-    hipLaunchKernelGGL((k_partials_mfma_cc_big<16>), grid, block, lds, c->stream, pack, c->gg, tm, entries, ipw, c->mfma_flags.p, fstride,
-                       c->cherry_bits.p, c->cherry_rowsums.p, slots, ncodes);
-  }
-  else
-  {
-    raise_lds_limit((const void *)k_partials_mfma_cc<NG>, c->device, lds);
-    // parents beyond what the Infinity Cache keeps for the next level: streamed out like the cherries (as the 4x4 groups do)
-    unsigned stream_parent = ((size_t)ngroups * entries * S * R * 8u > c->stream_parent_bytes) ? 1u : 0u;
-    if (const char *ev = getenv("PLL_AMD_CC_STREAM_PARENT")) stream_parent = atoi(ev) != 0;
-    hipLaunchKernelGGL((k_partials_mfma_cc<NG>), grid, block, lds, c->stream, pack, c->gg, tm, entries, ipw, c->mfma_flags.p, fstride,
-                       c->cherry_bits.p, slots, ncodes, stream_parent);
-  }
+  raise_lds_limit((const void *)k_partials_mfma_cc<NG>, c->device, lds);
+  // parents beyond what the Infinity Cache keeps for the next level: streamed out like the cherries (as the 4x4 groups do)
+  unsigned stream_parent = ((size_t)ngroups * entries * S * R * 8u > c->stream_parent_bytes) ? 1u : 0u;
+  if (const char *ev = getenv("PLL_AMD_CC_STREAM_PARENT")) stream_parent = atoi(ev) != 0;
+  hipLaunchKernelGGL((k_partials_mfma_cc<NG>), grid, block, lds, c->stream, pack, c->gg, tm, entries, ipw, c->mfma_flags.p, fstride,
+                     c->cherry_bits.p, slots, ncodes, stream_parent);
   if (scaling)
     hipLaunchKernelGGL((k_mfma_scale_epilogue<false>), dim3((entries + 255) / 256, ngroups), dim3(256), 0, c->stream, parents, c->gg,
                        c->mfma_flags.p, fstride);
@@ -1189,7 +1120,6 @@ static int launch_mfma_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroup
 static int launch_mfma_cc(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries)
 {
   if (c->mfma_ng == 5) return launch_mfma_cc_t<5>(c, pack, ngroups, entries);
-  if (c->mfma_ng == 16) return launch_mfma_cc_t<16>(c, pack, ngroups, entries);
   return launch_mfma_cc_t<8>(c, pack, ngroups, entries);
 }
 
@@ -1258,44 +1188,6 @@ static bool lean_serves(const pllgpu_ctx *c, const OpPack &pack, unsigned nops, 
   return true;
 }
 
-// (inner x inner, inner x inner -> inner x inner) groups of the 17..20-state shapes (kernels_lean.h: k_partials_lean3)
-// ... one rate category per workgroup, per-site scaling finished by an epilogue (k_partials_mfma_iii)
-static int launch_mfma_iii(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries)
-{
-  const unsigned R = c->gg.R;
-  const unsigned items = (entries + 31) / 32;
-  unsigned ipw = (unsigned)(((size_t)items * ngroups * R + 8191) / 8192);
-  ipw = std::max(1u, std::min(ipw, 8u));
-  if (const char *ev = getenv("PLL_AMD_MFMA_IPW")) ipw = std::max(1, atoi(ev));
-  dim3 grid((items + 4 * ipw - 1) / (4 * ipw), ngroups, R), block(256);
-  const size_t lds = (size_t)6u * 400u * sizeof(double);
-  const unsigned fstride = (entries + 63u) & ~63u;
-  bool scaling = false;
-  for (unsigned i = 0; i < ngroups; ++i) scaling = scaling || pack.g[i].a.pscaler || pack.g[i].b.pscaler || pack.g[i].p.pscaler;
-  scaling = scaling && c->gg.scale_mode == 1;
-  if (scaling && c->mfma_flags.ensure((size_t)3 * kMaxGroups * R * fstride)) return PLLGPU_ENOMEM;
-  raise_lds_limit((const void *)k_partials_mfma_iii<5>, c->device, lds);
-  hipLaunchKernelGGL((k_partials_mfma_iii<5>), grid, block, lds, c->stream, pack, c->gg, entries, ipw, c->mfma_flags.p, fstride);
-  if (scaling)
-    hipLaunchKernelGGL(k_iii_epilogue, dim3((entries + 255) / 256, ngroups), dim3(256), 0, c->stream, pack, c->gg, entries, c->mfma_flags.p, fstride);
-  return 0;
-}
-
-static int launch_lean3(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries)
-{
-  if (c->lean_groups == 2) return launch_mfma_iii(c, pack, ngroups, entries);
-  const unsigned R = c->gg.R;
-  const unsigned items = (entries + 31) / 32;
-  unsigned ipb = (unsigned)(((size_t)items * ngroups) / 2048u);
-  ipb = std::max(2u, std::min(ipb, 16u));
-  if (const char *ev = getenv("PLL_AMD_LEAN_IPB")) ipb = std::max(1, atoi(ev));
-  dim3 grid((items + ipb - 1) / ipb, ngroups), block(64u * R);
-  const size_t lds = (size_t)R * 6u * 400u * sizeof(double) + 3u * 2u * R * 32u;
-  raise_lds_limit((const void *)k_partials_lean3<5>, c->device, lds);
-  hipLaunchKernelGGL((k_partials_lean3<5>), grid, block, lds, c->stream, pack, c->gg, entries, ipb);
-  return 0;
-}
-
 static int launch_partials(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
 {
   if (c->dna_fast)
@@ -1354,19 +1246,16 @@ static int plan_and_launch_levels(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigne
   c->launch_rc = 0;
   std::vector<int> role;
   std::vector<FusedGroup> groups;
-  // FMA-path groups look their cherries up in a table over all pairs of tip codes: only for a sane number of codes
-  const bool cherry_groups = (c->fuse_mfma && c->tipmap_set && c->tip_ncodes <= (c->gg.S > 32u ? 128u : 32u)) ||
-                             (c->fuse_generic && (c->tipmap_set ? c->tip_ncodes : (1u << std::min(c->gg.S, 8u))) <= 64u);
-  const bool generic_groups = cherry_groups || c->lean_groups;
+  // the groups look their cherries' scaling decisions up in a table over all pairs of tip codes: only for a sane number of codes
+  const bool cherry_groups = c->fuse_mfma && c->tipmap_set && c->tip_ncodes <= 32u;
+  const bool generic_groups = cherry_groups;
   plan_fusion(c->fuse || generic_groups, c->fuse_cc, c->geo.nodes, ops, count, role, groups);
   if (generic_groups)
   {
-    // of the groups the 4x4 planner knows, the other shapes have two: both children cherries, or (17..20 states) both
-    // children inner x inner ops over CLVs in memory
+    // of the groups the 4x4 planner knows, the other shapes have one: both children cherries
     std::vector<FusedGroup> keep;
     for (const FusedGroup &gq : groups)
-      if ((cherry_groups && gq.lk == CK_FTT && gq.rk == CK_FTT && gq.a >= 0 && gq.b >= 0) ||
-          (c->lean_groups && gq.lk == CK_FII && gq.rk == CK_FII && gq.a >= 0 && gq.b >= 0))
+      if (gq.lk == CK_FTT && gq.rk == CK_FTT && gq.a >= 0 && gq.b >= 0)
         keep.push_back(gq);
       else
       {
@@ -1564,17 +1453,9 @@ static int plan_and_launch_levels(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigne
         unsigned n = 0, entries = 0;
         auto flush = [&]() -> int {
           if (!n) return 0;
-          if (!c->dna_fast && lk == CK_FII)
-            emit(c, [c, pack, n, entries]() {
-              if (int rc = launch_lean3(c, pack, n, entries)) c->launch_rc = rc;
-            });
-          else if (c->use_mfma || c->fuse_mfma)
+          if (!c->dna_fast)
             emit(c, [c, pack, n, entries]() {
               if (int rc = launch_mfma_cc(c, pack, n, entries)) c->launch_rc = rc;
-            });
-          else if (!c->dna_fast)
-            emit(c, [c, pack, n, entries]() {
-              if (int rc = launch_tiled_cc(c, pack, n, entries)) c->launch_rc = rc;
             });
           else
             emit(c, [c, pack, n, entries, lk, rk]() {
@@ -1907,21 +1788,6 @@ static int run_lnl(pllgpu_ctx *c, DevEdge &e, bool ctip, bool gather, const unsi
     // one tile per workgroup pass (the waves split its rate categories), tpw tiles per workgroup
     tpw = (tiles + max_blocks - 1) / max_blocks;
     blocks = (tiles + tpw - 1) / tpw;
-    if (c->lean && c->lean_edge && !gather && (!ctip || c->tipmap_set) && c->gg.S >= 17 && c->gg.S <= 20)
-    {
-      // 17..20 states, both ends in the tiled layout: the matrix-pipe form (kernels_lean.h: k_edge_lean)
-      const unsigned items = (g.sites + 31) / 32, R = c->gg.R;
-      const unsigned ipb = std::max(1u, (items + 1023u) / 1024u);
-      const unsigned nb = (items + ipb - 1) / ipb;
-      const size_t lds = (size_t)R * LeanGeo<5>::mat * sizeof(double) + (size_t)2 * 2 * R * 32 * sizeof(double) + 256u;
-      const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
-      const unsigned ncodes = std::min(c->tip_ncodes, 256u);
-      if (ctip)
-        hipLaunchKernelGGL((k_edge_lean<5, true>), dim3(nb), dim3(64u * R), lds, c->stream, e, c->gg, tm, ipb, ncodes);
-      else
-        hipLaunchKernelGGL((k_edge_lean<5, false>), dim3(nb), dim3(64u * R), lds, c->stream, e, c->gg, tm, ipb, ncodes);
-    }
-    else
     switch (c->ich)
     {
       case 4: launch_edge_generic<4>(c, e, blocks, tpw, ctip, gather); break;

@@ -373,28 +373,21 @@ def test_dna_without_fusion(amd_lib, kw, monkeypatch):
 @pytest.mark.parametrize("kw", [dict(states=20, tips=16, sites=1500, seed=301),
                                 dict(states=20, tips=64, sites=700, seed=302, attributes=api.RATE_SCALERS),
                                 dict(states=20, tips=16, sites=333, seed=303, attributes=api.PATTERN_TIP, ambiguity_pct=8, partial_pct=6),  # masks with several states
-                                dict(states=7, tips=32, sites=900, seed=304, ambiguity_pct=5),
-                                dict(states=5, tips=16, sites=400, seed=305, attributes=api.RATE_SCALERS | api.PATTERN_TIP, partial_pct=10),
                                 dict(states=20, tips=8, sites=500, seed=306, tiny_p=1e-80),   # near-identity matrices: a cherry of two different states is all below 2^-256 -> rescaled
                                 dict(states=20, tips=8, sites=500, seed=307, tiny_p=1e-80, attributes=api.RATE_SCALERS),
                                 dict(states=20, tips=16, sites=300, seed=308, rate_cats=2), dict(states=20, tips=16, sites=300, seed=309, rate_cats=1),
                                 dict(states=20, tips=24, sites=600, seed=310, tree="random"), dict(states=32, tips=16, sites=200, seed=311),
                                 dict(states=20, tips=16, sites=300, seed=312, scalers=False)], ids=_id)
-@pytest.mark.parametrize("pipe", ["fma", "mfma", "mixed"])
-def test_cherry_groups_of_fma_shapes_are_bit_identical(amd_lib, kw, pipe, monkeypatch):
-    """any-state FMA path: an op over two cherries is evaluated together with them (k_partials_tiled_cc), its
-    contraction fed from the staged tip matrices instead of HBM; PLL_AMD_NO_FUSE=1 launches level by level -
-    the same numbers, bit for bit, including the cherries' and the parent's scaling decisions"""
+@pytest.mark.parametrize("pipe", ["mfma", "mixed"])
+def test_cherry_groups_on_the_matrix_pipe(amd_lib, kw, pipe, monkeypatch):
+    """17..32 states: an op over two cherries is evaluated together with them (k_partials_mfma_cc), the parent's
+    contraction from registers; PLL_AMD_NO_FUSE=1 launches level by level. pipe = mfma: the level launches on the matrix
+    pipe as well - the same numbers, bit for bit, including the cherries' and the parent's scaling decisions; mixed (the
+    shipped default): every other launch on the FMA kernels - the same numbers within the tolerance (the two pipes sum a
+    contraction in different orders), scaling decisions equal"""
     kw = dict(kw)
-    monkeypatch.setenv("PLL_AMD_FUSE_GENERIC", "1")  # the group kernels of these shapes are opt-in
-    if pipe == "mfma":  # the same groups on the matrix pipe (k_partials_mfma_cc), 17..32 states
-        if kw["states"] < 17:
-            pytest.skip("the matrix-pipe kernels start at 17 states")
+    if pipe == "mfma":
         monkeypatch.setenv("PLL_AMD_MFMA_MIN_STATES", "17")
-    if pipe == "mixed":  # the groups on the matrix pipe, every other launch on the FMA kernels: same numbers within the
-        if not 17 <= kw["states"] <= 32:  # tolerance (the two pipes sum a contraction in different orders), scaling decisions equal
-            pytest.skip("the matrix-pipe groups serve 17..32 states")
-        monkeypatch.setenv("PLL_AMD_FUSE_GENERIC", "2")
     tiny = kw.pop("tiny_p", None)
     case = W.make_case("ccg", **kw)
     if tiny:  # P = (1 - (s - 1) eps) on the diagonal, eps elsewhere (numpy's expm cannot produce such entries)
@@ -428,79 +421,6 @@ def test_cherry_groups_of_fma_shapes_are_bit_identical(amd_lib, kw, pipe, monkey
         assert sum(int(plain["scaler"][c].sum()) for c in cherries) > 0  # cherries were rescaled
 
 
-@pytest.mark.parametrize("kw", [dict(states=61, tips=16, sites=300, seed=330),
-                                dict(states=61, tips=8, sites=333, seed=331, ambiguity_pct=8, partial_pct=6),       # masks with several states: MFMA route, fragments from L2
-                                dict(states=61, tips=8, sites=200, seed=332, tiny_p=1e-80),                        # rescaled cherries
-                                dict(states=61, tips=8, sites=200, seed=333, tiny_p=1e-80, attributes=api.RATE_SCALERS),
-                                dict(states=40, tips=16, sites=129, seed=334, rate_cats=2),
-                                dict(states=61, tips=12, sites=257, seed=335, tree="random"),
-                                dict(states=64, tips=8, sites=100, seed=336, scalers=False)], ids=_id)
-def test_cherry_groups_of_the_matrix_pipe_shapes_are_bit_identical(amd_lib, kw, monkeypatch):
-    """33..64 states: an op over two cherries is evaluated together with them (k_partials_mfma_cc_big) - tip columns
-    read as rows of the stored matrices, the parent's contraction from registers; PLL_AMD_NO_FUSE=1 launches level
-    by level: the same numbers, bit for bit, including the cherries' and the parent's scaling decisions"""
-    kw = dict(kw)
-    monkeypatch.setenv("PLL_AMD_FUSE_BIG", "1")  # opt-in: slower than the level launches on C5 (the tip columns come from L2)
-    tiny = kw.pop("tiny_p", None)
-    case = W.make_case("ccb", **kw)
-    if tiny:
-        s_ = case.states
-        case.pmatrix[:] = np.full((s_, s_), tiny) + np.eye(s_) * (1.0 - s_ * tiny)
-    fused = driver.run_case(amd_lib, case, api.ARCH_AVX2)
-    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
-        s.update_partials()
-        nf = amd_lib.pll_gpu_last_launch_count(s.p)
-    monkeypatch.setenv("PLL_AMD_NO_FUSE", "1")
-    plain = driver.run_case(amd_lib, case, api.ARCH_AVX2)
-    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
-        s.update_partials()
-        npl = amd_lib.pll_gpu_last_launch_count(s.p)
-    assert_results_match(plain, O.run_case(case), what=_id(kw))
-    if kw.get("tree", "balanced") == "balanced":
-        assert nf < npl, (nf, npl)
-    assert fused["lnl"] == plain["lnl"]
-    for k in plain["clv"]:
-        assert np.array_equal(fused["clv"][k], plain["clv"][k]), k
-        if k in plain["scaler"]:
-            assert np.array_equal(fused["scaler"][k], plain["scaler"][k]), k
-    if tiny:
-        cherries = [op[0] for op in case.op_batches[0] if op[2] < case.tips and op[5] < case.tips]
-        assert sum(int(plain["scaler"][c].sum()) for c in cherries) > 0
-
-
-@pytest.mark.parametrize("kw", [dict(states=20, tips=32, sites=1500, seed=340), dict(states=20, tips=32, sites=333, seed=341, attributes=api.RATE_SCALERS),
-                                dict(states=20, tips=150, sites=300, seed=342, tree="caterpillar", brlen_scale=6),      # rescaling inside the groups
-                                dict(states=20, tips=40, sites=700, seed=343, tree="random", rate_cats=2), dict(states=18, tips=16, sites=200, seed=344, rate_cats=3),
-                                dict(states=20, tips=16, sites=500, seed=345, tiny_p=1e-80)], ids=_id)
-@pytest.mark.parametrize("form", ["1", "2"], ids=["all-rates-per-workgroup", "speculative"])
-def test_inner_groups_of_the_protein_shapes(amd_lib, kw, form, monkeypatch):
-    """17..20 states, opt-in (PLL_AMD_LEAN_GROUPS=1): an op over two inner x inner ops of the same call is evaluated
-    with them on the matrix pipe (k_partials_lean3), the per-site scaling decisions of all three meeting in LDS -
-    scaler vectors equal those of the level launches, CLVs and log-likelihood within the tolerance, oracle parity"""
-    kw = dict(kw)
-    tiny = kw.pop("tiny_p", None)
-    case = W.make_case("l3", **kw)
-    if tiny:
-        s_ = case.states
-        case.pmatrix[:] = np.full((s_, s_), tiny) + np.eye(s_) * (1.0 - s_ * tiny)
-    plain = driver.run_case(amd_lib, case, api.ARCH_AVX2)
-    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
-        s.update_partials()
-        npl = amd_lib.pll_gpu_last_launch_count(s.p)
-    monkeypatch.setenv("PLL_AMD_LEAN_GROUPS", form)
-    fused = driver.run_case(amd_lib, case, api.ARCH_AVX2)
-    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
-        s.update_partials()
-        nf = amd_lib.pll_gpu_last_launch_count(s.p)
-    exp = O.run_case(case)
-    assert_results_match(fused, exp, what=_id(kw))
-    assert_results_match(plain, exp, what=_id(kw))
-    if kw.get("tree", "balanced") == "balanced" and kw["tips"] >= 32:
-        assert nf < npl, (nf, npl)
-    for k in plain["scaler"]:
-        assert np.array_equal(fused["scaler"][k], plain["scaler"][k]), k
-
-
 @pytest.mark.parametrize("kw", [dict(states=61, tips=8, sites=3000, seed=350), dict(states=61, tips=16, sites=20000, seed=351),
                                 dict(states=20, tips=16, sites=5000, seed=352), dict(states=4, tips=32, sites=30000, seed=353),
                                 dict(states=40, tips=8, sites=4000, seed=354, attributes=api.PATTERN_TIP)], ids=_id)
@@ -519,24 +439,6 @@ def test_results_are_reproducible_run_to_run(amd_lib, kw):
             assert s.edge_lnl(e, persite=False)[0] == ref
         for _ in range(20):
             assert s.root_lnl((e[0], e[1]), persite=False)[0] == root
-
-
-@pytest.mark.parametrize("kw", [dict(states=20, tips=16, sites=1500, seed=370), dict(states=20, tips=16, sites=333, seed=371, attributes=api.RATE_SCALERS, rate_cats=3),
-                                dict(states=18, tips=8, sites=200, seed=372, attributes=api.PATTERN_TIP, ambiguity_pct=10), dict(states=20, tips=150, sites=300, seed=373, tree="caterpillar", brlen_scale=6),
-                                dict(states=20, tips=8, sites=500, seed=374, pinv=0.2)], ids=_id)
-def test_matrix_pipe_edge_kernel_of_the_protein_shapes(amd_lib, kw, monkeypatch):
-    """17..20 states, opt-in (PLL_AMD_LEAN_EDGE=1): edge and root log-likelihoods on the matrix pipe (k_edge_lean) against
-    the oracle, per-site values included; reproducible run to run"""
-    monkeypatch.setenv("PLL_AMD_LEAN_EDGE", "1")
-    case = W.make_case("el", **kw)
-    exp = O.run_case(case)
-    got = driver.run_case(amd_lib, case, api.ARCH_AVX2)
-    assert_results_match(got, exp, what=_id(kw))
-    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
-        s.update_partials()
-        v = s.edge_lnl(case.edges[0], persite=False)[0]
-        for _ in range(20):
-            assert s.edge_lnl(case.edges[0], persite=False)[0] == v
 
 
 def test_cherry_tables_follow_the_matrices(amd_lib, monkeypatch):
@@ -904,9 +806,10 @@ def test_matrix_pipe_kernels_for_all_group_counts(amd_lib, kw, monkeypatch):
                                 dict(states=33, tips=16, sites=700, seed=428)], ids=_id)
 def test_wide_matrix_pipe_kernel(amd_lib, kw, monkeypatch):
     """k_partials_mfma_wide (kernels_mfma_wide.h), the inner x inner kernel of 33..64 states: lanes own adjacent sites
-    (16-byte loads and stores), items are whole tiles (one wave per SIMD) or half tiles, and 61 states contract over 15
-    full groups on the matrix pipe with the 61st column as the chains' initial value. Against the oracle (CLVs, scalers,
-    lnL) in every form; the padded forms (64-state contraction) are bit-identical to the first-generation kernel."""
+    (16-byte loads and stores), hand-counted load waits, and 61 states contract over 15 full groups on the matrix pipe
+    with the 61st column as the chains' initial value. Against the oracle (CLVs, scalers, lnL) in every form; the padded
+    form (64-state contraction) is bit-identical to the first-generation kernel. Site counts: one half tile per wave,
+    several (the counted waits cross the loop's back edge), ragged last tiles."""
     kw = dict(kw)
     tips_as = kw.pop("tips_as", None)
     case = W.make_case("wide", **kw)
@@ -915,7 +818,7 @@ def test_wide_matrix_pipe_kernel(amd_lib, kw, monkeypatch):
     exp = O.run_case(case)
     deep = kw.get("brlen_scale", 1) > 1
     got = {}
-    for wide, pad in (("4", "0"), ("2", "0"), ("4", "1"), ("2", "1"), ("0", "0")):
+    for wide, pad in (("1", "0"), ("1", "1"), ("0", "0")):
         monkeypatch.setenv("PLL_AMD_MFMA_WIDE", wide)
         monkeypatch.setenv("PLL_AMD_MFMA_PAD", pad)
         got[wide, pad] = driver.run_case(amd_lib, case, api.ARCH_AVX2)
@@ -924,7 +827,7 @@ def test_wide_matrix_pipe_kernel(amd_lib, kw, monkeypatch):
             assert sum(int(v.sum()) for v in got[wide, pad]["scaler"].values()) > 0
             assert scalers_equal(got[wide, pad], exp)
     old = got["0", "0"]
-    for key in (("4", "1"), ("2", "1")) + ((("4", "0"), ("2", "0")) if case.states != 61 else ()):
+    for key in (("1", "1"),) + ((("1", "0"),) if case.states != 61 else ()):
         assert got[key]["lnl"] == old["lnl"], key
         for c in old["clv"]:
             assert np.array_equal(got[key]["clv"][c], old["clv"][c]), (key, c)

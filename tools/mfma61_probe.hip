@@ -10,9 +10,14 @@
 
 constexpr unsigned kFrag = 17;
 
-template <int NSG, int NGJ, int NGI, int MINW>
+typedef double probe_d2 __attribute__((ext_vector_type(2)));
+
+// HBM = 1: every pass also streams NGJ x 1 KB per wave in (the next x, non-temporal) and NGI / 2 x 1 KB out - the memory
+// traffic of the real kernel (kernels_mfma_wide.h) beside its MFMAs, to see what clock the chip holds with both
+template <int NSG, int NGJ, int NGI, int MINW, int HBM = 0>
 __global__ __launch_bounds__(256, MINW) void k_loop(const double *__restrict__ pm, const double *__restrict__ xin, double *__restrict__ out,
-                                                    int iters, unsigned long long *__restrict__ stamps)
+                                                    int iters, unsigned long long *__restrict__ stamps, const double *__restrict__ stream_in = nullptr,
+                                                    double *__restrict__ stream_out = nullptr, size_t stream_doubles = 0)
 {
   extern __shared__ double lds[];
   for (unsigned t = threadIdx.x; t < 16u * 16u * kFrag; t += 256u) lds[t] = pm[t];
@@ -56,6 +61,23 @@ __global__ __launch_bounds__(256, MINW) void k_loop(const double *__restrict__ p
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (HBM && NSG == 2)
+    {
+      // one pass of the real kernel: NGJ row groups of 64 lanes x 16 bytes in, NGI / 2 out, each wave its own stream
+      const size_t wave_id = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+      const size_t pass = (wave_id * (size_t)iters + (size_t)it) % (stream_doubles / (128u * 16u));
+      const double *src = stream_in + pass * (128u * 16u) + (threadIdx.x & 63u) * 2u;
+      double *dst = stream_out + pass * (128u * 16u) + (threadIdx.x & 63u) * 2u;
+#pragma unroll
+      for (int jg = 0; jg < NGJ; ++jg)
+      {
+        const probe_d2 v = __builtin_nontemporal_load((const probe_d2 *)(src + jg * 128));
+        x[jg][0] = v.x * 1e-3 + x[jg][0] * 0.5;
+        x[jg][NSG - 1] = v.y * 1e-3 + x[jg][NSG - 1] * 0.5;
+      }
+#pragma unroll
+      for (int ig = 0; ig < NGI; ig += 2) *(probe_d2 *)(dst + (ig / 2) * 128) = probe_d2{D[ig][0], D[ig + 1][NSG - 1]};
+    }
     // keep the values bounded and the loop honest: x changes sign pattern from pass to pass
 #pragma unroll
     for (int jg = 0; jg < NGJ; ++jg)
@@ -76,14 +98,15 @@ __global__ __launch_bounds__(256, MINW) void k_loop(const double *__restrict__ p
   }
 }
 
-template <int NSG, int NGJ, int NGI, int MINW>
-static void run(const char *what, int wg_per_cu, const double *pm, const double *xin, double *out, unsigned long long *stamps)
+template <int NSG, int NGJ, int NGI, int MINW, int HBM = 0>
+static void run(const char *what, int wg_per_cu, const double *pm, const double *xin, double *out, unsigned long long *stamps,
+                const double *sin = nullptr, double *sout = nullptr, size_t sdoubles = 0)
 {
   const int blocks = 256 * wg_per_cu;
   if (blocks > 1024) return; // the buffers in main() are sized for 1024 blocks
   const int iters = 4000 / NSG;
   const size_t lds = 16 * 16 * kFrag * sizeof(double);
-  hipFuncSetAttribute((const void *)k_loop<NSG, NGJ, NGI, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void *)k_loop<NSG, NGJ, NGI, MINW, HBM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
@@ -91,7 +114,7 @@ static void run(const char *what, int wg_per_cu, const double *pm, const double 
   for (int rep = 0; rep < 4; ++rep)
   {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k_loop<NSG, NGJ, NGI, MINW>), dim3(blocks), dim3(256), lds, 0, pm, xin, out, iters, stamps);
+    hipLaunchKernelGGL((k_loop<NSG, NGJ, NGI, MINW, HBM>), dim3(blocks), dim3(256), lds, 0, pm, xin, out, iters, stamps, sin, sout, sdoubles);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -105,6 +128,8 @@ static void run(const char *what, int wg_per_cu, const double *pm, const double 
   std::sort(clk.begin(), clk.end());
   const double mfmas = (double)blocks * 4 * iters * NGJ * NGI * NSG;
   const double cyc_per_mfma = (double)h[0] / ((double)iters * NGJ * NGI * NSG) / (wg_per_cu > 1 ? 1.0 : 1.0);
+  const double gb = HBM ? (double)blocks * 4 * iters * (NGJ + NGI / 2) * 1024.0 / 1e9 : 0.0;
+  if (HBM) printf("  (+ %.0f GB/s of streaming beside the MFMAs) ", gb / (best * 1e-3));
   printf("%-44s %6.2f TFLOP/s  %.3f ms  clock %.0f MHz  wave cycles per own MFMA %.2f (x%d waves per SIMD)\n", what,
          mfmas * 512 / (best * 1e-3) / 1e12, best, clk[clk.size() / 2], cyc_per_mfma, wg_per_cu);
   fflush(stdout);
@@ -133,5 +158,16 @@ int main()
   run<3, 16, 16, 1>("48 sites, 16x16 groups, 1 wave / SIMD", 1, pm, xin, out, stamps);
   run<2, 15, 15, 2>("32 sites, 15x15 groups, 2 waves / SIMD", 2, pm, xin, out, stamps);
   run<1, 16, 16, 4>("16 sites, 16x16 groups, 4 waves / SIMD", 4, pm, xin, out, stamps);
+  {
+    // the real kernel's mix: 15 x 16 groups, two waves per SIMD, plus its HBM streams (1 GiB each way: past the Infinity Cache)
+    const size_t sd = (size_t)1 << 27;
+    double *sin, *sout;
+    hipMalloc(&sin, sd * 8);
+    hipMalloc(&sout, sd * 8);
+    hipMemset(sin, 0x3c, sd * 8);
+    run<2, 15, 16, 2, 1>("32 sites, 15x16 groups, 2 waves / SIMD + HBM", 2, pm, xin, out, stamps, sin, sout, sd);
+    run<2, 15, 16, 2, 0>("32 sites, 15x16 groups, 2 waves / SIMD", 2, pm, xin, out, stamps);
+    run<2, 15, 16, 2, 1>("32 sites, 15x16 groups, 2 waves / SIMD + HBM", 2, pm, xin, out, stamps, sin, sout, sd);
+  }
   return 0;
 }
