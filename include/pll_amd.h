@@ -490,7 +490,12 @@ int pll_gpu_sync_sumtable(pll_partition_t *partition, double *sumtable);
 /* a partition keeps up to 16 device sumtables alive, one per host buffer handed to
  * pll_update_sumtable; beyond that the least recently used is recycled and an evaluation on ITS
  * handle fails with PLL_ERROR_GPU_RUNTIME (never a silent read of the unwritten host buffer). A
- * caller that is done with a table (about to free the host buffer) gives its HBM back here. */
+ * caller that is done with a table (about to free the host buffer) gives its HBM back here.
+ * A recycled handle stays marked until pll_update_sumtable or this call names it again: a caller that frees an
+ * evicted table and later fills a NEW buffer that malloc happened to place at the same address must announce it
+ * (pll_gpu_release_sumtable(partition, buffer) before the first pll_compute_likelihood_derivatives on it) - otherwise
+ * the evaluation fails with PLL_ERROR_GPU_RUNTIME instead of uploading the buffer. Resident tables are CLV-sized
+ * (1M-site DNA: 128 MB each, up to 16 per partition): release what is no longer needed. */
 int pll_gpu_release_sumtable(pll_partition_t *partition, const double *sumtable);
 /* stream plumbing: by default each partition owns a stream; a harness may substitute its own
  * (a hipStream_t passed as void*) so that its events see the kernels. pll_update_partials is

@@ -218,6 +218,15 @@ int pllgpu_compress_patterns(const unsigned char *encoded, unsigned int count, u
                              unsigned int *site_pattern_map, unsigned int *patterns_out, int device);
 const char *pllgpu_compress_last_error(void);
 
+/* ---- the flat seam's tip-tip pair (src/pll.h:1049-1071, src/core_partials.c:1013-1210, :82-200) --------------
+ * The caller's lookup table in the REFERENCE's layout: entry (j, k) of two tip codes at index (j << ceil(log2(ncodes)))
+ * + k (16 j + k for 4 states, where the code is the state mask) of rate_cats x states_padded doubles = the parent entry
+ * of a cherry showing j and k. Matrices in the caller's layout [rate][row][states_padded]. Both calls synchronise. */
+int pllgpu_create_lookup(pllgpu_ctx_t *ctx, double *lookup_host, const double *left_host, const double *right_host,
+                         const unsigned long long *tipmap_host, unsigned int ncodes);
+int pllgpu_tt_from_lookup(pllgpu_ctx_t *ctx, double *parent_host, const unsigned char *left_codes,
+                          const unsigned char *right_codes, const double *lookup_host, unsigned int sites, unsigned int ncodes);
+
 /* ---- the exchange of a site-sharded run (pll_gpu_edge_loglikelihood_allreduce) ---------------- */
 /* two doubles of device memory owned by the context: {lnL, sequence}, the operand of the all-reduce */
 double *pllgpu_reduce_buffer(pllgpu_ctx_t *ctx);

@@ -189,7 +189,16 @@ __device__ __forceinline__ double partial_load(const double *p)
 }
 
 // The three ordering points of such a hand-off. Default: wait for the wave's own stores (they were performed at
-// the coherent level), nothing else. fenced (PLL_AMD_FENCED_HANDOFF=1, a diagnosis switch): the textbook form
+// the coherent level), nothing else.
+// THE ASSUMPTION, stated once: this is ISA-level reasoning, outside the HIP memory model. On gfx950 an
+// agent-scope atomic store is performed at the coherent level (the memory side of the XCD's L2: `sc1`, write-through)
+// and is acknowledged - the wave's vmcnt decrements - only once it has been; so after "s_waitcnt vmcnt(0)" the
+// partial is where an agent-scope atomic load of any other XCD finds it, and the ticket taken afterwards cannot
+// overtake it (MI355X_MICROARCH.md, "Valid forms": 8-byte agent atomics on both sides, drained before the counter
+// add). Another architecture gets no such promise: the library refuses anything but gfx950 at context creation
+// (pllgpu_create), PLL_AMD_FENCED_HANDOFF=1 is the in-model form, and the GPU suite compares the two bit for bit on
+// cases that span all eight XCDs (tests/test_gpu_parity.py::test_fenced_handoff_*) and under load
+// (tools/handoff_stress.py). fenced (PLL_AMD_FENCED_HANDOFF=1, a diagnosis switch): the textbook form
 // inside the HIP memory model - release fence before the ticket / the sequence word, acquire fence in the
 // workgroup that arrived last - at the price of an L2 write-back per workgroup.
 __device__ __forceinline__ void handoff_before_ticket(int fenced)

@@ -534,6 +534,51 @@ __global__ __launch_bounds__(256) void k_edge_tiled(const DevEdge e, const GenGe
 }
 
 // ------------------------------------------------------------------------------------------------
+// The flat seam's tip-tip pair (src/pll.h:1049-1071): pll_core_create_lookup leaves, for every pair (j, k) of tip
+// codes, the parent entry of a cherry whose tips show j and k - the product of the two sums over the set bits of the
+// codes' state masks (ascending states, src/core_partials.c:1013-1071, :1149-1209) - in the caller's table, and
+// pll_core_update_partial_tt copies one entry per site (:180-199). Table layout = the reference's: entry (j, k) at
+// index (j << log2(maxstates)) + k - 16 j + k for 4 states - of rate_cats x states_padded doubles (padding lanes 0).
+// matrices: the caller's layout [rate][row i][states_padded]. One thread per table double.
+__global__ __launch_bounds__(256) void k_create_lookup(double *__restrict__ table, const double *__restrict__ lmat, const double *__restrict__ rmat,
+                                                       const unsigned long long *__restrict__ tipmap /* null: the code is the mask */,
+                                                       unsigned S, unsigned SP, unsigned R, unsigned ncodes, unsigned shift)
+{
+  const unsigned span = R * SP;
+  const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (idx >= (size_t)ncodes * ncodes * span) return;
+  const unsigned i = (unsigned)(idx % SP), n = (unsigned)((idx / SP) % R);
+  const unsigned pair = (unsigned)(idx / span), j = pair / ncodes, k = pair % ncodes;
+  double v = 0.0;
+  if (i < S)
+  {
+    unsigned long long mj = tipmap ? tipmap[j] : (unsigned long long)j, mk = tipmap ? tipmap[k] : (unsigned long long)k;
+    const double *lrow = lmat + ((size_t)n * S + i) * SP, *rrow = rmat + ((size_t)n * S + i) * SP;
+    double tj = 0.0, tk = 0.0;
+    for (unsigned m = 0; m < S; ++m)
+    {
+      if (mj & 1ull) tj += lrow[m];
+      if (mk & 1ull) tk += rrow[m];
+      mj >>= 1;
+      mk >>= 1;
+    }
+    v = tj * tk;
+  }
+  table[((size_t)((j << shift) + k)) * span + (size_t)n * SP + i] = v;
+}
+
+// parent[site] = table[(left code << shift) + right code]: span doubles per site, one thread per double
+__global__ __launch_bounds__(256) void k_tt_from_lookup(double *__restrict__ parent, const double *__restrict__ table,
+                                                        const unsigned char *__restrict__ lc, const unsigned char *__restrict__ rc,
+                                                        unsigned sites, unsigned span, unsigned shift)
+{
+  const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (idx >= (size_t)sites * span) return;
+  const unsigned n = (unsigned)(idx / span), q = (unsigned)(idx % span);
+  parent[idx] = table[(size_t)(((unsigned)lc[n] << shift) + rc[n]) * span + q];
+}
+
+// ------------------------------------------------------------------------------------------------
 // layout converters between the host mirror [entry][rate][SP] and the tiled device layout. One
 // thread per tiled element (coalesced on the tiled side). Not on the hot path.
 __global__ __launch_bounds__(256) void k_aos_to_tiled(const double *__restrict__ aos, double *__restrict__ tiled,

@@ -2105,6 +2105,67 @@ extern "C" int pllgpu_root_loglikelihood(pllgpu_ctx_t *c, unsigned clv, int scal
   return run_lnl(c, e, false, gather != 0, freqs_indices, persite_host, lnl_out);
 }
 
+// ---- the flat seam's tip-tip pair: the caller's lookup table in the reference's layout ---------------------
+static unsigned lookup_shift(unsigned states, unsigned ncodes)
+{
+  if (states == 4) return 4; // 16 j + k (src/core_partials.c:1013-1071)
+  unsigned sh = 0;
+  while ((1u << sh) < ncodes) ++sh; // ceil(log2(maxstates)), :1152
+  return sh;
+}
+
+extern "C" int pllgpu_create_lookup(pllgpu_ctx_t *c, double *lookup_host, const double *left_host, const double *right_host,
+                                    const unsigned long long *tipmap_host, unsigned ncodes)
+{
+  CHECK_CTX(c);
+  const unsigned S = c->gg.S, SP = c->gg.SP, R = c->gg.R, span = R * SP, shift = lookup_shift(S, ncodes);
+  if (S == 4) ncodes = 16;
+  if (!ncodes || ncodes > 256) return fail(PLLGPU_EINVAL, "lookup table over %u tip codes", ncodes);
+  const size_t entries = (size_t)((ncodes - 1u) << shift) + ncodes, tab = entries * span, mat = (size_t)R * S * SP;
+  if (int rc = c->scratch.ensure(tab + 2 * mat)) return rc;
+  double *d_tab = c->scratch.p, *d_l = d_tab + tab, *d_r = d_l + mat;
+  HIP_TRY(hipMemsetAsync(d_tab, 0, tab * sizeof(double), c->stream)); // (entries between the rows of a padded index stay 0)
+  HIP_TRY(hipMemcpyAsync(d_l, left_host, mat * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d_r, right_host, mat * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  const unsigned long long *tm = nullptr;
+  if (S != 4)
+  {
+    if (!tipmap_host) return fail(PLLGPU_EINVAL, "a lookup table of %u states needs the code -> state mask map", S);
+    if (int rc = c->tipmap.ensure(256)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->tipmap.p, tipmap_host, ncodes * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    tm = c->tipmap.p;
+  }
+  const size_t n = (size_t)ncodes * ncodes * span;
+  hipLaunchKernelGGL(k_create_lookup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_tab, d_l, d_r, tm, S, SP, R, ncodes, shift);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(lookup_host, d_tab, tab * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int pllgpu_tt_from_lookup(pllgpu_ctx_t *c, double *parent_host, const unsigned char *left_codes, const unsigned char *right_codes,
+                                     const double *lookup_host, unsigned sites, unsigned ncodes)
+{
+  CHECK_CTX(c);
+  const unsigned S = c->gg.S, SP = c->gg.SP, R = c->gg.R, span = R * SP, shift = lookup_shift(S, ncodes);
+  if (S == 4) ncodes = 16;
+  if (!ncodes || ncodes > 256 || !sites) return fail(PLLGPU_EINVAL, "tip-tip update over %u codes, %u sites", ncodes, sites);
+  for (unsigned n = 0; n < sites; ++n)
+    if (left_codes[n] >= ncodes || right_codes[n] >= ncodes) return fail(PLLGPU_EINVAL, "site %u: tip code beyond the lookup table's %u codes", n, ncodes);
+  const size_t entries = (size_t)((ncodes - 1u) << shift) + ncodes, tab = entries * span, out = (size_t)sites * span;
+  if (int rc = c->scratch.ensure(tab + out + (2 * (size_t)sites + 7) / 8 + 1)) return rc;
+  double *d_tab = c->scratch.p, *d_out = d_tab + tab;
+  unsigned char *d_l = reinterpret_cast<unsigned char *>(d_out + out), *d_r = d_l + sites;
+  HIP_TRY(hipMemcpyAsync(d_tab, lookup_host, tab * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d_l, left_codes, sites, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d_r, right_codes, sites, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_tt_from_lookup, dim3((unsigned)((out + 255) / 256)), dim3(256), 0, c->stream, d_out, d_tab, d_l, d_r, sites, span, shift);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(parent_host, d_out, out * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 // ---- the exchange of a site-sharded run ---------------------------------------------------------
 extern "C" double *pllgpu_reduce_buffer(pllgpu_ctx_t *c)
 {
@@ -2578,7 +2639,8 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
   CHECK_CTX(c);
   const pllgpu_geometry_t &g = c->geo;
   const unsigned sites = g.sites;
-  const unsigned nblk = (sites + kRepBlock - 1) / kRepBlock;
+  const unsigned nblk = (sites + kRepBlock - 1) / kRepBlock, words = (sites + 31u) / 32u;
+  const size_t wstride = ((size_t)words + 32767u) & ~(size_t)32767u; // k_rep_scan works in whole chunks of 32768 words
   const size_t table_cap = (size_t)64 << 20; // cells per batch (256 MB); a single larger op still gets its slice
   unsigned done = 0;
   while (done < count)
@@ -2599,7 +2661,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     }
     if (cells >= 0x7FFFFFFFull) return fail(PLLGPU_EINVAL, "repeats table of %zu cells exceeds 31-bit addressing", cells);
     if (int rc = c->rep_table.ensure(cells)) return rc;
-    if (int rc = c->rep_blocksum.ensure((size_t)kRepOps * nblk)) return rc;
+    if (int rc = c->rep_blocksum.ensure((size_t)kRepOps * 2u * wstride)) return rc; // per op: the bitmap, then the word prefixes
     if (int rc = c->rep_counts.ensure(kRepOps)) return rc;
     if (int rc = c->rep_ops.ensure((size_t)kRepOps * sizeof(RepOp))) return rc;
     std::vector<RepOp> &rops = c->rep_ops_host;
@@ -2622,7 +2684,8 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
       r.pids = c->id_site[o.parent].p;
       r.lent = c->lent[o.parent].p;
       r.rent = c->rent[o.parent].p;
-      r.blocksum = c->rep_blocksum.p + (size_t)i * nblk;
+      r.bitmap = c->rep_blocksum.p + (size_t)i * 2u * wstride;
+      r.wprefix = r.bitmap + wstride;
       r.nleft = o.nleft;
       r.ncells = o.nleft * o.nright;
       r.tab_off = (unsigned)off;
@@ -2641,16 +2704,24 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     pk.ticket = c->counter.p + 2; // [0]: log-likelihood / derivative reductions
     pk.sequence = ++c->rep_seq;
     pk.sites = sites;
-    pk.nblk = nblk;
+    pk.words = words;
     pk.fenced = c->fenced;
     HIP_TRY(hipMemsetAsync(c->rep_table.p, 0xFF, cells * sizeof(unsigned), c->stream));
-    const dim3 grid(nblk, n), block(256);
-    hipLaunchKernelGGL(k_rep_mark, dim3((sites + kRepMarkSites - 1) / kRepMarkSites, n), block, kRepLdsCells * sizeof(unsigned), c->stream, pk);
-    hipLaunchKernelGGL(k_rep_count, grid, block, 0, c->stream, pk);
-    hipLaunchKernelGGL(k_rep_rank, grid, block, 0, c->stream, pk);
-    hipLaunchKernelGGL(k_rep_assign, grid, block, 0, c->stream, pk);
+    HIP_TRY(hipMemsetAsync(c->rep_blocksum.p, 0, (size_t)n * 2u * wstride * sizeof(unsigned), c->stream));
+    unsigned maxcells = 0;
+    for (unsigned i = 0; i < n; ++i) maxcells = std::max(maxcells, rops[i].ncells);
+    const dim3 block(256), cgrid((maxcells + kRepBlock - 1) / kRepBlock, n);
+    // LDS for the largest slice that is reduced there (near the tips a few hundred bytes: more workgroups per CU)
+    unsigned lds_cells = 64;
+    for (unsigned i = 0; i < n; ++i)
+      if (rops[i].ncells <= kRepLdsCells) lds_cells = std::max(lds_cells, rops[i].ncells);
+    hipLaunchKernelGGL(k_rep_mark, dim3((sites + kRepMarkSites - 1) / kRepMarkSites, n), block, lds_cells * sizeof(unsigned), c->stream, pk);
+    hipLaunchKernelGGL(k_rep_bitmap, cgrid, block, 0, c->stream, pk);
+    hipLaunchKernelGGL(k_rep_scan, dim3(1, n), dim3(1024), 0, c->stream, pk);
+    hipLaunchKernelGGL(k_rep_rank_cells, cgrid, block, 0, c->stream, pk);
+    hipLaunchKernelGGL(k_rep_assign, dim3(nblk, n), block, 0, c->stream, pk);
     HIP_TRY(hipGetLastError());
-    // the class counts arrive in mapped host memory as soon as k_rep_rank knows them (k_rep_assign still runs;
+    // the class counts arrive in mapped host memory as soon as k_rep_scan knows them (the last two kernels still run;
     // whatever uses the maps is ordered behind it by the stream): poll the sequence word for a bounded time
     {
       volatile unsigned *seq = c->rep_host + kRepOps;

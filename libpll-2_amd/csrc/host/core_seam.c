@@ -159,22 +159,30 @@ static size_t matrix_doubles(unsigned int states, unsigned int rate_cats, unsign
   return (size_t)rate_cats * states * sp;
 }
 
+/* The tip-tip pair of the flat seam (src/pll.h:1049-1071). pll_core_create_lookup fills the CALLER's table in the
+ * reference's own layout (src/core_partials.c:1013-1071 for 4 states, :1149-1209 otherwise; stride states_padded of
+ * `attrib` as the vectorised forms, src/core_partials_avx.c:59-118): entry (j, k) of two tip codes at index
+ * (j << ceil(log2(tipmap_size))) + k - 16 j + k for 4 states - holds the parent entry of a cherry showing j and k.
+ * pll_core_update_partial_tt copies one entry per site and zeroes the scaler (:180-199). A table made by the reference
+ * works with this library's tt and vice versa; both run on the device (k_create_lookup, k_tt_from_lookup). */
 void pll_core_create_lookup(unsigned int states, unsigned int rate_cats, double *lookup, const double *left_matrix,
                             const double *right_matrix, const pll_state_t *tipmap, unsigned int tipmap_size, unsigned int attrib)
 {
-  (void)tipmap;
-  (void)tipmap_size;
-  /* the table belongs to the pair create_lookup / update_partial_tt; the caller sized it for
-   * maxstates^2 entries of rate_cats x states_padded doubles (src/pll.c:369-383), the two matrices fit */
-  const size_t n = matrix_doubles(states, rate_cats, attrib);
-  memcpy(lookup, left_matrix, n * sizeof(double));
-  memcpy(lookup + n, right_matrix, n * sizeof(double));
+  seam_t s;
+  if (!seam_open(&s, states, 1, rate_cats, 1, 1, 1, attrib)) return;
+  pll_amd_ext_t *x = pll_ext(s.p);
+  if (!x || !x->ctx || pllgpu_create_lookup(x->ctx, lookup, left_matrix, right_matrix, tipmap, tipmap_size) != 0)
+  {
+    pll_set_gpu_error("pll_core_create_lookup");
+    fprintf(stderr, "libpll_amd: pll_core_create_lookup: [%d] %s\n", pll_errno, pll_errmsg);
+  }
+  seam_close(&s);
 }
 
 void pll_core_create_lookup_4x4(unsigned int rate_cats, double *lookup, const double *left_matrix, const double *right_matrix)
 {
-  /* the 4x4 form has no attrib argument: the reference's table holds 4-double rows whatever the
-   * architecture (src/core_partials.c:1015-1071); so do the matrices of a 4-state partition */
+  /* the 4x4 form has no attrib argument: the table holds 4-double rows whatever the architecture
+   * (src/core_partials.c:1015-1071); so do the matrices of a 4-state partition */
   pll_core_create_lookup(4, rate_cats, lookup, left_matrix, right_matrix, NULL, 16, PLL_ATTRIB_ARCH_CPU);
 }
 
@@ -183,15 +191,17 @@ void pll_core_update_partial_tt(unsigned int states, unsigned int sites, unsigne
                                 const unsigned char *right_tipchars, const pll_state_t *tipmap, unsigned int tipmap_size,
                                 const double *lookup, unsigned int attrib)
 {
-  (void)tipmap_size;
+  (void)tipmap;
   seam_t s;
-  if (!seam_open(&s, states, sites, rate_cats, 3, 2, 1, attrib)) return;
-  const size_t n = matrix_doubles(states, rate_cats, attrib);
-  seam_put_tip(&s, 1, left_tipchars, tipmap, sites);
-  seam_put_tip(&s, 2, right_tipchars, tipmap, sites);
-  seam_put_matrix(&s, 0, lookup);
-  seam_put_matrix(&s, 1, lookup + n);
-  seam_update(&s, parent_clv, parent_scaler, 0, 0, sites);
+  if (!seam_open(&s, states, 1, rate_cats, 1, 1, 1, attrib)) return;
+  pll_amd_ext_t *x = pll_ext(s.p);
+  if (!x || !x->ctx || pllgpu_tt_from_lookup(x->ctx, parent_clv, left_tipchars, right_tipchars, lookup, sites, tipmap_size) != 0)
+  {
+    pll_set_gpu_error("pll_core_update_partial_tt");
+    fprintf(stderr, "libpll_amd: pll_core_update_partial_tt: [%d] %s\n", pll_errno, pll_errmsg);
+  }
+  else if (parent_scaler)
+    memset(parent_scaler, 0, sizeof(unsigned int) * ((attrib & PLL_ATTRIB_RATE_SCALERS) ? (size_t)sites * rate_cats : sites));
   seam_close(&s);
 }
 

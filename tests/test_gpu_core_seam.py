@@ -211,8 +211,28 @@ def test_tip_forms(amd_lib, ref_lib, states, arch):
             d.pll_core_edge_loglikelihood_ti.restype = C.c_double
             d.pll_core_edge_loglikelihood_ti.argtypes = [C.c_uint] * 3 + [D, U, B, S64, C.c_uint, D, DP, D, U, D, I, U, D, C.c_uint]
             v = d.pll_core_edge_loglikelihood_ti(states, n, rates, dp(inner), up(isc), bp(codes[1]), tm, nchar, dp(lm), fp, dp(rw), up(pw), dp(pinv), None, up(fi), None, attrib)
-        res[tag] = (pc, ps, tc, ts, v)
+        res[tag] = (pc, ps, tc, ts, v, look)
     a, r = res["amd"], res["ref"]
+    # the lookup table itself is the reference's (a caller may inspect it, or hand a table made by one
+    # library to the other's tt): same entries at the same places ...
+    used = pow2 * pow2 * rates * sp if states != 4 else 256 * rates * 4
+    stride = rates * sp if states != 4 else rates * 4
+    tab_a, tab_r = a[5][:used].reshape(-1, stride), r[5][:used].reshape(-1, stride)
+    idx = [(j << int(np.ceil(np.log2(nchar)))) + k if states != 4 else 16 * j + k
+           for j in range(nchar if states != 4 else 16) for k in range(nchar if states != 4 else 16)]
+    lanes = np.arange(stride).reshape(rates, -1)[:, :states].ravel()
+    np.testing.assert_allclose(tab_a[idx][:, lanes], tab_r[idx][:, lanes], rtol=1e-13, atol=0)
+    # ... and each library's tt reads the other's table
+    for lib, table, want in ((amd_lib, r[5], r[2]), (ref_lib, a[5], a[2])):
+        d = lib.dll
+        tc = aligned(np.zeros((n, rates, sp)))
+        ts = np.ones(n, dtype=np.uint32)
+        if states == 4:
+            d.pll_core_update_partial_tt_4x4(n, rates, dp(tc), up(ts), bp(codes[0]), bp(codes[1]), dp(table), attrib)
+        else:
+            d.pll_core_update_partial_tt(states, n, rates, dp(tc), up(ts), bp(codes[0]), bp(codes[1]), tm, nchar, dp(table), attrib)
+        np.testing.assert_allclose(tc[..., :states], want[..., :states], rtol=1e-13, atol=0)
+        assert (ts == 0).all()
     np.testing.assert_allclose(a[0][..., :states], r[0][..., :states], rtol=RTOL, atol=0)
     assert (a[1] == r[1]).all()
     np.testing.assert_allclose(a[2][..., :states], r[2][..., :states], rtol=RTOL, atol=0)

@@ -747,6 +747,34 @@ def test_tip_parent_edge_keeps_the_callers_orientation(amd_lib):
     assert_results_match(got, exp, what="orientation")
 
 
+@pytest.mark.parametrize("kw", [dict(states=61, tips=8, sites=20000, seed=211), dict(states=40, tips=8, sites=24000, seed=212),
+                                dict(states=4, tips=16, sites=600000, seed=213)], ids=_id)
+def test_fenced_handoff_spanning_all_xcds(amd_lib, kw, monkeypatch):
+    """the result hand-off of the reduction kernels relies on agent-scope atomics being performed at the
+    coherent level before vmcnt decrements (kernels_common.h: handoff_*) - outside the HIP memory model. Cases whose
+    log-likelihood kernels run several hundred workgroups (every XCD takes part; the 61- and 40-state edge kernel hands
+    per-rate partials AND per-item-block sums across workgroups): the in-model form (PLL_AMD_FENCED_HANDOFF=1, release /
+    acquire fences) must give the same bits, evaluation after evaluation, with CLV updates in flight in front of each."""
+    case = W.make_case("xcd", **kw)
+    e = case.edges[0]
+
+    def observe():
+        with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+            out = []
+            for _ in range(12):
+                s.update_partials()  # hundreds of MB of stores in flight when the evaluation starts
+                out.append(s.edge_lnl(e, persite=False)[0])
+            out.append(s.root_lnl((e[0], e[1]), persite=False)[0])
+        return out
+
+    plain = observe()
+    monkeypatch.setenv("PLL_AMD_FENCED_HANDOFF", "1")
+    fenced = observe()
+    assert len(set(plain[:-1])) == 1 and plain == fenced
+    exp = O.run_case(case)["lnl"][0]
+    assert abs(plain[0] - exp) <= RTOL * abs(exp)
+
+
 def test_fenced_handoff_and_auto_device_switches(amd_lib, monkeypatch):
     """PLL_AMD_FENCED_HANDOFF=1 puts release / acquire fences back into the result hand-off of the reduction
     kernels (edge and root lnL, chain tail, derivatives, class counts): the same bits, only slower.

@@ -1,6 +1,8 @@
+#!/bin/bash
 # usage: pmc_sets.sh <outdir-name> <kernel substring> -- bench args...   (each counter set under its own timeout)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+if [ $# -lt 3 ]; then echo "usage: pmc_sets.sh <outdir-name> <kernel substring> -- bench args..." >&2; exit 2; fi
 NAME=$1; KSUB=$2; shift 3
 O=$R/gpurun_out/$NAME; mkdir -p $O
 i=0

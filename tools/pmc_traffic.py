@@ -53,7 +53,13 @@ def main():
     fetch = sum(float(r["Counter_Value"]) for r in res["FETCH_SIZE"])
     write = sum(float(r["Counter_Value"]) for r in res["WRITE_SIZE"])
     per_launch = (2.0 * fetch / nf + write / nw) * 1024.0
-    out = dict(hbm_bytes_per_launch=int(round(per_launch)), algorithmic_bytes_per_launch=int(a.algorithmic),
+    import subprocess
+    try:
+        commit = subprocess.check_output(['git', '-C', os.path.dirname(os.path.abspath(__file__)), 'rev-parse', '--short', 'HEAD'], text=True, stderr=subprocess.DEVNULL).strip()
+    except Exception:
+        commit = os.environ.get('PLL_COMMIT', 'unknown (no git on the GPU box: set PLL_COMMIT)')
+    grids = sorted({int(r['Grid_Size']) for r in res['WRITE_SIZE']})
+    out = dict(hbm_bytes_per_launch=int(round(per_launch)), commit=commit, grid_sizes_seen=grids, algorithmic_bytes_per_launch=int(a.algorithmic),
                ratio=round(per_launch / a.algorithmic, 4), kernel=a.kernel, grid_sizes=a.grid,
                method="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (with --kernel-trace only) around "
                       "`python3 bench.py --steps 3 --warmup 1 --no-cpu`; mean over the dispatches of the kernel with the grid sizes "

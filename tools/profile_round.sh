@@ -21,7 +21,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc3_fetch"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc3_write" -- python3 "$R/bench.py" --config c3 --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1
 python3 "$R/tools/pmc_traffic.py" --fetch "$O/pmc3_fetch" --write "$O/pmc3_write" --kernel 'k_partials_mfma_cc<5>' \
   --algorithmic 1548800000 --out "$O/traffic_c3.json" --trim "$O/c3_pmc" > /dev/null
-cp "$O/traffic_c3.json" "$R/profiles/traffic_c3.json"   # bench.py's c3 line reads it (only on this box: copy it home with the rest)
+# (outputs stay under gpurun_out/: copy traffic_c2.json / traffic_c3.json into profiles/ deliberately, with the commit they were measured at)
 for c in c3 c3r c4 c5; do
   python3 "$R/bench.py" --config $c --steps 10 > "$O/${c}_bench.json" 2> "$O/${c}_bench.err"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$c" -- python3 "$R/bench.py" --config $c --steps 10 --no-cpu > /dev/null 2>&1
