@@ -26,6 +26,7 @@ constexpr int kRepOps = 128;              // ops per batch (descriptors in devic
 constexpr unsigned kRepBlock = 1024;      // sites (k_rep_assign) or cells (k_rep_bitmap, k_rep_rank_cells) per workgroup: 256 threads x 4
 constexpr unsigned kRepMarkSites = 4096;  // sites per workgroup of k_rep_mark: 256 threads x 4 groups of 4 consecutive sites
 constexpr unsigned kRepLdsCells = 8192;   // table slices up to this many cells are reduced in LDS first (32 KB)
+constexpr unsigned kRepFilterBits = 12, kRepFilter = 1u << kRepFilterBits; // entries of k_rep_mark's LDS filter (8 bytes each)
 constexpr unsigned kRepClassFlag = 0x80000000u; // a table cell that holds its class number instead of its first site
 
 struct RepOp
@@ -78,11 +79,17 @@ __global__ __launch_bounds__(256) void k_rep_mark(const RepPack p)
   const unsigned nleft = o->nleft, ncells = o->ncells;
   unsigned *table = p.table + o->tab_off;
   const bool in_lds = ncells <= kRepLdsCells; // workgroup-uniform
+  // slices too large for LDS get a FILTER there instead: kRepFilter entries {cell, lowest site of this workgroup seen with
+  // it}, direct-mapped by a hash of the cell. A site whose cell sits in its slot with a lower site has nothing to tell
+  // the table (that lower site's thread does, or was itself told so); anything else - another cell in the slot, a race -
+  // just goes to the table as before. What this path costs is its atomics on the table, and in a pattern-sorted
+  // alignment the sites of a class come in clusters.
+  unsigned long long *filter = reinterpret_cast<unsigned long long *>(rep_lds);
   if (in_lds)
-  {
     for (unsigned i = threadIdx.x; i < ncells; i += 256u) rep_lds[i] = 0xFFFFFFFFu;
-    __syncthreads();
-  }
+  else
+    for (unsigned i = threadIdx.x; i < kRepFilter; i += 256u) filter[i] = ~0ull;
+  __syncthreads();
   // a thread takes four CONSECUTIVE sites at a time (16-byte loads of the two maps; round 2 read them 4 bytes per lane
   // and the kernel ran at 1 TB/s), four such groups 1024 sites apart, all requested before the first is looked at.
   // Consecutive sites of a pattern-sorted alignment mostly share their cell: only the first of a run goes to the table.
@@ -127,8 +134,14 @@ __global__ __launch_bounds__(256) void k_rep_mark(const RepPack p)
       // atomic, never a wrong minimum (an agent-scope load per site was 16M trips to the coherent level per level of
       // C4). One look, then its atomic, site after site: with all looks first a thread's own lower sites no longer
       // shield the later ones and the atomics - what this path costs - tripled (measured: 0.37 -> 1.9 ms).
-      else if (table[c[e]] > s + e)
-        atomicMin(&table[c[e]], s + e);
+      else
+      {
+        const unsigned slot = (c[e] * 2654435761u) >> (32 - kRepFilterBits);
+        const unsigned long long ent = filter[slot];
+        if ((unsigned)(ent >> 32) == c[e] && (unsigned)ent < s + e) continue;
+        filter[slot] = ((unsigned long long)c[e] << 32) | (s + e);
+        if (table[c[e]] > s + e) atomicMin(&table[c[e]], s + e);
+      }
     }
   }
   if (!in_lds) return;

@@ -2714,7 +2714,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     // LDS for the largest slice that is reduced there (near the tips a few hundred bytes: more workgroups per CU)
     unsigned lds_cells = 64;
     for (unsigned i = 0; i < n; ++i)
-      if (rops[i].ncells <= kRepLdsCells) lds_cells = std::max(lds_cells, rops[i].ncells);
+      lds_cells = std::max(lds_cells, rops[i].ncells <= kRepLdsCells ? rops[i].ncells : 2u * kRepFilter); // (the filter: 8 bytes per entry)
     hipLaunchKernelGGL(k_rep_mark, dim3((sites + kRepMarkSites - 1) / kRepMarkSites, n), block, lds_cells * sizeof(unsigned), c->stream, pk);
     hipLaunchKernelGGL(k_rep_bitmap, cgrid, block, 0, c->stream, pk);
     hipLaunchKernelGGL(k_rep_scan, dim3(1, n), dim3(1024), 0, c->stream, pk);
