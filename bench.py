@@ -14,8 +14,9 @@ pll_compute_edge_loglikelihood at the root edge, which synchronises and returns 
     --gpus N > 1         BASELINE configs[3] "C4", STRONG scaling: ONE alignment - 4-state DNA, 128 taxa,
                          1M sites, PLL_ATTRIB_SITE_REPEATS, the same bytes on every rank - is pattern-sorted
                          (pll_compress_site_patterns, as applications do before they shard) and cut into N
-                         contiguous site ranges of equal COST (pllamd/sharding.py: balanced_bounds; --cut equal
-                         for equal site counts); rank r owns an independent partition over range r and the
+                         contiguous site ranges of equal site count (--cut balanced: of equal modelled cost,
+                         pllamd/sharding.py - measured slower: the larger shards fall out of the Infinity
+                         Cache); rank r owns an independent partition over range r and the
                          only exchange is ONE sum of the shard log-likelihoods per step (SURVEY.md section 8e;
                          the sum it stands for: src/core_likelihood.c:1489):
                            --reduce peer (default)  fixed rank order through shared host memory
@@ -832,7 +833,8 @@ def main():
                          "gloo + PLL_BENCH_SAME_DEVICE=1 rehearses the N>1 flow on a one-GPU box")
     ap.add_argument("--reduce", default="peer", choices=["peer", "rccl"],
                     help="N > 1: how the shard log-likelihoods are summed (see the docstring)")
-    ap.add_argument("--cut", default="balanced", choices=["balanced", "equal"], help="N > 1: shards of equal cost or of equal site count")
+    ap.add_argument("--cut", default="equal", choices=["equal", "balanced"],
+                    help="N > 1: shards of equal site count (default) or of equal modelled cost (pllamd/sharding.py: balanced_bounds - measured slower, see there)")
     ap.add_argument("--driver", default="c", choices=["c", "python"], help="who issues the steps of the timed region")
     args = ap.parse_args()
     if args.gpus < 1 or args.blocks < 1 or args.steps < 1:

@@ -86,6 +86,40 @@ static void fail_loudly(const char *what)
     return;                                   \
   } while (0)
 
+/* Re-evaluations of one tree - the common case between two topology changes, and bench.py's timed loop - hand over the
+ * same operation list again and again. When nothing the device would have to be told about is dirty and nothing the
+ * classification depends on has changed since that list last went through the whole function (fast_valid is cleared
+ * wherever tip forms, class counts or caller-written arrays change), the classified, level-sorted list of that call
+ * (x->gops) is still right: skip levels, flushes and classification (126 ops: ~4 us of host time between one step's
+ * result and the next step's first kernel). */
+static int nothing_dirty(const pll_partition_t *p, const pll_amd_ext_t *x)
+{
+  unsigned int i;
+  if (x->rate_weights_dirty | x->pattern_weights_dirty | x->invariant_dirty | x->prop_invar_dirty | x->tipmap_dirty) return 0;
+  if (memchr(x->freqs_dirty, 1, p->rate_matrices)) return 0;
+  for (i = x->fast_lo; i <= x->fast_hi; ++i)
+    if (x->pmatrix_dirty[i] && !x->pmatrix_stale[i]) return 0;
+  if (memchr(x->tipchars_dirty, 1, p->tips)) return 0;
+  if (pll_repeats_enabled(p) && memchr(x->repeats_dirty, 1, p->nodes)) return 0;
+  if (memchr(x->clv_side, SIDE_HOST, p->nodes)) return 0;
+  if (p->scale_buffers && memchr(x->scaler_side, SIDE_HOST, p->scale_buffers)) return 0;
+  return 1;
+}
+
+static void mark_results(pll_partition_t *p, pll_amd_ext_t *x, const pll_operation_t *ops, unsigned int count)
+{
+  unsigned int i;
+  for (i = 0; i < count; ++i)
+  {
+    x->clv_side[ops[i].parent_clv_index] = SIDE_DEVICE;
+    if (ops[i].parent_scaler_index >= 0)
+    {
+      x->scaler_side[ops[i].parent_scaler_index] = SIDE_DEVICE;
+      x->scaler_entries[ops[i].parent_scaler_index] = pll_get_sites_number(p, ops[i].parent_clv_index);
+    }
+  }
+}
+
 void pll_update_partials(pll_partition_t *p, const pll_operation_t *ops, unsigned int count)
 {
   pll_update_partials_rep(p, ops, count, 1);
@@ -113,6 +147,19 @@ void pll_update_partials_rep(pll_partition_t *p, const pll_operation_t *ops, uns
       fail_loudly("pll_update_partials");
       return;
     }
+  if (x->fast_valid && count == x->fast_count && !(update_repeats && pll_repeats_enabled(p)) && !x->always_upload && !x->eager_mirror &&
+      memcmp(ops, x->fast_ops, (size_t)count * sizeof *ops) == 0 && nothing_dirty(p, x))
+  {
+    if (pllgpu_update_partials(x->ctx, x->gops, count) != 0)
+    {
+      x->fast_valid = 0;
+      pll_set_gpu_error("pll_update_partials");
+      return;
+    }
+    mark_results(p, x, ops, count);
+    return;
+  }
+  x->fast_valid = 0;
   if (!grow_scratch(p, x, count))
   {
     pll_set_error(PLL_ERROR_MEM_ALLOC, "pll_update_partials: out of memory");
@@ -210,14 +257,21 @@ void pll_update_partials_rep(pll_partition_t *p, const pll_operation_t *ops, uns
     pll_set_gpu_error("pll_update_partials");
     return;
   }
-  for (i = 0; i < count; ++i)
+  mark_results(p, x, ops, count);
+  /* remember the list: the next call with the same one may skip everything above (nothing_dirty) */
+  if (count > x->fast_cap)
   {
-    x->clv_side[ops[i].parent_clv_index] = SIDE_DEVICE;
-    if (ops[i].parent_scaler_index >= 0)
-    {
-      x->scaler_side[ops[i].parent_scaler_index] = SIDE_DEVICE;
-      x->scaler_entries[ops[i].parent_scaler_index] = pll_get_sites_number(p, ops[i].parent_clv_index);
-    }
+    free(x->fast_ops);
+    x->fast_ops = (pll_operation_t *)malloc(sizeof(pll_operation_t) * count);
+    x->fast_cap = x->fast_ops ? count : 0;
+  }
+  if (x->fast_ops)
+  {
+    memcpy(x->fast_ops, ops, sizeof(pll_operation_t) * count);
+    x->fast_count = count;
+    x->fast_lo = lo;
+    x->fast_hi = hi;
+    x->fast_valid = 1;
   }
   if (x->eager_mirror)
     for (i = 0; i < count; ++i)

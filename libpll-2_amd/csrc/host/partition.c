@@ -73,6 +73,7 @@ void pll_tip_densify(pll_partition_t *p, unsigned int clv_index)
   if (x->tip_compact[clv_index])
   {
     x->tip_compact[clv_index] = 0;
+    x->fast_valid = 0;
     x->clv_side[clv_index] = SIDE_HOST; /* the host mirror holds the indicator CLV */
   }
 }
@@ -92,6 +93,7 @@ static void free_ext(pll_amd_ext_t *x)
   free(x->eigen_dirty);
   free(x->pmatrix_stale);
   free(x->pmatrix_params);
+  free(x->fast_ops);
   free(x->model_version);
   free(x->model_foreign);
   free(x->pmatrix_version);
@@ -791,6 +793,7 @@ void pll_gpu_invalidate(pll_partition_t *p, unsigned int what, int index)
   pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
   unsigned int i;
   if (!x) return;
+  x->fast_valid = 0; /* the caller wrote something: the next traversal takes the whole path again */
 #define MARK(arr, n, val)                                             \
   do                                                                  \
   {                                                                   \

@@ -76,6 +76,12 @@ typedef struct pll_amd_ext
    * upload the caller's (never written) buffer */
   const double *sumtable_evicted[PLLGPU_SUMTABLE_SLOTS];
   unsigned int sumtable_evicted_next;
+  /* the last operation list that went through the whole of pll_update_partials_rep (partials.c): the same list again,
+   * with nothing dirty and nothing that its classification depends on changed (fast_valid is cleared wherever tip forms,
+   * class counts or caller-written arrays change), goes straight to the device layer */
+  pll_operation_t *fast_ops;
+  unsigned int fast_count, fast_cap, fast_lo, fast_hi;
+  int fast_valid;
   double reduce_step;           /* collective evaluations issued so far (group.c: the ranks count in step) */
   /* scheduler scratch (grown on demand) */
   pllgpu_op_t *gops;

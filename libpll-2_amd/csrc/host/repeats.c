@@ -22,6 +22,7 @@ int pll_repeats_enabled(const pll_partition_t *p) { return (p->attributes & PLL_
 
 void pll_resize_repeats_lookup(pll_partition_t *p, unsigned int size)
 {
+  { pll_amd_ext_t *xf_ = p ? pll_ext(p) : NULL; if (xf_) xf_->fast_valid = 0; } /* class counts may change: partials.c's fast path starts over */
   if (!size) return;
   pll_repeats_t *r = p->repeats;
   free(r->lookup_buffer);
@@ -90,6 +91,7 @@ unsigned int pll_no_enable_repeats(pll_partition_t *p, unsigned int left, unsign
 
 int pll_repeats_initialize(pll_partition_t *p)
 {
+  { pll_amd_ext_t *xf_ = p ? pll_ext(p) : NULL; if (xf_) xf_->fast_valid = 0; } /* class counts may change: partials.c's fast path starts over */
   const unsigned int n = pll_sites_alloc(p);
   unsigned int i;
   pll_repeats_t *r = (pll_repeats_t *)calloc(1, sizeof(pll_repeats_t));
@@ -134,6 +136,7 @@ void pll_disable_bclv(pll_partition_t *p)
 /* classes of a tip = distinct state masks of its sequence (src/repeats.c:189-254) */
 int pll_update_repeats_tips(pll_partition_t *p, unsigned int tip, const pll_state_t *map, const char *seq)
 {
+  { pll_amd_ext_t *xf_ = p ? pll_ext(p) : NULL; if (xf_) xf_->fast_valid = 0; } /* class counts may change: partials.c's fast path starts over */
   pll_repeats_t *r = p->repeats;
   unsigned int i, j, s, next = 0;
   if (!r->lookup_buffer) pll_resize_repeats_lookup(p, PLL_REPEATS_LOOKUP_SIZE);
@@ -196,6 +199,7 @@ int pll_update_repeats_tips(pll_partition_t *p, unsigned int tip, const pll_stat
 void pll_default_reallocate_repeats(pll_partition_t *p, unsigned int parent, int scaler_index,
                                     unsigned int sites_to_alloc)
 {
+  { pll_amd_ext_t *xf_ = p ? pll_ext(p) : NULL; if (xf_) xf_->fast_valid = 0; }
   pll_repeats_t *r = p->repeats;
   if (sites_to_alloc == r->pernode_allocated_clvs[parent]) return;
   r->pernode_allocated_clvs[parent] = sites_to_alloc;
@@ -238,6 +242,7 @@ static void adopt_classes(pll_partition_t *p, const pll_operation_t *op, unsigne
 int pll_update_repeats_device(pll_partition_t *p, pll_amd_ext_t *x, const pll_operation_t *ops,
                               unsigned int count, const unsigned int *level, unsigned int nlevels)
 {
+  x->fast_valid = 0;
   pll_repeats_t *r = p->repeats;
   unsigned int l, i, k, n;
   int ok = PLL_FAILURE;
@@ -302,6 +307,7 @@ static void pll_update_repeats_host(pll_partition_t *p, const pll_operation_t *o
 
 void pll_update_repeats(pll_partition_t *p, const pll_operation_t *op)
 {
+  { pll_amd_ext_t *xf_ = p ? pll_ext(p) : NULL; if (xf_) xf_->fast_valid = 0; } /* class counts may change: partials.c's fast path starts over */
   pll_amd_ext_t *x = pll_ext(p);
   if (x && x->ctx)
   {

@@ -224,6 +224,7 @@ static int encode_tipclv(pll_partition_t *p, unsigned int tip, const pll_state_t
     }
   }
   if (x) x->tip_compact[tip] = (unsigned char)compact;
+  if (x) x->fast_valid = 0;
   return PLL_SUCCESS;
 }
 
@@ -325,6 +326,7 @@ int pll_set_tip_clv(pll_partition_t *p, unsigned int tip, const double *clv, int
         else x->tipcodes[tip][n + i] = (unsigned char)code;
       }
     x->tip_compact[tip] = (unsigned char)compact;
+    x->fast_valid = 0;
     if (compact)
     {
       x->tipchars_dirty[tip] = 1;

@@ -47,7 +47,14 @@ def balanced_bounds(case: Case, world, align=64, rounds=6):
     pattern-sorted alignment holds very different class counts depending on where it lies (the first and last
     eighth of the sorted 1M-site alignment: 127k entries at the 8-tip level, the second: 234k). cost(range) =
     sites + ENTRY_COST_PER_SITE_COST x sum over tip-only subtrees of the distinct columns in the range; the cuts
-    move until the costs agree. Every rank computes the same cuts from the same alignment: nothing is exchanged."""
+    move until the costs agree. Every rank computes the same cuts from the same alignment: nothing is exchanged.
+
+    MEASURED (round 3, tools/c4_projection.py --cut balanced against --cut equal, two boxes): NOT a gain for the 1M-site
+    configuration on 8 ranks - the slowest shard went 0.121 -> 0.123-0.127 ms. The cuts give the entry-poor first and
+    last eighth 134k sites instead of 125k, and at 134k sites a shard's uncompressed CLVs (14 nodes x 17 MB) no longer
+    fit the 256 MB Infinity Cache beside the compressed ones: what the model gains in entries it loses to HBM.
+    bench.py therefore cuts by site count (--cut equal) unless told otherwise; the function stays for alignments
+    whose shards are far from that cliff."""
     if world == 1 or case.sequences is None or not case.op_batches:
         return shard_bounds(case.sites, world, align)
     keys = _tip_subtree_keys(case)

@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--sites", type=int, default=0)
     ap.add_argument("--exchange-us", type=float, default=-1.0, help="< 0: measure the shared-memory exchange with tools/group_latency.c")
-    ap.add_argument("--cut", default="balanced", choices=["balanced", "equal"])
+    ap.add_argument("--cut", default="equal", choices=["equal", "balanced"])
     ap.add_argument("--blocks", type=int, default=5)
     ap.add_argument("--driver", default="c", choices=["c", "python"])
     ap.add_argument("--shard-only", type=int, default=-1, help="time just this shard (profiling runs)")
