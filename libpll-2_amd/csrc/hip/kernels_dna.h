@@ -1020,6 +1020,9 @@ typedef const SubItem __attribute__((address_space(4))) *csubitem_p;
 // SIMD - 46 us for C4's shard, nearly all of it waiting for the scalar loads of the next matrix. A quarter of
 // that per wave and four times the waves hide it. What the rates of an entry share is the per-site scaling
 // decision (SM 1): one ballot exchange through LDS per LEVEL of the subtree (three barriers).
+// (Round 3 tried the matrices through LDS instead of the scalar path - every op's pair requested at once with vector
+// loads by lanes 0-31 of the rate's wave, coefficients read back as broadcasts: a shard's launch 27 -> 35 us. The
+// scalar path is not what a workgroup's 12 us are made of; removed.)
 template <int SM>
 __device__ __forceinline__ void dna_sub_level(csubitem_p it, unsigned node_mask, unsigned scaler_mask, unsigned rate, int first, int count,
                                               const double (*below)[4], const unsigned *sc_below, const unsigned (&code)[15], double (*out)[4],
