@@ -613,7 +613,8 @@ def roofline_leg(args, cfg, lib, api, runner, reps=20):
               20: "k_partials_mfma_cc<5>%.0s" if grouped else
                   ("k_partials_lean<5,false,false,true>%.0s (gathering launches) + k_partials_tiled<20,false,false,false>"
                    if cfg.get("repeats") and not os.environ.get("PLL_AMD_NO_LEAN", "0").strip("0") else "k_partials_tiled<20,false,false,%s>"),
-              61: "k_partials_mfma<false,false,%s>" if mfma else "k_partials_tiled<32,false,false,%s>"
+              61: ("k_partials_mfma<16,false,false,%s>" if cfg.get("repeats") or os.environ.get("PLL_AMD_MFMA_WIDE") == "0" else
+                   "k_partials_mfma_wide<15,1,8>%.0s") if mfma else "k_partials_tiled<32,false,false,%s>"
               }[cfg["states"]] % ("true" if cfg.get("repeats") else "false")
     if args.tree != "balanced":
         kernel = "all update launches of the traversal"

@@ -44,15 +44,15 @@ constexpr unsigned kFrag = 17;
 // frag[ig][jg][kk][ii] = P[4 ig + ii][4 jg + kk] = PT[4 jg + kk][4 ig + ii], zero beyond S. Every thread of the
 // 256 issues ALL its requests (coalesced: thread t takes elements t, t + 256, ...) before the first LDS write - a
 // loop of load / wait / write made this 16 L2 round trips long, a fifth of a 61-state workgroup's time.
-template <int NG, int NM>
+template <int NG, int NM, unsigned NT = 256u>
 __device__ __forceinline__ void mfma_stage(double *const (&dst)[NM], const double *const (&src)[NM], unsigned S, unsigned SPT)
 {
-  constexpr unsigned W = 4 * NG, N = W * W, PER = (N + 255u) / 256u;
+  constexpr unsigned W = 4 * NG, N = W * W, PER = (N + NT - 1u) / NT; // NT = threads of the workgroup
   double v[NM][PER];
 #pragma unroll
   for (unsigned q = 0; q < PER; ++q)
   {
-    const unsigned lin = threadIdx.x + 256u * q, j = lin / W, i = lin % W;
+    const unsigned lin = threadIdx.x + NT * q, j = lin / W, i = lin % W;
     const bool in = lin < N && j < S && i < SPT;
     const size_t off = in ? (size_t)j * SPT + i : 0;
 #pragma unroll
@@ -65,7 +65,7 @@ __device__ __forceinline__ void mfma_stage(double *const (&dst)[NM], const doubl
 #pragma unroll
   for (unsigned q = 0; q < PER; ++q)
   {
-    const unsigned lin = threadIdx.x + 256u * q, j = lin / W, i = lin % W;
+    const unsigned lin = threadIdx.x + NT * q, j = lin / W, i = lin % W;
     if (lin < N)
     {
       const unsigned pos = ((i >> 2) * NG + (j >> 2)) * kFrag + (j & 3u) * 4u + (i & 3u);

@@ -235,10 +235,12 @@ __device__ __forceinline__ void wide_body(const DevOp &op, const GenGeo &g, cons
   }
 }
 
-// grid = (blocks of 4 waves, ops, rate categories); each wave walks `halves_per_wave` consecutive half tiles of its op
-template <int NGJ, int TAIL>
-__global__ __launch_bounds__(256, 2) void k_partials_mfma_wide(const OpPack pack, const GenGeo g, unsigned halves_per_wave,
-                                                               unsigned char *__restrict__ flagbuf, unsigned flag_stride)
+// grid = (workgroups of WAVES waves, ops, rate categories); a workgroup owns `halves_per_wg` consecutive half tiles of
+// its op and deals them to its SIMDs evenly, give or take one (waves w and w + 4 of an 8-wave workgroup sit on one
+// SIMD and share its share: the two of them finish together whichever way the odd half tile falls)
+template <int NGJ, int TAIL, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void k_partials_mfma_wide(const OpPack pack, const GenGeo g, unsigned halves_per_wg,
+                                                                     unsigned char *__restrict__ flagbuf, unsigned flag_stride)
 {
   extern __shared__ double lds[];
   typedef MfmaGeo<16> MG;
@@ -250,11 +252,23 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma_wide(const OpPack pack
   const unsigned row = lane >> 4, col = lane & 15u;
   const unsigned S = g.S, k = blockIdx.z;
   const unsigned nhalves = (op.entries + 31u) / 32u;
-  if (blockIdx.x * 4u * halves_per_wave >= nhalves) return; // whole workgroup
+  const unsigned base = blockIdx.x * halves_per_wg;
+  if (base >= nhalves) return; // whole workgroup
+  unsigned h, count;
+  {
+    const unsigned n = min(halves_per_wg, nhalves - base), simd = wave & 3u, q4 = n >> 2, r4 = n & 3u;
+    count = q4 + (simd < r4 ? 1u : 0u);
+    h = base + simd * q4 + min(simd, r4);
+    if (WAVES == 8)
+    {
+      const unsigned first = (count + 1u) >> 1;
+      if (wave >= 4u) h += first, count -= first;
+      else count = first;
+    }
+  }
   const int mode = op.pscaler ? g.scale_mode : 0;
   const unsigned fragoff = row * 4u + (lane & 3u);
-  unsigned h = (blockIdx.x * 4u + wave) * halves_per_wave;
-  const unsigned h1 = min(h + halves_per_wave, nhalves);
+  const unsigned h1 = h + count;
   const unsigned hfirst = h < nhalves ? h : nhalves - 1u; // (a wave without work requests like the others and leaves behind the barrier)
   wide_d2 x[NGJ + TAIL];
   {
@@ -273,10 +287,10 @@ __global__ __launch_bounds__(256, 2) void k_partials_mfma_wide(const OpPack pack
   {
     double *const dst[2] = {PL, PR};
     const double *const src[2] = {op.lmat + (size_t)k * S * g.SPT, op.rmat + (size_t)k * S * g.SPT};
-    mfma_stage<16, 2>(dst, src, S, g.SPT);
+    mfma_stage<16, 2, 64u * WAVES>(dst, src, S, g.SPT);
   }
   __syncthreads();
-  if (h >= nhalves) return; // no barriers below
+  if (count == 0u) return; // no barriers below
   for (; h < h1; ++h)
   {
     const unsigned hn = h + 1u < h1 ? h + 1u : h; // behind the last item: the same item again (loads nobody uses)

@@ -920,18 +920,33 @@ static void launch_gg(pllgpu_ctx *c, const GGPack &pack, unsigned ngroups, unsig
 // k_partials_mfma_wide counts its own vector-memory operations (kernels_mfma_wide.h): a register spilled to scratch
 // would be one the count does not know about. The build is checked once per process; a compiler that spills sends the
 // shape back to the first-generation kernel (and says so).
-static bool wide_kernel_is_sound(bool exact61)
+template <int NGJ, int TAIL, int WAVES>
+static bool wide_kernel_is_sound()
 {
-  static int state[2] = {-1, -1};
-  int &st = state[exact61 ? 1 : 0];
+  static int st = -1;
   if (st < 0)
   {
     hipFuncAttributes at;
-    const void *fn = exact61 ? (const void *)k_partials_mfma_wide<15, 1> : (const void *)k_partials_mfma_wide<16, 0>;
-    st = (hipFuncGetAttributes(&at, fn) == hipSuccess && at.localSizeBytes == 0) ? 1 : 0;
+    st = (hipFuncGetAttributes(&at, (const void *)k_partials_mfma_wide<NGJ, TAIL, WAVES>) == hipSuccess && at.localSizeBytes == 0) ? 1 : 0;
     if (!st) fprintf(stderr, "libpll_amd: k_partials_mfma_wide was built with scratch memory; using k_partials_mfma instead\n");
   }
   return st == 1;
+}
+
+// One round of workgroups, one (8 waves) or two (4 waves) per CU; every (op, rate category) gets the same number of
+// them and cuts its half tiles into that many runs.
+template <int NGJ, int TAIL, int WAVES>
+static bool launch_wide(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned halves, unsigned char *fb, unsigned fstride)
+{
+  if (!wide_kernel_is_sound<NGJ, TAIL, WAVES>()) return false;
+  const unsigned R = c->gg.R, max_wgs = 2048u / WAVES;
+  const unsigned per_pair = std::max(1u, max_wgs / (nops * R));
+  const unsigned hw = std::max(1u, (halves + per_pair - 1) / per_pair);
+  dim3 grid((halves + hw - 1) / hw, nops, R), block(64 * WAVES);
+  const size_t lds = MfmaGeo<16>::lds_doubles * sizeof(double);
+  raise_lds_limit((const void *)k_partials_mfma_wide<NGJ, TAIL, WAVES>, c->device, lds);
+  hipLaunchKernelGGL((k_partials_mfma_wide<NGJ, TAIL, WAVES>), grid, block, lds, c->stream, pack, c->gg, hw, fb, fstride);
+  return true;
 }
 
 template <int NG>
@@ -939,39 +954,29 @@ static int launch_mfma_t(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsig
 {
   const unsigned R = c->gg.R;
   const unsigned items = (maxent + 31) / 32; // 32 sites per item
-  if (NG == 16 && kind == 0 && !gather && c->mfma_wide && wide_kernel_is_sound(c->gg.S == 61 && !c->mfma_pad))
+  if (NG == 16 && kind == 0 && !gather && c->mfma_wide)
   {
     // 33..64 states, inner x inner, tiled CLVs: the second-generation kernel (kernels_mfma_wide.h). Work is dealt in
-    // half tiles: every SIMD gets two waves and every wave the same number of half tiles, give or take one; ONE round
-    // of workgroups (two per CU: 70 KB of fragments each).
-    const unsigned max_wgs = 512u;
-    const size_t total = (size_t)items * nops * R;
-    unsigned hpw = (unsigned)std::max<size_t>(1, (total + 4u * max_wgs - 1) / (4u * max_wgs));
-    while ((size_t)((items + 4u * hpw - 1) / (4u * hpw)) * nops * R > max_wgs) ++hpw;
-    dim3 grid((items + 4 * hpw - 1) / (4 * hpw), nops, R), block(256);
-    const size_t lds = MfmaGeo<16>::lds_doubles * sizeof(double);
+    // half tiles: every SIMD gets two waves and the pair the same number of half tiles, give or take one
     bool scaling = false;
     for (unsigned i = 0; i < nops; ++i) scaling = scaling || pack.ops[i].pscaler != nullptr;
     scaling = scaling && c->gg.scale_mode != 0;
     const unsigned fstride = (maxent + 63u) & ~63u;
     if (c->mfma_flags.ensure(std::max<size_t>(64, scaling ? (size_t)kMaxOpsPerLaunch * R * fstride : 0))) return PLLGPU_ENOMEM;
     unsigned char *fb = c->mfma_flags.p;
-    if (c->gg.S == 61 && !c->mfma_pad)
+    const bool exact61 = c->gg.S == 61 && !c->mfma_pad;
+    // (8-wave workgroups, one per CU: against two of 4 waves the matrices are staged once per CU and a SIMD's two waves
+    // split an odd share - C5's 2-op launch 66 -> 58 us, the step 0.549 -> 0.537 ms, profiles/README.md round 3)
+    const bool done = exact61 ? launch_wide<15, 1, 8>(c, pack, nops, items, fb, fstride) : launch_wide<16, 0, 8>(c, pack, nops, items, fb, fstride);
+    if (done)
     {
-      raise_lds_limit((const void *)k_partials_mfma_wide<15, 1>, c->device, lds);
-      hipLaunchKernelGGL((k_partials_mfma_wide<15, 1>), grid, block, lds, c->stream, pack, c->gg, hpw, fb, fstride);
+      if (scaling)
+      {
+        dim3 eg((maxent + 255) / 256, nops);
+        hipLaunchKernelGGL((k_mfma_scale_epilogue<false>), eg, dim3(256), 0, c->stream, pack, c->gg, fb, fstride);
+      }
+      return 0;
     }
-    else
-    {
-      raise_lds_limit((const void *)k_partials_mfma_wide<16, 0>, c->device, lds);
-      hipLaunchKernelGGL((k_partials_mfma_wide<16, 0>), grid, block, lds, c->stream, pack, c->gg, hpw, fb, fstride);
-    }
-    if (scaling)
-    {
-      dim3 eg((maxent + 255) / 256, nops);
-      hipLaunchKernelGGL((k_mfma_scale_epilogue<false>), eg, dim3(256), 0, c->stream, pack, c->gg, fb, fstride);
-    }
-    return 0;
   }
   // aim at two workgroups of four waves on every CU (2048 waves) - four where the small shapes leave room;
   // more work -> more items per wave

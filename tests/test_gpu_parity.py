@@ -831,13 +831,14 @@ def test_matrix_pipe_kernels_for_all_group_counts(amd_lib, kw, monkeypatch):
                                 dict(states=61, tips=64, sites=260, seed=424, tree="caterpillar", brlen_scale=8),  # deep: per-site rescaling
                                 dict(states=61, tips=64, sites=260, seed=425, tree="caterpillar", brlen_scale=8, attributes=api.RATE_SCALERS),
                                 dict(states=64, tips=8, sites=4100, seed=426), dict(states=48, tips=8, sites=4100, seed=427),
-                                dict(states=33, tips=16, sites=700, seed=428)], ids=_id)
+                                dict(states=33, tips=16, sites=700, seed=428),
+                                dict(states=61, tips=8, sites=2500, seed=429)], ids=_id)                         # 5 / 7 half tiles per workgroup: uneven wave pairs
 def test_wide_matrix_pipe_kernel(amd_lib, kw, monkeypatch):
     """k_partials_mfma_wide (kernels_mfma_wide.h), the inner x inner kernel of 33..64 states: lanes own adjacent sites
     (16-byte loads and stores), hand-counted load waits, and 61 states contract over 15 full groups on the matrix pipe
     with the 61st column as the chains' initial value. Against the oracle (CLVs, scalers, lnL) in every form; the padded
     form (64-state contraction) is bit-identical to the first-generation kernel. Site counts: one half tile per wave,
-    several (the counted waits cross the loop's back edge), ragged last tiles."""
+    several (the counted waits cross the loop's back edge), ragged last tiles, uneven shares inside a workgroup."""
     kw = dict(kw)
     tips_as = kw.pop("tips_as", None)
     case = W.make_case("wide", **kw)
@@ -855,10 +856,10 @@ def test_wide_matrix_pipe_kernel(amd_lib, kw, monkeypatch):
             assert sum(int(v.sum()) for v in got[wide, pad]["scaler"].values()) > 0
             assert scalers_equal(got[wide, pad], exp)
     old = got["0", "0"]
-    for key in (("1", "1"),) + ((("1", "0"),) if case.states != 61 else ()):
-        assert got[key]["lnl"] == old["lnl"], key
-        for c in old["clv"]:
-            assert np.array_equal(got[key]["clv"][c], old["clv"][c]), (key, c)
+    for key, ref in [(("1", "1"), old)] + ([(("1", "0"), old)] if case.states != 61 else []):
+        assert got[key]["lnl"] == ref["lnl"], key
+        for c in ref["clv"]:
+            assert np.array_equal(got[key]["clv"][c], ref["clv"][c]), (key, c)
 
 
 def test_partitions_in_concurrent_threads(amd_lib):
