@@ -388,11 +388,14 @@ __global__ __launch_bounds__(256) void k_mfma_scale_epilogue(const OpPack pack, 
   const unsigned char *f = flagbuf + (size_t)blockIdx.y * R * flag_stride + n;
   if (g.scale_mode == 1)
   {
+    // (the children's counts are requested before the flags are looked at: one memory round trip, not two - the
+    // kernel is nothing but latency, 4 of them per 61-state traversal)
+    const unsigned below = (op.lscaler ? op.lscaler[le] : 0u) + (op.rscaler ? op.rscaler[re] : 0u);
     bool all = true;
     for (unsigned k = 0; k < R; ++k) all = all && f[(size_t)k * flag_stride];
     if (all)
       for (unsigned q = 0; q < R * S; ++q) base[(size_t)q * 64] *= PLLGPU_SCALE_FACTOR;
-    op.pscaler[n] = (op.lscaler ? op.lscaler[le] : 0u) + (op.rscaler ? op.rscaler[re] : 0u) + (all ? 1u : 0u);
+    op.pscaler[n] = below + (all ? 1u : 0u);
   }
   else
   {

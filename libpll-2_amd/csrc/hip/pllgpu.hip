@@ -141,7 +141,7 @@ struct pllgpu_ctx
   bool no_tip_columns = false;   // PLL_AMD_NO_TIP_COLUMNS=1: tips always through the FMA contraction
   bool no_par_lds = false;       // PLL_AMD_NO_PARENT_LDS=1 (A/B): entry-contiguous parents stored 8 bytes per lane
   bool no_coop_fetch = false;    // PLL_AMD_NO_COOP_FETCH=1 (A/B): the FMA kernels' entry-contiguous children fetched per lane
-  size_t stream_parent_bytes = (size_t)256 << 20; // PLL_AMD_STREAM_PARENT_MB overrides (experiments)
+  size_t stream_parent_bytes = (size_t)256 << 20; // parents of a grouped launch beyond this leave with streaming stores (the Infinity Cache)
   bool defer_tail = false;       // DNA: hold the traversal's last ops for one call (k_edge_dna_tail)
   std::vector<pllgpu_op_t> deferred; // ops accepted by pllgpu_update_partials and not launched yet
   bool fuse_cc = false;          // DNA: also two producer levels under a group parent (cherry-cherry children)
@@ -161,7 +161,6 @@ struct pllgpu_ctx
   int fenced = 0;                   // PLL_AMD_FENCED_HANDOFF=1 (kernels_common.h: handoff_*)
   unsigned long long plan_stamp = 0;
   bool plan_cache = true;           // PLL_AMD_NO_PLAN_CACHE=1 plans every call afresh
-  int gather_stream = 0;            // PLL_AMD_GATHER_STREAM: 1 always streaming loads from compressed children, -1 never, 0 by size
   DevBuf<unsigned char> cherry_bits; // k_cherry_bits: which cherry entries are rescaled, [slot][rate][pair of tip codes]
   struct CherrySlot
   {
@@ -173,7 +172,6 @@ struct pllgpu_ctx
   unsigned tip_ncodes = 0;          // codes in use: 1 + the highest code with a non-empty mask
   bool generic_aos = true;          // PLL_AMD_NO_GENERIC_AOS=1: compressed nodes of non-4x4 shapes stay tiled (A/B)
   bool lean = false;                // 17..20 states, <= 4 rates: the level launches on the matrix pipe (kernels_lean.h)
-  bool lean_plain = false;          // ... also the ones that do not gather (PLL_AMD_LEAN_PLAIN=1)
   bool fuse_mfma = false;           // 17..32 states on the matrix pipe: the same groups (kernels_mfma.h: k_partials_mfma_cc)
   bool subtrees = false;            // DNA + site repeats: all-tip subtrees straight from the tip codes (subtree_plan.h)
   DevBuf<unsigned char> sub_dev;    // their descriptors on the device ...
@@ -288,14 +286,12 @@ static void derive_geometry(pllgpu_ctx *c)
   c->defer_tail = c->dna_fast;
   if (const char *v = getenv("PLL_AMD_NO_TAIL_FUSION"))
     if (*v && *v != '0') c->defer_tail = false;
-  if (const char *v = getenv("PLL_AMD_STREAM_PARENT_MB")) c->stream_parent_bytes = (size_t)atol(v) << 20;
   c->fuse_cc = c->fuse;
   if (const char *v = getenv("PLL_AMD_NO_FUSE_CC"))
     if (*v && *v != '0') c->fuse_cc = false;
   c->chains = c->fuse;
   if (const char *v = getenv("PLL_AMD_NO_CHAINS"))
     if (*v && *v != '0') c->chains = false;
-  if (const char *v = getenv("PLL_AMD_GATHER_STREAM")) c->gather_stream = atoi(v);
   if (const char *v = getenv("PLL_AMD_NO_GENERIC_AOS"))
     if (*v && *v != '0') c->generic_aos = false;
   if (const char *v = getenv("PLL_AMD_FENCED_HANDOFF"))
@@ -333,8 +329,6 @@ static void derive_geometry(pllgpu_ctx *c)
   c->lean = !c->dna_fast && !c->use_mfma && g.states >= 17 && g.states <= 20 && g.rate_cats <= 4;
   if (const char *v = getenv("PLL_AMD_NO_LEAN")) // A/B switch: the scalar-fed FMA kernels for these shapes
     if (*v && *v != '0') c->lean = false;
-  if (const char *v = getenv("PLL_AMD_LEAN_PLAIN"))
-    c->lean_plain = *v && *v != '0';
   c->pm_stride = (size_t)g.rate_cats * g.states * gg.SPT;
   c->span = g.rate_cats * g.states_padded;
 }
@@ -746,8 +740,8 @@ static int resolve_op(pllgpu_ctx *c, const pllgpu_op_t &o, DevOp &d)
   if (d.layout && !(o.flags & PLLGPU_OP_GATHER)) return fail(PLLGPU_EINVAL, "a class-compressed CLV met an operation without the gather flag");
   // a compressed child with about as many entries as the parent is read once per entry: streaming loads;
   // a much smaller one is a table the parent's tiles keep coming back to: cacheable loads
-  if ((d.layout & kAosLeft) && c->gather_stream >= 0 && (c->gather_stream > 0 || (size_t)c->ids[o.left_clv] * 2u > o.parent_entries)) d.layout |= kStreamLeft;
-  if ((d.layout & kAosRight) && c->gather_stream >= 0 && (c->gather_stream > 0 || (size_t)c->ids[o.right_clv] * 2u > o.parent_entries)) d.layout |= kStreamRight;
+  if ((d.layout & kAosLeft) && (size_t)c->ids[o.left_clv] * 2u > o.parent_entries) d.layout |= kStreamLeft;
+  if ((d.layout & kAosRight) && (size_t)c->ids[o.right_clv] * 2u > o.parent_entries) d.layout |= kStreamRight;
   if (o.flags & PLLGPU_OP_LEFT_TIP)
   {
     if (o.left_clv >= g.tips || !c->tipchars[o.left_clv].p) return fail(PLLGPU_EINVAL, "tip %u has no codes on the device", o.left_clv);
@@ -983,7 +977,6 @@ static int launch_mfma_t(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsig
   const unsigned want = NG > 8 ? 2048u : 4096u;
   unsigned ipw = (unsigned)(((size_t)items * nops * R + want - 1) / want);
   ipw = std::max(1u, std::min(ipw, NG > 8 ? ~0u : 8u));
-  if (const char *ev = getenv("PLL_AMD_MFMA_IPW")) ipw = std::max(1, atoi(ev));
   dim3 grid((items + 4 * ipw - 1) / (4 * ipw), nops, R), block(256);
   const size_t lds = MfmaGeo<NG>::lds_doubles * sizeof(double);
   const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
@@ -1033,7 +1026,6 @@ static int launch_mfma_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroup
   const unsigned want = 4096u;
   unsigned ipw = (unsigned)(((size_t)items * ngroups * R + want - 1) / want);
   ipw = std::max(1u, std::min(ipw, 8u));
-  if (const char *ev = getenv("PLL_AMD_MFMA_IPW")) ipw = std::max(1, atoi(ev));
   dim3 grid((items + 4 * ipw - 1) / (4 * ipw), ngroups, R), block(256);
   const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
   const unsigned ncodes = c->tip_ncodes;
@@ -1112,8 +1104,7 @@ static int launch_mfma_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroup
   if (scaling && c->mfma_flags.ensure((size_t)kMaxOpsPerLaunch * R * fstride)) return PLLGPU_ENOMEM;
   raise_lds_limit((const void *)k_partials_mfma_cc<NG>, c->device, lds);
   // parents beyond what the Infinity Cache keeps for the next level: streamed out like the cherries (as the 4x4 groups do)
-  unsigned stream_parent = ((size_t)ngroups * entries * S * R * 8u > c->stream_parent_bytes) ? 1u : 0u;
-  if (const char *ev = getenv("PLL_AMD_CC_STREAM_PARENT")) stream_parent = atoi(ev) != 0;
+  const unsigned stream_parent = ((size_t)ngroups * entries * S * R * 8u > c->stream_parent_bytes) ? 1u : 0u;
   hipLaunchKernelGGL((k_partials_mfma_cc<NG>), grid, block, lds, c->stream, pack, c->gg, tm, entries, ipw, c->mfma_flags.p, fstride,
                      c->cherry_bits.p, slots, ncodes, stream_parent);
   if (scaling)
@@ -1150,7 +1141,6 @@ static int launch_lean(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigne
   // a tip x tip item is two dozen LDS reads and five stores: staging has to be spread over more of them (C3's 32 cherries:
   // 295 / 240 / 205 / 204 / 254 us with 2 / 8 / 16 / 32 / 64 items per workgroup)
   if (kind == 2 && !gather) ipb = std::max(2u, std::min((unsigned)(((size_t)items * nops) / 1536u), 32u));
-  if (const char *ev = getenv("PLL_AMD_LEAN_IPB")) ipb = std::max(1, atoi(ev));
   dim3 grid((items + ipb - 1) / ipb, nops), block(64u * R);
   const size_t lds = LeanGeo<5>::lds_bytes(R, gather);
   if (gather)
@@ -1182,7 +1172,7 @@ static int launch_lean(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigne
 // (the rule unless PLL_AMD_NO_GENERIC_AOS=1), states_padded = 20
 static bool lean_serves(const pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned kind, bool gather)
 {
-  if (!gather) return c->lean_plain || kind == 2; // tip x tip: 204 us against the FMA kernel's 251 for C3's 32 cherries (same box)
+  if (!gather) return kind == 2; // tip x tip: 204 us against the FMA kernel's 251 for C3's 32 cherries (same box)
   if (c->gg.SP != 20u) return false;
   for (unsigned i = 0; i < nops; ++i)
   {
