@@ -234,6 +234,8 @@ double *pllgpu_reduce_buffer(pllgpu_ctx_t *ctx);
  * pair to mapped host memory (value first, sequence word behind it) and the call polls for
  * expected_sequence (= ranks x the sequence every rank used). Synchronises only on time-out. */
 int pllgpu_reduce_fetch(pllgpu_ctx_t *ctx, double expected_sequence, double *value_out);
+/* a rank whose evaluation failed: {-inf, sequence} as its operand, so that it still takes part in the collective */
+int pllgpu_reduce_poison(pllgpu_ctx_t *ctx, double sequence);
 
 /* ---- stream / timing ---------------------------------------------------------------------- */
 int pllgpu_set_stream(pllgpu_ctx_t *ctx, void *hip_stream);

@@ -2170,6 +2170,23 @@ extern "C" double *pllgpu_reduce_buffer(pllgpu_ctx_t *c)
   return c->reduce.p;
 }
 
+// a rank whose evaluation failed still brings an operand to the collective (-inf poisons the sum: every rank learns
+// of the failure instead of waiting inside the all-reduce)
+__global__ void k_set_pair(double *__restrict__ pair, double value, double sequence)
+{
+  pair[0] = value;
+  pair[1] = sequence;
+}
+
+extern "C" int pllgpu_reduce_poison(pllgpu_ctx_t *c, double sequence)
+{
+  CHECK_CTX(c);
+  if (!c->reduce.p) return fail(PLLGPU_EINVAL, "no reduce buffer");
+  hipLaunchKernelGGL(k_set_pair, dim3(1), dim3(1), 0, c->stream, c->reduce.p, -HUGE_VAL, sequence);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // value, then - once the value has been performed - the sequence word: the order the host's poll relies on
 __global__ void k_publish_pair(const double *__restrict__ pair, double *__restrict__ host)
 {

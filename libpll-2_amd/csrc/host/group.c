@@ -15,6 +15,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <math.h>
+#include <pthread.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
@@ -225,25 +226,29 @@ typedef int (*nccl_count_fn)(const void *, int *);
 typedef const char *(*nccl_errstr_fn)(int);
 static struct
 {
-  int tried;
   void *handle;
   nccl_allreduce_fn allreduce;
   nccl_count_fn count;
   nccl_errstr_fn errstr;
 } g_rccl;
 
-static int rccl_bind(void)
+static void rccl_bind_once(void)
 {
-  if (g_rccl.tried) return g_rccl.allreduce != NULL;
-  g_rccl.tried = 1;
   const char *names[] = {getenv("PLL_AMD_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (size_t i = 0; i < sizeof names / sizeof *names && !g_rccl.handle; ++i)
     if (names[i] && names[i][0]) g_rccl.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
-  if (!g_rccl.handle) return 0;
+  if (!g_rccl.handle) return;
   g_rccl.allreduce = (nccl_allreduce_fn)dlsym(g_rccl.handle, "ncclAllReduce");
   g_rccl.count = (nccl_count_fn)dlsym(g_rccl.handle, "ncclCommCount");
   g_rccl.errstr = (nccl_errstr_fn)dlsym(g_rccl.handle, "ncclGetErrorString");
   if (!g_rccl.allreduce || !g_rccl.count) g_rccl.allreduce = NULL;
+}
+
+/* (partitions may be driven from concurrent threads: the library is bound once) */
+static int rccl_bind(void)
+{
+  static pthread_once_t once = PTHREAD_ONCE_INIT;
+  pthread_once(&once, rccl_bind_once);
   return g_rccl.allreduce != NULL;
 }
 
@@ -312,14 +317,30 @@ double pll_gpu_edge_loglikelihood_allreduce(pll_partition_t *p, void *comm, unsi
   }
   /* the ranks number their collective evaluations in step: the reduced sequence word is ranks x step */
   x->reduce_step += 1.0;
-  if (!pll_gpu_edge_loglikelihood_numbered(p, parent_clv_index, parent_scaler_index, child_clv_index, child_scaler_index,
-                                           matrix_index, freqs_indices, pair, x->reduce_step))
-    return -INFINITY;
+  /* a rank whose evaluation failed still takes part, as in pll_gpu_group_edge_loglikelihood: its operand is -inf and
+   * every rank returns -inf, nobody is left waiting inside the collective */
+  const int mine_ok = pll_gpu_edge_loglikelihood_numbered(p, parent_clv_index, parent_scaler_index, child_clv_index,
+                                                          child_scaler_index, matrix_index, freqs_indices, pair, x->reduce_step);
+  const int my_errno = pll_errno;
+  char my_errmsg[sizeof pll_errmsg];
+  memcpy(my_errmsg, pll_errmsg, sizeof my_errmsg);
+  if (!mine_ok && pllgpu_reduce_poison(x->ctx, x->reduce_step) != 0) return -INFINITY; /* (the device is gone: nothing to send) */
   if (!pll_gpu_allreduce_lnl(p, comm, pair, 2)) return -INFINITY;
   double sum = -INFINITY;
   if (pllgpu_reduce_fetch(x->ctx, x->reduce_step * ranks, &sum) != 0)
   {
     pll_set_gpu_error("pll_gpu_edge_loglikelihood_allreduce");
+    return -INFINITY;
+  }
+  if (!mine_ok)
+  {
+    pll_errno = my_errno;
+    memcpy(pll_errmsg, my_errmsg, sizeof my_errmsg);
+    return -INFINITY;
+  }
+  if (!isfinite(sum))
+  {
+    pll_set_error(PLL_ERROR_GPU_RUNTIME, "pll_gpu_edge_loglikelihood_allreduce: another rank's evaluation failed");
     return -INFINITY;
   }
   return sum;

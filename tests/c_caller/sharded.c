@@ -109,6 +109,16 @@ static int rccl_main(void)
   double lnl = 0;
   for (int step = 0; step < 5; ++step)
     lnl = pll_gpu_edge_loglikelihood_allreduce(p, comm, 6, PLL_SCALE_BUFFER_NONE, 7, PLL_SCALE_BUFFER_NONE, 0, params);
+  /* a failing evaluation still takes part in the collective (operand -inf), reports the rank's own error, and the
+   * next collective evaluation is in step again */
+  const double failed = pll_gpu_edge_loglikelihood_allreduce(p, comm, 6, PLL_SCALE_BUFFER_NONE, 99, PLL_SCALE_BUFFER_NONE, 0, params);
+  const int failed_errno = pll_errno;
+  if (isfinite(failed) || failed_errno != PLL_ERROR_PARAM_INVALID)
+  {
+    fprintf(stderr, "a bad CLV index gave %g, errno %d\n", failed, failed_errno);
+    return 6;
+  }
+  lnl = pll_gpu_edge_loglikelihood_allreduce(p, comm, 6, PLL_SCALE_BUFFER_NONE, 7, PLL_SCALE_BUFFER_NONE, 0, params);
   const double plain = pll_compute_edge_loglikelihood(p, 6, PLL_SCALE_BUFFER_NONE, 7, PLL_SCALE_BUFFER_NONE, 0, params, NULL);
   printf("rccl lnl %.6f plain %.6f\n", lnl, plain);
   if (!isfinite(lnl)) fprintf(stderr, "[%d] %s\n", pll_errno, pll_errmsg);
