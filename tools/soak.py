@@ -1,5 +1,5 @@
 """Soak: many partition lifecycles and hot-path calls in one process; device memory before / after
-(leaks), results stable. python tools/soak.py"""
+(leaks), results stable. python tools/soak.py [cycles]"""
 import ctypes as C
 import os
 import sys
@@ -30,7 +30,8 @@ with driver.Session(lib, cases[0], api.ARCH_AVX2) as s:  # warm the runtime
 start = free_mb()
 ref = {}
 t0 = time.perf_counter()
-for it in range(60):
+CYCLES = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+for it in range(CYCLES):
     for ci, case in enumerate(cases):
         with driver.Session(lib, case, api.ARCH_AVX2) as s:
             for _ in range(20):
