@@ -1022,7 +1022,9 @@ typedef const SubItem __attribute__((address_space(4))) *csubitem_p;
 // decision (SM 1): one ballot exchange through LDS per LEVEL of the subtree (three barriers).
 // (Round 3 tried the matrices through LDS instead of the scalar path - every op's pair requested at once with vector
 // loads by lanes 0-31 of the rate's wave, coefficients read back as broadcasts: a shard's launch 27 -> 35 us. The
-// scalar path is not what a workgroup's 12 us are made of; removed.)
+// scalar path is not what a workgroup's 12 us are made of; removed. Nor is the launch about workgroup count or scalar-cache
+// locality: two tiles per workgroup 27 -> 30 us, the tiles dealt to the eight XCDs in contiguous eighths 27.0 -> 27.7 us.
+// Counters: 49 scalar loads per wave, 36 % of them missing the scalar cache, waves waiting 53 % of their cycles.)
 template <int SM>
 __device__ __forceinline__ void dna_sub_level(csubitem_p it, unsigned node_mask, unsigned scaler_mask, unsigned rate, int first, int count,
                                               const double (*below)[4], const unsigned *sc_below, const unsigned (&code)[15], double (*out)[4],
