@@ -77,3 +77,31 @@ def test_a_name_in_use_with_another_size_is_refused():
         pass
     assert "error" in ob and "exists with 2 ranks" in ob["error"], ob
     assert "error" in oa, oa
+
+
+def test_a_finished_run_removes_its_name_and_a_stale_segment_is_refused():
+    """the last rank to leave unlinks the segment; one that a crashed run of the SAME size left behind (its ranks
+    counted as joined) is refused by the next run under that name instead of being silently reused"""
+    name = "/pllamd-test-" + uuid.uuid4().hex[:12]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "group_worker.py"), name, str(r), "2", "3", "1", "20000"],
+                              stdout=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [json.loads(p.communicate(timeout=120)[0].strip().splitlines()[-1]) for p in procs]
+    assert all("error" not in o for o in outs), outs
+    assert not os.path.exists("/dev/shm" + name)
+    # the header of a run of two ranks that never left: {magic, size = 2, joined = 2, left = 0} (csrc/host/group.c)
+    stale = bytearray(64 + 2 * 2 * 64)
+    stale[0:8] = (0x504c4c4752503031).to_bytes(8, "little")
+    stale[8:12] = (2).to_bytes(4, "little")
+    stale[12:16] = (2).to_bytes(4, "little")
+    with open("/dev/shm" + name, "wb") as f:
+        f.write(stale)
+    try:
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "group_worker.py"), name, str(r), "2", "1", "1", "1500"],
+                                  stdout=subprocess.PIPE, text=True) for r in range(2)]
+        outs = [json.loads(p.communicate(timeout=60)[0].strip().splitlines()[-1]) for p in procs]
+        assert all("error" in o and "stale" in o["error"] for o in outs), outs
+    finally:
+        try:
+            os.unlink("/dev/shm" + name)
+        except OSError:
+            pass
