@@ -27,12 +27,13 @@
 //   behind a wave's last item the "next" item is that item again - and NO register may be spilled (a scratch access is
 //   a memory operation the count does not know): the host checks the built kernel and falls back to k_partials_mfma
 //   if the compiler ever does (pllgpu.hip: wide_kernel_is_sound).
-// * Work is dealt in half tiles (32 entries): two waves per SIMD on every SIMD of the chip in one round, each with the
-//   same number of half tiles give or take one (2 ops x 20 000 sites x 4 rates = 5000 half tiles over 2048 waves).
+// * Work is dealt in half tiles (32 entries): ONE workgroup of eight waves per CU (the matrices are staged once per CU),
+//   one round; the two waves of a SIMD split the SIMD's share, so an odd share costs nobody a whole item (2 ops x
+//   20 000 sites x 4 rates = 5000 half tiles over 1024 SIMDs: 5 item times, not the 2 x 3 of equal shares per wave).
 //
 // What bounds it: ENERGY. tools/mfma61_probe.hip: this loop's MFMAs + LDS reads alone run at 76 TF and 2.39 GHz; with
-// the kernel's HBM streams beside them (5.3 TB/s) the chip holds 1.97 GHz and 55 TF. C5's launches: 45 TF (0.57 of
-// the 78.6 TF the matrix pipe has at 2.4 GHz, 0.82 of what the probe reaches under the same memory load). Taking work
+// the kernel's HBM streams beside them (5.3 TB/s) the chip holds 1.97 GHz and 55 TF. C5's launches: 45-47.5 TF (0.58-0.60
+// of the 78.6 TF the matrix pipe has at 2.4 GHz, 0.82-0.86 of what the probe reaches under the same memory load). Taking work
 // away (tools/r3_wide_experiments.sh; results wrong on purpose): children served from cache - no change; a quarter
 // of the MFMAs gone - 12 % less time; 6 % of the MFMAs moved to the vector ALU (the 61st parent state) - no change;
 // no store drain at the top of an item - 3.5 % fewer wave cycles, the same time. Cycles saved come back as clock lost.
