@@ -246,7 +246,13 @@ def spawn_ranks(args):
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
     worst, line = 0, None
     pending = set(range(args.gpus))
+    deadline = time.monotonic() + float(os.environ.get("PLL_BENCH_TIMEOUT_S", "1500"))
     while pending:
+        if time.monotonic() > deadline:  # ranks that wait for each other forever must not keep the launcher forever
+            print(f"bench.py: ranks {sorted(pending)} still running at the launcher's time limit; stopping them", file=sys.stderr)
+            for q in pending:  # exactly the children started here, by pid
+                procs[q].kill()
+            return worst or 124
         for r in sorted(pending):
             rc = procs[r].poll()
             if rc is None:
