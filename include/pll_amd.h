@@ -557,7 +557,9 @@ double pll_gpu_group_edge_loglikelihood(pll_partition_t *partition, pll_gpu_grou
 int pll_gpu_allreduce_lnl(pll_partition_t *partition, void *nccl_comm, double *device_values, unsigned int count);
 /* the whole step without a host round trip before the exchange: the shard's log-likelihood stays in
  * device memory, is all-reduced there and only the sum comes back. Collective: every rank of the
- * communicator calls it, the same number of times. Returns the sum, -inf on failure. */
+ * communicator calls it, the same number of times. Returns the sum, -inf on failure. A rank whose own
+ * evaluation fails still takes part (its operand is -inf): every rank returns -inf - that rank with its own
+ * pll_errno, the others with PLL_ERROR_GPU_RUNTIME - and nobody is left waiting inside the collective. */
 double pll_gpu_edge_loglikelihood_allreduce(pll_partition_t *partition, void *nccl_comm,
                                             unsigned int parent_clv_index, int parent_scaler_index,
                                             unsigned int child_clv_index, int child_scaler_index,
