@@ -231,20 +231,40 @@ def free_port():
         return sk.getsockname()[1]
 
 
-def spawn_ranks(args):
+def spawn_ranks(args, command=None):
     """--gpus N > 1 without a launcher: this process becomes the launcher. It starts N children of this very
     command line (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous), relays rank 0's stdout
-    - the one JSON line - and returns the worst exit code. It never touches the GPU (nor imports torch)."""
+    - the one JSON line - and returns the worst exit code. It never touches the GPU (nor imports torch).
+    (`command`: what a rank runs instead of this file - tests/test_bench_launcher.py.)"""
     import subprocess
+    command = command or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     port = os.environ.get("MASTER_PORT") or str(free_port())
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    worst, line = 0, None
+        procs.append(subprocess.Popen(command, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    # rank 0's stdout is drained while it runs: a child that writes more than a pipe buffer (a long line, library
+    # diagnostics on stdout) would otherwise block in write() and the launcher sit out its whole time limit (ADVICE r3)
+    import threading
+    chunks = []
+
+    def drain():
+        for piece in iter(lambda: procs[0].stdout.read(65536), b""):
+            chunks.append(piece)
+
+    reader = threading.Thread(target=drain, daemon=True)
+    reader.start()
+
+    def relay():
+        reader.join(timeout=10)
+        text = b"".join(chunks).decode(errors="replace")
+        if text:
+            sys.stdout.write(text)
+            sys.stdout.flush()
+
+    worst = 0
     pending = set(range(args.gpus))
     deadline = time.monotonic() + float(os.environ.get("PLL_BENCH_TIMEOUT_S", "1500"))
     while pending:
@@ -252,23 +272,25 @@ def spawn_ranks(args):
             print(f"bench.py: ranks {sorted(pending)} still running at the launcher's time limit; stopping them", file=sys.stderr)
             for q in pending:  # exactly the children started here, by pid
                 procs[q].kill()
+            for q in pending:  # ... reaped, so that none is left a zombie and rank 0's pipe reaches its end
+                try:
+                    procs[q].wait(timeout=30)
+                except subprocess.TimeoutExpired:
+                    print(f"bench.py: rank {q} (pid {procs[q].pid}) did not die within 30 s of SIGKILL", file=sys.stderr)
+            relay()  # whatever rank 0 had printed is evidence, not something to drop
             return worst or 124
         for r in sorted(pending):
             rc = procs[r].poll()
             if rc is None:
                 continue
             pending.discard(r)
-            if r == 0:
-                line = procs[0].stdout.read().decode()
             if rc != 0:
                 worst = worst or rc
                 print(f"bench.py: rank {r} exited with {rc}; stopping the others", file=sys.stderr)
                 for q in pending:  # exactly the children started here, by pid
                     procs[q].terminate()
         time.sleep(0.05)
-    if line:
-        sys.stdout.write(line)
-        sys.stdout.flush()
+    relay()
     return worst
 
 

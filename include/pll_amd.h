@@ -555,11 +555,21 @@ double pll_gpu_group_edge_loglikelihood(pll_partition_t *partition, pll_gpu_grou
 /* enqueue ncclAllReduce(device_values, device_values, count, ncclDouble, ncclSum, comm) on the
  * partition's stream (count doubles of DEVICE memory, e.g. what pll_gpu_edge_loglikelihood_async left) */
 int pll_gpu_allreduce_lnl(pll_partition_t *partition, void *nccl_comm, double *device_values, unsigned int count);
+/* set-up of a (partition, communicator) pair, once: binds librccl, asks ncclCommCount, reserves the 16-byte operand
+ * in device memory. Everything that can fail before a collective is enqueued fails HERE - call it on every rank
+ * after creating the communicator and agree on the results before the first collective evaluation
+ * (pll_gpu_edge_loglikelihood_allreduce calls it itself when it meets a new communicator, but a rank that fails
+ * there has not joined the collective its peers are in). PLL_SUCCESS / PLL_FAILURE + pll_errno. */
+int pll_gpu_allreduce_prepare(pll_partition_t *partition, void *nccl_comm);
 /* the whole step without a host round trip before the exchange: the shard's log-likelihood stays in
  * device memory, is all-reduced there and only the sum comes back. Collective: every rank of the
- * communicator calls it, the same number of times. Returns the sum, -inf on failure. A rank whose own
- * evaluation fails still takes part (its operand is -inf): every rank returns -inf - that rank with its own
- * pll_errno, the others with PLL_ERROR_GPU_RUNTIME - and nobody is left waiting inside the collective. */
+ * communicator calls it, the same number of times. Returns the sum, -inf on failure. Once the pair is
+ * prepared, a rank whose own evaluation fails still takes part (its operand is -inf): every rank returns
+ * -inf - that rank with its own pll_errno, the others with PLL_ERROR_GPU_RUNTIME - and nobody is left
+ * waiting inside the collective for a rank that merely failed to evaluate. A rank that never calls (it died,
+ * or returned from a failed set-up) cannot be helped by the callers that did: their all-reduce never completes;
+ * they get -inf + PLL_ERROR_GPU_RUNTIME after PLL_AMD_REDUCE_TIMEOUT_MS (default 60 000) instead of blocking
+ * for ever, with the partition's stream still stuck behind the collective - fatal for the job, but reported. */
 double pll_gpu_edge_loglikelihood_allreduce(pll_partition_t *partition, void *nccl_comm,
                                             unsigned int parent_clv_index, int parent_scaler_index,
                                             unsigned int child_clv_index, int child_scaler_index,

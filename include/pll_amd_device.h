@@ -232,8 +232,10 @@ int pllgpu_tt_from_lookup(pllgpu_ctx_t *ctx, double *parent_host, const unsigned
 double *pllgpu_reduce_buffer(pllgpu_ctx_t *ctx);
 /* after the collective has been enqueued on the context's stream: a one-lane kernel copies the reduced
  * pair to mapped host memory (value first, sequence word behind it) and the call polls for
- * expected_sequence (= ranks x the sequence every rank used). Synchronises only on time-out. */
-int pllgpu_reduce_fetch(pllgpu_ctx_t *ctx, double expected_sequence, double *value_out);
+ * expected_sequence (= ranks x the sequence every rank used). Never synchronises: a collective that a peer does not
+ * join never completes, so after 50 ms the poll turns to hipStreamQuery and gives up with PLLGPU_ERUNTIME after
+ * timeout_ms (<= 0: 60 s); a drained stream with another sequence word = the ranks are out of step. */
+int pllgpu_reduce_fetch(pllgpu_ctx_t *ctx, double expected_sequence, double *value_out, int timeout_ms);
 /* a rank whose evaluation failed: {-inf, sequence} as its operand, so that it still takes part in the collective */
 int pllgpu_reduce_poison(pllgpu_ctx_t *ctx, double sequence);
 

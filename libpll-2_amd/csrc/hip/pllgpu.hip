@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -913,7 +914,10 @@ static void launch_gg(pllgpu_ctx *c, const GGPack &pack, unsigned ngroups, unsig
 // fp64 MFMA 4x4x4 kernels, matrices staged in LDS (kernels_mfma.h): NG = number of 4-state groups
 // k_partials_mfma_wide counts its own vector-memory operations (kernels_mfma_wide.h): a register spilled to scratch
 // would be one the count does not know about. The build is checked once per process; a compiler that spills sends the
-// shape back to the first-generation kernel (and says so).
+// shape back to the first-generation kernel (and says so). This run-time look sees scratch only; what a compiler could
+// also do - copy, move or park in accumulation registers a load's destination before its wait - is checked where it
+// can be seen, on the emitted instructions at build time (tools/check_wide_isa.py, a prerequisite of libpll_amd.so in
+// the Makefile; tests/test_wide_isa_check.py plants those failures into the real instruction stream).
 template <int NGJ, int TAIL, int WAVES>
 static bool wide_kernel_is_sound()
 {
@@ -2196,7 +2200,7 @@ __global__ void k_publish_pair(const double *__restrict__ pair, double *__restri
   __hip_atomic_store(host + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-extern "C" int pllgpu_reduce_fetch(pllgpu_ctx_t *c, double expected_sequence, double *value_out)
+extern "C" int pllgpu_reduce_fetch(pllgpu_ctx_t *c, double expected_sequence, double *value_out, int timeout_ms)
 {
   CHECK_CTX(c);
   if (!c->reduce.p) return fail(PLLGPU_EINVAL, "no reduce buffer");
@@ -2207,15 +2211,30 @@ extern "C" int pllgpu_reduce_fetch(pllgpu_ctx_t *c, double expected_sequence, do
   memcpy(&want, &expected_sequence, sizeof want);
   volatile double *res = c->result_host;
   const auto t0 = std::chrono::steady_clock::now();
+  const auto arrived = [&] { return __atomic_load_n((const unsigned long long *)&res[5], __ATOMIC_ACQUIRE) == want; };
   unsigned spins = 0;
-  while (__atomic_load_n((const unsigned long long *)&res[5], __ATOMIC_ACQUIRE) != want)
-    if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2000))
+  bool slow = false;
+  while (!arrived())
+  {
+    if (!slow)
     {
-      HIP_TRY(hipStreamSynchronize(c->stream));
-      if (__atomic_load_n((const unsigned long long *)&res[5], __ATOMIC_ACQUIRE) != want)
-        return fail(PLLGPU_ERUNTIME, "the reduced sequence word is %.17g, expected %.17g: the ranks are out of step", (double)res[5], expected_sequence);
-      break;
+      if ((++spins & 1023u) != 0 || std::chrono::steady_clock::now() - t0 <= std::chrono::milliseconds(50)) continue;
+      slow = true; // not the microseconds a collective takes: from here on look at the stream as well, and yield the core
     }
+    // A collective a peer never joins does not finish, and hipStreamSynchronize on its stream would never return
+    // (ADVICE r3): ask the stream instead, for a bounded time.
+    const hipError_t q = hipStreamQuery(c->stream);
+    if (q == hipSuccess)
+    {
+      if (arrived()) break;
+      return fail(PLLGPU_ERUNTIME, "the reduced sequence word is %.17g, expected %.17g: the ranks are out of step", (double)res[5], expected_sequence);
+    }
+    if (q != hipErrorNotReady) HIP_TRY(q);
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms > 0 ? timeout_ms : 60000))
+      return fail(PLLGPU_ERUNTIME, "the all-reduce did not complete within %d ms: a rank of the communicator never joined it (the partition's stream stays blocked behind the collective)",
+                  timeout_ms > 0 ? timeout_ms : 60000);
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
   *value_out = c->result_host[4];
   return 0;
 }

@@ -16,6 +16,7 @@
 #include <fcntl.h>
 #include <math.h>
 #include <pthread.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
@@ -23,8 +24,9 @@
 
 #include "pll_internal.h"
 
-#define GROUP_MAGIC 0x504c4c4752503031ull /* "PLLGRP01" */
+#define GROUP_MAGIC 0x504c4c4752503032ull /* "PLLGRP02" */
 #define GROUP_MAX_VALUES 6u
+#define GROUP_JOIN_ATTEMPTS 200u /* x 1 ms: how long a rank keeps looking for the segment that replaces a stale one */
 
 /* one cache line per (rank, parity): the step word is written last (release) and read first (acquire) */
 typedef struct group_slot
@@ -38,16 +40,22 @@ typedef struct group_header
 {
   _Alignas(64) volatile unsigned long long magic;
   volatile unsigned int size;
-  volatile unsigned int joined; /* ranks that have cleared their slots */
-  volatile unsigned int left;   /* ranks that have gone: the last one unlinks the name */
+  volatile unsigned int joined;   /* ranks that have cleared their slots */
+  volatile unsigned int left;     /* ranks that have gone: the last one unlinks the name */
+  volatile unsigned int poisoned; /* a rank found the segment stale, was refused or gave up waiting: whoever still
+                                   * waits in it stops at once (whoever set the word has removed the name) */
 } group_header_t;
+
+/* segment = header | owner[size] (one word per rank: who sits there, 0 = free) | slots[size][2] */
+static size_t owners_bytes(unsigned int size) { return (((size_t)size * sizeof(unsigned int)) + 63u) & ~(size_t)63u; }
 
 struct pll_gpu_group
 {
   unsigned int rank, size;
   unsigned long long step;
   group_header_t *hdr;
-  group_slot_t *slots; /* [size][2] */
+  volatile unsigned int *owner; /* [size] */
+  group_slot_t *slots;          /* [size][2] */
   size_t bytes;
   int timeout_ms;
   char name[96];
@@ -67,6 +75,111 @@ static inline void cpu_relax(void)
 #endif
 }
 
+/* The first to call a segment unusable removes its name - exactly once, so that the fresh segment another rank may
+ * already have created under the name is never the one removed - and everybody who still waits in it learns of it. */
+static void group_poison(pll_gpu_group_t *g)
+{
+  if (__atomic_exchange_n(&g->hdr->poisoned, 1u, __ATOMIC_ACQ_REL) == 0) shm_unlink(g->name);
+}
+
+static void group_unmap(pll_gpu_group_t *g)
+{
+  if (g->hdr) munmap((void *)g->hdr, g->bytes);
+  g->hdr = NULL;
+}
+
+/* A seat holds the process id of the rank that took it. A run that was killed while joining leaves seats of processes
+ * that no longer exist: the ranks of the next run under the name would otherwise count them as present and walk through
+ * the barrier (ranks of one group share a PID namespace: processes or threads of one node). */
+static int seated_by_the_dead(const pll_gpu_group_t *g)
+{
+  for (unsigned int r = 0; r < g->size; ++r)
+  {
+    const unsigned int o = __atomic_load_n(&g->owner[r], __ATOMIC_ACQUIRE);
+    if (o && kill((pid_t)(o & 0x7FFFFFFFu), 0) != 0 && errno == ESRCH) return 1;
+  }
+  return 0;
+}
+
+/* one attempt: 1 joined, 0 failed for good (pll_errno set), -1 the segment under the name was not this run's (a run
+ * that crashed or gave up left it behind; it has been poisoned and its name removed): look again */
+static int group_join_once(pll_gpu_group_t *g, double t0)
+{
+  const unsigned int size = g->size, rank = g->rank;
+  /* whoever comes first creates the segment (zero-filled by the kernel) and sizes it; the others find it */
+  int fd = shm_open(g->name, O_RDWR | O_CREAT, 0600);
+  if (fd < 0)
+  {
+    pll_set_error(PLL_ERROR_GPU_RUNTIME, "pll_gpu_group_join: shm_open(%s): %s", g->name, strerror(errno));
+    return 0;
+  }
+  struct stat st;
+  if (fstat(fd, &st) != 0 || ((size_t)st.st_size < g->bytes && ftruncate(fd, (off_t)g->bytes) != 0))
+  {
+    pll_set_error(PLL_ERROR_GPU_RUNTIME, "pll_gpu_group_join: sizing %s: %s", g->name, strerror(errno));
+    close(fd);
+    return 0;
+  }
+  void *mem = mmap(NULL, g->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (mem == MAP_FAILED)
+  {
+    pll_set_error(PLL_ERROR_GPU_RUNTIME, "pll_gpu_group_join: mmap(%s): %s", g->name, strerror(errno));
+    return 0;
+  }
+  g->hdr = (group_header_t *)mem;
+  g->owner = (volatile unsigned int *)((char *)mem + sizeof(group_header_t));
+  g->slots = (group_slot_t *)((char *)mem + sizeof(group_header_t) + owners_bytes(size));
+  /* a segment of a run of another size under the same name is refused, not reused (and not removed: it may be alive) */
+  unsigned int expect = 0;
+  if (!__atomic_compare_exchange_n(&g->hdr->size, &expect, size, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE) && expect != size)
+  {
+    pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_gpu_group_join: %s exists with %u ranks, not %u (names must be unique per run)", g->name, expect, size);
+    group_unmap(g);
+    return 0;
+  }
+  /* Not this run's segment: somebody already gave it up, a rank of it has already left (every rank of a run joins
+   * before the first one can leave), all its ranks are there already, or this rank's seat is taken. (a
+   * segment a failed or killed run left behind let the first ranks of the next run through the barrier at once and
+   * the rest spin until their time-out.) */
+  unsigned int seat = 0;
+  if (__atomic_load_n(&g->hdr->poisoned, __ATOMIC_ACQUIRE) || __atomic_load_n(&g->hdr->left, __ATOMIC_ACQUIRE) != 0 ||
+      __atomic_load_n(&g->hdr->joined, __ATOMIC_ACQUIRE) >= size || seated_by_the_dead(g) ||
+      !__atomic_compare_exchange_n(&g->owner[rank], &seat, (unsigned int)getpid() | 0x80000000u, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE))
+  {
+    group_poison(g);
+    group_unmap(g);
+    return -1;
+  }
+  memset((void *)&g->slots[2 * rank], 0, 2 * sizeof(group_slot_t));
+  __atomic_store_n(&g->hdr->magic, GROUP_MAGIC, __ATOMIC_RELEASE);
+  __atomic_fetch_add(&g->hdr->joined, 1u, __ATOMIC_ACQ_REL);
+  unsigned int spins = 0;
+  while (__atomic_load_n(&g->hdr->joined, __ATOMIC_ACQUIRE) < size)
+  {
+    cpu_relax();
+    if ((++spins & 0xFFu) != 0) continue;
+    if (__atomic_load_n(&g->hdr->poisoned, __ATOMIC_ACQUIRE))
+    {
+      group_unmap(g);
+      return -1;
+    }
+    if (now_ms() - t0 > g->timeout_ms)
+    {
+      pll_set_error(PLL_ERROR_GPU_RUNTIME, "pll_gpu_group_join: %u of %u ranks joined %s within %d ms", g->hdr->joined, size, g->name, g->timeout_ms);
+      group_poison(g); /* (and the name is gone: the next run under it starts from nothing) */
+      group_unmap(g);
+      return 0;
+    }
+  }
+  if (__atomic_load_n(&g->hdr->poisoned, __ATOMIC_ACQUIRE))
+  {
+    group_unmap(g);
+    return -1;
+  }
+  return 1;
+}
+
 pll_gpu_group_t *pll_gpu_group_join(const char *name, unsigned int rank, unsigned int size, int timeout_ms)
 {
   if (!name || name[0] != '/' || strlen(name) >= sizeof(((pll_gpu_group_t *)0)->name) || size == 0 || rank >= size || size > 4096)
@@ -74,70 +187,33 @@ pll_gpu_group_t *pll_gpu_group_join(const char *name, unsigned int rank, unsigne
     pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_gpu_group_join: name must start with '/', rank < size <= 4096");
     return NULL;
   }
-  if (timeout_ms <= 0) timeout_ms = 60000;
-  const size_t bytes = sizeof(group_header_t) + (size_t)size * 2 * sizeof(group_slot_t);
-  /* whoever comes first creates the segment (zero-filled by the kernel) and sizes it; the others find it */
-  int fd = shm_open(name, O_RDWR | O_CREAT, 0600);
-  if (fd < 0)
-  {
-    pll_set_error(PLL_ERROR_GPU_RUNTIME, "pll_gpu_group_join: shm_open(%s): %s", name, strerror(errno));
-    return NULL;
-  }
-  struct stat st;
-  if (fstat(fd, &st) != 0 || ((size_t)st.st_size < bytes && ftruncate(fd, (off_t)bytes) != 0))
-  {
-    pll_set_error(PLL_ERROR_GPU_RUNTIME, "pll_gpu_group_join: sizing %s: %s", name, strerror(errno));
-    close(fd);
-    return NULL;
-  }
-  void *mem = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (mem == MAP_FAILED)
-  {
-    pll_set_error(PLL_ERROR_GPU_RUNTIME, "pll_gpu_group_join: mmap(%s): %s", name, strerror(errno));
-    return NULL;
-  }
   pll_gpu_group_t *g = (pll_gpu_group_t *)calloc(1, sizeof *g);
   if (!g)
   {
-    munmap(mem, bytes);
     pll_set_error(PLL_ERROR_MEM_ALLOC, "pll_gpu_group_join: out of memory");
     return NULL;
   }
   g->rank = rank;
   g->size = size;
-  g->hdr = (group_header_t *)mem;
-  g->slots = (group_slot_t *)((char *)mem + sizeof(group_header_t));
-  g->bytes = bytes;
-  g->timeout_ms = timeout_ms;
+  g->bytes = sizeof(group_header_t) + owners_bytes(size) + (size_t)size * 2 * sizeof(group_slot_t);
+  g->timeout_ms = timeout_ms > 0 ? timeout_ms : 60000;
   strcpy(g->name, name);
-  /* a segment left behind by a run of another size under the same name is refused, not reused */
-  unsigned int expect = 0;
-  if (!__atomic_compare_exchange_n(&g->hdr->size, &expect, size, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE) && expect != size)
-  {
-    pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_gpu_group_join: %s exists with %u ranks, not %u (names must be unique per run)", name, expect, size);
-    munmap(mem, bytes);
-    free(g);
-    return NULL;
-  }
-  memset((void *)&g->slots[2 * rank], 0, 2 * sizeof(group_slot_t));
-  __atomic_store_n(&g->hdr->magic, GROUP_MAGIC, __ATOMIC_RELEASE);
-  __atomic_fetch_add(&g->hdr->joined, 1u, __ATOMIC_ACQ_REL);
   const double t0 = now_ms();
-  while (__atomic_load_n(&g->hdr->joined, __ATOMIC_ACQUIRE) < size)
+  int rc = -1;
+  for (unsigned int attempt = 0; rc < 0 && attempt < GROUP_JOIN_ATTEMPTS && now_ms() - t0 <= g->timeout_ms; ++attempt)
   {
-    cpu_relax();
-    if (now_ms() - t0 > timeout_ms)
+    if (attempt)
     {
-      pll_set_error(PLL_ERROR_GPU_RUNTIME, "pll_gpu_group_join: %u of %u ranks joined %s within %d ms", g->hdr->joined, size, name, timeout_ms);
-      pll_gpu_group_leave(g);
-      return NULL;
+      const struct timespec ms = {0, 1000000};
+      nanosleep(&ms, NULL); /* whoever poisoned the stale segment is about to remove its name */
     }
+    rc = group_join_once(g, t0);
   }
-  if (__atomic_load_n(&g->hdr->joined, __ATOMIC_ACQUIRE) > size)
+  if (rc < 0)
+    pll_set_error(PLL_ERROR_GPU_RUNTIME, "pll_gpu_group_join: %s stayed a stale or foreign segment (rank %u seated twice? names must be unique per run)", name, rank);
+  if (rc <= 0)
   {
-    pll_set_error(PLL_ERROR_PARAM_INVALID, "pll_gpu_group_join: more than %u ranks joined %s (a stale segment? names must be unique per run)", size, name);
-    pll_gpu_group_leave(g);
+    free(g);
     return NULL;
   }
   return g;
@@ -146,9 +222,11 @@ pll_gpu_group_t *pll_gpu_group_join(const char *name, unsigned int rank, unsigne
 void pll_gpu_group_leave(pll_gpu_group_t *g)
 {
   if (!g) return;
-  /* the last rank to leave removes the name; a crashed run leaves it behind (hence: unique names) */
-  if (__atomic_add_fetch(&g->hdr->left, 1u, __ATOMIC_ACQ_REL) >= g->size) shm_unlink(g->name);
-  munmap((void *)g->hdr, g->bytes);
+  /* the last rank to leave removes the name (unless the segment was given up: then the name is gone already, and a
+   * later run may own it); a killed run leaves it behind, for the next run under the name to find stale and replace */
+  if (__atomic_add_fetch(&g->hdr->left, 1u, __ATOMIC_ACQ_REL) >= g->size && !__atomic_load_n(&g->hdr->poisoned, __ATOMIC_ACQUIRE))
+    shm_unlink(g->name);
+  group_unmap(g);
   free(g);
 }
 
@@ -184,9 +262,15 @@ int pll_gpu_group_sum(pll_gpu_group_t *g, const double *local, unsigned int coun
       {
         const double t = now_ms();
         if (t0 == 0) t0 = t;
+        if (__atomic_load_n(&g->hdr->poisoned, __ATOMIC_ACQUIRE))
+        {
+          pll_set_error(PLL_ERROR_GPU_RUNTIME, "pll_gpu_group_sum: the group was given up at step %llu (a rank timed out, or another run claimed %s)", step, g->name);
+          return PLL_FAILURE;
+        }
         if (t - t0 > g->timeout_ms)
         {
           pll_set_error(PLL_ERROR_GPU_RUNTIME, "pll_gpu_group_sum: rank %u did not reach step %llu within %d ms", r, step, g->timeout_ms);
+          group_poison(g); /* the others stop waiting too */
           return PLL_FAILURE;
         }
       }
@@ -297,28 +381,52 @@ int pll_gpu_allreduce_lnl(pll_partition_t *p, void *comm, double *device_values,
   return PLL_SUCCESS;
 }
 
-double pll_gpu_edge_loglikelihood_allreduce(pll_partition_t *p, void *comm, unsigned int parent_clv_index,
-                                            int parent_scaler_index, unsigned int child_clv_index, int child_scaler_index,
-                                            unsigned int matrix_index, const unsigned int *freqs_indices)
+/* Everything about a (partition, communicator) pair that can fail BEFORE a collective is enqueued - no context, no
+ * RCCL library, ncclCommCount, the 16 bytes of device memory for the operand - is established here, once. A rank that
+ * failed at one of these inside a collective step would return without joining the all-reduce and leave its peers
+ * blocked in it; failing here, before the rank's first collective, is a set-up error the job sees while
+ * it can still agree on it (call it on every rank after creating the communicator and compare the results). */
+int pll_gpu_allreduce_prepare(pll_partition_t *p, void *comm)
 {
-  pll_amd_ext_t *x = reduce_ctx(p, comm, "pll_gpu_edge_loglikelihood_allreduce");
-  if (!x) return -INFINITY;
+  pll_amd_ext_t *x = reduce_ctx(p, comm, "pll_gpu_allreduce_prepare");
+  if (!x) return PLL_FAILURE;
+  if (x->reduce_comm == comm && x->reduce_pair) return PLL_SUCCESS;
   int ranks = 0;
-  if (g_rccl.count(comm, &ranks) != 0 || ranks < 1)
+  const int rc = g_rccl.count(comm, &ranks);
+  if (rc != 0 || ranks < 1)
   {
-    pll_set_error(PLL_ERROR_GPU_RUNTIME, "ncclCommCount failed");
-    return -INFINITY;
+    pll_set_error(PLL_ERROR_GPU_RUNTIME, "ncclCommCount: %s", (rc && g_rccl.errstr) ? g_rccl.errstr(rc) : "failed");
+    return PLL_FAILURE;
   }
   double *pair = pllgpu_reduce_buffer(x->ctx);
   if (!pair)
   {
-    pll_set_gpu_error("pll_gpu_edge_loglikelihood_allreduce");
-    return -INFINITY;
+    pll_set_gpu_error("pll_gpu_allreduce_prepare");
+    return PLL_FAILURE;
   }
+  const char *t = getenv("PLL_AMD_REDUCE_TIMEOUT_MS");
+  x->reduce_timeout_ms = (t && atoi(t) > 0) ? atoi(t) : 60000;
+  x->reduce_ranks = ranks;
+  x->reduce_pair = pair;
+  x->reduce_comm = comm;
+  return PLL_SUCCESS;
+}
+
+double pll_gpu_edge_loglikelihood_allreduce(pll_partition_t *p, void *comm, unsigned int parent_clv_index,
+                                            int parent_scaler_index, unsigned int child_clv_index, int child_scaler_index,
+                                            unsigned int matrix_index, const unsigned int *freqs_indices)
+{
+  /* first call with this communicator: the set-up (a failure here is before this rank's first collective) */
+  pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
+  if ((!x || x->reduce_comm != comm || !x->reduce_pair) && !pll_gpu_allreduce_prepare(p, comm)) return -INFINITY;
+  x = pll_ext(p);
+  double *pair = x->reduce_pair;
+  const int ranks = x->reduce_ranks;
   /* the ranks number their collective evaluations in step: the reduced sequence word is ranks x step */
   x->reduce_step += 1.0;
-  /* a rank whose evaluation failed still takes part, as in pll_gpu_group_edge_loglikelihood: its operand is -inf and
-   * every rank returns -inf, nobody is left waiting inside the collective */
+  /* From here on the rank always reaches the all-reduce. A rank whose evaluation failed takes part as in
+   * pll_gpu_group_edge_loglikelihood: its operand is -inf and every rank returns -inf. (The one exception is a device
+   * that cannot launch the one-lane kernel that writes that operand: then no collective can be enqueued on it either.) */
   const int mine_ok = pll_gpu_edge_loglikelihood_numbered(p, parent_clv_index, parent_scaler_index, child_clv_index,
                                                           child_scaler_index, matrix_index, freqs_indices, pair, x->reduce_step);
   const int my_errno = pll_errno;
@@ -327,7 +435,7 @@ double pll_gpu_edge_loglikelihood_allreduce(pll_partition_t *p, void *comm, unsi
   if (!mine_ok && pllgpu_reduce_poison(x->ctx, x->reduce_step) != 0) return -INFINITY; /* (the device is gone: nothing to send) */
   if (!pll_gpu_allreduce_lnl(p, comm, pair, 2)) return -INFINITY;
   double sum = -INFINITY;
-  if (pllgpu_reduce_fetch(x->ctx, x->reduce_step * ranks, &sum) != 0)
+  if (pllgpu_reduce_fetch(x->ctx, x->reduce_step * ranks, &sum, x->reduce_timeout_ms) != 0)
   {
     pll_set_gpu_error("pll_gpu_edge_loglikelihood_allreduce");
     return -INFINITY;

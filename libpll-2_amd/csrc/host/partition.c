@@ -814,6 +814,11 @@ void pll_gpu_invalidate(pll_partition_t *p, unsigned int what, int index)
     MARK(freqs_dirty, p->rate_matrices, 1);
     for (i = 0; i < p->rate_matrices; ++i) /* matrices formed with the old frequencies are not reversible for the new */
       if (index < 0 || i == (unsigned int)index) x->model_version[i]++;
+    /* ... and neither is a matrix formed LATER from the eigensystem that still stands: a direct write leaves
+     * eigen_decomp_valid set (as in the reference, whose pll_update_prob_matrices then keeps using the old
+     * eigensystem, src/models.c:412-443), so until pll_update_eigen recomputes it from the new frequencies the
+     * eigensystem is foreign to its set and swap_is_exact() (likelihood.c) must not trust matrices made from it */
+    MARK(model_foreign, p->rate_matrices, 1);
   }
   if (what & PLL_GPU_DIRTY_RATE_WEIGHTS) x->rate_weights_dirty = x->prop_invar_dirty = 1;
   if (what & PLL_GPU_DIRTY_PATTERN_WEIGHTS) x->pattern_weights_dirty = 1;

@@ -83,6 +83,12 @@ typedef struct pll_amd_ext
   unsigned int fast_count, fast_cap, fast_lo, fast_hi;
   int fast_valid;
   double reduce_step;           /* collective evaluations issued so far (group.c: the ranks count in step) */
+  /* what pll_gpu_allreduce_prepare established for the communicator last used with this partition: everything that
+   * can fail before a collective is enqueued is done once, there, not on the per-step path */
+  void *reduce_comm;
+  int reduce_ranks;
+  int reduce_timeout_ms;
+  double *reduce_pair;
   /* scheduler scratch (grown on demand) */
   pllgpu_op_t *gops;
   unsigned int gops_cap;

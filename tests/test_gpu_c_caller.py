@@ -23,7 +23,8 @@ def test_c_caller_reproduces_the_reference_kat(tmp_path):
 def _build_sharded(tmp_path):
     exe = str(tmp_path / "sharded")
     libdir = os.path.join(ROOT, "libpll-2_amd", "csrc")
-    subprocess.check_call(["gcc", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_caller", "sharded.c"),
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "c_caller"),
+                           os.path.join(ROOT, "tests", "c_caller", "sharded.c"),
                            "-L" + libdir, "-lpll_amd", "-ldl", "-lm", "-Wl,-rpath," + libdir, "-o", exe])
     return exe
 
@@ -46,6 +47,36 @@ def test_c_caller_all_reduces_through_rccl_without_python(tmp_path):
         pytest.skip("no RCCL library on this host")
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rccl lnl -58.88731" in out.stdout
+
+
+def _build_rccl_double(tmp_path):
+    """tests/c_caller/rccl_double.c: the stream-ordered stand-in for librccl (test infrastructure)"""
+    so = str(tmp_path / "librccl_double.so")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "c_caller", "rccl_double.c"), "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", so])
+    return so
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_c_caller_collective_evaluation_with_several_ranks(tmp_path, world):
+    """pll_gpu_edge_loglikelihood_allreduce had only ever met a one-rank communicator. `world` forked
+    ranks on this one device, the communicator a stand-in that keeps RCCL's contract (asynchronous, on the
+    partition's stream, device operands): the reduced sequence word is ranks x step, every rank returns the same
+    bits = the reference's value for the 12 sites, a step in which the last rank's evaluation fails gives -inf
+    everywhere with each rank's own pll_errno, and the next step is in step again"""
+    out = subprocess.run([_build_sharded(tmp_path), "double", str(world), _build_rccl_double(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    vals = [ln.split()[-1] for ln in out.stdout.strip().splitlines()]
+    assert len(vals) == world and len(set(vals)) == 1
+
+
+def test_c_caller_collective_evaluation_with_a_missing_rank_returns(tmp_path):
+    """a peer that never joins the all-reduce used to leave the others in an unbounded
+    hipStreamSynchronize; now they poll the stream for PLL_AMD_REDUCE_TIMEOUT_MS and return -inf + an error"""
+    out = subprocess.run([_build_sharded(tmp_path), "missing", "2", _build_rccl_double(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "did not complete" in out.stdout
 
 
 def _captured(fn):

@@ -101,14 +101,17 @@ def test_host_written_matrix_overrides_device_one(amd_lib):
         assert abs(v2 - ref0) <= 1e-12 * abs(ref0)
 
 
-@pytest.mark.parametrize("how", ["setter", "direct-write"])
+@pytest.mark.parametrize("how", ["setter", "direct-write", "direct-write-reform"])
 def test_stale_matrix_with_a_revalidated_eigensystem_keeps_the_orientation(amd_lib, ref_lib, how):
     """a matrix formed by pll_update_prob_matrices with frequencies A, then the frequencies of the
     same set become B and the eigensystem is valid again (another matrix was formed, or the caller wrote
     p->frequencies and invalidated - which never clears eigen_decomp_valid). The stale matrix is reversible
     for A, the evaluation weighs with B: swapping the ends of a tip-parent edge would change the value, so the
     caller's orientation must be evaluated (src/likelihood.c:626-634 - the reference never swaps without
-    PLL_ATTRIB_PATTERN_TIP). The set's version counter, not the current eigen_decomp_valid flag, decides."""
+    PLL_ATTRIB_PATTERN_TIP). The set's version counter, not the current eigen_decomp_valid flag, decides.
+    ADVICE r3 ("direct-write-reform"): after the direct write the caller forms matrix m AGAIN - eigen_decomp_valid was
+    never cleared, so both libraries form it from the OLD eigensystem (reversible for A) and it carries the set's NEW
+    version; the eigensystem is foreign to its set until pll_update_eigen recomputes it, so no swap either."""
     case = W.make_case("orient-stale", 4, 12, 500, tree="caterpillar", seed=62, ambiguity_pct=5)
     p, ps, c, cs, m = case.edges[0]
     assert c < case.tips  # the child end of the caterpillar's root edge is a tip
@@ -134,6 +137,10 @@ def test_stale_matrix_with_a_revalidated_eigensystem_keeps_the_orientation(amd_l
                 api.as_np(s.part.frequencies[0], 4, np.float64)[:] = fb
                 if lib.is_amd:
                     lib.pll_gpu_invalidate(s.p, api.DIRTY_FREQS, 0)
+                if how == "direct-write-reform":
+                    assert s.part.eigen_decomp_valid[0] == 1
+                    again = np.array([m], dtype=np.uint32)
+                    assert lib.pll_update_prob_matrices(s.p, api.uptr(pi), api.uptr(again), api.dptr(brl[m:m + 1].copy()), 1)
             vals[lib.is_amd] = (before, s.edge_lnl(tip_parent, persite=False)[0], s.edge_lnl((p, ps, c, cs, m), persite=False)[0])
     (b0, g_tp, g_usual), (r0, e_tp, e_usual) = vals[True], vals[False]
     assert abs(b0 - r0) <= 1e-10 * abs(r0)

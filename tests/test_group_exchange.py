@@ -79,29 +79,79 @@ def test_a_name_in_use_with_another_size_is_refused():
     assert "error" in oa, oa
 
 
-def test_a_finished_run_removes_its_name_and_a_stale_segment_is_refused():
-    """the last rank to leave unlinks the segment; one that a crashed run of the SAME size left behind (its ranks
-    counted as joined) is refused by the next run under that name instead of being silently reused"""
-    name = "/pllamd-test-" + uuid.uuid4().hex[:12]
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "group_worker.py"), name, str(r), "2", "3", "1", "20000"],
-                              stdout=subprocess.PIPE, text=True) for r in range(2)]
-    outs = [json.loads(p.communicate(timeout=120)[0].strip().splitlines()[-1]) for p in procs]
-    assert all("error" not in o for o in outs), outs
-    assert not os.path.exists("/dev/shm" + name)
-    # the header of a run of two ranks that never left: {magic, size = 2, joined = 2, left = 0} (csrc/host/group.c)
-    stale = bytearray(64 + 2 * 2 * 64)
-    stale[0:8] = (0x504c4c4752503031).to_bytes(8, "little")
-    stale[8:12] = (2).to_bytes(4, "little")
-    stale[12:16] = (2).to_bytes(4, "little")
+def _stale_segment(name, size, joined, left=0, seated=()):
+    """the bytes a run of `size` ranks leaves under /dev/shm when it dies: header {magic, size, joined, left, poisoned},
+    one owner word per seated rank, the slots (csrc/host/group.c)"""
+    owners = (size * 4 + 63) // 64 * 64
+    stale = bytearray(64 + owners + size * 2 * 64)
+    stale[0:8] = (0x504c4c4752503032).to_bytes(8, "little")
+    stale[8:12] = size.to_bytes(4, "little")
+    stale[12:16] = joined.to_bytes(4, "little")
+    stale[16:20] = left.to_bytes(4, "little")
+    for r in seated:
+        stale[64 + 4 * r:68 + 4 * r] = (0x80000000 | 4242).to_bytes(4, "little")
     with open("/dev/shm" + name, "wb") as f:
         f.write(stale)
+
+
+def _run_two(name, steps=3, timeout_ms=20000):
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "group_worker.py"), name, str(r), "2", str(steps), "1", str(timeout_ms)],
+                              stdout=subprocess.PIPE, text=True) for r in range(2)]
+    return [json.loads(p.communicate(timeout=120)[0].strip().splitlines()[-1]) for p in procs]
+
+
+@pytest.mark.parametrize("joined,left,seated", [(2, 0, (0, 1)), (1, 0, (0,)), (1, 0, (1,)), (1, 1, (0,)), (2, 1, (0, 1))],
+                         ids=["killed-after-the-barrier", "killed-in-join-rank0", "killed-in-join-rank1", "gave-up-in-join", "one-rank-left"])
+def test_a_finished_run_removes_its_name_and_a_stale_segment_is_replaced(joined, left, seated):
+    """the last rank to leave unlinks the segment; one that a killed or failed run of the SAME size left behind -
+    ranks counted as joined that will never come (the first ranks of the next run walked through the
+    barrier at once and the others spun until their time-out) - is recognised by the next run under that name,
+    poisoned, removed and replaced: the new run completes, nobody waits for a time-out"""
+    name = "/pllamd-test-" + uuid.uuid4().hex[:12]
+    outs = _run_two(name)
+    assert all("error" not in o for o in outs), outs
+    assert not os.path.exists("/dev/shm" + name)
+    _stale_segment(name, 2, joined, left, seated)
     try:
-        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "group_worker.py"), name, str(r), "2", "1", "1", "1500"],
-                                  stdout=subprocess.PIPE, text=True) for r in range(2)]
-        outs = [json.loads(p.communicate(timeout=60)[0].strip().splitlines()[-1]) for p in procs]
-        assert all("error" in o and "stale" in o["error"] for o in outs), outs
+        import time
+        t0 = time.time()
+        outs = _run_two(name, timeout_ms=8000)
+        assert all("error" not in o for o in outs), outs
+        assert outs[0]["sums"] == outs[1]["sums"]
+        assert time.time() - t0 < 7.0  # (two interpreter starts; far from the 8 s time-out)
+        assert not os.path.exists("/dev/shm" + name)
     finally:
         try:
             os.unlink("/dev/shm" + name)
         except OSError:
             pass
+
+
+def test_a_failed_join_leaves_nothing_behind():
+    """a rank whose join times out removes the name before it goes: the next run under it starts from nothing"""
+    name = "/pllamd-test-" + uuid.uuid4().hex[:12]
+    outs = run_ranks(2, steps=1, timeout_ms=300, ranks=[0], name=name + "x")
+    assert "error" in outs[0] and "joined" in outs[0]["error"]
+    a = subprocess.Popen([sys.executable, os.path.join(HERE, "group_worker.py"), name, "0", "2", "1", "1", "300"], stdout=subprocess.PIPE, text=True)
+    oa = json.loads(a.communicate(timeout=60)[0].strip().splitlines()[-1])
+    assert "error" in oa
+    assert not os.path.exists("/dev/shm" + name)
+    outs = _run_two(name)
+    assert all("error" not in o for o in outs), outs
+
+
+def test_a_rank_seated_twice_is_an_error_not_a_hang():
+    """two processes claim rank 0 of a group of two: the second finds the seat taken, gives the segment up (the first
+    stops waiting at once) and both fail well before the time-out"""
+    import time
+    name = "/pllamd-test-" + uuid.uuid4().hex[:12]
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "group_worker.py"), name, "0", "2", "1", "1", "2500"],
+                              stdout=subprocess.PIPE, text=True) for _ in range(2)]
+    outs = [json.loads(p.communicate(timeout=60)[0].strip().splitlines()[-1]) for p in procs]
+    try:
+        os.unlink("/dev/shm" + name)
+    except OSError:
+        pass
+    assert all("error" in o for o in outs), outs
+    assert time.time() - t0 < 20
