@@ -138,14 +138,15 @@ template <int LK, int RK>
 static void launch_fused_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroups, unsigned entries)
 {
   const unsigned tiles = (entries + 63) / 64;
-  const unsigned want_blocks = 4096;
-  unsigned tpw = (unsigned)(((size_t)tiles * ngroups + 4 * want_blocks - 1) / (4 * want_blocks));
-  tpw = std::max(1u, std::min(tpw, 8u));
-  dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), ngroups), block(256);
+  const unsigned tpw = kDnaTilesPerWave;
+  const unsigned nx = (tiles + 4 * tpw - 1) / (4 * tpw);
   // parents of this launch: entries x 128 B each. Beyond the 256 MB Infinity Cache nothing of them
   // survives until the next level reads it: stream them out as well
   unsigned stream_parent = ((size_t)ngroups * entries * 128u > c->stream_parent_bytes) ? 1u : 0u;
-  hipLaunchKernelGGL((k_partials_dna_fused<LK, RK>), grid, block, 0, c->stream, pack, entries, c->gg.scale_mode, tpw, stream_parent);
+  // only the groups that are fed from tip codes are store traffic (kernels_common.h: xcd_block); the others keep the natural order
+  const unsigned xcd = (c->xcd_order && LK != CK_INNER && LK != CK_FII && RK != CK_FII) ? 1u : 0u;
+  hipLaunchKernelGGL((k_partials_dna_fused<LK, RK>), xcd_grid(nx, ngroups), dim3(256), 0, c->stream, pack, entries, c->gg.scale_mode, tpw, stream_parent,
+                     nx, ngroups, xcd);
 }
 
 static void to_top(const DevOp &d, TOp &t)
@@ -162,12 +163,11 @@ template <int LK, int RK>
 static void launch_cc_t(pllgpu_ctx *c, const CCPack &pack, unsigned ngroups, unsigned entries)
 {
   const unsigned tiles = (entries + 63) / 64;
-  const unsigned want_blocks = 4096;
-  unsigned tpw = (unsigned)(((size_t)tiles * ngroups + 4 * want_blocks - 1) / (4 * want_blocks));
-  tpw = std::max(1u, std::min(tpw, 8u));
-  dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), ngroups), block(256);
+  const unsigned tpw = kDnaTilesPerWave;
+  const unsigned nx = (tiles + 4 * tpw - 1) / (4 * tpw);
   unsigned stream_parent = ((size_t)ngroups * entries * 128u > c->stream_parent_bytes) ? 1u : 0u;
-  hipLaunchKernelGGL((k_partials_dna_cc<LK, RK>), grid, block, 0, c->stream, pack, entries, c->gg.scale_mode, tpw, stream_parent);
+  hipLaunchKernelGGL((k_partials_dna_cc<LK, RK>), xcd_grid(nx, ngroups), dim3(256), 0, c->stream, pack, entries, c->gg.scale_mode, tpw, stream_parent,
+                     nx, ngroups, c->xcd_order);
 }
 
 static int launch_cc(pllgpu_ctx *c, const CCPack &pack, unsigned ngroups, unsigned entries, int lk, int rk)

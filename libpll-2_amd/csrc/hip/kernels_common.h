@@ -75,6 +75,35 @@ struct GenGeo
   int scale_mode;     // 0 none, 1 per site, 2 per rate
 };
 
+// ---- XCD-aware workgroup order -----------------------------------------------------------------------------------
+// Workgroups go to the eight XCDs round-robin by linear id (workgroup b runs on XCD b % 8), so with the natural mapping
+// eight neighbouring pieces of a CLV are written through eight different L2s. tools/store_probe2.hip (round 4,
+// profiles/r4_store_probe2.txt): a pure store stream over 0.7 ... 4 GB sustains 5.5-5.75 TB/s that way and 6.3-6.4 TB/s
+// when every XCD writes its own CONTIGUOUS eighth of the work - whatever the store's width or cache-policy bits; read
+// streams do not care (7.25 TB/s either way), 2 reads + 1 write hardly; runs of 16 workgroups (512 KB) per XCD already
+// give all of it. The launches that are store traffic and nothing else - the groups fed from tip codes:
+// k_partials_dna_cc, the tip-fed kinds of k_partials_dna_fused, k_partials_mfma_cc - therefore run as a 1-D grid of
+// 8 x `per` workgroups and take their logical block from here: XCD x owns logical blocks [x per, (x + 1) per), walked in
+// dispatch order. Measured on the launches themselves (same box, alternating): C2's seven-op launch 113-115 -> 108-110 us
+// (0.82 -> 0.86 of the HBM peak), at 400k sites 518 -> 498 us; C3's group launch 332 -> 286-327 us. NOT used where it did
+// not pay: chains (random trees 0.206 -> 0.217 ms per step: their siblings' reads), plain tip x tip levels of 20 and 61
+// states (within the spread). `on` = 0 keeps the natural order on the same grid (PLL_AMD_NO_XCD_ORDER=1: the A/B switch).
+__device__ __forceinline__ unsigned xcd_linear(unsigned total, unsigned on) // logical block number, or ~0u for the grid's padding
+{
+  const unsigned per = gridDim.x >> 3;
+  const unsigned l = on ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+  return l < total ? l : ~0u; // (the grid is rounded up to a multiple of eight)
+}
+__device__ __forceinline__ bool xcd_block(unsigned nx, unsigned ny, unsigned on, unsigned &bx, unsigned &by)
+{
+  const unsigned l = xcd_linear(nx * ny, on);
+  if (l == ~0u) return false;
+  by = l / nx;
+  bx = l - by * nx;
+  return true;
+}
+static inline dim3 xcd_grid(unsigned nx, unsigned ny, unsigned nz = 1) { return dim3((nx * ny * nz + 7u) / 8u * 8u); }
+
 // Workgroup barrier for an exchange through LDS in the middle of a kernel's loop: wait for the wave's own LDS
 // accesses, then s_barrier. __syncthreads() carries workgroup-scope release / acquire semantics for GLOBAL memory
 // too, i.e. s_waitcnt vmcnt(0): every such barrier drained the wave's prefetched loads and its stores in flight -

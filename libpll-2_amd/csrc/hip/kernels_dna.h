@@ -119,6 +119,14 @@ constexpr unsigned kAosRow = 18;
 #ifndef DNA_GATHER_WAVES
 #define DNA_GATHER_WAVES 3
 #endif
+
+// Tiles a wave of the update kernels walks one after the other. Rounds 1-3 sized it so that a launch had about 4096
+// workgroups (up to 8 tiles per wave at 1M sites); round 4 measured that against one tile per wave wherever more than
+// 4096 workgroups exist (tools/round4_calls/r4_tpw_exp.sh, same box): the seven-op groups at 400k sites 498 -> 468 us
+// (6.0 -> 6.4 TB/s), the plain inner x inner level 207 -> 195 us, the 1M-site site-repeats step 0.749 -> 0.711 ms, the
+// one-level groups unchanged. A second tile behind the first means a wave whose stores are in flight waits before it may
+// ask for the next tile's children; more, shorter waves hide that for each other. The kernels keep the loop.
+constexpr unsigned kDnaTilesPerWave = 1;
 template <bool LTIP, bool RTIP, bool GATHER>
 __global__ __launch_bounds__(256, GATHER ? DNA_GATHER_WAVES : 1) void k_partials_dna(const OpPack pack, int scale_mode, unsigned tiles_per_wave)
 {
@@ -649,9 +657,11 @@ __device__ __forceinline__ void dna_child_store(const FOp &cop, size_t off, unsi
 
 template <int LK, int RK>
 __global__ __launch_bounds__(256) void k_partials_dna_fused(const FusePack pack, unsigned entries, int scale_mode, unsigned tiles_per_wave,
-                                                              unsigned stream_parent)
+                                                              unsigned stream_parent, unsigned nx, unsigned ny, unsigned xcd_order)
 {
-  const FGroup &g = pack.g[blockIdx.y];
+  unsigned bx, by;
+  if (!xcd_block(nx, ny, xcd_order, bx, by)) return;
+  const FGroup &g = pack.g[by];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned ntiles = (entries + 63u) / 64u;
@@ -660,7 +670,7 @@ __global__ __launch_bounds__(256) void k_partials_dna_fused(const FusePack pack,
 
   for (unsigned t = 0; t < tiles_per_wave; ++t)
   {
-    const unsigned tile = (blockIdx.x * 4u + wave) * tiles_per_wave + t;
+    const unsigned tile = (bx * 4u + wave) * tiles_per_wave + t;
     if (tile >= ntiles) break; // wave-uniform
     const unsigned n0 = tile * 64u + lane;
     const bool valid = n0 < entries;
@@ -947,15 +957,17 @@ __device__ __forceinline__ void dna_cc_child(const FOp &pop, bool left_side, con
 
 template <int LK, int RK>
 __global__ __launch_bounds__(256) void k_partials_dna_cc(const CCPack pack, unsigned entries, int scale_mode, unsigned tiles_per_wave,
-                                                          unsigned stream_parent)
+                                                          unsigned stream_parent, unsigned nx, unsigned ny, unsigned xcd_order)
 {
-  const CCGroup &g = pack.g[blockIdx.y];
+  unsigned bx, by;
+  if (!xcd_block(nx, ny, xcd_order, bx, by)) return; // a store-bound launch: every XCD on its own run of tiles (kernels_common.h)
+  const CCGroup &g = pack.g[by];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned ntiles = (entries + 63u) / 64u;
   for (unsigned t = 0; t < tiles_per_wave; ++t)
   {
-    const unsigned tile = (blockIdx.x * 4u + wave) * tiles_per_wave + t;
+    const unsigned tile = (bx * 4u + wave) * tiles_per_wave + t;
     if (tile >= ntiles) break; // wave-uniform
     const unsigned n0 = tile * 64u + lane;
     const bool valid = n0 < entries;
@@ -1616,6 +1628,8 @@ template <int SM, bool C0, bool S1, bool C1, class SRC>
 __device__ __forceinline__ void chain_body(const SRC src, unsigned entries)
 {
   __shared__ unsigned long long ballots[4][4]; // [step parity x decision][rate]
+  // (round 4 tried the XCD-aware workgroup order of the store-bound group launches here, kernels_common.h: random
+  // 64-taxon trees 0.206 -> 0.217 ms per step, the ladder within the spread - the siblings' reads want the natural order)
   const ChainHead h = src.head(blockIdx.y);
   const ChainGeo g = chain_geo(entries);
   double acc[4];

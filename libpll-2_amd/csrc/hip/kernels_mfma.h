@@ -536,8 +536,18 @@ template <int NG>
 __global__ __launch_bounds__(256, 4) void k_partials_mfma_cc(const FusePack pack, const GenGeo g, const unsigned long long *__restrict__ tipmap,
                                                              unsigned entries, unsigned items_per_wave, unsigned char *__restrict__ flagbuf,
                                                              unsigned flag_stride, const unsigned char *__restrict__ bits, const CherrySlots slots,
-                                                             unsigned ncodes, unsigned stream_parent)
+                                                             unsigned ncodes, unsigned stream_parent, unsigned nx, unsigned ny, unsigned xcd_order)
 {
+  // A store-bound launch (kernels_common.h: xcd_block). Logical order with the XCD-aware mapping: rate category fastest,
+  // then the item block, then the group - the four workgroups that write the four rate pieces of the same tiles follow
+  // each other on one XCD, which so writes whole tiles in runs; natural order (A/B): item block, group, rate.
+  unsigned bx, by, k;
+  {
+    const unsigned l = xcd_linear(nx * ny * g.R, xcd_order);
+    if (l == ~0u) return;
+    if (xcd_order) k = l % g.R, bx = (l / g.R) % nx, by = l / (g.R * nx);
+    else bx = l % nx, by = (l / nx) % ny, k = l / (nx * ny);
+  }
   typedef CcGeo<NG> CG;
   constexpr unsigned LD = CG::LD;
   typedef double __attribute__((ext_vector_type(2))) double2v;
@@ -546,13 +556,13 @@ __global__ __launch_bounds__(256, 4) void k_partials_mfma_cc(const FusePack pack
   unsigned short *BITS = reinterpret_cast<unsigned short *>(lds + 6u * CG::mat);    // [2][ncodes * ncodes]
   unsigned char *CIDX = reinterpret_cast<unsigned char *>(BITS + 2u * ncodes * ncodes); // [ncodes]
 
-  const FGroup &grp = pack.g[blockIdx.y];
+  const FGroup &grp = pack.g[by];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned row = lane >> 4, col = lane & 15u;
-  const unsigned S = g.S, k = blockIdx.z;
+  const unsigned S = g.S;
   const unsigned nitems = (entries + 31u) / 32u;
-  if (blockIdx.x * 4u * items_per_wave >= nitems) return; // whole workgroup
+  if (bx * 4u * items_per_wave >= nitems) return; // whole workgroup
   const unsigned long long full = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
   {
     const double *src[6] = {grp.a.lmat, grp.a.rmat, grp.b.lmat, grp.b.rmat, grp.p.lmat, grp.p.rmat};
@@ -568,7 +578,7 @@ __global__ __launch_bounds__(256, 4) void k_partials_mfma_cc(const FusePack pack
     for (unsigned idx = threadIdx.x; idx < 2u * npairs; idx += 256u)
     {
       const unsigned ch = idx >= npairs ? 1u : 0u, pr = idx - ch * npairs;
-      const unsigned char *t = bits + (size_t)slots.s[2u * blockIdx.y + ch] * g.R * npairs + pr;
+      const unsigned char *t = bits + (size_t)slots.s[2u * by + ch] * g.R * npairs + pr;
       unsigned v = 0;
       for (unsigned kk = 0; kk < g.R; ++kk) v |= (unsigned)t[(size_t)kk * npairs] << kk;
       BITS[idx] = (unsigned short)v;
@@ -590,7 +600,7 @@ __global__ __launch_bounds__(256, 4) void k_partials_mfma_cc(const FusePack pack
   }
   __syncthreads();
   const int ma = grp.a.pscaler ? g.scale_mode : 0, mb = grp.b.pscaler ? g.scale_mode : 0, mp = grp.p.pscaler ? g.scale_mode : 0;
-  const unsigned item0 = (blockIdx.x * 4u + wave) * items_per_wave;
+  const unsigned item0 = (bx * 4u + wave) * items_per_wave;
   if (item0 >= nitems) return; // no barriers below
   const unsigned nmine = min(items_per_wave, nitems - item0);
   const unsigned last_pair = (entries - 1u) & ~1u;
@@ -775,7 +785,7 @@ __global__ __launch_bounds__(256, 4) void k_partials_mfma_cc(const FusePack pack
         int sm = sp[sg] ? 1 : 0; // a site's states are spread over the four row groups of the wave
         sm &= __shfl_xor(sm, 16, 64);
         sm &= __shfl_xor(sm, 32, 64);
-        if (row == 0 && valid[sg]) flagbuf[((size_t)blockIdx.y * g.R + k) * flag_stride + e0 + sg] = (unsigned char)sm;
+        if (row == 0 && valid[sg]) flagbuf[((size_t)by * g.R + k) * flag_stride + e0 + sg] = (unsigned char)sm;
       }
     }
 #pragma unroll

@@ -98,6 +98,7 @@ struct pllgpu_ctx
   int mfma_ng = 16;         // 4-state groups the MFMA kernels run with: 16 (33..64 states), 8 (21..32), 5 (17..20)
   unsigned mfma_wide = 1;   // 33..64 states, inner x inner: k_partials_mfma_wide (kernels_mfma_wide.h); PLL_AMD_MFMA_WIDE=0 (A/B, parity tests): k_partials_mfma
   bool mfma_pad = false;    // PLL_AMD_MFMA_PAD=1 (A/B): 61 states through the padded 64-state contraction
+  unsigned xcd_order = 1;   // PLL_AMD_NO_XCD_ORDER=1 (A/B): store-bound launches in the natural workgroup order (kernels_common.h: xcd_block)
   bool tiled = false;       // generic shapes keep CLVs in the tiled sites-contiguous layout
   DevBuf<double> scratch;   // host-layout staging for mirror copies of tiled CLVs
   size_t pm_stride = 0; // doubles per matrix in PT layout
@@ -317,6 +318,7 @@ static void derive_geometry(pllgpu_ctx *c)
     if (*v && *v != '0') c->use_mfma = false;
   if (const char *v = getenv("PLL_AMD_MFMA_WIDE")) c->mfma_wide = atoi(v) != 0 ? 1u : 0u;
   if (const char *v = getenv("PLL_AMD_MFMA_PAD")) c->mfma_pad = *v && *v != '0';
+  if (const char *v = getenv("PLL_AMD_NO_XCD_ORDER")) c->xcd_order = (*v && *v != '0') ? 0u : 1u;
   // (tip x tip, tip x tip -> inner x inner) groups of 17..32 states: on the matrix pipe (kernels_mfma.h:
   // k_partials_mfma_cc), whatever pipe the level launches use - C3 (20 states) 4.0 -> 5.1 G updates/s on the same box
   // (profiles/README.md, round 2). PLL_AMD_FUSE_GENERIC=0 or PLL_AMD_NO_FUSE=1: level launches only (A/B, parity tests).
@@ -877,11 +879,9 @@ static void launch_generic(pllgpu_ctx *c, const OpPack &pack, unsigned nops, uns
 
 static void launch_dna(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
 {
-  // one wave per 64-site tile; a wave takes tpw consecutive tiles so that ~4096 workgroups exist
+  // one wave per 64-site tile (kDnaTilesPerWave, kernels_dna.h)
   const unsigned tiles = (maxent + 63) / 64;
-  const unsigned want_blocks = 4096;
-  unsigned tpw = (unsigned)(((size_t)tiles * nops + 4 * want_blocks - 1) / (4 * want_blocks));
-  tpw = std::max(1u, std::min(tpw, 8u));
+  const unsigned tpw = kDnaTilesPerWave;
   dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), nops), block(256);
   const int mode = c->gg.scale_mode;
 #define DNA_LAUNCH(LT, RT, GA) hipLaunchKernelGGL((k_partials_dna<LT, RT, GA>), grid, block, 0, c->stream, pack, mode, tpw)
@@ -904,8 +904,7 @@ static void launch_dna(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigne
 static void launch_gg(pllgpu_ctx *c, const GGPack &pack, unsigned ngroups, unsigned entries)
 {
   const unsigned tiles = (entries + 63) / 64;
-  unsigned tpw = (unsigned)(((size_t)tiles * ngroups + 4 * 4096 - 1) / (4 * 4096));
-  tpw = std::max(1u, std::min(tpw, 8u));
+  const unsigned tpw = kDnaTilesPerWave;
   dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), ngroups), block(256);
   const unsigned stream_parent = ((size_t)ngroups * entries * 128u > c->stream_parent_bytes) ? 1u : 0u;
   hipLaunchKernelGGL(k_partials_dna_gg, grid, block, 0, c->stream, pack, entries, c->gg.scale_mode, tpw, stream_parent);
@@ -1026,11 +1025,14 @@ static int launch_mfma_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroup
 {
   const unsigned R = c->gg.R, S = c->gg.S;
   const unsigned items = (entries + 31) / 32;
-  // store-bound: many small workgroups
+  // store-bound: many small workgroups - but each stages its six matrices and two tables (20-50 KB from L2), so not
+  // too small: C3 (1563 items x 16 groups x 4 rates) with 8 / 4 / 2 / 1 items per wave and the XCD-aware order: step
+  // 0.550 / 0.537 / 0.563 / 0.622 ms on one box (round 4, tools/round4_calls/r4_c3_exp.sh; natural order: 0.555 / - / 0.622 / -)
   const unsigned want = 4096u;
   unsigned ipw = (unsigned)(((size_t)items * ngroups * R + want - 1) / want);
-  ipw = std::max(1u, std::min(ipw, 8u));
-  dim3 grid((items + 4 * ipw - 1) / (4 * ipw), ngroups, R), block(256);
+  ipw = std::max(1u, std::min(ipw, 4u));
+  const unsigned nx = (items + 4 * ipw - 1) / (4 * ipw);
+  dim3 grid = xcd_grid(nx, ngroups, R), block(256);
   const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
   const unsigned ncodes = c->tip_ncodes;
   const size_t lds = CcGeo<NG>::lds_bytes(ncodes);
@@ -1110,7 +1112,7 @@ static int launch_mfma_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroup
   // parents beyond what the Infinity Cache keeps for the next level: streamed out like the cherries (as the 4x4 groups do)
   const unsigned stream_parent = ((size_t)ngroups * entries * S * R * 8u > c->stream_parent_bytes) ? 1u : 0u;
   hipLaunchKernelGGL((k_partials_mfma_cc<NG>), grid, block, lds, c->stream, pack, c->gg, tm, entries, ipw, c->mfma_flags.p, fstride,
-                     c->cherry_bits.p, slots, ncodes, stream_parent);
+                     c->cherry_bits.p, slots, ncodes, stream_parent, nx, ngroups, c->xcd_order);
   if (scaling)
     hipLaunchKernelGGL((k_mfma_scale_epilogue<false>), dim3((entries + 255) / 256, ngroups), dim3(256), 0, c->stream, parents, c->gg,
                        c->mfma_flags.p, fstride);
