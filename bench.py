@@ -311,6 +311,7 @@ class Harness:
         self.real_stdout = None
         self.group = None
         self.group_lib = None
+        self.rccl = None  # (ncclComm_t, librccl) of make_rccl_comm, or (None, reason)
         if self.world > 1 or os.environ.get("PLL_BENCH_FORCE_DIST") == "1":
             import torch
             import torch.distributed as dist
@@ -378,6 +379,10 @@ class Harness:
         if self.group:
             self.group_lib.pll_gpu_group_leave(self.group)
             self.group = None
+        if self.rccl and self.rccl[0] is not None:
+            self.tsync()
+            self.rccl[1].ncclCommDestroy(self.rccl[0])
+            self.rccl = None
         if self.dist:
             self.dist.barrier()
             self.dist.destroy_process_group()
@@ -404,6 +409,53 @@ def step_loop_fn():
     return _STEP_LOOP
 
 
+def make_rccl_comm(h):
+    """A communicator of this run's ranks for the LIBRARY's all-reduce entry point (pll_gpu_edge_loglikelihood_allreduce
+    takes a caller-made ncclComm_t; torch does not hand its own out): rank 0 draws the id, the control plane carries it,
+    every rank calls ncclCommInitRank on its device. Returns (comm, dll) or (None, reason)."""
+    import ctypes as C
+    try:
+        dll = C.CDLL(os.environ.get("PLL_AMD_RCCL_LIB") or "librccl.so.1", mode=C.RTLD_GLOBAL)
+    except OSError as exc:
+        return None, f"librccl not loadable: {exc}"
+
+    class UniqueId(C.Structure):  # ncclUniqueId: 128 opaque bytes, passed BY VALUE to ncclCommInitRank
+        _fields_ = [("internal", C.c_ubyte * 128)]
+
+    uid = UniqueId()
+    if h.rank == 0 and dll.ncclGetUniqueId(C.byref(uid)) != 0:
+        return None, "ncclGetUniqueId failed"
+    blob = [bytes(uid.internal) if h.rank == 0 else None]
+    h.dist.broadcast_object_list(blob, src=0)
+    C.memmove(C.byref(uid), blob[0], 128)
+    dll.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    dll.ncclCommInitRank.restype = C.c_int
+    comm = C.c_void_p()
+    rc = dll.ncclCommInitRank(C.byref(comm), h.world, uid, h.rank)
+    # every rank learns whether ALL of them have a communicator (a collective on a partial one would hang)
+    ok = h.torch.tensor([1.0 if (rc == 0 and comm.value) else 0.0], dtype=h.torch.float64, device=h.tdev)
+    h.dist.all_reduce(ok, op=h.dist.ReduceOp.MIN)
+    if float(ok.item()) != 1.0:
+        return None, f"ncclCommInitRank failed on some rank (here: rc {rc})"
+    return comm, dll
+
+
+_ALLREDUCE_LOOP = None
+
+
+def _allreduce_loop_fn():
+    global _ALLREDUCE_LOOP
+    if _ALLREDUCE_LOOP is None:
+        import ctypes as C
+        dll = C.CDLL(os.path.join(ROOT, "libpll-2_amd", "csrc", "libpll_workload.so"))
+        fn = dll.pllwl_step_loop_allreduce
+        fn.restype = C.c_double
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint,
+                       C.POINTER(C.c_int), C.POINTER(C.c_uint), C.c_uint, C.POINTER(C.c_double)]
+        _ALLREDUCE_LOOP = fn
+    return _ALLREDUCE_LOOP
+
+
 class Runner:
     """one partition + the step the benchmark times. reduce: None (one partition is the whole job), 'peer' (fixed
     rank order through shared host memory) or 'rccl' (all-reduce on the device)."""
@@ -423,6 +475,7 @@ class Runner:
         self.fi = np.ascontiguousarray(case.freqs_indices, dtype=np.uint32)
         self.edge_c = (C.c_int * 5)(*[int(v) for v in self.edge])
         self.device_path = False
+        self.rccl_comm, self.rccl_via = None, None
         if self.reduce == "peer":
             self.group = h.join_group(lib)
         elif self.reduce == "rccl":
@@ -431,7 +484,23 @@ class Runner:
     def setup_rccl(self):
         h, lib = self.h, self.lib
         self.device_path = h.on_device
+        self.rccl_comm, self.rccl_via = None, "torch.distributed.all_reduce on a host value"
+        if self.device_path and os.environ.get("PLL_BENCH_TORCH_ALLREDUCE") != "1":
+            # the product's own exchange: the library's C entry point on a communicator of this run's ranks
+            if h.rccl is None:
+                h.rccl = make_rccl_comm(h)
+            comm, what = h.rccl
+            if comm is not None:
+                ok = h.torch.tensor([1.0 if lib.pll_gpu_allreduce_prepare(self.sess.p, comm) else 0.0], dtype=h.torch.float64, device=h.tdev)
+                h.dist.all_reduce(ok, op=h.dist.ReduceOp.MIN)  # set-up failures are agreed on BEFORE the first collective
+                if float(ok.item()) == 1.0:
+                    self.rccl_comm = comm
+                    self.rccl_via = "pll_gpu_edge_loglikelihood_allreduce (the library's C entry point, ncclAllReduce on the partition's stream)"
+                    return
+                what = f"pll_gpu_allreduce_prepare: [{lib.errno()}] {lib.errmsg()}"
+            print(f"bench.py: rank {h.rank}: no communicator for the library's all-reduce ({what}); torch.distributed.all_reduce instead", file=sys.stderr)
         if self.device_path:
+            self.rccl_via = "pll_gpu_edge_loglikelihood_async + torch.distributed.all_reduce on the device value"
             torch = h.torch
             # the partition works on torch's stream, the shard's lnL stays in HBM ({lnL, sequence} in `red`)
             # and RCCL reduces it there: no host round trip before the one exchange of the path
@@ -453,6 +522,8 @@ class Runner:
             self.upd = 0
         if self.reduce == "peer":
             return lib.pll_gpu_group_edge_loglikelihood(sess.p, self.group, e[0], e[1], e[2], e[3], e[4], self.api.uptr(self.fi), None)
+        if self.reduce == "rccl" and self.rccl_comm is not None:
+            return lib.pll_gpu_edge_loglikelihood_allreduce(sess.p, self.rccl_comm, e[0], e[1], e[2], e[3], e[4], self.api.uptr(self.fi))
         if self.device_path:
             if not lib.pll_gpu_edge_loglikelihood_async(sess.p, e[0], e[1], e[2], e[3], e[4], self.api.uptr(self.fi),
                                                         self.red.data_ptr()):
@@ -494,6 +565,17 @@ class Runner:
                            fp(lib.pll_gpu_group_edge_loglikelihood), C.cast(sess.p, C.c_void_p), grp,
                            C.cast(sess._op_arrays[0], C.c_void_p), len(self.case.op_batches[0]), self.upd, self.edge_c,
                            self.api.uptr(self.fi), n, C.byref(lnl))
+            if self.repeats:
+                self.upd = 0
+            return lnl.value
+        if self.c_driver and self.reduce == "rccl" and self.rccl_comm is not None and len(self.case.op_batches) == 1:
+            import ctypes as C
+            lib, sess = self.lib, self.sess
+            fp = lambda f: C.cast(f, C.c_void_p)
+            lnl = C.c_double(0.0)
+            fn = _allreduce_loop_fn()
+            fn(fp(lib.pll_update_partials_rep), fp(lib.pll_gpu_edge_loglikelihood_allreduce), C.cast(sess.p, C.c_void_p), self.rccl_comm,
+               C.cast(sess._op_arrays[0], C.c_void_p), len(self.case.op_batches[0]), self.upd, self.edge_c, self.api.uptr(self.fi), n, C.byref(lnl))
             if self.repeats:
                 self.upd = 0
             return lnl.value
@@ -776,12 +858,19 @@ def main_strong(args, h):
     value = total_sites * nops / (tN_ms * 1e-3) / 1e6
     exchange = {"reduce": reduce, reduce + "_ms_per_step": round(tN_ms, 4)}
     # the same steps with the other exchange, for the record (both in one line): RCCL needs the nccl backend
+    if reduce == "rccl":
+        exchange["rccl_via"] = runner.rccl_via
     if reduce == "peer" and h.on_device:
-        runner.reduce = "rccl"
-        runner.setup_rccl()
-        b2, lnl2 = runner.timed(args.warmup, args.steps, args.blocks)
-        exchange["rccl_ms_per_step"] = round(block_stats(b2, args.steps)[0], 4)
-        exchange["rccl_lnl_rel_diff"] = abs(lnl2 - lnl) / abs(lnl)
+        # (a failure of this second leg must not cost the line its first: the headline is the peer exchange)
+        try:
+            runner.reduce = "rccl"
+            runner.setup_rccl()
+            b2, lnl2 = runner.timed(args.warmup, args.steps, args.blocks)
+            exchange["rccl_ms_per_step"] = round(block_stats(b2, args.steps)[0], 4)
+            exchange["rccl_lnl_rel_diff"] = abs(lnl2 - lnl) / abs(lnl)
+            exchange["rccl_via"] = runner.rccl_via
+        except Exception as exc:  # noqa: BLE001
+            exchange["rccl_error"] = f"{type(exc).__name__}: {exc}"
         runner.reduce, runner.device_path = "peer", False
     # what the exchange adds behind a result that is already in host memory: the group sum alone, all ranks in step
     if reduce == "peer":
@@ -877,7 +966,10 @@ def main():
               file=sys.stderr)
         sys.exit(2)
     h = Harness(args)
-    out = main_strong(args, h) if h.world > 1 else main_single(args, h)
+    # (PLL_BENCH_FORCE_STRONG=1 + PLL_BENCH_FORCE_DIST=1: the sharded flow with a world of one - tests/test_gpu_bench_flow.py
+    # rehearses the RCCL form of the exchange on the one GPU a test box has, where RCCL refuses two ranks on a device)
+    strong = h.world > 1 or (os.environ.get("PLL_BENCH_FORCE_STRONG") == "1" and h.dist is not None)
+    out = main_strong(args, h) if strong else main_single(args, h)
     h.finish()
     if h.rank == 0:
         print(json.dumps(out))

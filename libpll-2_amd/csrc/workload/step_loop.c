@@ -38,3 +38,28 @@ double pllwl_step_loop(update_fn update, edge_fn edge_lnl, group_edge_fn group_e
   *lnl = v;
   return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
 }
+
+/* the same loop for a run whose exchange is the library's RCCL form (include/pll_amd.h:
+ * pll_gpu_edge_loglikelihood_allreduce - evaluation, one ncclAllReduce on the partition's stream, the sum back) */
+typedef double (*allreduce_edge_fn)(void *partition, void *nccl_comm, unsigned int parent_clv, int parent_scaler,
+                                    unsigned int child_clv, int child_scaler, unsigned int matrix,
+                                    const unsigned int *freqs_indices);
+
+double pllwl_step_loop_allreduce(update_fn update, allreduce_edge_fn allreduce_edge_lnl, void *partition, void *nccl_comm,
+                                 const void *ops, unsigned int count, unsigned int first_update_repeats, const int *edge,
+                                 const unsigned int *freqs_indices, unsigned int steps, double *lnl)
+{
+  struct timespec a, b;
+  double v = 0.0;
+  unsigned int k, ur = first_update_repeats;
+  clock_gettime(CLOCK_MONOTONIC, &a);
+  for (k = 0; k < steps; ++k)
+  {
+    update(partition, ops, count, ur);
+    ur = first_update_repeats ? 0u : ur;
+    v = allreduce_edge_lnl(partition, nccl_comm, (unsigned int)edge[0], edge[1], (unsigned int)edge[2], edge[3], (unsigned int)edge[4], freqs_indices);
+  }
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  *lnl = v;
+  return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+}

@@ -34,6 +34,24 @@ def test_gpus_2_starts_two_ranks_and_runs_the_strong_scaling_flow(cut):
     assert "roofline" in out and out["t1_ms"] > 0
 
 
+@pytest.mark.parametrize("reduce", ["rccl", "peer"])
+def test_the_rccl_form_of_the_exchange_runs_through_the_librarys_entry_point(reduce):
+    """`--reduce rccl` called torch's all_reduce, never pll_gpu_edge_loglikelihood_allreduce. Now bench.py
+    makes a communicator of its ranks (ncclGetUniqueId over the control plane, ncclCommInitRank) and its steps call the
+    library's C entry point from the C step loop. RCCL refuses two ranks on one device, so the one-GPU rehearsal is the
+    sharded flow with a world of ONE rank and a real communicator (several ranks: tests/test_gpu_c_caller.py through
+    the stream-ordered stand-in); with --reduce peer the RCCL form is the line's second, guarded leg."""
+    out = run_bench("--gpus", "1", "--backend", "nccl", "--reduce", reduce, "--sites", "200000", "--steps", "3", "--blocks", "2", "--warmup", "2",
+                    env={"PLL_BENCH_FORCE_DIST": "1", "PLL_BENCH_FORCE_STRONG": "1"})
+    ex = out["exchange"]
+    assert ex["reduce"] == reduce and "rccl_error" not in ex
+    assert "pll_gpu_edge_loglikelihood_allreduce" in ex["rccl_via"], ex
+    assert ex["rccl_ms_per_step"] > 0
+    assert out["lnl_rel_err_vs_unsharded"] <= 1e-12
+    if reduce == "peer":
+        assert ex["rccl_lnl_rel_diff"] <= 1e-14
+
+
 def test_default_line_carries_the_contract_fields():
     out = run_bench("--steps", "5", "--blocks", "3", "--warmup", "2")
     assert out["n_gpus"] == 1 and out["scaling"] is None and out["blocks"] == 3 and out["dtype"] == "f64"
