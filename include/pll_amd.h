@@ -552,6 +552,15 @@ double pll_gpu_group_edge_loglikelihood(pll_partition_t *partition, pll_gpu_grou
                                         unsigned int child_clv_index, int child_scaler_index,
                                         unsigned int matrix_index, const unsigned int *freqs_indices,
                                         double *persite_lnl);
+/* pll_compute_likelihood_derivatives (src/pll.h:2400-2412 region; src/derivatives.c:296-418) on this rank's partition
+ * followed by the exchange of {d_f, dd_f}: the derivatives of the WHOLE alignment's log-likelihood on every rank,
+ * the same bits everywhere (rank order), so that all ranks of a sharded branch-length optimisation take the same
+ * Newton step. Every rank calls it with the same branch length. PLL_FAILURE on every rank if any rank failed
+ * (that rank keeps its own pll_errno). group == NULL: the plain evaluation. */
+int pll_gpu_group_likelihood_derivatives(pll_partition_t *partition, pll_gpu_group_t *group,
+                                         int parent_scaler_index, int child_scaler_index, double branch_length,
+                                         const unsigned int *params_indices, const double *sumtable,
+                                         double *d_f, double *dd_f);
 /* enqueue ncclAllReduce(device_values, device_values, count, ncclDouble, ncclSum, comm) on the
  * partition's stream (count doubles of DEVICE memory, e.g. what pll_gpu_edge_loglikelihood_async left) */
 int pll_gpu_allreduce_lnl(pll_partition_t *partition, void *nccl_comm, double *device_values, unsigned int count);

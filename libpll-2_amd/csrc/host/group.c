@@ -304,6 +304,41 @@ double pll_gpu_group_edge_loglikelihood(pll_partition_t *p, pll_gpu_group_t *g, 
   return isfinite(all) ? all : -INFINITY;
 }
 
+/* Branch-length optimisation of a sharded run (SURVEY section 8 row f1 next to row e): every rank evaluates the two
+ * derivatives of ITS sites' log-likelihood at the same branch length; the whole alignment's are their sums
+ * (src/core_derivatives.c:643-849 accumulates over sites exactly like the log-likelihood does). Added in rank order, so
+ * every rank holds the same bits and takes the same Newton step: the ranks' branch lengths cannot drift apart by an
+ * ulp, which an arrival-order reduction would allow. A rank whose evaluation failed brings NaN. */
+int pll_gpu_group_likelihood_derivatives(pll_partition_t *p, pll_gpu_group_t *g, int parent_scaler_index, int child_scaler_index,
+                                         double branch_length, const unsigned int *params_indices, const double *sumtable,
+                                         double *d_f, double *dd_f)
+{
+  double mine[2] = {NAN, NAN}, all[2] = {NAN, NAN};
+  const int ok = pll_compute_likelihood_derivatives(p, parent_scaler_index, child_scaler_index, branch_length, params_indices, sumtable,
+                                                    &mine[0], &mine[1]);
+  if (!g)
+  {
+    if (ok) *d_f = mine[0], *dd_f = mine[1];
+    return ok;
+  }
+  const int my_errno = pll_errno;
+  if (!ok) mine[0] = mine[1] = NAN;
+  if (!pll_gpu_group_sum(g, mine, 2, all)) return PLL_FAILURE;
+  if (!ok)
+  {
+    pll_errno = my_errno;
+    return PLL_FAILURE;
+  }
+  if (isnan(all[0]) || isnan(all[1]))
+  {
+    pll_set_error(PLL_ERROR_GPU_RUNTIME, "pll_gpu_group_likelihood_derivatives: another rank's evaluation failed");
+    return PLL_FAILURE;
+  }
+  *d_f = all[0];
+  *dd_f = all[1];
+  return PLL_SUCCESS;
+}
+
 /* ---- RCCL, bound at run time ------------------------------------------------------------------ */
 typedef int (*nccl_allreduce_fn)(const void *, void *, size_t, int, int, void *, void *);
 typedef int (*nccl_count_fn)(const void *, int *);

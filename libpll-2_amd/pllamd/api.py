@@ -181,6 +181,8 @@ _GPU_PROTOS = {
     "pll_gpu_group_sum": (C.c_int, [C.c_void_p, c_double_p, C.c_uint, c_double_p]),
     "pll_gpu_group_edge_loglikelihood": (
         C.c_double, [PartitionP, C.c_void_p, C.c_uint, C.c_int, C.c_uint, C.c_int, C.c_uint, c_uint_p, c_double_p]),
+    "pll_gpu_group_likelihood_derivatives": (
+        C.c_int, [PartitionP, C.c_void_p, C.c_int, C.c_int, C.c_double, c_uint_p, c_double_p, c_double_p, c_double_p]),
     "pll_gpu_allreduce_lnl": (C.c_int, [PartitionP, C.c_void_p, C.c_void_p, C.c_uint]),
     "pll_gpu_allreduce_prepare": (C.c_int, [PartitionP, C.c_void_p]),
     "pll_gpu_edge_loglikelihood_allreduce": (
