@@ -128,13 +128,16 @@ constexpr unsigned kAosRow = 18;
 // ask for the next tile's children; more, shorter waves hide that for each other. The kernels keep the loop.
 constexpr unsigned kDnaTilesPerWave = 1;
 template <bool LTIP, bool RTIP, bool GATHER>
-__global__ __launch_bounds__(256, GATHER ? DNA_GATHER_WAVES : 1) void k_partials_dna(const OpPack pack, int scale_mode, unsigned tiles_per_wave)
+__global__ __launch_bounds__(256, GATHER ? DNA_GATHER_WAVES : 1) void k_partials_dna(const OpPack pack, int scale_mode, unsigned tiles_per_wave, unsigned nx, unsigned ny,
+                                                                                    unsigned xcd_order)
 {
+  unsigned bx, by;
+  if (!xcd_block(nx, ny, xcd_order, bx, by)) return;
   // entry-contiguous parents leave through LDS: a lane holds ITS entry's 128 bytes, but 64 lanes
   // writing 16 bytes each at a 128-byte stride reach only half the store bandwidth of dense 1 KB
   // rows (tools/store_probe.hip: 3.3 vs 6.6 TB/s)
   __shared__ double transpose[GATHER ? 4 * 64 * kAosRow : 1];
-  const DevOp &op = pack.ops[blockIdx.y];
+  const DevOp &op = pack.ops[by];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned ntiles = (op.entries + 63u) / 64u;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256, GATHER ? DNA_GATHER_WAVES : 1) void k_partials
 
   for (unsigned t = 0; t < tiles_per_wave; ++t)
   {
-    const unsigned tile = (blockIdx.x * 4u + wave) * tiles_per_wave + t;
+    const unsigned tile = (bx * 4u + wave) * tiles_per_wave + t;
     if (tile >= ntiles) break; // wave-uniform
     const unsigned n = tile * 64u + lane;
     const bool valid = n < op.entries;
@@ -168,7 +171,9 @@ __global__ __launch_bounds__(256, GATHER ? DNA_GATHER_WAVES : 1) void k_partials
       // One child after the other: fetch (entry-contiguous: cooperatively, through LDS), contract, and only then
       // touch the second child. With both children's 16 values and both fetches' pieces alive at once the kernel
       // needed 246 registers = two waves per SIMD (the unified file: architected + accumulation registers), and a
-      // gather launch lives on the number of waves that wait for memory side by side.
+      // gather launch lives on the number of waves that wait for memory side by side. (Round 4 requested both children's
+      // pieces together, as k_partials_dna_gg now does for its producers: this kernel, with its tiled / entry-contiguous
+      // / tip branches alive side by side, spilled - 300 bytes of scratch at the 168 registers of three waves. Not kept.)
       double *mine = transpose + (size_t)wave * 64 * kAosRow;
       double a[4][4];
       {
@@ -736,29 +741,28 @@ struct GGPack
   GGroup g[kMaxGGroups];
 };
 
-// one gathering inner x inner op for the lane's site n (clamped nn): its 16 values, scaled, and its scaler words
-__device__ __forceinline__ void dna_gather_op(const DevOp &op, unsigned nn, unsigned lane, double *mine, int scale_mode, double (&v)[4][4],
-                                              uint4 &sc)
+// one gathering inner x inner op for the lane's site: its 16 values, scaled, and its scaler words. The caller has
+// looked the child entries (le, re) up already and - `pl`, `pr` - requested BOTH children's entries: round 2 fetched one
+// child after the other (four dependent round trips per group and tile behind four dependent map look-ups) to stay at
+// three waves per SIMD; with the look-ups of both producers first and a producer's two fetches in flight together a
+// tile waits three times instead of eight and the kernel still fits three waves (round 4: the shard's launch 57 -> see
+// profiles/README.md).
+__device__ __forceinline__ void dna_gather_op_finish(const DevOp &op, unsigned le, unsigned re, const DnaCoop &pl, const DnaCoop &pr, unsigned lane,
+                                                     double *mine, int scale_mode, double (&v)[4][4], uint4 &sc)
 {
-  unsigned le = nn, re = nn;
-  gather_entries(op, nn, le, re);
   cdouble_p lm = as_const(op.lmat), rm = as_const(op.rmat);
   const int mode = op.pscaler ? scale_mode : 0;
+  const uint4 lsc = dna_load_scaler(op.lscaler, le, scale_mode), rsc = dna_load_scaler(op.rscaler, re, scale_mode);
   double a[4][4];
   {
     double cl[4][4];
-    DnaCoop pl;
-    dna_coop_issue(pl, op.left, le, lane, (op.layout & kStreamLeft) != 0);
     dna_coop_finish(pl, mine, lane, kAosRow, cl);
 #pragma unroll
     for (int k = 0; k < 4; ++k) dna_matvec(a[k], lm + k * 16, cl[k]);
   }
-  __builtin_amdgcn_sched_barrier(0); // the right child's fetch starts after the left child's values are dead
   bool small[4];
   {
     double cr[4][4];
-    DnaCoop pr;
-    dna_coop_issue(pr, op.right, re, lane, (op.layout & kStreamRight) != 0);
     dna_coop_finish(pr, mine, lane, kAosRow, cr);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -774,7 +778,6 @@ __device__ __forceinline__ void dna_gather_op(const DevOp &op, unsigned nn, unsi
       }
     }
   }
-  const uint4 lsc = dna_load_scaler(op.lscaler, le, scale_mode), rsc = dna_load_scaler(op.rscaler, re, scale_mode);
   dna_scale(v, small, mode, lsc, rsc, sc);
 }
 
@@ -782,10 +785,12 @@ __device__ __forceinline__ void dna_gather_op(const DevOp &op, unsigned nn, unsi
 #define DNA_GG_WAVES 3
 #endif
 __global__ __launch_bounds__(256, DNA_GG_WAVES) void k_partials_dna_gg(const GGPack pack, unsigned entries, int scale_mode, unsigned tiles_per_wave,
-                                                                       unsigned stream_parent)
+                                                                       unsigned stream_parent, unsigned nx, unsigned ny, unsigned xcd_order)
 {
   __shared__ double transpose[4 * 64 * kAosRow];
-  const GGroup &g = pack.g[blockIdx.y];
+  unsigned bx, by;
+  if (!xcd_block(nx, ny, xcd_order, bx, by)) return;
+  const GGroup &g = pack.g[by];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned ntiles = (entries + 63u) / 64u;
@@ -795,7 +800,7 @@ __global__ __launch_bounds__(256, DNA_GG_WAVES) void k_partials_dna_gg(const GGP
 
   for (unsigned t = 0; t < tiles_per_wave; ++t)
   {
-    const unsigned tile = (blockIdx.x * 4u + wave) * tiles_per_wave + t;
+    const unsigned tile = (bx * 4u + wave) * tiles_per_wave + t;
     if (tile >= ntiles) break; // wave-uniform
     const unsigned n0 = tile * 64u + lane;
     const bool valid = n0 < entries;
@@ -819,12 +824,25 @@ __global__ __launch_bounds__(256, DNA_GG_WAVES) void k_partials_dna_gg(const GGP
     };
     double va[4][4], v[4][4];
     uint4 sca, scb, sc;
-    dna_gather_op(g.a, n, lane, mine, scale_mode, va, sca);
-    put(g.a.parent, g.a.pscaler, g.a.pscaler ? scale_mode : 0, va, sca, true);
+    // the four look-ups first (independent loads), then producer A's two children together
+    unsigned ale = n, are = n, ble = n, bre = n;
+    gather_entries(g.a, n, ale, are);
+    gather_entries(g.b, n, ble, bre);
+    {
+      DnaCoop al, ar;
+      dna_coop_issue(al, g.a.left, ale, lane, (g.a.layout & kStreamLeft) != 0);
+      dna_coop_issue(ar, g.a.right, are, lane, (g.a.layout & kStreamRight) != 0);
+      dna_gather_op_finish(g.a, ale, are, al, ar, lane, mine, scale_mode, va, sca);
+    }
     bool small[4];
     {
       double vb[4][4];
-      dna_gather_op(g.b, n, lane, mine, scale_mode, vb, scb);
+      DnaCoop bl, br;
+      // producer B's children are requested before A's CLV leaves: the stores and the loads overlap
+      dna_coop_issue(bl, g.b.left, ble, lane, (g.b.layout & kStreamLeft) != 0);
+      dna_coop_issue(br, g.b.right, bre, lane, (g.b.layout & kStreamRight) != 0);
+      put(g.a.parent, g.a.pscaler, g.a.pscaler ? scale_mode : 0, va, sca, true);
+      dna_gather_op_finish(g.b, ble, bre, bl, br, lane, mine, scale_mode, vb, scb);
       put(g.b.parent, g.b.pscaler, g.b.pscaler ? scale_mode : 0, vb, scb, true);
 #pragma unroll
       for (int k = 0; k < 4; ++k)

@@ -882,9 +882,13 @@ static void launch_dna(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigne
   // one wave per 64-site tile (kDnaTilesPerWave, kernels_dna.h)
   const unsigned tiles = (maxent + 63) / 64;
   const unsigned tpw = kDnaTilesPerWave;
-  dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), nops), block(256);
+  const unsigned nx = (tiles + 4 * tpw - 1) / (4 * tpw);
+  dim3 grid = xcd_grid(nx, nops), block(256);
   const int mode = c->gg.scale_mode;
-#define DNA_LAUNCH(LT, RT, GA) hipLaunchKernelGGL((k_partials_dna<LT, RT, GA>), grid, block, 0, c->stream, pack, mode, tpw)
+  // gathering launches: a pattern-sorted alignment's neighbouring sites gather neighbouring entries, and with the XCD-aware
+  // order (kernels_common.h) an XCD's L2 holds the entries of ITS run of sites, not a copy of everybody's
+  const unsigned xcd = (c->xcd_order && gather) ? 1u : 0u;
+#define DNA_LAUNCH(LT, RT, GA) hipLaunchKernelGGL((k_partials_dna<LT, RT, GA>), grid, block, 0, c->stream, pack, mode, tpw, nx, nops, xcd)
   if (kind == 0)
   {
     if (gather) DNA_LAUNCH(false, false, true); else DNA_LAUNCH(false, false, false);
@@ -905,9 +909,11 @@ static void launch_gg(pllgpu_ctx *c, const GGPack &pack, unsigned ngroups, unsig
 {
   const unsigned tiles = (entries + 63) / 64;
   const unsigned tpw = kDnaTilesPerWave;
-  dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), ngroups), block(256);
+  const unsigned nx = (tiles + 4 * tpw - 1) / (4 * tpw);
+  dim3 grid = xcd_grid(nx, ngroups), block(256);
   const unsigned stream_parent = ((size_t)ngroups * entries * 128u > c->stream_parent_bytes) ? 1u : 0u;
-  hipLaunchKernelGGL(k_partials_dna_gg, grid, block, 0, c->stream, pack, entries, c->gg.scale_mode, tpw, stream_parent);
+  const unsigned xcd = c->xcd_order; // (C4's shard, same box: 0.1104-0.1111 -> 0.1089-0.1102 ms per step for the slowest shards)
+  hipLaunchKernelGGL(k_partials_dna_gg, grid, block, 0, c->stream, pack, entries, c->gg.scale_mode, tpw, stream_parent, nx, ngroups, xcd);
 }
 
 // fp64 MFMA 4x4x4 kernels, matrices staged in LDS (kernels_mfma.h): NG = number of 4-state groups
