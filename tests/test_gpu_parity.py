@@ -964,3 +964,28 @@ def test_tiny_inputs(amd_lib, states, sites, tips, attrs):
         s.update_partials()
         v, ps = s.edge_lnl(case.edges[0])
         assert abs(v - exp["lnl"][0]) <= RTOL * max(abs(exp["lnl"][0]), 1.0) and abs(ps.sum() - v) <= 1e-9 * max(abs(v), 1.0)
+
+
+@pytest.mark.parametrize("kw", [dict(states=4, tips=64, sites=9000, seed=401),                                   # seven-op groups (k_partials_dna_cc), chain tail
+                                dict(states=4, tips=64, sites=9000, seed=402, attributes=api.RATE_SCALERS),
+                                dict(states=4, tips=32, sites=5001, seed=403, tree="random"),                      # one-level groups of every kind, ragged last tile
+                                dict(states=4, tips=128, sites=20000, seed=404, attributes=api.SITE_REPEATS, mutate_pct=8),  # gathering launches, groups over gathering producers
+                                dict(states=20, tips=64, sites=3000, seed=405),                                    # k_partials_mfma_cc: rate category as the fastest logical index
+                                dict(states=20, tips=16, sites=777, seed=406, rate_cats=2, attributes=api.RATE_SCALERS),
+                                dict(states=20, tips=16, sites=64, seed=407, rate_cats=1)], ids=_id)               # fewer logical blocks than the 8 XCDs
+def test_xcd_aware_workgroup_order_changes_nothing(amd_lib, kw, monkeypatch):
+    """round 4: the store-bound group launches and the gathering 4 x 4 launches run as 1-D grids whose workgroups take
+    their logical block from xcd_block() (kernels_common.h) - every XCD on its own contiguous run of the work, the grid
+    rounded up to a multiple of eight. PLL_AMD_NO_XCD_ORDER=1 keeps the natural order on the same grid: every CLV,
+    scaler and log-likelihood bit for bit the same, and right against the oracle (a block skipped or done twice by the
+    mapping would show in either)"""
+    case = W.make_case("xcd", **kw)
+    ordered = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    monkeypatch.setenv("PLL_AMD_NO_XCD_ORDER", "1")
+    natural = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+    assert_results_match(ordered, O.run_case(case), what=_id(kw))
+    assert ordered["lnl"] == natural["lnl"]
+    for k in natural["clv"]:
+        assert (ordered["clv"][k] == natural["clv"][k]).all(), k
+        if k in natural["scaler"]:
+            assert (ordered["scaler"][k] == natural["scaler"][k]).all(), k
