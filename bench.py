@@ -412,30 +412,39 @@ def step_loop_fn():
 def make_rccl_comm(h):
     """A communicator of this run's ranks for the LIBRARY's all-reduce entry point (pll_gpu_edge_loglikelihood_allreduce
     takes a caller-made ncclComm_t; torch does not hand its own out): rank 0 draws the id, the control plane carries it,
-    every rank calls ncclCommInitRank on its device. Returns (comm, dll) or (None, reason)."""
+    every rank calls ncclCommInitRank on its device. Every step that one rank can fail alone is followed by an agreement
+    over the control plane, so that no rank walks into a collective the others have given up on.
+    Returns (comm, dll) or (None, reason) - the same kind on every rank."""
     import ctypes as C
+
+    def all_ok(mine):
+        t = h.torch.tensor([1.0 if mine else 0.0], dtype=h.torch.float64, device=h.tdev)
+        h.dist.all_reduce(t, op=h.dist.ReduceOp.MIN)
+        return float(t.item()) == 1.0
+
+    dll, why = None, ""
     try:
         dll = C.CDLL(os.environ.get("PLL_AMD_RCCL_LIB") or "librccl.so.1", mode=C.RTLD_GLOBAL)
     except OSError as exc:
-        return None, f"librccl not loadable: {exc}"
+        why = f"librccl not loadable: {exc}"
+    if not all_ok(dll is not None):
+        return None, why or "librccl not loadable on another rank"
 
     class UniqueId(C.Structure):  # ncclUniqueId: 128 opaque bytes, passed BY VALUE to ncclCommInitRank
         _fields_ = [("internal", C.c_ubyte * 128)]
 
     uid = UniqueId()
-    if h.rank == 0 and dll.ncclGetUniqueId(C.byref(uid)) != 0:
-        return None, "ncclGetUniqueId failed"
-    blob = [bytes(uid.internal) if h.rank == 0 else None]
+    drawn = h.rank != 0 or dll.ncclGetUniqueId(C.byref(uid)) == 0
+    blob = [bytes(uid.internal) if (h.rank == 0 and drawn) else None]
     h.dist.broadcast_object_list(blob, src=0)
+    if blob[0] is None:
+        return None, "ncclGetUniqueId failed on rank 0"
     C.memmove(C.byref(uid), blob[0], 128)
     dll.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
     dll.ncclCommInitRank.restype = C.c_int
     comm = C.c_void_p()
     rc = dll.ncclCommInitRank(C.byref(comm), h.world, uid, h.rank)
-    # every rank learns whether ALL of them have a communicator (a collective on a partial one would hang)
-    ok = h.torch.tensor([1.0 if (rc == 0 and comm.value) else 0.0], dtype=h.torch.float64, device=h.tdev)
-    h.dist.all_reduce(ok, op=h.dist.ReduceOp.MIN)
-    if float(ok.item()) != 1.0:
+    if not all_ok(rc == 0 and bool(comm.value)):
         return None, f"ncclCommInitRank failed on some rank (here: rc {rc})"
     return comm, dll
 

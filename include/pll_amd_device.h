@@ -228,6 +228,10 @@ int pllgpu_tt_from_lookup(pllgpu_ctx_t *ctx, double *parent_host, const unsigned
                           const unsigned char *right_codes, const double *lookup_host, unsigned int sites, unsigned int ncodes);
 
 /* ---- the exchange of a site-sharded run (pll_gpu_edge_loglikelihood_allreduce) ---------------- */
+/* make the context's device the calling thread's current one while a collective library enqueues on the context's
+ * stream from the host side of this boundary; *previous (-1: nothing changed) goes to pllgpu_leave_device afterwards */
+int pllgpu_enter_device(pllgpu_ctx_t *ctx, int *previous);
+void pllgpu_leave_device(int previous);
 /* two doubles of device memory owned by the context: {lnL, sequence}, the operand of the all-reduce */
 double *pllgpu_reduce_buffer(pllgpu_ctx_t *ctx);
 /* after the collective has been enqueued on the context's stream: a one-lane kernel copies the reduced

@@ -2174,6 +2174,26 @@ extern "C" int pllgpu_tt_from_lookup(pllgpu_ctx_t *c, double *parent_host, const
 }
 
 // ---- the exchange of a site-sharded run ---------------------------------------------------------
+// a collective library enqueues on the context's stream from the HOST side of the boundary (group.c: ncclAllReduce):
+// the calling thread's current device must be the context's while it does (its own may be another, e.g. with
+// PLL_AMD_DEVICE=auto); *previous = what pllgpu_leave_device puts back, -1 = nothing to do
+extern "C" int pllgpu_enter_device(pllgpu_ctx_t *c, int *previous)
+{
+  if (!c || !previous) return fail(PLLGPU_EINVAL, "null context");
+  *previous = -1;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+  if (cur == c->device) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  *previous = cur;
+  return 0;
+}
+
+extern "C" void pllgpu_leave_device(int previous)
+{
+  if (previous >= 0) (void)hipSetDevice(previous);
+}
+
 extern "C" double *pllgpu_reduce_buffer(pllgpu_ctx_t *c)
 {
   if (!c) return nullptr;

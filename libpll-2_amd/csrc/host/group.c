@@ -407,7 +407,16 @@ int pll_gpu_allreduce_lnl(pll_partition_t *p, void *comm, double *device_values,
     return PLL_FAILURE;
   }
   void *stream = pllgpu_get_stream(x->ctx); /* launches whatever the partition still holds back */
+  /* the communicator's rank lives on the partition's device; the calling thread's current device may be another
+   * (PLL_AMD_DEVICE=auto, a caller that drives several devices from one thread) */
+  int previous = -1;
+  if (pllgpu_enter_device(x->ctx, &previous) != 0)
+  {
+    pll_set_gpu_error("pll_gpu_allreduce_lnl");
+    return PLL_FAILURE;
+  }
   const int rc = g_rccl.allreduce(device_values, device_values, count, NCCL_DOUBLE, NCCL_SUM, comm, stream);
+  pllgpu_leave_device(previous);
   if (rc != 0)
   {
     pll_set_error(PLL_ERROR_GPU_RUNTIME, "ncclAllReduce: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "failed");
