@@ -982,7 +982,9 @@ static int launch_mfma_t(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsig
     }
   }
   // aim at two workgroups of four waves on every CU (2048 waves) - four where the small shapes leave room;
-  // more work -> more items per wave
+  // more work -> more items per wave. (Round 4, C5's tip x tip launch with 1024 / 2048 / 4096 / 8192 / 16384 / 40000
+  // waves wanted: 1020 / 1063 / 1076 / 1051 / 1020 / 908 M updates/s for the step - flat around the choice, unlike the
+  // 4 x 4 kernels, which gained 6 % from one tile per wave: every workgroup here stages 64 KB of matrices first)
   const unsigned want = NG > 8 ? 2048u : 4096u;
   unsigned ipw = (unsigned)(((size_t)items * nops * R + want - 1) / want);
   ipw = std::max(1u, std::min(ipw, NG > 8 ? ~0u : 8u));
