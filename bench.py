@@ -671,6 +671,7 @@ def roofline_leg(args, cfg, lib, api, runner, reps=20):
         ii_ops = list(all_ops)
     fused = cfg["states"] == 4 and not cfg.get("repeats") and not os.environ.get("PLL_AMD_NO_FUSE", "0").strip("0")
     cc = fused and codes and not os.environ.get("PLL_AMD_NO_FUSE_CC", "0").strip("0")
+    cc16 = False
     if cc:
         # 4x4 with tips as codes: most of the step is ONE launch, the groups of seven ops over complete
         # 8-tip subtrees (k_partials_dna_cc<5,5>). The leg re-runs exactly those ops: everything within
@@ -679,7 +680,11 @@ def roofline_leg(args, cfg, lib, api, runner, reps=20):
         for op in all_ops:
             depth[op[0]] = 1 + max(depth[op[2]], depth[op[5]])
         low = [op for op in all_ops if depth[op[0]] <= 3]
-        if len(low) == 7 * (case.tips // 8):
+        # round 4: complete 16-tip subtrees are groups of FIFTEEN ops (k_partials_dna_cc16): everything within four levels
+        low16 = [op for op in all_ops if depth[op[0]] <= 4]
+        if len(low16) == 15 * (case.tips // 16) and case.tips >= 32 and not os.environ.get("PLL_AMD_NO_FUSE_CC16", "0").strip("0"):
+            ii_ops, cc16 = low16, True
+        elif len(low) == 7 * (case.tips // 8):
             ii_ops = low
         else:
             cc = False
@@ -697,7 +702,7 @@ def roofline_leg(args, cfg, lib, api, runner, reps=20):
         else:
             grouped = False
     if args.tree != "balanced":  # irregular levels: no single dominant launch shape - the leg is the whole traversal
-        ii_ops, cc, grouped = list(all_ops), False, False
+        ii_ops, cc, cc16, grouped = list(all_ops), False, False, False
     ii_arr = api.make_ops(ii_ops)
     for _ in range(3):
         lib.pll_update_partials_rep(sess.p, ii_arr, len(ii_ops), 0)
@@ -727,7 +732,7 @@ def roofline_leg(args, cfg, lib, api, runner, reps=20):
             note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/profile_round.sh), not this run")
     mfma = cfg["states"] > 32 and not os.environ.get("PLL_AMD_NO_MFMA", "0").strip("0")
     gg = cfg["states"] == 4 and cfg.get("repeats") and not os.environ.get("PLL_AMD_NO_FUSE_GG", "0").strip("0")
-    kernel = {4: "k_partials_dna_cc<5,5>%.0s" if cc else "k_partials_dna_fused<4,4>%.0s" if fused else
+    kernel = {4: "k_partials_dna_cc16%.0s" if cc16 else "k_partials_dna_cc<5,5>%.0s" if cc else "k_partials_dna_fused<4,4>%.0s" if fused else
                  "k_partials_dna<false,false,true>%.0s (compressed levels) + k_partials_dna_gg (where compression ends)" if gg else "k_partials_dna<false,false,%s>",
               20: "k_partials_mfma_cc<5>%.0s" if grouped else
                   ("k_partials_lean<5,false,false,true>%.0s (gathering launches) + k_partials_tiled<20,false,false,false>"

@@ -27,6 +27,7 @@ struct ChainPlan
   unsigned long long epoch = 0;
   unsigned entries = 0;
   std::vector<CCLaunch> cc;            // stage 1, before the chains
+  std::vector<CC16Launch> cc16;        // stage 1 as well: complete 16-tip subtrees (fifteen ops per group)
   std::vector<ChainLaunchRec> stages;
   std::vector<ChainHead> heads;
   std::vector<ChainStepLoad> loads;
@@ -118,6 +119,8 @@ static void launch_chain_heads(pllgpu_ctx *c, const ChainPlan &pl, unsigned firs
 // the next call shows whether it is the evaluation of the edge those chains end in
 static int launch_chain_plan(pllgpu_ctx *c, const ChainPlan &pl, bool hold)
 {
+  for (const CC16Launch &l : pl.cc16)
+    if (int rc = launch_cc16(c, l.pack, l.n, l.entries)) return rc;
   for (const CCLaunch &l : pl.cc)
     if (int rc = launch_cc(c, l.pack, l.n, l.entries, l.lk, CK_FCC)) return rc;
   const size_t upto = hold ? pl.held_from : pl.stages.size();
@@ -163,7 +166,8 @@ struct ChainPartition
 };
 
 // host logic only (no device state): does the list qualify, and how is it partitioned
-static bool partition_chains(const pllgpu_op_t *ops, unsigned count, unsigned nodes, unsigned nsb, unsigned entries, bool fuse_cc, ChainPartition &P)
+static bool partition_chains(const pllgpu_op_t *ops, unsigned count, unsigned nodes, unsigned nsb, unsigned entries, bool fuse_cc, bool fuse_cc16,
+                             ChainPartition &P)
 {
   // ---- is the list dependency-only?
   std::vector<int> producer(nodes, -1), sc_writer(nsb, -1), consumers(count, 0);
@@ -202,7 +206,7 @@ static bool partition_chains(const pllgpu_op_t *ops, unsigned count, unsigned no
   // a tip child whose codes were replaced by a dense CLV arrives as an inner child: nothing to do here
   std::vector<int> &role = P.role;
   std::vector<FusedGroup> &groups = P.groups;
-  plan_fusion(true, fuse_cc, nodes, ops, count, role, groups, true); // cherry-cherry groups only
+  plan_fusion(true, fuse_cc, nodes, ops, count, role, groups, true, fuse_cc16); // cherry-cherry groups (and groups of two of them) only
   // ---- stages, bottom-up
   std::vector<unsigned> &S = P.S;
   std::vector<unsigned char> &acc_side = P.acc_side, &absorb = P.absorb;
@@ -299,7 +303,8 @@ extern "C" int pllgpu_debug_chain_plan(const pllgpu_op_t *ops, unsigned count, u
 {
   if (!ops || count == 0) return 0;
   ChainPartition P;
-  if (!partition_chains(ops, count, nodes, scale_buffers, ops[0].parent_entries, fuse_cc != 0, P)) return 0;
+  // fuse_cc: bit 0 = seven-op groups, bit 1 = fifteen-op groups over two of them
+  if (!partition_chains(ops, count, nodes, scale_buffers, ops[0].parent_entries, (fuse_cc & 1) != 0, (fuse_cc & 2) != 0, P)) return 0;
   unsigned stages = 0;
   for (unsigned i = 0; i < count; ++i)
   {
@@ -332,7 +337,7 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
   if (entries == 0 || aos_entries(c, entries) || (size_t)entries * 128u >= ((size_t)1 << 31)) return 0; // 32-bit buffer offsets
   const unsigned nodes = c->geo.nodes, nsb = c->geo.scale_buffers;
   ChainPartition part;
-  if (!partition_chains(ops, count, nodes, nsb, entries, c->fuse_cc, part)) return 0;
+  if (!partition_chains(ops, count, nodes, nsb, entries, c->fuse_cc, c->fuse_cc16, part)) return 0;
   ChainPlan *pl = new ChainPlan();
   std::vector<int> (&pr_of)[2] = part.pr_of;
   std::vector<int> &role = part.role;
@@ -355,6 +360,11 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
   {
     std::stable_sort(groups.begin(), groups.end(), [](const FusedGroup &x, const FusedGroup &y) { return x.level < y.level; });
     if (int rc = build_cc_launches(c, ops, groups, 0, groups.size(), pl->cc))
+    {
+      delete pl;
+      return rc;
+    }
+    if (int rc = build_cc16_launches(c, ops, groups, pl->cc16))
     {
       delete pl;
       return rc;
@@ -519,7 +529,7 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
     if (tail_heads && tail_steps + (2u - std::min(tail_heads, 2u)) > (unsigned)kChainPackSteps) pl->in_kernarg = false;
   }
   pl->bytes += c->last_bytes; // the cherry-cherry groups (build_cc_launches counted them)
-  pl->launches = (unsigned)(pl->cc.size() + pl->stages.size());
+  pl->launches = (unsigned)(pl->cc.size() + pl->cc16.size() + pl->stages.size());
   if (!pl->in_kernarg)
   {
     const size_t hb = pl->heads.size() * sizeof(ChainHead), lb = pl->loads.size() * sizeof(ChainStepLoad),

@@ -14,6 +14,8 @@ struct FusedGroup
   int lk, rk;     // DnaChildKind of the left / right child
   unsigned level; // execution level (= level of the lowest producers)
   int aa = -1, ab = -1, ba = -1, bb = -1; // CK_FCC sides: the cherries under a / b
+  int ga = -1, gb = -1;                   // CK_F8 sides: the complete 8-tip groups (indices into the group list) whose parents are a / b
+  bool absorbed = false;                  // a complete 8-tip group that a fifteen-op group evaluates: not launched on its own
 };
 
 static int child_kind(const pllgpu_op_t &prod)
@@ -23,7 +25,7 @@ static int child_kind(const pllgpu_op_t &prod)
 }
 
 static void plan_fusion(bool fuse, bool fuse_cc, unsigned nodes, const pllgpu_op_t *ops, unsigned count, std::vector<int> &role,
-                        std::vector<FusedGroup> &groups, bool cc_only = false)
+                        std::vector<FusedGroup> &groups, bool cc_only = false, bool cc16 = false)
 {
   // role: 0 plain, 1 parent of a group, 2 fused into a group as a child
   role.assign(count, 0);
@@ -90,6 +92,43 @@ static void plan_fusion(bool fuse, bool fuse_cc, unsigned nodes, const pllgpu_op
       }
       groups.push_back(g);
     }
+  // second pass (chain plans only, kernels_dna.h: k_partials_dna_cc16): a parent three levels above the cherries whose
+  // children are the parents of two COMPLETE 8-tip groups takes both with it. The groups' own conditions (scalers,
+  // entries, nothing touching their outputs from the cherries' level on) were checked above; the same for P here.
+  if (fuse_cc && cc16)
+  {
+    std::vector<int> group_of(count, -1);
+    const size_t n8 = groups.size();
+    for (size_t gi = 0; gi < n8; ++gi) group_of[groups[gi].p] = (int)gi;
+    for (unsigned i = 0; i < count; ++i)
+    {
+      const pllgpu_op_t &P = ops[i];
+      if (role[i] || (P.flags & (PLLGPU_OP_GATHER | PLLGPU_OP_LEFT_TIP | PLLGPU_OP_RIGHT_TIP)) || P.level < 3) continue;
+      const unsigned L = P.level - 3;
+      if (P.war_level >= (int)L) continue;
+      const int pa = prod_l[i], pb = prod_r[i];
+      if (pa < 0 || pb < 0 || pa == pb) continue;
+      const int ga = group_of[pa], gb = group_of[pb];
+      if (ga < 0 || gb < 0) continue;
+      auto full8 = [&](const FusedGroup &g) { return g.lk == CK_FCC && g.rk == CK_FCC && g.level == L && !g.absorbed; };
+      if (!full8(groups[ga]) || !full8(groups[gb])) continue;
+      if (ops[pa].parent_scaler != P.left_scaler || ops[pb].parent_scaler != P.right_scaler) continue;
+      if (ops[pa].parent_entries != P.parent_entries || ops[pb].parent_entries != P.parent_entries) continue;
+      FusedGroup g;
+      g.p = i;
+      g.a = pa;
+      g.b = pb;
+      g.lk = g.rk = CK_F8;
+      g.level = L;
+      g.ga = ga;
+      g.gb = gb;
+      groups[ga].absorbed = groups[gb].absorbed = true;
+      role[i] = 1;
+      role[pa] = role[pb] = 2;
+      eff[i] = L;
+      groups.push_back(g);
+    }
+  }
   if (cc_only) return;
   for (unsigned i = 0; i < count; ++i)
   {
@@ -170,6 +209,16 @@ static void launch_cc_t(pllgpu_ctx *c, const CCPack &pack, unsigned ngroups, uns
                      nx, ngroups, c->xcd_order);
 }
 
+static int launch_cc16(pllgpu_ctx *c, const CC16Pack &pack, unsigned ngroups, unsigned entries)
+{
+  const unsigned tiles = (entries + 63) / 64;
+  const unsigned nx = (tiles + 1) / 2; // a pair of waves per tile, two tiles per workgroup
+  const unsigned stream_parent = ((size_t)ngroups * entries * 128u > c->stream_parent_bytes) ? 1u : 0u;
+  hipLaunchKernelGGL(k_partials_dna_cc16, xcd_grid(nx, ngroups), dim3(256), 0, c->stream, pack, entries, c->gg.scale_mode, stream_parent, nx, ngroups,
+                     c->xcd_order);
+  return 0;
+}
+
 static int launch_cc(pllgpu_ctx *c, const CCPack &pack, unsigned ngroups, unsigned entries, int lk, int rk)
 {
   if (lk == CK_INNER && rk == CK_FCC) launch_cc_t<CK_INNER, CK_FCC>(c, pack, ngroups, entries);
@@ -231,6 +280,7 @@ static int build_cc_launches(pllgpu_ctx *c, const pllgpu_op_t *ops, const std::v
     {
       const FusedGroup &g = groups[gi];
       if (g.lk != CK_FCC && g.rk != CK_FCC) continue;
+      if (g.absorbed) continue; // evaluated by a fifteen-op group (build_cc16_launches)
       const bool swap = g.lk == CK_FCC && g.rk != CK_FCC; // canonical order: the memory side on the left
       const int glk = swap ? g.rk : g.lk;
       if (glk != lk) continue;
@@ -276,3 +326,64 @@ static int build_cc_launches(pllgpu_ctx *c, const pllgpu_op_t *ops, const std::v
   return 0;
 }
 
+// descriptor packs of the fifteen-op groups (kind CK_F8 on both sides: complete 16-tip subtrees), one per entry count
+struct CC16Launch
+{
+  CC16Pack pack;
+  unsigned n, entries;
+};
+
+// a complete (CK_FCC, CK_FCC) group as the kernels read it; counts its seven ops' bytes
+static int fill_cc8(pllgpu_ctx *c, const pllgpu_op_t *ops, const FusedGroup &g, CCGroup &cg)
+{
+  memset(&cg, 0, sizeof cg);
+  DevOp d;
+  auto side = [&](int a, int x, int y, FOp &fa, TOp &tx, TOp &ty) -> int {
+    if (int rc = resolve_op(c, ops[x], d)) return rc;
+    to_top(d, tx);
+    c->last_bytes += op_traffic(c, ops[x], true, true);
+    if (int rc = resolve_op(c, ops[y], d)) return rc;
+    to_top(d, ty);
+    c->last_bytes += op_traffic(c, ops[y], true, true);
+    if (int rc = resolve_op(c, ops[a], d)) return rc;
+    to_fop(d, fa);
+    c->last_bytes += op_traffic(c, ops[a], false, false);
+    return 0;
+  };
+  if (int rc = side(g.a, g.aa, g.ab, cg.a, cg.aa, cg.ab)) return rc;
+  if (int rc = side(g.b, g.ba, g.bb, cg.b, cg.ba, cg.bb)) return rc;
+  if (int rc = resolve_op(c, ops[g.p], d)) return rc;
+  c->last_bytes += op_traffic(c, ops[g.p], false, false);
+  to_fop(d, cg.p);
+  return 0;
+}
+
+static int build_cc16_launches(pllgpu_ctx *c, const pllgpu_op_t *ops, const std::vector<FusedGroup> &groups, std::vector<CC16Launch> &out)
+{
+  CC16Launch cur;
+  cur.n = 0;
+  cur.entries = 0;
+  auto flush = [&]() {
+    if (cur.n) out.push_back(cur);
+    cur.n = 0;
+  };
+  for (const FusedGroup &g : groups)
+  {
+    if (g.lk != CK_F8) continue;
+    const pllgpu_op_t &P = ops[g.p];
+    if (P.parent_entries == 0) continue;
+    if (cur.n && P.parent_entries != cur.entries) flush();
+    cur.entries = P.parent_entries;
+    CC16Group &cg = cur.pack.g[cur.n];
+    memset(&cg, 0, sizeof cg);
+    if (int rc = fill_cc8(c, ops, groups[g.ga], cg.a)) return rc;
+    if (int rc = fill_cc8(c, ops, groups[g.gb], cg.b)) return rc;
+    DevOp d;
+    if (int rc = resolve_op(c, P, d)) return rc;
+    c->last_bytes += op_traffic(c, P, false, false);
+    to_fop(d, cg.p);
+    if (++cur.n == (unsigned)kMaxCC16Groups) flush();
+  }
+  flush();
+  return 0;
+}

@@ -1005,6 +1005,93 @@ __global__ __launch_bounds__(256) void k_partials_dna_cc(const CCPack pack, unsi
 }
 
 // ------------------------------------------------------------------------------------------------
+// Three levels of producers (round 4): a parent whose two children are the parents of COMPLETE 8-tip subtrees -
+// (CK_FCC, CK_FCC) groups - is evaluated with both of them: a complete 16-tip subtree, fifteen ops per site from
+// sixteen code bytes, every CLV and scaler stored as always. The left subtree's top CLV waits in registers while the
+// right subtree is formed (four CLVs live instead of three). What it saves over two seven-op groups and a later step:
+// the two 8-tip tops are not read back (2 x 132 B per site) and their parent's store leaves in the streaming launch
+// instead of the latency-bound top of the tree. The arithmetic is dna_cherry / dna_combine's: bit-identical to every
+// other route (tests/test_gpu_parity.py::test_fifteen_op_groups_are_bit_identical).
+constexpr int CK_F8 = 7; // (host planner) a child that is the parent of a complete (CK_FCC, CK_FCC) group
+
+struct CC16Group // 944 bytes
+{
+  FOp p;
+  CCGroup a, b; // complete 8-tip subtrees: their p is the left / right child of this group's p
+};
+
+constexpr int kMaxCC16Groups = 4; // 4 * 944 B = 3776 B of kernarg
+
+struct CC16Pack
+{
+  CC16Group g[kMaxCC16Groups];
+};
+
+// a complete 8-tip subtree for the lane's site: seven ops, all stored (streaming), its top left in registers
+__device__ __forceinline__ void dna_cc8(const CCGroup &g, size_t off, unsigned n, bool valid, int scale_mode, double (&v)[4][4], uint4 &sc)
+{
+  double va[4][4], vb[4][4];
+  uint4 sca, scb;
+  int mode;
+  dna_cc_child<CK_FCC>(g.p, true, g.a, g.aa, g.ab, off, n, valid, scale_mode, va, sca);
+  dna_cc_child<CK_FCC>(g.p, false, g.b, g.ba, g.bb, off, n, valid, scale_mode, vb, scb);
+  dna_combine(g.p, scale_mode, va, sca, vb, scb, v, sc, mode);
+  dna_store<true>(g.p, off, n, valid, mode, v, sc);
+}
+
+// Work split: a PAIR of waves per 64-site tile - one forms the left 8-tip subtree, the other the right one, the right
+// one's top CLV crosses through LDS and the left wave forms and stores the group parent. (The first version gave a wave
+// the whole group: 187 registers = two waves per SIMD and half as many, twice as long waves as the seven-op kernel -
+// at 100k sites 151 us for the 60 ops that two seven-op launches' worth of bytes would take 121 us for: the last round
+// of such waves runs on a nearly empty chip. At 400k sites the two forms were equal per byte.)
+__global__ __launch_bounds__(256) void k_partials_dna_cc16(const CC16Pack pack, unsigned entries, int scale_mode, unsigned stream_parent, unsigned nx,
+                                                            unsigned ny, unsigned xcd_order)
+{
+  __shared__ double xv[2][16][64]; // [tile of the workgroup][value][lane]: the right subtree's top CLV
+  __shared__ uint4 xs[2][64];      // ... and its scaler words
+  unsigned bx, by;
+  if (!xcd_block(nx, ny, xcd_order, bx, by)) return; // store traffic: every XCD on its own run of tiles (kernels_common.h)
+  const CC16Group &g = pack.g[by];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned pair = wave >> 1, right = wave & 1u;
+  const unsigned ntiles = (entries + 63u) / 64u;
+  const unsigned tile0 = bx * 2u + pair;
+  const bool live = tile0 < ntiles; // wave-uniform; a pair without a tile still meets the barrier (and stores nothing)
+  const unsigned tile = live ? tile0 : ntiles - 1u;
+  const unsigned n0 = tile * 64u + lane;
+  const bool valid = live && n0 < entries;
+  const unsigned n = n0 < entries ? n0 : entries - 1;
+  const size_t off = (size_t)(n >> 6) * kDnaTile + (n & 63u);
+  double v8[4][4];
+  uint4 sc8;
+  dna_cc8(right ? g.b : g.a, off, n, valid, scale_mode, v8, sc8);
+  if (right)
+  {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xv[pair][k * 4 + i][lane] = v8[k][i];
+    xs[pair][lane] = sc8;
+  }
+  __syncthreads();
+  if (right) return;
+  double vb[4][4], v[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vb[k][i] = xv[pair][k * 4 + i][lane];
+  const uint4 scb = xs[pair][lane];
+  uint4 sc;
+  int mode;
+  dna_combine(g.p, scale_mode, v8, sc8, vb, scb, v, sc, mode);
+  if (stream_parent)
+    dna_store<true>(g.p, off, n, valid, mode, v, sc);
+  else
+    dna_store<false>(g.p, off, n, valid, mode, v, sc);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Site repeats, the bottom of the tree. Near the tips a class-compressed node holds a handful of
 // entries (a DNA cherry: at most 16, a 4-tip clade: 256, an 8-tip clade a few thousand), so the level
 // scheduler spends its time on launches that each wait for the one before: C4's shard took 40 us for

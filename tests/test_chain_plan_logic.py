@@ -121,6 +121,32 @@ def test_balanced_tree_stage_counts(hook, tips, with_cc, without_cc):
     check_invariants(arr, tips, stages, stage, chain, form)
 
 
+@pytest.mark.parametrize("tips,stages16,members", [(16, 1, 14), (32, 1, 30), (64, 2, 60), (128, 2, 120), (256, 3, 240), (1024, 4, 960)])
+def test_balanced_tree_with_fifteen_op_groups(hook, tips, stages16, members):
+    """fuse_cc bit 1 (round 4, k_partials_dna_cc16): a parent over two complete 8-tip groups takes both - complete
+    16-tip subtrees are fifteen-op groups of stage 1; what is left of a balanced tree is shallower by one level (the
+    un-rooted 16-tip tree is two 8-tip groups joined by the evaluated edge: nothing above them to take)"""
+    ops, _, _ = W.balanced_ops(tips)
+    arr = classify(ops, tips)
+    stages, stage, chain, form = plan(hook, arr, tips, fuse_cc=3)
+    assert stages == stages16 and form.count(3) == members
+    check_invariants(arr, tips, stages, stage, chain, form)
+    s7, _, _, form7 = plan(hook, arr, tips, fuse_cc=1)
+    assert s7 >= stages and form7.count(3) <= members
+
+
+@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("tips", [5, 33, 64, 300])
+def test_random_trees_with_fifteen_op_groups(hook, tips, seed):
+    ops, _, _ = W.random_tree_ops(tips, seed=seed)
+    arr = classify(ops, tips)
+    if len(arr) < 1:
+        return
+    stages, stage, chain, form = plan(hook, arr, tips, fuse_cc=3)
+    assert stages >= 1
+    check_invariants(arr, tips, stages, stage, chain, form)
+
+
 @pytest.mark.parametrize("seed", range(12))
 @pytest.mark.parametrize("tips", [5, 33, 64, 300])
 def test_random_trees(hook, tips, seed):
