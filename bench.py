@@ -682,7 +682,9 @@ def roofline_leg(args, cfg, lib, api, runner, reps=20):
         low = [op for op in all_ops if depth[op[0]] <= 3]
         # round 4: complete 16-tip subtrees are groups of FIFTEEN ops (k_partials_dna_cc16): everything within four levels
         low16 = [op for op in all_ops if depth[op[0]] <= 4]
-        if len(low16) == 15 * (case.tips // 16) and case.tips >= 32 and not os.environ.get("PLL_AMD_NO_FUSE_CC16", "0").strip("0"):
+        # (used by size - csrc/hip/chain_plan.h: use_cc16 - unless PLL_AMD_FUSE_CC16 says 0 / 1)
+        want16 = {"0": False, "1": True}.get(os.environ.get("PLL_AMD_FUSE_CC16", ""), sites * nops >= 9000000)
+        if len(low16) == 15 * (case.tips // 16) and case.tips >= 32 and want16:
             ii_ops, cc16 = low16, True
         elif len(low) == 7 * (case.tips // 8):
             ii_ops = low

@@ -322,6 +322,16 @@ extern "C" int pllgpu_debug_chain_plan(const pllgpu_op_t *ops, unsigned count, u
   return (int)stages;
 }
 
+// Fifteen-op groups pay where the launch is long: same box, alternating (tools/round4_calls/r4_cc16.sh) - 64 taxa x 100k
+// sites 0.160-0.162 ms per step with either form (the group launch gains what the shorter chain tail saves: nothing
+// left over), 128 taxa x 100k sites +7 %, 64 taxa x 200k / 400k sites +8 / +12 %. By size unless PLL_AMD_FUSE_CC16 says
+// 0 / 1: entries x ops of the list, the crossover between the first and the other cases.
+static bool use_cc16(const pllgpu_ctx *c, unsigned entries, unsigned count)
+{
+  if (c->fuse_cc16 >= 0) return c->fuse_cc16 != 0;
+  return (size_t)entries * count >= (size_t)9000000;
+}
+
 // returns 0 and sets used = true when the list was planned and launched as chains
 static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count, bool &used)
 {
@@ -337,7 +347,7 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
   if (entries == 0 || aos_entries(c, entries) || (size_t)entries * 128u >= ((size_t)1 << 31)) return 0; // 32-bit buffer offsets
   const unsigned nodes = c->geo.nodes, nsb = c->geo.scale_buffers;
   ChainPartition part;
-  if (!partition_chains(ops, count, nodes, nsb, entries, c->fuse_cc, c->fuse_cc16, part)) return 0;
+  if (!partition_chains(ops, count, nodes, nsb, entries, c->fuse_cc, use_cc16(c, entries, count), part)) return 0;
   ChainPlan *pl = new ChainPlan();
   std::vector<int> (&pr_of)[2] = part.pr_of;
   std::vector<int> &role = part.role;

@@ -147,7 +147,8 @@ struct pllgpu_ctx
   bool defer_tail = false;       // DNA: hold the traversal's last ops for one call (k_edge_dna_tail)
   std::vector<pllgpu_op_t> deferred; // ops accepted by pllgpu_update_partials and not launched yet
   bool fuse_cc = false;          // DNA: also two producer levels under a group parent (cherry-cherry children)
-  bool fuse_cc16 = false;        // DNA, chain plans: also a parent over two complete 8-tip groups (fifteen ops, k_partials_dna_cc16)
+  int fuse_cc16 = -1;            // DNA, chain plans: also a parent over two complete 8-tip groups (fifteen ops, k_partials_dna_cc16):
+                                 // -1 by size (chain_plan.h: use_cc16), 0 never, 1 always (PLL_AMD_FUSE_CC16)
   bool fuse_gg = true;           // DNA + site repeats: groups over two gathering producers (PLL_AMD_NO_FUSE_GG=1: off)
   bool fuse = false;             // DNA: evaluate producer + consumer ops in one kernel (kernels_dna.h)
   bool chains = false;           // DNA: chain plans (k_partials_dna_chain) for dependency-only op lists
@@ -290,8 +291,9 @@ static void derive_geometry(pllgpu_ctx *c)
   if (const char *v = getenv("PLL_AMD_NO_TAIL_FUSION"))
     if (*v && *v != '0') c->defer_tail = false;
   c->fuse_cc = c->fuse;
-  if (const char *v16 = getenv("PLL_AMD_NO_FUSE_CC16")) c->fuse_cc16 = !(*v16 && *v16 != '0');
-  else c->fuse_cc16 = true;
+  c->fuse_cc16 = -1;
+  if (const char *v16 = getenv("PLL_AMD_FUSE_CC16"))
+    if (*v16) c->fuse_cc16 = *v16 != '0' ? 1 : 0;
   if (const char *v = getenv("PLL_AMD_NO_FUSE_CC"))
     if (*v && *v != '0') c->fuse_cc = false;
   c->chains = c->fuse;

@@ -127,11 +127,15 @@ def test_bench_inputs_against_the_pinned_reference_value(amd_lib, key):
     assert abs(ps.sum() - lnl) <= 1e-11 * abs(lnl)
 
 
-def test_c2_intermediate_clvs_at_full_size(amd_lib, reference):
+@pytest.mark.parametrize("groups", ["seven-op", "fifteen-op"])
+def test_c2_intermediate_clvs_at_full_size(amd_lib, reference, groups, monkeypatch):
     """C2 as bench.py runs it: 56 of the 62 CLVs leave the seven-op kernel through non-temporal stores and
     are never read back by the traversal - so the root-edge check above cannot see an addressing error in
     them. Whole CLVs and scalers of a cherry, a level-2 and a level-3 node at both ends of the node range
-    (every tile: first, middle, last) and of the top levels against the reference."""
+    (every tile: first, middle, last) and of the top levels against the reference. fifteen-op (round 4): the same
+    through k_partials_dna_cc16, which larger alignments and trees take by default - 60 of the 62 CLVs out of one launch,
+    the level-4 nodes its plainly stored group parents."""
+    monkeypatch.setenv("PLL_AMD_FUSE_CC16", "1" if groups == "fifteen-op" else "0")
     b = _bench()
     cfg = b.CONFIGS["c2"]
     case = b.build_case(cfg, cfg["sites"], 0)

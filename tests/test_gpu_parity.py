@@ -479,11 +479,12 @@ def test_cherry_tables_follow_the_matrices(amd_lib, monkeypatch):
 
 
 def test_fusion_plan_on_a_balanced_tree(amd_lib, monkeypatch):
-    """64 taxa, full traversal. Round 4: 4 groups of FIFTEEN ops (complete 16-tip subtrees: two complete 8-tip
-    subtrees and the op above them) in one launch; the top two ops are two chains of one step that end in the two ends of
-    the root edge - they are held for the edge evaluation and run inside it (chain tail): 2 launches for traversal +
-    log-likelihood. PLL_AMD_NO_FUSE_CC16=1 (rounds 1-3): 8 groups of seven ops (complete 8-tip subtrees: four cherries,
-    two ops above them, one above those) in one launch, the top six ops as two chains of two steps.
+    """64 taxa, full traversal. With fifteen-op groups (round 4; by size, here forced with PLL_AMD_FUSE_CC16=1): 4 groups of
+    FIFTEEN ops (complete 16-tip subtrees: two complete 8-tip subtrees and the op above them) in one launch; the top two
+    ops are two chains of one step that end in the two ends of the root edge - they are held for the edge evaluation and
+    run inside it (chain tail): 2 launches for traversal + log-likelihood. Without (this size's default): 8 groups of seven
+    ops (complete 8-tip subtrees: four cherries, two ops above them, one above those) in one launch, the top six ops as
+    two chains of two steps.
     Without the two-level groups a chain plan needs 3 stages.
     PLL_AMD_NO_CHAINS=1 brings back the level scheduler with its groups: 16 (tt, tt -> ii) groups,
     4 (ii, ii -> ii) groups and the two root-side ops, which are held for the edge evaluation."""
@@ -518,9 +519,10 @@ def test_fusion_plan_on_a_balanced_tree(amd_lib, monkeypatch):
             return v, r
 
     # 4 x (16 B + 15 CLVs + scalers) + 2 x (2 CLVs in, 1 out) = 8776 B per site; the 30 inner x inner ops: two stages
+    monkeypatch.setenv("PLL_AMD_FUSE_CC16", "1")
     v16, r16 = full_and_partial(1, (8700, 8800), 1)
     # 8 x (8 B + 7 CLVs + scalers) + 2 x (4 CLVs in, 3 out)
-    monkeypatch.setenv("PLL_AMD_NO_FUSE_CC16", "1")
+    monkeypatch.delenv("PLL_AMD_FUSE_CC16")
     v0, r0 = full_and_partial(1, (8800, 9900), 1)
     assert v16 == v0 and r16 == r0
     monkeypatch.setenv("PLL_AMD_NO_FUSE_CC", "1")
@@ -1010,18 +1012,19 @@ def test_xcd_aware_workgroup_order_changes_nothing(amd_lib, kw, monkeypatch):
                                 dict(states=4, tips=48, sites=900, seed=511, tree="random")], ids=_id)       # whatever complete 16-tip subtrees a random tree has
 def test_fifteen_op_groups_are_bit_identical(amd_lib, kw, monkeypatch):
     """round 4 (k_partials_dna_cc16): a parent over two complete 8-tip groups is evaluated with both - a pair of waves
-    per tile, the right subtree's top CLV crossing through LDS. PLL_AMD_NO_FUSE_CC16=1: the seven-op groups of rounds
+    per tile, the right subtree's top CLV crossing through LDS. PLL_AMD_FUSE_CC16=0: the seven-op groups of rounds
     1-3; PLL_AMD_NO_FUSE=1: one launch per op group. The same bits in every CLV, scaler and log-likelihood, and right
     against the oracle"""
     kw = dict(kw)
     tiny = kw.pop("tiny_p", None)
+    monkeypatch.setenv("PLL_AMD_FUSE_CC16", "1")  # (by size otherwise: not at these site counts)
     case = W.make_case("cc16", **kw)
     if tiny:  # P = (1 - (s - 1) eps) on the diagonal, eps elsewhere: a cherry of two different states is all below 2^-256
         case.pmatrix[:] = np.full((4, 4), tiny) + np.eye(4) * (1.0 - 4 * tiny)
     fifteen = driver.run_case(amd_lib, case, api.ARCH_AVX2)
     assert_results_match(fifteen, O.run_case(case), what=_id(kw))
-    for switch in ("PLL_AMD_NO_FUSE_CC16", "PLL_AMD_NO_FUSE"):
-        monkeypatch.setenv(switch, "1")
+    for switch, val in (("PLL_AMD_FUSE_CC16", "0"), ("PLL_AMD_NO_FUSE", "1")):
+        monkeypatch.setenv(switch, val)
         other = driver.run_case(amd_lib, case, api.ARCH_AVX2)
         assert fifteen["lnl"] == other["lnl"], switch
         for k in other["clv"]:

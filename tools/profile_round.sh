@@ -14,8 +14,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c2" -- python3 
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_fetch" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1
 find "$O/prof_c2" -name "*kernel_stats.csv" -exec cp {} "$O/c2_kernel_stats.csv" \;
-PLL_COMMIT="${PLL_COMMIT:-$(cat "$R/tools/.commit" 2>/dev/null)}" python3 "$R/tools/pmc_traffic.py" --fetch "$O/pmc_fetch" --write "$O/pmc_write" --kernel 'k_partials_dna_cc16' \
-  --algorithmic 798400000 --out "$O/traffic_c2.json" --trim "$O/c2_pmc" > /dev/null
+PLL_COMMIT="${PLL_COMMIT:-$(cat "$R/tools/.commit" 2>/dev/null)}" python3 "$R/tools/pmc_traffic.py" --fetch "$O/pmc_fetch" --write "$O/pmc_write" --kernel 'k_partials_dna_cc<5, 5>' \
+  --algorithmic 745600000 --out "$O/traffic_c2.json" --trim "$O/c2_pmc" > /dev/null
 # C3: HBM bytes per launch of the group kernel (the dominant launch of the 20-state step)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc3_fetch" -- python3 "$R/bench.py" --config c3 --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc3_write" -- python3 "$R/bench.py" --config c3 --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1

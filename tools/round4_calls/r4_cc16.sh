@@ -1,5 +1,5 @@
 #!/bin/bash
-# fifteen-op groups (complete 16-tip subtrees): parity, then A/B against PLL_AMD_NO_FUSE_CC16=1 on one box
+# fifteen-op groups (complete 16-tip subtrees): parity, then A/B against PLL_AMD_FUSE_CC16=0 on one box
 R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/r4_cc16"; rm -rf "$O"; mkdir -p "$O"; cd "$R"
 timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py -m gpu -x -q > "$O/pytest.log" 2>&1; rc=$?; tail -3 "$O/pytest.log"; [ $rc -eq 0 ] || exit $rc
 run() { # label, args..., -- env...
@@ -13,10 +13,10 @@ print(f"{sys.argv[2]:30s} value {d['value']:9.1f} ms/step {d['ms_per_step']:.4f}
 PY
 }
 for rep in 1 2 3; do
-  run "c2 fifteen-op groups" --config c2 -- A=1
-  run "c2 seven-op groups" --config c2 -- PLL_AMD_NO_FUSE_CC16=1
+  run "c2 fifteen-op groups" --config c2 -- PLL_AMD_FUSE_CC16=1
+  run "c2 seven-op groups" --config c2 -- PLL_AMD_FUSE_CC16=0
 done
-run "c2 400k fifteen" --config c2 --sites 400000 -- A=1
-run "c2 400k seven" --config c2 --sites 400000 -- PLL_AMD_NO_FUSE_CC16=1
-run "c2 128 taxa fifteen" --config c2 --taxa 128 -- A=1
-run "c2 128 taxa seven" --config c2 --taxa 128 -- PLL_AMD_NO_FUSE_CC16=1
+run "c2 400k fifteen" --config c2 --sites 400000 -- PLL_AMD_FUSE_CC16=1
+run "c2 400k seven" --config c2 --sites 400000 -- PLL_AMD_FUSE_CC16=0
+run "c2 128 taxa fifteen" --config c2 --taxa 128 -- PLL_AMD_FUSE_CC16=1
+run "c2 128 taxa seven" --config c2 --taxa 128 -- PLL_AMD_FUSE_CC16=0
