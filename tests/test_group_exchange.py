@@ -155,3 +155,30 @@ def test_a_rank_seated_twice_is_an_error_not_a_hang():
         pass
     assert all("error" in o for o in outs), outs
     assert time.time() - t0 < 20
+
+
+def test_sharded_derivatives_with_failing_ranks_return_instead_of_waiting():
+    """pll_gpu_group_likelihood_derivatives when EVERY rank's evaluation fails (host-only shells here): each rank still
+    takes part in the exchange (NaN operands), gets PLL_FAILURE with its own error and nobody waits for a time-out"""
+    import time
+    name = "/pllamd-test-" + uuid.uuid4().hex[:12]
+    code = r'''
+import ctypes as C, json, os, sys
+sys.path.insert(0, os.path.join(%r, "libpll-2_amd"))
+os.environ["PLL_AMD_HOST_ONLY"] = "1"
+import numpy as np
+from pllamd import api
+lib = api.PllLib()
+rank = int(sys.argv[1])
+g = lib.pll_gpu_group_join(%r.encode(), rank, 2, 20000)
+p = lib.pll_partition_create(4, 2, 4, 32, 1, 5, 4, 2, api.ARCH_AVX2)
+fi = np.zeros(4, dtype=np.uint32); st = np.zeros(32 * 16); d1, d2 = C.c_double(), C.c_double()
+ok = lib.pll_gpu_group_likelihood_derivatives(p, g, -1, -1, 0.1, api.uptr(fi), api.dptr(st), C.byref(d1), C.byref(d2))
+print(json.dumps(dict(ok=bool(ok), errno=lib.errno())))
+lib.pll_gpu_group_leave(g)
+''' % (os.path.dirname(HERE), name)
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for r in range(2)]
+    outs = [json.loads(p.communicate(timeout=60)[0].strip().splitlines()[-1]) for p in procs]
+    assert all(not o["ok"] and o["errno"] == 900 for o in outs), outs
+    assert time.time() - t0 < 15

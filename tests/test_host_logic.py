@@ -432,3 +432,24 @@ def test_hardware_record(amd_lib):
     assert hw.init == 1 and hw.sse2 == 1  # every x86-64 host has SSE2
     amd_lib.dll.pll_hardware_ignore()
     assert all(getattr(hw, k) == 1 for k, _ in HW._fields_)
+
+
+def test_collective_entry_points_fail_loudly_without_a_device(amd_lib, capfd):
+    """round 4: the set-up of the RCCL form and the sharded derivative evaluation on a host-only shell - an error and
+    the reference's failure values, never a wait for a collective that cannot happen"""
+    import ctypes as C
+    case = W.make_case("t", 4, 4, 32)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        fake_comm = C.c_void_p(0x1234)
+        assert not amd_lib.pll_gpu_allreduce_prepare(s.p, fake_comm)
+        assert amd_lib.errno() == 900 and "no MI355X context" in amd_lib.errmsg()
+        assert not amd_lib.pll_gpu_allreduce_prepare(s.p, None)
+        fi = np.zeros(4, dtype=np.uint32)
+        v = amd_lib.pll_gpu_edge_loglikelihood_allreduce(s.p, fake_comm, case.edges[0][0], case.edges[0][1], case.edges[0][2],
+                                                          case.edges[0][3], case.edges[0][4], api.uptr(fi))
+        assert v == -np.inf and amd_lib.errno() == 900
+        st = np.zeros(32 * 4 * 4)
+        d1, d2 = C.c_double(7.0), C.c_double(7.0)
+        ok = amd_lib.pll_gpu_group_likelihood_derivatives(s.p, None, -1, -1, 0.1, api.uptr(fi), api.dptr(st), C.byref(d1), C.byref(d2))
+        assert not ok and amd_lib.errno() == 900 and d1.value == 7.0  # outputs untouched on failure
+    assert "no MI355X context" in capfd.readouterr().err
