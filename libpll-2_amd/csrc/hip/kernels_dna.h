@@ -864,6 +864,10 @@ __global__ __launch_bounds__(256, DNA_GG_WAVES) void k_partials_dna_gg(const GGP
   }
 }
 
+// (Round 4 also built this group with a PAIR of waves per tile, as k_partials_dna_cc16 has it - one wave gathers and forms
+// producer A, the other B, B's values cross through the wave's transpose buffer: 107 registers, four waves per SIMD, half
+// the waits per wave. Same box, alternating: slowest shards 0.1088-0.1125 ms against 0.1077-0.1089 with one wave per
+// tile, the 1M-site step 0.741 against 0.735 ms. Occupancy is not what a shard's launch waits for; removed.)
 // ------------------------------------------------------------------------------------------------
 // Two levels of producers: a child of the group parent P may be an inner x inner op A whose own
 // children are both CHERRIES (tip x tip ops) of the level below - kind CK_FCC. The four tip codes are
