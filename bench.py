@@ -968,7 +968,7 @@ def main():
     ap.add_argument("--reduce", default="peer", choices=["peer", "rccl"],
                     help="N > 1: how the shard log-likelihoods are summed (see the docstring)")
     ap.add_argument("--cut", default="equal", choices=["equal", "balanced"],
-                    help="N > 1: shards of equal site count (default) or of equal modelled cost (pllamd/sharding.py: balanced_bounds - measured slower, see there)")
+                    help="N > 1: shards of equal site count (default) or of equal modelled cost with a size cap (pllamd/sharding.py: balanced_bounds - about 2 % better on one GPU, inside the spread: see there)")
     ap.add_argument("--driver", default="c", choices=["c", "python"], help="who issues the steps of the timed region")
     args = ap.parse_args()
     if args.gpus < 1 or args.blocks < 1 or args.steps < 1:

@@ -1,6 +1,8 @@
 """Site sharding for multi-GPU runs: contiguous site ranges per rank, every
 rank owns an independent partition over its range; the only exchange is the sum of the per-shard
 log-likelihoods. No data-path collective exists anywhere else."""
+import os
+
 import numpy as np
 
 from .driver import Case
@@ -41,7 +43,7 @@ def _tip_subtree_keys(case: Case):
     return keys
 
 
-def balanced_bounds(case: Case, world, align=64, rounds=6):
+def balanced_bounds(case: Case, world, align=64, rounds=6, max_ratio=1.04):
     """Cuts that equalise the COST of the shards rather than their site counts. With site repeats a shard
     computes one entry per class below the level where compression ends, and a contiguous range of the
     pattern-sorted alignment holds very different class counts depending on where it lies (the first and last
@@ -54,10 +56,22 @@ def balanced_bounds(case: Case, world, align=64, rounds=6):
     last eighth 134k sites instead of 125k, and at 134k sites a shard's uncompressed CLVs (14 nodes x 17 MB) no longer
     fit the 256 MB Infinity Cache beside the compressed ones: what the model gains in entries it loses to HBM.
     bench.py therefore cuts by site count (--cut equal) unless told otherwise; the function stays for alignments
-    whose shards are far from that cliff."""
+    whose shards are far from that cliff.
+
+    Round 4: with `max_ratio` (no shard larger than 1.04 x the mean: below the cliff) the same cost model no longer
+    loses - tools/round4_calls/r4_cuts.sh, same box, alternating, slowest shard in ms: equal sizes 0.1123 / 0.1127,
+    uncapped 0.1137 / 0.1139, capped at 1.03 0.1120 / 0.1076, at 1.04 0.1089 / 0.1122, at 1.05 0.1110 / 0.1123: about 2 %
+    better than equal sizes on average, inside the per-shard spread of one call (+-3 %). --cut equal stays the default;
+    --cut balanced now means the capped form (PLL_SHARD_MAX_RATIO=0 removes the cap)."""
     if world == 1 or case.sequences is None or not case.op_batches:
         return shard_bounds(case.sites, world, align)
     keys = _tip_subtree_keys(case)
+    # Round 4: no shard more than `max_ratio` x the mean size (the cliff described above sits at ~1.055 x for the 1M-site
+    # configuration on 8 ranks: 132k sites). None = uncapped (round 3's form).
+    env = os.environ.get("PLL_SHARD_MAX_RATIO")
+    if env is not None:
+        max_ratio = float(env) if float(env) > 0 else None
+    cap = None if max_ratio is None else int(np.ceil(max_ratio * case.sites / world / align)) * align
 
     def cost(lo, hi):
         return (hi - lo) + ENTRY_COST_PER_SITE_COST * sum(len(np.unique(k[lo:hi])) for k in keys)
@@ -73,10 +87,25 @@ def balanced_bounds(case: Case, world, align=64, rounds=6):
             c = int(round(np.interp(r * target, cum, cuts) / align)) * align
             new.append(min(max(c, new[-1] + align), case.sites - (world - r) * align))
         new.append(case.sites)
+        new = _cap_shards(new, cap, align)
         if new == cuts:
             break
         cuts = new
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def _cap_shards(cuts, cap, align):
+    """no shard larger than `cap` sites: the excess moves on to the next shard (forward pass), then back from the last
+    (backward pass); cuts stay multiples of `align`"""
+    if cap is None:
+        return cuts
+    cuts = list(cuts)
+    world = len(cuts) - 1
+    for r in range(1, world):          # forward: shard r - 1 gives its excess to shard r
+        cuts[r] = min(cuts[r], cuts[r - 1] + cap)
+    for r in range(world - 1, 0, -1):  # backward: shard r gives its excess to shard r - 1
+        cuts[r] = max(cuts[r], cuts[r + 1] - cap)
+    return cuts
 
 
 def shard_case(case: Case, rank, world, bounds=None):
