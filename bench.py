@@ -876,18 +876,6 @@ def main_strong(args, h):
     # the same steps with the other exchange, for the record (both in one line): RCCL needs the nccl backend
     if reduce == "rccl":
         exchange["rccl_via"] = runner.rccl_via
-    if reduce == "peer" and h.on_device:
-        # (a failure of this second leg must not cost the line its first: the headline is the peer exchange)
-        try:
-            runner.reduce = "rccl"
-            runner.setup_rccl()
-            b2, lnl2 = runner.timed(args.warmup, args.steps, args.blocks)
-            exchange["rccl_ms_per_step"] = round(block_stats(b2, args.steps)[0], 4)
-            exchange["rccl_lnl_rel_diff"] = abs(lnl2 - lnl) / abs(lnl)
-            exchange["rccl_via"] = runner.rccl_via
-        except Exception as exc:  # noqa: BLE001
-            exchange["rccl_error"] = f"{type(exc).__name__}: {exc}"
-        runner.reduce, runner.device_path = "peer", False
     # what the exchange adds behind a result that is already in host memory: the group sum alone, all ranks in step
     if reduce == "peer":
         v = np.array([1.0])
@@ -905,7 +893,6 @@ def main_strong(args, h):
     # roofline of the dominant kernel on this rank's shard (rank 0 reports)
     args.config = "c4"
     roofline, _ = roofline_leg(args, cfg, lib, api, runner)
-    runner.close()
     h.barrier()
     out = None
     if h.rank == 0:
@@ -944,6 +931,39 @@ def main_strong(args, h):
         if pin is not None:
             out["lnl_pinned_reference"] = pin
             out["lnl_rel_err_pinned"] = abs(lnl - pin) / abs(pin)
+    # ---- LAST: the same steps with the other exchange, for the record (both in one line). The RCCL form goes through the
+    # library's entry point on a communicator made here - the one part of this flow that only a multi-GPU node exercises -
+    # so it runs when everything else of the line exists, under a watchdog: if it does not come back (a collective that
+    # never completes), rank 0 prints the line without it and every rank leaves; if it raises, the line says so.
+    if reduce == "peer" and h.on_device:
+        h.barrier()
+        limit = float(os.environ.get("PLL_BENCH_RCCL_LEG_TIMEOUT_S", "180"))
+
+        def give_up():
+            if h.rank == 0 and out is not None:
+                out["exchange"]["rccl_error"] = f"the RCCL leg did not finish within {limit:.0f} s; line printed by the watchdog"
+                line = (json.dumps(out) + "\n").encode()
+                os.write(h.real_stdout if h.real_stdout is not None else 1, line)
+            os._exit(0)
+
+        import threading
+        dog = threading.Timer(limit, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            runner.reduce = "rccl"
+            runner.setup_rccl()
+            b2, lnl2 = runner.timed(args.warmup, args.steps, args.blocks)
+            if out is not None:
+                out["exchange"]["rccl_ms_per_step"] = round(block_stats(b2, args.steps)[0], 4)
+                out["exchange"]["rccl_lnl_rel_diff"] = abs(lnl2 - lnl) / abs(lnl)
+                out["exchange"]["rccl_via"] = runner.rccl_via
+        except Exception as exc:  # noqa: BLE001
+            if out is not None:
+                out["exchange"]["rccl_error"] = f"{type(exc).__name__}: {exc}"
+        dog.cancel()
+        runner.reduce, runner.device_path = "peer", False
+    runner.close()
     return out
 
 

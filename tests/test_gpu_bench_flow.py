@@ -52,6 +52,17 @@ def test_the_rccl_form_of_the_exchange_runs_through_the_librarys_entry_point(red
         assert ex["rccl_lnl_rel_diff"] <= 1e-14
 
 
+def test_a_stuck_rccl_leg_does_not_cost_the_line():
+    """the RCCL form of the exchange is the line's LAST leg and runs under a watchdog: when it does not come back in
+    time (here: a limit it cannot meet) rank 0 still prints the one line, complete but for that leg, and exits 0"""
+    out = run_bench("--gpus", "1", "--backend", "nccl", "--reduce", "peer", "--sites", "200000", "--steps", "3", "--blocks", "2", "--warmup", "2",
+                    env={"PLL_BENCH_FORCE_DIST": "1", "PLL_BENCH_FORCE_STRONG": "1", "PLL_BENCH_RCCL_LEG_TIMEOUT_S": "0.02"})
+    ex = out["exchange"]
+    assert "watchdog" in ex["rccl_error"] and "rccl_ms_per_step" not in ex
+    assert out["scaling"] == "strong" and out["t1_ms"] > 0 and out["speedup"] > 0 and "roofline" in out
+    assert out["lnl_rel_err_vs_unsharded"] <= 1e-12
+
+
 def test_default_line_carries_the_contract_fields():
     out = run_bench("--steps", "5", "--blocks", "3", "--warmup", "2")
     assert out["n_gpus"] == 1 and out["scaling"] is None and out["blocks"] == 3 and out["dtype"] == "f64"
