@@ -1040,7 +1040,8 @@ static int launch_mfma_cc_t(pllgpu_ctx *c, const FusePack &pack, unsigned ngroup
   const unsigned items = (entries + 31) / 32;
   // store-bound: many small workgroups - but each stages its six matrices and two tables (20-50 KB from L2), so not
   // too small: C3 (1563 items x 16 groups x 4 rates) with 8 / 4 / 2 / 1 items per wave and the XCD-aware order: step
-  // 0.550 / 0.537 / 0.563 / 0.622 ms on one box (round 4, tools/round4_calls/r4_c3_exp.sh; natural order: 0.555 / - / 0.622 / -)
+  // 0.550 / 0.537 / 0.563 / 0.622 ms on one box (round 4, tools/round4_calls/r4_c3_exp.sh; natural order: 0.555 / - / 0.622 / -);
+  // 3 / 4 / 5 / 6 on another: 0.551-0.554 / 0.549-0.558 / 0.550-0.554 / 0.553-0.557 - flat between three and six
   const unsigned want = 4096u;
   unsigned ipw = (unsigned)(((size_t)items * ngroups * R + want - 1) / want);
   ipw = std::max(1u, std::min(ipw, 4u));
