@@ -117,18 +117,29 @@ int pllgpu_repeats_upload(pllgpu_ctx_t *ctx, unsigned int node, const unsigned i
                           const unsigned int *id_site, unsigned int ids);
 
 /* ---- compute ------------------------------------------------------------------------------ */
-/* class maps computed ON the device (SURVEY section 8 row f4; replaces the table walk of
- * pll_update_repeats, src/repeats.c:299-382): for every op the parent's site -> class map and
- * class -> first-site map from the children's maps (which must be on the device, nleft/nright their
- * class counts; nleft * nright cells of direct-address table per op). The ops must be mutually
- * independent (one dependency level). counts_out[i] = classes of ops[i].parent. Synchronises. */
+/* class maps computed ON the device (SURVEY section 8 rows a8 / f4; replaces the table walk of
+ * pll_update_repeats, src/repeats.c:299-382, and - for ops with force == 0 - the decision of
+ * pll_default_enable_repeats, src/repeats.c:100-110): for every op the parent's site -> class and
+ * class -> first-site maps from the children's maps. The ops of a whole traversal go in ONE call,
+ * sorted by dependency level (ops of one level are mutually independent): a child produced by an
+ * earlier op of the call is named by that op's index (lsrc / rsrc), its class count is taken from
+ * device memory; a child from outside the call (lsrc / rsrc = -1) must have its maps on the device,
+ * nleft / nright are its class counts (0: not compressed). force = 1: the host has decided to
+ * compress this parent (a caller-supplied enable_repeats callback), both children from outside.
+ * lookup_size = pll_repeats_t::lookup_buffer_size. counts_out[i] = PLLGPU_REPEATS_COMPRESSED |
+ * classes of ops[i].parent, or 0 where the rule said no. Synchronises once, at the end. */
+#define PLLGPU_REPEATS_COMPRESSED 0x80000000u
+#define PLLGPU_REPEATS_MAX_OPS 65536u
 typedef struct pllgpu_repop
 {
   unsigned int parent, left, right;
   unsigned int nleft, nright;
+  int lsrc, rsrc;
+  unsigned int level;
+  unsigned int force;
 } pllgpu_repop_t;
 int pllgpu_repeats_classes(pllgpu_ctx_t *ctx, const pllgpu_repop_t *ops, unsigned int count,
-                           unsigned int *counts_out);
+                           unsigned int lookup_size, unsigned int *counts_out);
 /* how many classes the kernels shall assume for `node` (0 = one entry per site, maps unused) */
 int pllgpu_repeats_set_ids(pllgpu_ctx_t *ctx, unsigned int node, unsigned int ids);
 /* device maps of `node` back to the host: site_id[sites], id_site[ids]. Synchronises. */

@@ -1,305 +1,668 @@
-// kernels_repeats.h - site-repeats class maps on the device (SURVEY.md section 8 row f4;
-// src/repeats.c:299-382, pll_update_repeats).
+// kernels_repeats.h - site-repeats class maps on the device (SURVEY.md section 8 rows a8 / f4;
+// src/repeats.c:299-382, pll_update_repeats, and the decision of src/repeats.c:100-110).
 //
-// A parent's classes are the distinct pairs (left class, right class) of its sites, numbered in
-// order of first occurrence; id_site[class] is that first site. The reference walks the sites
-// sequentially through a direct-address table (cell = lid + rid * ids_left). The same numbering
-// without the sequential walk:
-//   1. table[cell] = min over the sites that map to the cell            (k_rep_mark, atomicMin)
-//   2. a site is a class representative iff it is the lowest site of its cell; the class number of a
-//      representative is the count of representatives before it. Counted over the CELLS, not the sites
-//      (round 3: the two passes over all sites this step used to be were 40 % of the update): the
-//      representatives are set as bits of a bitmap over the sites (k_rep_bitmap, one atomicOr per non-empty
-//      cell), one workgroup per op forms the running bit count per 32-site word (k_rep_scan), and every
-//      non-empty cell looks its class number up: words before + bits before in its word (k_rep_rank_cells).
-//      The cell index IS the pair (left class, right class), so the class -> child entry maps need no
-//      site data either.
-//   3. site_id[site] = class number of table[cell(site)]                (k_rep_assign)
-// Integer work only: the maps are bit-identical to the reference's. All ops of one dependency level
-// go through each kernel together (grid.y = op); every op owns a slice of the table, cleared with
-// one memset before the level instead of the reference's to-clean list.
+// A parent's classes are the distinct pairs (left class, right class) of its sites, numbered in order of first
+// occurrence; id_site[class] is that first site. The reference walks the sites sequentially through a direct-address
+// table (cell = lid + rid * ids_left). The same numbering without the sequential walk, two launches per dependency
+// level (four where a level may hold large tables), every op of the level in each, NO host round trip between levels:
+//
+//   k_rep_mark    first[cell] = the lowest site of the cell. A workgroup owns a PART of the op's table (in LDS) and a
+//                 RANGE of its sites; what it finds goes to its own copy of the part in the op's slice of the arena
+//                 with plain write-through stores - no atomics on the table, nothing to clear beforehand (round 4 spent
+//                 62 % of the update on device-scope atomicMin). The workgroup that finishes a part LAST (a ticket per
+//                 part) takes the minimum over the ranges. Then the classes are numbered: a cell's class is the count
+//                 of cells with a lower first site.
+//                   small tables (<= kRepSmallCells cells: the levels next to the tips, where ops x sites is largest):
+//                     counted directly, in LDS, by that same workgroup - the op is finished inside this launch;
+//                   large tables: through a bitmap over the sites (bit s = site s is the first of its cell) and its
+//                     running bit count: the part's last workgroup sets the bits, k_rep_scan (one workgroup per op)
+//                     counts, k_rep_rank (cells in parallel) looks every cell's class up.
+//                 Either way the op leaves table[cell] = class, the class -> first site / child entry maps (the cell
+//                 index IS the pair), and its class count for the levels above.
+//   k_rep_assign  site_id[site] = table[cell(site)].
+//
+// Whether a parent is compressed at all is decided HERE, by the reference's default rule, from the children's class
+// counts as the launches of the levels below left them in device memory: the host enqueues all levels back to back
+// and reads every count once at the end (round 4: one blocking hand-off per level). A caller-supplied
+// enable_repeats callback keeps the level-by-level form (RepOp::force).
+//
+// site -> class maps of nodes with at most 256 classes are kept as BYTES (the tips and the first levels above them,
+// which is where all sites x ops of the work are): 2 bytes read and 1 written per site and op instead of 8 and 4.
+// The 32-bit form the API shows (pll_get_site_id) and the gathering kernels read is produced on demand (k_rep_widen).
+// Integer work only: the maps are bit-identical to the reference's.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernels_common.h"
 
-constexpr int kRepOps = 128;              // ops per batch (descriptors in device memory, class counts in mapped host memory)
-constexpr unsigned kRepBlock = 1024;      // sites (k_rep_assign) or cells (k_rep_bitmap, k_rep_rank_cells) per workgroup: 256 threads x 4
-constexpr unsigned kRepMarkSites = 4096;  // sites per workgroup of k_rep_mark: 256 threads x 4 groups of 4 consecutive sites
-constexpr unsigned kRepLdsCells = 8192;   // table slices up to this many cells are reduced in LDS first (32 KB)
-constexpr unsigned kRepFilterBits = 12, kRepFilter = 1u << kRepFilterBits; // entries of k_rep_mark's LDS filter (8 bytes each)
-constexpr unsigned kRepClassFlag = 0x80000000u; // a table cell that holds its class number instead of its first site
+constexpr int kRepOps = 128;                // ops per launch
+constexpr unsigned kRepThreads = 512;       // k_rep_mark workgroup
+constexpr unsigned kRepLdsCells = 16384;    // cells of its table part (64 KB of LDS: two workgroups per CU)
+constexpr unsigned kRepSmallCells = 1024;   // tables up to here are ranked by direct counting in LDS
+constexpr unsigned kRepSeedCells = 4096;    // tables up to here: a few sites seed the LDS table before the scan (rep_seed)
+constexpr unsigned kRepAssignLds = 8192;    // k_rep_assign copies tables up to this many cells into LDS
+constexpr unsigned kRepAssignThreads = 256;
+constexpr unsigned kRepAssignTile = kRepAssignThreads * 16u * 2u; // sites per workgroup of k_rep_assign
+constexpr unsigned kRepScanThreads = 1024;                        // k_rep_scan workgroup
+constexpr unsigned kRepScanChunk = kRepScanThreads * 32u;         // bitmap words per round of its scan
+constexpr unsigned kRepMaxParts = 64;                             // tickets per op: parts of a table that has ranges (<= workgroups per op)
+constexpr unsigned kRepRankThreads = 256, kRepRankTiles = 64;     // k_rep_rank: workgroups per op (grid-stride over the cells)
+constexpr unsigned kRepNarrow = 256;        // up to this many classes: site -> class map in bytes
+constexpr unsigned kRepEmpty = 0xFFFFFFFFu;
+constexpr unsigned kRepFlag = 0x80000000u;  // counts[]: the op was compressed (low bits: its classes)
 
 struct RepOp
 {
-  const unsigned *lid;   // site -> class of the left child  [sites]
-  const unsigned *rid;
-  unsigned *psid;        // out: site -> class of the parent   [sites]
-  unsigned *pids;        // out: class -> first site           [<= sites]
-  unsigned *lent, *rent; // out: class -> entry of the left / right child (what the gather kernels want)
-  unsigned *bitmap;      // scratch [words]: bit s = site s is the lowest site of its cell (zero before k_rep_bitmap)
-  unsigned *wprefix;     // scratch [words]: representatives in the words before
-  unsigned nleft;        // classes of the left child
-  unsigned ncells;       // nleft * classes of the right child: this op's table slice
-  unsigned tab_off;      // first cell of the slice
+  const unsigned char *l8, *r8; // children's site -> class maps, byte form (valid when the child has <= kRepNarrow classes)
+  const unsigned *l32, *r32;    // ... 32-bit form (valid otherwise)
+  unsigned char *p8;            // out: the parent's map, in the form its class count asks for
+  unsigned *p32;
+  unsigned *pids;               // out: class -> first site
+  unsigned *lent, *rent;        // out: class -> entry of the left / right child (what the gather kernels want)
+  unsigned *table;              // this op's slice of the arena: ranges x cells while marking, then cell -> class
+  unsigned *bitmap;             // large tables: [wstride] bitmap over the sites (ZERO between launches), then [wstride] running bit counts
+  int lsrc, rsrc;               // op of this call that produces the child (index into counts[]), or -1: nleft / nright are given
+  unsigned nleft, nright;
+  unsigned slot;                // this op's index in counts[]
+  unsigned force;               // 1: the host decided to compress (enable_repeats callback); 0: the default rule, here
+  unsigned slice;               // cells in `table`
   unsigned pad;
 };
 typedef const RepOp __attribute__((address_space(4))) *crepop_p;
 
 struct RepPack
 {
-  const RepOp *ops;      // device array [nops]
-  unsigned *table;
-  unsigned *counts;      // out [nops]: classes per op
-  unsigned *host_counts; // the same in host-mapped memory, followed by ...
-  unsigned *host_seq;    // ... the sequence word the host polls (written last)
-  unsigned *ticket;      // arrival counter of the ops' last workgroups (0 between calls)
-  unsigned sequence;
+  const RepOp *ops;       // device array: this launch's ops
+  unsigned *counts;       // [ncounts] per op of the CALL: kRepFlag | classes, or 0 (not compressed)
+  unsigned *tickets;      // [kRepOps][kRepMaxParts] arrivals per table part of the launch's ops (0 between launches)
+  unsigned *launch_ticket; // ops of the launch whose count is known (0 between launches)
+  unsigned *host_counts;  // mapped host memory: counts[] for the host, then the sequence word, then an error word
+  unsigned ncounts;       // ops in the call
+  unsigned host_cap;      // entries before the sequence word
+  unsigned nops;          // ops in this launch
+  unsigned wgs;           // workgroups per op
   unsigned sites;
-  unsigned words;        // (sites + 31) / 32; the bitmap / prefix buffers hold `wstride` >= words words per op, a multiple of 32768
-  int fenced;            // kernels_common.h: handoff_*
+  unsigned lookup;        // pll_repeats_t::lookup_buffer_size: the pair table a compressed parent may use
+  unsigned lds_cells;     // LDS cells per workgroup
+  unsigned wstride;       // words per bitmap, a multiple of kRepScanChunk
+  unsigned sequence;
+  unsigned publish;       // the call's last kernel that produces counts: the op that reports last hands the counts to the host
+  unsigned has_rank;      // k_rep_scan + k_rep_rank follow this k_rep_mark (without them a large table is an error: 2)
+  unsigned max_ranges;    // site ranges per part of a large table
+  int fenced;             // kernels_common.h: handoff_*
 };
 
-__device__ __forceinline__ crepop_p rep_op(const RepPack &p)
+// classes of a node as the levels above see them (pernode_ids): 0 when it is not compressed - the op was not enabled,
+// or it found as many classes as sites (src/repeats.c:364-370)
+__device__ __forceinline__ unsigned rep_ids(unsigned count_word, unsigned sites)
 {
-  return (crepop_p)(uintptr_t)p.ops + blockIdx.y;
+  const unsigned n = count_word & ~kRepFlag;
+  return (count_word & kRepFlag) && n < sites ? n : 0u;
 }
 
-// Step 1: table[cell] = the lowest site of the cell. Many sites share a cell - that is the point of site
-// repeats; near the tips ALL of them share a handful (a DNA cherry: 16 cells for every site of the alignment),
-// and one atomic per site on a handful of L2 lines is a queue (C4's shard: 0.2-0.35 ms per level, 80 % of the
-// whole class-map update). So a workgroup first reduces its 4096 sites in LDS - a read before the LDS atomic:
-// after the first 256 sites nearly every later (higher) site finds a lower one in its cell and moves on - and
-// then sends ONE candidate per cell it touched, again after a look at what is there already. Slices too large
-// for LDS (deep nodes: many cells, few sites each) keep the direct form, where contention is no issue.
-__global__ __launch_bounds__(256) void k_rep_mark(const RepPack p)
+struct RepShape
+{
+  unsigned nl, nr, ncells;
+  bool on;
+};
+
+// the decision of pll_default_enable_repeats (src/repeats.c:100-110) from the children's counts
+__device__ __forceinline__ RepShape rep_shape(const RepPack &p, crepop_p o)
+{
+  RepShape s;
+  s.nl = o->lsrc >= 0 ? rep_ids(p.counts[o->lsrc], p.sites) : o->nleft;
+  s.nr = o->rsrc >= 0 ? rep_ids(p.counts[o->rsrc], p.sites) : o->nright;
+  const unsigned long long cells = (unsigned long long)s.nl * s.nr;
+  s.on = cells != 0ull && cells <= (unsigned long long)o->slice;
+  if (!o->force) s.on = s.on && cells < (unsigned long long)p.lookup && s.nl <= p.sites / 2u && s.nr <= p.sites / 2u;
+  s.ncells = s.on ? (unsigned)cells : 0u;
+  return s;
+}
+
+// sixteen consecutive entries of a site -> class map as they come from memory (the buffers are padded to whole groups
+// of sixteen), and as numbers
+template <bool NARROW>
+struct RepRaw
+{
+  uint4 q[NARROW ? 1 : 4];
+};
+
+template <bool NARROW>
+__device__ __forceinline__ RepRaw<NARROW> rep_fetch16(const unsigned char *m8, const unsigned *m32, unsigned s)
+{
+  RepRaw<NARROW> raw;
+  if (NARROW)
+    raw.q[0] = *reinterpret_cast<const uint4 *>(m8 + s);
+  else
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(m32 + s);
+#pragma unroll
+    for (unsigned q = 0; q < 4u; ++q) raw.q[q] = src[q];
+  }
+  return raw;
+}
+
+template <bool NARROW>
+__device__ __forceinline__ void rep_unpack16(const RepRaw<NARROW> &raw, unsigned (&v)[16])
+{
+  if (NARROW)
+  {
+    const unsigned w[4] = {raw.q[0].x, raw.q[0].y, raw.q[0].z, raw.q[0].w};
+#pragma unroll
+    for (unsigned e = 0; e < 16u; ++e) v[e] = (w[e >> 2] >> (8u * (e & 3u))) & 255u;
+  }
+  else
+  {
+#pragma unroll
+    for (unsigned q = 0; q < 4u; ++q)
+    {
+      v[4u * q] = raw.q[NARROW ? 0 : q].x;
+      v[4u * q + 1u] = raw.q[NARROW ? 0 : q].y;
+      v[4u * q + 2u] = raw.q[NARROW ? 0 : q].z;
+      v[4u * q + 3u] = raw.q[NARROW ? 0 : q].w;
+    }
+  }
+}
+
+template <bool NARROW>
+__device__ __forceinline__ void rep_load16(const unsigned char *m8, const unsigned *m32, unsigned s, unsigned (&v)[16])
+{
+  rep_unpack16<NARROW>(rep_fetch16<NARROW>(m8, m32, s), v);
+}
+
+// sites [s0, s1) of one op against the table part [lo, lo + pcells) in LDS. Ascending sites per thread and a look
+// before the LDS atomic: after its first few sites a thread mostly finds a lower site already there. The next group's
+// maps are requested before this one is worked on.
+template <bool L8, bool R8>
+__device__ __forceinline__ void rep_scan(crepop_p o, unsigned nleft, unsigned s0, unsigned s1, unsigned lo, unsigned pcells, unsigned *lds)
+{
+  const unsigned char *l8 = o->l8, *r8 = o->r8;
+  const unsigned *l32 = o->l32, *r32 = o->r32;
+  unsigned s = s0 + threadIdx.x * 16u;
+  if (s >= s1) return;
+  RepRaw<L8> lraw = rep_fetch16<L8>(l8, l32, s);
+  RepRaw<R8> rraw = rep_fetch16<R8>(r8, r32, s);
+  for (;;)
+  {
+    const unsigned sn = s + kRepThreads * 16u;
+    const bool more = sn < s1;
+    RepRaw<L8> lnext = lraw;
+    RepRaw<R8> rnext = rraw;
+    if (more)
+    {
+      lnext = rep_fetch16<L8>(l8, l32, sn);
+      rnext = rep_fetch16<R8>(r8, r32, sn);
+    }
+    unsigned l[16], r[16];
+    rep_unpack16<L8>(lraw, l);
+    rep_unpack16<R8>(rraw, r);
+    // all sixteen looks first (a site outside the range or the part looks at cell 0 and is dropped afterwards), then the
+    // few atomics: one wait for LDS per group instead of one per site. Two sites of the group in one cell both see the
+    // state before the group - the atomic sorts them out.
+    unsigned idx[16], seen[16];
+#pragma unroll
+    for (unsigned e = 0; e < 16u; ++e)
+    {
+      const unsigned i = l[e] + r[e] * nleft - lo;
+      idx[e] = (s + e < s1 && i < pcells) ? i : kRepEmpty;
+      seen[e] = lds[idx[e] != kRepEmpty ? idx[e] : 0u];
+    }
+#pragma unroll
+    for (unsigned e = 0; e < 16u; ++e)
+      if (idx[e] != kRepEmpty && seen[e] > s + e) atomicMin(&lds[idx[e]], s + e);
+    if (!more) return;
+    lraw = lnext;
+    rraw = rnext;
+    s = sn;
+  }
+}
+
+// A few hundred sites from the front of the range, one per thread and round, before rep_scan: with an empty table every
+// look of rep_scan's first group fails and all sixteen sites of all threads go to the LDS atomic unit - 8192 atomics on
+// the handful of cells a table next to the tips has, which the unit takes one at a time (this was 20 us of every such
+// launch, whatever the number of sites). After these rounds the cells that occur at all are mostly there.
+template <bool L8, bool R8>
+__device__ __forceinline__ void rep_seed(crepop_p o, unsigned nleft, unsigned s0, unsigned s1, unsigned lo, unsigned pcells, unsigned *lds)
+{
+  const unsigned char *l8 = o->l8, *r8 = o->r8;
+  const unsigned *l32 = o->l32, *r32 = o->r32;
+  for (unsigned round = 0; round < 4u; ++round)
+  {
+    const unsigned s = s0 + round * kRepThreads + threadIdx.x;
+    if (s < s1)
+    {
+      const unsigned l = L8 ? l8[s] : l32[s], r = R8 ? r8[s] : r32[s];
+      const unsigned idx = l + r * nleft - lo;
+      if (idx < pcells && lds[idx] > s) atomicMin(&lds[idx], s);
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ unsigned rep_coherent_load(const unsigned *p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The hand-over of the class counts. Called by every thread of ONE workgroup per op of the launch, in the kernel of the
+// launch that knows the last counts (p.publish): the workgroup that arrives last copies the counts of the whole call
+// to the host and then writes the sequence word the host polls.
+__device__ __forceinline__ void rep_arrive(const RepPack &p)
+{
+  __shared__ unsigned s_lastop;
+  if (!p.publish) return; // (uniform over the launch)
+  if (threadIdx.x == 0u)
+  {
+    handoff_before_ticket(p.fenced); // this op's count has been performed
+    const unsigned t = __hip_atomic_fetch_add(p.launch_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_lastop = (t == p.nops - 1u) ? 1u : 0u;
+    if (s_lastop)
+    {
+      handoff_after_last_ticket(p.fenced);
+      __hip_atomic_store(p.launch_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  if (!s_lastop) return;
+  for (unsigned i = threadIdx.x; i < p.ncounts; i += blockDim.x)
+    __hip_atomic_store(&p.host_counts[i], rep_coherent_load(&p.counts[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  handoff_before_sequence(p.fenced); // every wave: its counts are in host memory ...
+  __syncthreads();
+  if (threadIdx.x == 0u) __hip_atomic_store(&p.host_counts[p.host_cap], p.sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // ... before the word the host polls
+}
+
+__device__ __forceinline__ void rep_store_count(const RepPack &p, crepop_p o, unsigned count_word, unsigned error)
+{
+  if (threadIdx.x != 0u) return;
+  __hip_atomic_store(&p.counts[o->slot], count_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (error) __hip_atomic_store(&p.host_counts[p.host_cap + 1u], error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// the other workgroups' copies of a table part folded into this workgroup's own (still in LDS): `nranges` copies of
+// `ncells` cells each, the part is cells [lo, lo + pcells), `mine` is the copy to leave out. All requests of a round
+// first: every load is a trip to the coherent level.
+__device__ __forceinline__ void rep_fold_copies(const unsigned *table, unsigned ncells, unsigned nranges, unsigned mine, unsigned lo, unsigned pcells, unsigned *lds)
+{
+  for (unsigned base = 0; base < pcells; base += 16u * kRepThreads)
+    for (unsigned r = 0; r < nranges; ++r)
+    {
+      if (r == mine) continue;
+      unsigned t[16];
+#pragma unroll
+      for (unsigned q = 0; q < 16u; ++q)
+      {
+        const unsigned c = base + q * kRepThreads + threadIdx.x;
+        t[q] = c < pcells ? rep_coherent_load(table + (size_t)r * ncells + lo + c) : kRepEmpty;
+      }
+#pragma unroll
+      for (unsigned q = 0; q < 16u; ++q)
+      {
+        const unsigned c = base + q * kRepThreads + threadIdx.x;
+        if (c < pcells && t[q] < lds[c]) lds[c] = t[q]; // (cell c of the part belongs to this thread alone)
+      }
+    }
+}
+
+// small table, complete in LDS: a cell's class = the cells with a lower first site. Returns the class count (every thread).
+__device__ __forceinline__ unsigned rep_rank_small(crepop_p o, unsigned ncells, unsigned nl, const unsigned *lds, unsigned *s_count)
+{
+  unsigned *table = o->table;
+  unsigned *__restrict__ pids = o->pids, *__restrict__ lent = o->lent, *__restrict__ rent = o->rent;
+  if (threadIdx.x == 0u) *s_count = 0u;
+  __syncthreads();
+  for (unsigned c = threadIdx.x; c < ncells; c += kRepThreads)
+  {
+    const unsigned v = lds[c];
+    if (v == kRepEmpty)
+    {
+      table[c] = kRepEmpty;
+      continue;
+    }
+    unsigned rank = 0;
+    for (unsigned j = 0; j < ncells; ++j) rank += lds[j] < v ? 1u : 0u; // (an empty cell is never lower)
+    table[c] = rank;
+    pids[rank] = v;
+    lent[rank] = c % nl;
+    rent[rank] = c / nl;
+    atomicAdd(s_count, 1u);
+  }
+  __syncthreads();
+  return *s_count;
+}
+
+// Launch: a 1-D grid of (ops rounded up to eight) x wgs workgroups. Workgroups go to the XCDs round-robin by linear id:
+// the workgroups of one op are placed on ONE XCD (op = 8 * group + id % 8), so that the parts of an op's table, which
+// all scan the same two maps, find them in that XCD's L2.
+__global__ __launch_bounds__(kRepThreads) void k_rep_mark(const RepPack p)
 {
   extern __shared__ unsigned rep_lds[];
-  crepop_p o = rep_op(p);
-  const unsigned *__restrict__ lid = o->lid, *__restrict__ rid = o->rid;
-  const unsigned nleft = o->nleft, ncells = o->ncells;
-  unsigned *table = p.table + o->tab_off;
-  const bool in_lds = ncells <= kRepLdsCells; // workgroup-uniform
-  // slices too large for LDS get a FILTER there instead: kRepFilter entries {cell, lowest site of this workgroup seen with
-  // it}, direct-mapped by a hash of the cell. A site whose cell sits in its slot with a lower site has nothing to tell
-  // the table (that lower site's thread does, or was itself told so); anything else - another cell in the slot, a race -
-  // just goes to the table as before. What this path costs is its atomics on the table, and in a pattern-sorted
-  // alignment the sites of a class come in clusters.
-  unsigned long long *filter = reinterpret_cast<unsigned long long *>(rep_lds);
-  if (in_lds)
-    for (unsigned i = threadIdx.x; i < ncells; i += 256u) rep_lds[i] = 0xFFFFFFFFu;
-  else
-    for (unsigned i = threadIdx.x; i < kRepFilter; i += 256u) filter[i] = ~0ull;
-  __syncthreads();
-  // a thread takes four CONSECUTIVE sites at a time (16-byte loads of the two maps; round 2 read them 4 bytes per lane
-  // and the kernel ran at 1 TB/s), four such groups 1024 sites apart, all requested before the first is looked at.
-  // Consecutive sites of a pattern-sorted alignment mostly share their cell: only the first of a run goes to the table.
-  const unsigned wg0 = blockIdx.x * kRepMarkSites;
-  uint4 l[4], r[4];
-#pragma unroll
-  for (unsigned q = 0; q < 4; ++q)
+  __shared__ unsigned s_count;
+  __shared__ unsigned s_last;
+  const unsigned j = blockIdx.x >> 3, grp = j / p.wgs, w = j - grp * p.wgs, opi = grp * 8u + (blockIdx.x & 7u);
+  if (opi >= p.nops) return;
+  crepop_p o = (crepop_p)(uintptr_t)p.ops + opi;
+  const RepShape sh = rep_shape(p, o);
+  const bool large = sh.ncells > kRepSmallCells;
+  if (!sh.on || (large && !p.has_rank))
   {
-    const unsigned s = wg0 + q * 1024u + threadIdx.x * 4u;
-    if (s + 3u < p.sites)
+    if (w != 0u) return;
+    const unsigned long long cells = (unsigned long long)sh.nl * sh.nr;
+    // 1: a table the slice cannot hold although the rule admits it - the host's bound was wrong; 2: a large table in
+    // a launch that came without k_rep_scan / k_rep_rank - the host's forecast was wrong (it repeats the call with them)
+    const bool overflow = !sh.on && cells > (unsigned long long)o->slice && (o->force || (cells < (unsigned long long)p.lookup && sh.nl <= p.sites / 2u && sh.nr <= p.sites / 2u));
+    rep_store_count(p, o, 0u, overflow ? 1u : sh.on ? 2u : 0u);
+    if (!p.has_rank) rep_arrive(p);
+    return;
+  }
+  // parts x ranges: as few parts as LDS allows (every part scans the op's sites again), the other workgroups split the
+  // sites - as far as the copies stay cheap to fold: all of them for a small table, max_ranges for a large one
+  const unsigned ncells = sh.ncells;
+  const unsigned nparts = (ncells + p.lds_cells - 1u) / p.lds_cells;
+  unsigned nranges = nparts < p.wgs ? p.wgs / nparts : 1u;
+  if (large && nranges > p.max_ranges) nranges = p.max_ranges;
+  if (nranges > (p.sites + 8191u) / 8192u) nranges = (p.sites + 8191u) / 8192u; // no range shorter than a pass of two workgroups
+  if (nranges > o->slice / ncells) nranges = o->slice / ncells; // (>= 1: rep_shape; the host sizes the slice for all of them)
+  const bool looped = nparts >= p.wgs || nparts > kRepMaxParts; // parts shared out over the workgroups, one range
+  if (looped) nranges = 1u;
+  const unsigned used = looped ? (nparts < p.wgs ? nparts : p.wgs) : nparts * nranges;
+  if (w >= used) return;
+  const unsigned pc = (ncells + nparts - 1u) / nparts; // cells per part (<= lds_cells)
+  const unsigned rs = ((p.sites + nranges - 1u) / nranges + 15u) & ~15u; // sites per range, whole groups of sixteen
+  const unsigned range = looped ? 0u : w / nparts;
+  const unsigned s0 = range * rs < p.sites ? range * rs : p.sites, s1 = s0 + rs < p.sites ? s0 + rs : p.sites;
+  const bool l8 = sh.nl <= kRepNarrow, r8 = sh.nr <= kRepNarrow;
+  for (unsigned part = looped ? w : w % nparts; part < nparts; part += looped ? used : nparts)
+  {
+    const unsigned lo = part * pc, pcells = lo + pc <= ncells ? pc : ncells - lo;
+    for (unsigned i = threadIdx.x; i < pcells; i += kRepThreads) rep_lds[i] = kRepEmpty;
+    __syncthreads();
+    if (ncells <= kRepSeedCells)
     {
-      l[q] = *reinterpret_cast<const uint4 *>(lid + s);
-      r[q] = *reinterpret_cast<const uint4 *>(rid + s);
+      if (l8 && r8) rep_seed<true, true>(o, sh.nl, s0, s1, lo, pcells, rep_lds);
+      else if (l8) rep_seed<true, false>(o, sh.nl, s0, s1, lo, pcells, rep_lds);
+      else if (r8) rep_seed<false, true>(o, sh.nl, s0, s1, lo, pcells, rep_lds);
+      else rep_seed<false, false>(o, sh.nl, s0, s1, lo, pcells, rep_lds);
+    }
+    if (l8 && r8) rep_scan<true, true>(o, sh.nl, s0, s1, lo, pcells, rep_lds);
+    else if (l8) rep_scan<true, false>(o, sh.nl, s0, s1, lo, pcells, rep_lds);
+    else if (r8) rep_scan<false, true>(o, sh.nl, s0, s1, lo, pcells, rep_lds);
+    else rep_scan<false, false>(o, sh.nl, s0, s1, lo, pcells, rep_lds);
+    __syncthreads();
+    if (nranges > 1u)
+    {
+      // this workgroup's copy of the part: written through to the coherent level (kernels_common.h: partial_store);
+      // every wave's stores have been performed before the workgroup takes its ticket
+      unsigned *dst = o->table + (size_t)range * ncells + lo;
+      for (unsigned i = threadIdx.x; i < pcells; i += kRepThreads) __hip_atomic_store(dst + i, rep_lds[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0u)
+      {
+        if (p.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        unsigned *ticket = &p.tickets[opi * kRepMaxParts + part];
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == nranges - 1u) ? 1u : 0u;
+        if (s_last)
+        {
+          handoff_after_last_ticket(p.fenced);
+          __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      __syncthreads();
+      if (!s_last) return; // (a workgroup with ranges has this one part)
+      rep_fold_copies(o->table, ncells, nranges, range, lo, pcells, rep_lds);
+      __syncthreads();
+    }
+    // the part's first sites are final, in LDS
+    if (!large)
+    {
+      const unsigned classes = rep_rank_small(o, ncells, sh.nl, rep_lds, &s_count); // (one part: the whole table)
+      rep_store_count(p, o, kRepFlag | classes, 0u);
+      if (!p.has_rank) rep_arrive(p);
+      return;
+    }
+    // large: the table for k_rep_rank (and the launches behind it: plain stores), the bits for k_rep_scan. The bitmap
+    // is shared by the op's parts: atomics at the coherent level.
+    unsigned *table = o->table + lo, *bitmap = o->bitmap;
+    for (unsigned i = threadIdx.x; i < pcells; i += kRepThreads)
+    {
+      const unsigned v = rep_lds[i];
+      table[i] = v;
+      if (v != kRepEmpty) __hip_atomic_fetch_or(&bitmap[v >> 5], 1u << (v & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads(); // rep_lds is reused by the next part
+  }
+}
+
+// Large tables, second step: ONE workgroup per op of the launch: wprefix[w] = set bits in the words before w, the
+// class count = all set bits. Every op of the launch passes here (small tables and parents that stay uncompressed
+// only to be counted: this is the kernel of such a launch that hands the counts over).
+__global__ __launch_bounds__(kRepScanThreads) void k_rep_scan(const RepPack p)
+{
+  __shared__ unsigned wsum[kRepScanThreads / 64u];
+  crepop_p o = (crepop_p)(uintptr_t)p.ops + blockIdx.x;
+  const RepShape sh = rep_shape(p, o);
+  if (sh.on && sh.ncells > kRepSmallCells)
+  {
+    const unsigned *__restrict__ bitmap = o->bitmap;
+    unsigned *__restrict__ wprefix = o->bitmap + p.wstride;
+    const unsigned words = (p.sites + 31u) / 32u;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned carried = 0; // set bits in the chunks before
+    // chunks of 1024 threads x 32 consecutive words (1M sites): eight 16-byte loads per thread, all in flight together
+    // (the buffers are allocated in whole chunks, zero beyond the last site)
+    for (unsigned chunk0 = 0; chunk0 < words; chunk0 += kRepScanChunk)
+    {
+      const unsigned w0 = chunk0 + threadIdx.x * 32u;
+      uint4 v[8];
+#pragma unroll
+      for (unsigned q = 0; q < 8u; ++q) v[q] = w0 < words ? *reinterpret_cast<const uint4 *>(bitmap + w0 + 4u * q) : make_uint4(0u, 0u, 0u, 0u);
+      unsigned n = 0;
+#pragma unroll
+      for (unsigned q = 0; q < 8u; ++q) n += __popc(v[q].x) + __popc(v[q].y) + __popc(v[q].z) + __popc(v[q].w);
+      unsigned inc = n;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1)
+      {
+        const unsigned t = __shfl_up(inc, off, 64);
+        if ((int)lane >= off) inc += t;
+      }
+      if (lane == 63u) wsum[wave] = inc;
+      __syncthreads();
+      unsigned before = 0, total = 0;
+      for (unsigned w = 0; w < kRepScanThreads / 64u; ++w)
+      {
+        before += w < wave ? wsum[w] : 0u;
+        total += wsum[w];
+      }
+      __syncthreads(); // wsum is reused by the next chunk
+      unsigned r = carried + before + inc - n;
+#pragma unroll
+      for (unsigned q = 0; q < 8u; ++q)
+      {
+        uint4 pre;
+        pre.x = r;
+        r += __popc(v[q].x);
+        pre.y = r;
+        r += __popc(v[q].y);
+        pre.z = r;
+        r += __popc(v[q].z);
+        pre.w = r;
+        r += __popc(v[q].w);
+        if (w0 < words) *reinterpret_cast<uint4 *>(wprefix + w0 + 4u * q) = pre;
+      }
+      carried += total;
+    }
+    rep_store_count(p, o, kRepFlag | carried, 0u);
+  }
+  rep_arrive(p);
+}
+
+// (op, piece) of a workgroup in a 1-D grid of (ops rounded up to eight) x `per` workgroups: the workgroups of one op on
+// ONE XCD (workgroups go to the XCDs round-robin by linear id), so that what they share - the op's table, its maps, its
+// bitmap - is found in that XCD's L2
+__device__ __forceinline__ bool rep_place(unsigned nops, unsigned per, unsigned &opi, unsigned &piece)
+{
+  const unsigned j = blockIdx.x >> 3, grp = j / per;
+  piece = j - grp * per;
+  opi = grp * 8u + (blockIdx.x & 7u);
+  return opi < nops;
+}
+
+// Large tables, third step: every non-empty cell takes its class number - the first sites before its own.
+// Grid: rep_place with kRepRankTiles workgroups per op, which stride over the op's cells.
+__global__ __launch_bounds__(kRepRankThreads) void k_rep_rank(const RepPack p)
+{
+  unsigned opi, tile;
+  if (!rep_place(p.nops, kRepRankTiles, opi, tile)) return;
+  crepop_p o = (crepop_p)(uintptr_t)p.ops + opi;
+  const RepShape sh = rep_shape(p, o);
+  if (!sh.on || sh.ncells <= kRepSmallCells) return;
+  unsigned *__restrict__ table = o->table;
+  const unsigned *__restrict__ bitmap = o->bitmap, *__restrict__ wprefix = o->bitmap + p.wstride;
+  const unsigned ncells = sh.ncells;
+  for (unsigned base = tile * kRepRankThreads * 4u; base < ncells; base += kRepRankTiles * kRepRankThreads * 4u)
+  {
+    unsigned v[4], pre[4], bits[4];
+#pragma unroll
+    for (unsigned q = 0; q < 4u; ++q)
+    {
+      const unsigned c = base + q * kRepRankThreads + threadIdx.x;
+      v[q] = c < ncells ? table[c] : kRepEmpty;
+    }
+#pragma unroll
+    for (unsigned q = 0; q < 4u; ++q)
+    {
+      const unsigned w = v[q] != kRepEmpty ? v[q] >> 5 : 0u;
+      pre[q] = wprefix[w];
+      bits[q] = bitmap[w];
+    }
+#pragma unroll
+    for (unsigned q = 0; q < 4u; ++q)
+    {
+      const unsigned c = base + q * kRepRankThreads + threadIdx.x;
+      if (c < ncells && v[q] != kRepEmpty) table[c] = pre[q] + __popc(bits[q] & ((1u << (v[q] & 31u)) - 1u));
+    }
+  }
+}
+
+// site -> class. FIRSTS (large tables): the sites the bitmap marks as the first of their cell also write the class ->
+// first site / child entry maps - in site order, which is class order: neighbouring stores (the cells, which know the
+// same, would scatter them).
+template <bool L8, bool R8, bool P8, bool LDS, bool FIRSTS>
+__device__ __forceinline__ void rep_assign_tile(crepop_p o, unsigned nleft, const unsigned *tab, unsigned sites, unsigned tile)
+{
+  const unsigned char *l8 = o->l8, *r8 = o->r8;
+  const unsigned *l32 = o->l32, *r32 = o->r32;
+  const unsigned tile0 = tile * kRepAssignTile;
+#pragma unroll
+  for (unsigned it = 0; it < kRepAssignTile / (kRepAssignThreads * 16u); ++it)
+  {
+    const unsigned s = tile0 + it * kRepAssignThreads * 16u + threadIdx.x * 16u;
+    if (s >= sites) continue;
+    unsigned l[16], r[16], v[16];
+    rep_load16<L8>(l8, l32, s, l);
+    rep_load16<R8>(r8, r32, s, r);
+    unsigned firsts = 0;
+    if (FIRSTS) firsts = (o->bitmap[s >> 5] >> (s & 16u)) & 0xFFFFu;
+#pragma unroll
+    for (unsigned e = 0; e < 16u; ++e) v[e] = tab[s + e < sites ? l[e] + r[e] * nleft : 0u]; // (the padding of the maps holds anything: cell 0, not stored beyond the map's padding)
+    if (P8)
+    {
+      uint4 out;
+      out.x = v[0] | v[1] << 8 | v[2] << 16 | v[3] << 24;
+      out.y = v[4] | v[5] << 8 | v[6] << 16 | v[7] << 24;
+      out.z = v[8] | v[9] << 8 | v[10] << 16 | v[11] << 24;
+      out.w = v[12] | v[13] << 8 | v[14] << 16 | v[15] << 24;
+      *reinterpret_cast<uint4 *>(o->p8 + s) = out;
     }
     else
     {
-      unsigned lv[4] = {0, 0, 0, 0}, rv[4] = {0, 0, 0, 0};
-      for (unsigned e = 0; e < 4; ++e)
-        if (s + e < p.sites)
+#pragma unroll
+      for (unsigned q = 0; q < 4u; ++q) *reinterpret_cast<uint4 *>(o->p32 + s + 4u * q) = make_uint4(v[4u * q], v[4u * q + 1u], v[4u * q + 2u], v[4u * q + 3u]);
+    }
+    if (FIRSTS && firsts)
+    {
+      unsigned *__restrict__ pids = o->pids, *__restrict__ lent = o->lent, *__restrict__ rent = o->rent;
+#pragma unroll
+      for (unsigned e = 0; e < 16u; ++e)
+        if (firsts >> e & 1u)
         {
-          lv[e] = lid[s + e];
-          rv[e] = rid[s + e];
+          pids[v[e]] = s + e;
+          lent[v[e]] = l[e];
+          rent[v[e]] = r[e];
         }
-      l[q] = make_uint4(lv[0], lv[1], lv[2], lv[3]);
-      r[q] = make_uint4(rv[0], rv[1], rv[2], rv[3]);
-    }
-  }
-#pragma unroll
-  for (unsigned q = 0; q < 4; ++q) // ascending sites: later groups mostly find a lower site already there
-  {
-    const unsigned s = wg0 + q * 1024u + threadIdx.x * 4u;
-    const unsigned c[4] = {l[q].x + r[q].x * nleft, l[q].y + r[q].y * nleft, l[q].z + r[q].z * nleft, l[q].w + r[q].w * nleft};
-#pragma unroll
-    for (unsigned e = 0; e < 4; ++e)
-    {
-      if (s + e >= p.sites || (e && c[e] == c[e - 1])) continue; // (a lower site of this thread has the cell)
-      if (in_lds)
-      {
-        if (rep_lds[c[e]] > s + e) atomicMin(&rep_lds[c[e]], s + e);
-      }
-      // slices too large for LDS. A PLAIN (cached) look: cells only ever go down, so a stale value can cost a redundant
-      // atomic, never a wrong minimum (an agent-scope load per site was 16M trips to the coherent level per level of
-      // C4). One look, then its atomic, site after site: with all looks first a thread's own lower sites no longer
-      // shield the later ones and the atomics - what this path costs - tripled (measured: 0.37 -> 1.9 ms).
-      else
-      {
-        const unsigned slot = (c[e] * 2654435761u) >> (32 - kRepFilterBits);
-        const unsigned long long ent = filter[slot];
-        if ((unsigned)(ent >> 32) == c[e] && (unsigned)ent < s + e) continue;
-        filter[slot] = ((unsigned long long)c[e] << 32) | (s + e);
-        if (table[c[e]] > s + e) atomicMin(&table[c[e]], s + e);
-      }
-    }
-  }
-  if (!in_lds) return;
-  __syncthreads();
-  for (unsigned i = threadIdx.x; i < ncells; i += 256u)
-  {
-    const unsigned v = rep_lds[i];
-    // a stale value read here can only cause a redundant atomic, never a wrong minimum
-    if (v != 0xFFFFFFFFu && __hip_atomic_load(&table[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > v) atomicMin(&table[i], v);
-  }
-}
-
-// Step 2a: the representatives as a bitmap over the sites
-__global__ __launch_bounds__(256) void k_rep_bitmap(const RepPack p)
-{
-  crepop_p o = rep_op(p);
-  const unsigned ncells = o->ncells;
-  const unsigned *__restrict__ table = p.table + o->tab_off;
-  unsigned *__restrict__ bitmap = o->bitmap;
-  const unsigned base = blockIdx.x * kRepBlock + threadIdx.x * 4u;
-  if (base >= ncells) return;
-#pragma unroll
-  for (unsigned q = 0; q < 4; ++q)
-  {
-    const unsigned cell = base + q;
-    if (cell < ncells)
-    {
-      const unsigned s = table[cell];
-      if (s != 0xFFFFFFFFu) atomicOr(&bitmap[s >> 5], 1u << (s & 31u));
     }
   }
 }
 
-// Step 2b: ONE workgroup per op: wprefix[w] = set bits in the words before w; the op's class count goes to the device
-// array and straight to the host (mapped memory); the op that arrives last publishes the sequence word (hand-off
-// without fences by default: kernels_common.h)
-__global__ __launch_bounds__(1024) void k_rep_scan(const RepPack p)
+template <bool L8, bool R8, bool P8>
+__device__ __forceinline__ void rep_assign_form(crepop_p o, unsigned nleft, unsigned ncells, unsigned lds_cells, unsigned *lds, unsigned sites, unsigned tile)
 {
-  __shared__ unsigned wsum[16];
-  crepop_p o = rep_op(p);
-  const unsigned *__restrict__ bitmap = o->bitmap;
-  unsigned *__restrict__ wprefix = o->wprefix;
-  const unsigned words = p.words;
-  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  unsigned carried = 0; // set bits in the chunks before
-  // chunks of 1024 threads x 32 consecutive words (1M sites): eight 16-byte loads per thread, all in flight together
-  // (the buffers are allocated in whole chunks: pllgpu_repeats_classes)
-  for (unsigned chunk0 = 0; chunk0 < words; chunk0 += 32768u)
+  const unsigned *table = o->table;
+  if (ncells <= lds_cells)
   {
-    const unsigned w0 = chunk0 + threadIdx.x * 32u;
-    uint4 v[8];
-#pragma unroll
-    for (unsigned q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const uint4 *>(bitmap + w0 + 4u * q);
-    unsigned n = 0;
-#pragma unroll
-    for (unsigned q = 0; q < 8; ++q) n += __popc(v[q].x) + __popc(v[q].y) + __popc(v[q].z) + __popc(v[q].w);
-    unsigned inc = n;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1)
-    {
-      const unsigned t = __shfl_up(inc, off, 64);
-      if ((int)lane >= off) inc += t;
-    }
-    if (lane == 63) wsum[wave] = inc;
+    for (unsigned i = threadIdx.x; i < ncells; i += kRepAssignThreads) lds[i] = table[i];
     __syncthreads();
-    unsigned before = 0, total = 0;
-    for (unsigned w = 0; w < 16u; ++w)
-    {
-      before += w < wave ? wsum[w] : 0u;
-      total += wsum[w];
-    }
-    __syncthreads(); // wsum is reused by the next chunk
-    unsigned r = carried + before + inc - n;
-#pragma unroll
-    for (unsigned q = 0; q < 8; ++q)
-    {
-      uint4 pre;
-      pre.x = r;
-      r += __popc(v[q].x);
-      pre.y = r;
-      r += __popc(v[q].y);
-      pre.z = r;
-      r += __popc(v[q].z);
-      pre.w = r;
-      r += __popc(v[q].w);
-      *reinterpret_cast<uint4 *>(wprefix + w0 + 4u * q) = pre;
-    }
-    carried += total;
+    if (ncells > kRepSmallCells) rep_assign_tile<L8, R8, P8, true, true>(o, nleft, lds, sites, tile);
+    else rep_assign_tile<L8, R8, P8, true, false>(o, nleft, lds, sites, tile);
   }
-  if (threadIdx.x == 0u)
+  else
+    rep_assign_tile<L8, R8, P8, false, true>(o, nleft, table, sites, tile);
+}
+
+// Grid: rep_place with one workgroup per tile of kRepAssignTile sites
+__global__ __launch_bounds__(kRepAssignThreads) void k_rep_assign(const RepPack p)
+{
+  extern __shared__ unsigned rep_lds[];
+  unsigned opi, tile;
+  if (!rep_place(p.nops, p.wgs, opi, tile)) return;
+  crepop_p o = (crepop_p)(uintptr_t)p.ops + opi;
+  const unsigned word = p.counts[o->slot];
+  if (!(word & kRepFlag)) return; // not compressed: no maps
+  const RepShape sh = rep_shape(p, o);
+  const unsigned form = (sh.nl <= kRepNarrow ? 4u : 0u) | (sh.nr <= kRepNarrow ? 2u : 0u) | ((word & ~kRepFlag) <= kRepNarrow ? 1u : 0u);
+  switch (form)
   {
-    p.counts[blockIdx.y] = carried;
-    __hip_atomic_store(&p.host_counts[blockIdx.y], carried, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    handoff_before_sequence(p.fenced);
-    const unsigned t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == gridDim.y - 1u)
-    {
-      __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(p.host_seq, p.sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+  case 7u: rep_assign_form<true, true, true>(o, sh.nl, sh.ncells, p.lds_cells, rep_lds, p.sites, tile); break;
+  case 6u: rep_assign_form<true, true, false>(o, sh.nl, sh.ncells, p.lds_cells, rep_lds, p.sites, tile); break;
+  case 5u: rep_assign_form<true, false, true>(o, sh.nl, sh.ncells, p.lds_cells, rep_lds, p.sites, tile); break;
+  case 4u: rep_assign_form<true, false, false>(o, sh.nl, sh.ncells, p.lds_cells, rep_lds, p.sites, tile); break;
+  case 3u: rep_assign_form<false, true, true>(o, sh.nl, sh.ncells, p.lds_cells, rep_lds, p.sites, tile); break;
+  case 2u: rep_assign_form<false, true, false>(o, sh.nl, sh.ncells, p.lds_cells, rep_lds, p.sites, tile); break;
+  case 1u: rep_assign_form<false, false, true>(o, sh.nl, sh.ncells, p.lds_cells, rep_lds, p.sites, tile); break;
+  default: rep_assign_form<false, false, false>(o, sh.nl, sh.ncells, p.lds_cells, rep_lds, p.sites, tile); break;
+  }
+  if (sh.ncells > kRepSmallCells)
+  {
+    // the op's bitmap goes back to zero for the next launch that uses the slot: this tile's sites, once every thread
+    // of the workgroup has read its bits
+    __syncthreads();
+    const unsigned w0 = tile * (kRepAssignTile / 32u) + threadIdx.x * 4u;
+    if (threadIdx.x < kRepAssignTile / 128u && w0 < p.wstride) *reinterpret_cast<uint4 *>(o->bitmap + w0) = make_uint4(0u, 0u, 0u, 0u);
   }
 }
 
-// Step 2c: every non-empty cell takes its class number - the representatives before its lowest site - and keeps it
-// (flagged: a flagged word can never equal a site), so that step 3 finds the class of any site with one look-up; the
-// class -> first site / child entry maps are written here: the cell index is left class + right class * nleft
-__global__ __launch_bounds__(256) void k_rep_rank_cells(const RepPack p)
+// the two forms of a site -> class map into each other (n = entries rounded up to whole groups of sixteen)
+__global__ __launch_bounds__(256) void k_rep_widen(const unsigned char *__restrict__ m8, unsigned *__restrict__ m32, unsigned n)
 {
-  crepop_p o = rep_op(p);
-  const unsigned ncells = o->ncells, nleft = o->nleft;
-  unsigned *__restrict__ table = p.table + o->tab_off;
-  const unsigned *__restrict__ bitmap = o->bitmap, *__restrict__ wprefix = o->wprefix;
-  unsigned *__restrict__ pids = o->pids, *__restrict__ lent = o->lent, *__restrict__ rent = o->rent;
-  const unsigned base = blockIdx.x * kRepBlock + threadIdx.x * 4u;
-  if (base >= ncells) return;
+  const unsigned s = (blockIdx.x * 256u + threadIdx.x) * 16u;
+  if (s >= n) return;
+  unsigned v[16];
+  rep_load16<true>(m8, nullptr, s, v);
 #pragma unroll
-  for (unsigned q = 0; q < 4; ++q)
-  {
-    const unsigned cell = base + q;
-    if (cell < ncells)
-    {
-      const unsigned s = table[cell];
-      if (s != 0xFFFFFFFFu)
-      {
-        const unsigned w = s >> 5;
-        const unsigned r = wprefix[w] + __popc(bitmap[w] & ((1u << (s & 31u)) - 1u));
-        table[cell] = r | kRepClassFlag;
-        pids[r] = s;
-        lent[r] = cell % nleft;
-        rent[r] = cell / nleft;
-      }
-    }
-  }
+  for (unsigned q = 0; q < 4u; ++q) *reinterpret_cast<uint4 *>(m32 + s + 4u * q) = make_uint4(v[4u * q], v[4u * q + 1u], v[4u * q + 2u], v[4u * q + 3u]);
 }
 
-// Step 3: site -> class
-__global__ __launch_bounds__(256) void k_rep_assign(const RepPack p)
+__global__ __launch_bounds__(256) void k_rep_narrow(const unsigned *__restrict__ m32, unsigned char *__restrict__ m8, unsigned n)
 {
-  crepop_p o = rep_op(p);
-  const unsigned *__restrict__ lid = o->lid, *__restrict__ rid = o->rid;
-  const unsigned nleft = o->nleft;
-  const unsigned *__restrict__ table = p.table + o->tab_off;
-  unsigned *__restrict__ psid = o->psid;
-  const unsigned base = blockIdx.x * kRepBlock + threadIdx.x * 4u;
-  if (base + 3u < p.sites)
-  {
-    const uint4 l = *reinterpret_cast<const uint4 *>(lid + base), r = *reinterpret_cast<const uint4 *>(rid + base);
-    uint4 v;
-    v.x = table[l.x + r.x * nleft] & ~kRepClassFlag;
-    v.y = table[l.y + r.y * nleft] & ~kRepClassFlag;
-    v.z = table[l.z + r.z * nleft] & ~kRepClassFlag;
-    v.w = table[l.w + r.w * nleft] & ~kRepClassFlag;
-    *reinterpret_cast<uint4 *>(psid + base) = v;
-    return;
-  }
-  for (unsigned q = 0; q < 4; ++q)
-  {
-    const unsigned s = base + q;
-    if (s < p.sites) psid[s] = table[lid[s] + rid[s] * nleft] & ~kRepClassFlag;
-  }
+  const unsigned s = (blockIdx.x * 256u + threadIdx.x) * 16u;
+  if (s >= n) return;
+  unsigned v[16];
+  rep_load16<false>(nullptr, m32, s, v);
+  uint4 out;
+  out.x = (v[0] & 255u) | (v[1] & 255u) << 8 | (v[2] & 255u) << 16 | v[3] << 24;
+  out.y = (v[4] & 255u) | (v[5] & 255u) << 8 | (v[6] & 255u) << 16 | v[7] << 24;
+  out.z = (v[8] & 255u) | (v[9] & 255u) << 8 | (v[10] & 255u) << 16 | v[11] << 24;
+  out.w = (v[12] & 255u) | (v[13] & 255u) << 8 | (v[14] & 255u) << 16 | v[15] << 24;
+  *reinterpret_cast<uint4 *>(m8 + s) = out;
 }

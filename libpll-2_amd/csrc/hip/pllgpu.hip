@@ -81,6 +81,8 @@ struct DevBuf
 // mapped result block: [0..7] lnL / derivative words, [8..) ascertainment-bias terms (up to 64 x 4 doubles)
 constexpr size_t kResultBytes = (8 + 4 * 64) * sizeof(double);
 constexpr unsigned kAscOff = 8;
+constexpr unsigned kRepHostCap = 1u << 16; // ops of one class-map call whose counts the mapped block holds (larger calls go in pieces)
+constexpr unsigned char kMap8 = 1, kMap32 = 2;
 
 struct pllgpu_ctx
 {
@@ -109,6 +111,8 @@ struct pllgpu_ctx
   std::vector<DevBuf<unsigned>> scaler;
   std::vector<DevBuf<unsigned char>> tipchars;
   std::vector<DevBuf<unsigned>> site_id, id_site;
+  std::vector<DevBuf<unsigned char>> site_id8; // site -> class in bytes: nodes with <= kRepNarrow classes (kernels_repeats.h)
+  std::vector<unsigned char> map_forms;        // per node: which forms of its site -> class map are current (kMap8 | kMap32)
   std::vector<DevBuf<unsigned>> lent, rent; // class -> child entry, per compressed node (kernels_repeats.h)
   std::vector<int> rep_left, rep_right;     // the children those maps were built for, or -1
   std::vector<unsigned> ids;
@@ -122,16 +126,24 @@ struct pllgpu_ctx
   DevBuf<double> eigenvals, rates, diag; // derivatives: [rate_matrices][SP], [R], [R][S][4]
   DevBuf<double> evecs, ievecs, brlen;   // device P-matrices: [rate_matrices][S][SP] x 2, staged branch lengths
   DevBuf<unsigned> mindex;               // staged matrix indices
-  DevBuf<unsigned> rep_table, rep_blocksum, rep_counts; // site-repeats class computation (kernels_repeats.h)
-  DevBuf<unsigned char> rep_ops;         // its op descriptors of one batch
+  DevBuf<unsigned> rep_table, rep_blocksum, rep_counts; // site-repeats class computation (kernels_repeats.h): arena, bitmaps, counts per op of a call
+  DevBuf<unsigned> rep_sync;             // [kRepOps] tickets per op of a launch, then the launch's own (zero between launches)
+  DevBuf<unsigned char> rep_ops;         // the op descriptors of one call
   std::vector<RepOp> rep_ops_host;
+  unsigned rep_wgs = 0;                  // PLL_AMD_REP_WGS: workgroups per op of k_rep_mark (0: by the launch's size)
+  unsigned rep_max_ranges = 4;           // PLL_AMD_REP_RANGES: site ranges per part of a large table (kernels_repeats.h)
+  bool rep_hints = true;                 // PLL_AMD_REP_HINTS=0: every level of a class-map call is launched (A/B, tests)
+  unsigned rep_hint_count = 0, rep_hint_level = 0; // the last call: its ops, the highest level with a compressed parent ...
+  bool rep_hint_any = false;                       // ... if there was one
+  bool rep_scratch_dirty = false;        // a class-map call did not complete: its bitmaps and tickets are cleared before the next
   DevBuf<double> sumtable[PLLGPU_SUMTABLE_SLOTS]; // device-resident sumtables (tiled like a CLV), allocated on first use
   double *result_dev = nullptr;  // device alias of result_host
   DevBuf<unsigned> pattern_weights;
   DevBuf<int> invariant;
   bool invariant_set = false;
-  unsigned *rep_host = nullptr;  // pinned + mapped: class counts of a repeats batch [kRepOps], then the sequence word
+  unsigned *rep_host = nullptr;  // pinned + mapped: class counts of a class-map call [rep_host_cap], the sequence word, an error word
   unsigned *rep_host_dev = nullptr;
+  unsigned rep_host_cap = 0;
   unsigned rep_seq = 0;
   double *result_host = nullptr; // pinned + mapped: [0] lnL, [1] sequence of the call that wrote it
   double seq = 0.0;
@@ -412,8 +424,9 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipHostMalloc((void **)&c->result_host, kResultBytes, hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void **)&c->result_dev, c->result_host, 0) == hipSuccess &&
-            hipHostMalloc((void **)&c->rep_host, (kRepOps + 2) * sizeof(unsigned), hipHostMallocMapped) == hipSuccess &&
+            hipHostMalloc((void **)&c->rep_host, (kRepHostCap + 2) * sizeof(unsigned), hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void **)&c->rep_host_dev, c->rep_host, 0) == hipSuccess;
+  c->rep_host_cap = kRepHostCap;
   if (!ok)
   {
     fail(PLLGPU_ERUNTIME, "stream/event creation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -422,13 +435,15 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   }
   c->own_stream = true;
   memset(c->result_host, 0, 8 * sizeof(double));
-  memset(c->rep_host, 0, (kRepOps + 2) * sizeof(unsigned));
+  memset(c->rep_host, 0, (kRepHostCap + 2) * sizeof(unsigned));
   c->clv.resize(geo->nodes);
   c->clv_aos.assign(geo->nodes, 0);
   c->scaler.resize(geo->scale_buffers);
   c->tipchars.resize(geo->tips);
   c->site_id.resize(geo->nodes);
   c->id_site.resize(geo->nodes);
+  c->site_id8.resize(geo->nodes);
+  c->map_forms.assign(geo->nodes, 0);
   c->lent.resize(geo->nodes);
   c->rent.resize(geo->nodes);
   c->rep_left.assign(geo->nodes, -1);
@@ -437,7 +452,7 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   if (c->pmat.ensure(c->pm_stride * (geo->prob_matrices + 2)) || c->freqs.ensure((size_t)geo->rate_matrices * geo->states_padded) ||
       c->rate_weights.ensure(geo->rate_cats) || c->prop_invar.ensure(geo->rate_matrices) ||
       c->pattern_weights.ensure(geo->sites_alloc) || c->persite.ensure(geo->sites_alloc) ||
-      c->block_sums.ensure(4096) || c->counter.ensure(4))
+      c->block_sums.ensure(4096) || c->counter.ensure(4) || c->rep_sync.ensure((size_t)kRepOps * kRepMaxParts + 1))
   {
     pllgpu_destroy(c);
     return nullptr;
@@ -446,6 +461,10 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   c->pm_version.assign(geo->prob_matrices + 2, 1ull);
   (void)hipMemsetAsync(c->prop_invar.p, 0, c->prop_invar.cap * sizeof(double), c->stream);
   (void)hipMemsetAsync(c->counter.p, 0, c->counter.cap * sizeof(unsigned), c->stream);
+  (void)hipMemsetAsync(c->rep_sync.p, 0, c->rep_sync.cap * sizeof(unsigned), c->stream);
+  if (const char *v = getenv("PLL_AMD_REP_WGS")) c->rep_wgs = (unsigned)std::max(0, atoi(v));
+  if (const char *v = getenv("PLL_AMD_REP_HINTS")) c->rep_hints = !(*v == '0');
+  if (const char *v = getenv("PLL_AMD_REP_RANGES")) c->rep_max_ranges = (unsigned)std::max(1, atoi(v));
   return c;
 }
 
@@ -470,6 +489,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   for (auto &b : c->tipchars) b.release();
   for (auto &b : c->site_id) b.release();
   for (auto &b : c->id_site) b.release();
+  for (auto &b : c->site_id8) b.release();
   for (auto &b : c->lent) b.release();
   for (auto &b : c->rent) b.release();
   c->tipmap.release();
@@ -494,6 +514,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->rep_ops.release();
   c->rep_blocksum.release();
   c->rep_counts.release();
+  c->rep_sync.release();
   c->rates.release();
   c->diag.release();
   for (auto &b : c->sumtable) b.release();
@@ -710,6 +731,9 @@ extern "C" int pllgpu_invariant_upload(pllgpu_ctx_t *c, const int *host, unsigne
   return 0;
 }
 
+// entries of a site -> class map buffer: whole groups of sixteen (kernels_repeats.h reads and writes them so)
+static inline size_t map_elems(const pllgpu_ctx *c) { return ((size_t)c->geo.sites_alloc + 15u) / 16u * 16u; }
+
 extern "C" int pllgpu_repeats_upload(pllgpu_ctx_t *c, unsigned node, const unsigned *site_id,
                                      const unsigned *id_site, unsigned ids)
 {
@@ -718,12 +742,39 @@ extern "C" int pllgpu_repeats_upload(pllgpu_ctx_t *c, unsigned node, const unsig
   c->ids[node] = ids;
   ++c->maps_epoch;
   c->rep_left[node] = c->rep_right[node] = -1; // host-built maps: no entry-indexed child maps
+  c->map_forms[node] = 0;
   if (!ids) return 0;
-  if (int rc = c->site_id[node].ensure(c->geo.sites_alloc)) return rc;
+  if (int rc = c->site_id[node].ensure(map_elems(c))) return rc;
   if (int rc = c->id_site[node].ensure(c->geo.sites_alloc)) return rc;
   HIP_TRY(hipMemcpyAsync(c->site_id[node].p, site_id, c->geo.sites_alloc * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
   if (id_site)
     HIP_TRY(hipMemcpyAsync(c->id_site[node].p, id_site, ids * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+  c->map_forms[node] = kMap32;
+  return 0;
+}
+
+// The 32-bit form of a node's site -> class map, produced from the byte form if that is what the class kernels left
+// (kernels_repeats.h); nullptr if the node has no maps on the device. Callers: the gathering launches that index by site,
+// the edge / root / derivative evaluations, the copy to the host.
+static const unsigned *wide_map(pllgpu_ctx *c, unsigned node)
+{
+  if (c->map_forms[node] & kMap32) return c->site_id[node].p;
+  if (!(c->map_forms[node] & kMap8)) return c->site_id[node].p; // (uploaded by an older path or never written: as before)
+  if (c->site_id[node].ensure(map_elems(c))) return nullptr;
+  const unsigned n = (unsigned)map_elems(c);
+  hipLaunchKernelGGL(k_rep_widen, dim3((n / 16u + 255u) / 256u), dim3(256), 0, c->stream, c->site_id8[node].p, c->site_id[node].p, n);
+  c->map_forms[node] |= kMap32;
+  return c->site_id[node].p;
+}
+
+static int narrow_map(pllgpu_ctx *c, unsigned node)
+{
+  if (c->map_forms[node] & kMap8) return 0;
+  if (!(c->map_forms[node] & kMap32) || !c->site_id[node].p) return fail(PLLGPU_EINVAL, "node %u has no class maps on the device", node);
+  if (int rc = c->site_id8[node].ensure(map_elems(c))) return rc;
+  const unsigned n = (unsigned)map_elems(c);
+  hipLaunchKernelGGL(k_rep_narrow, dim3((n / 16u + 255u) / 256u), dim3(256), 0, c->stream, c->site_id[node].p, c->site_id8[node].p, n);
+  c->map_forms[node] |= kMap8;
   return 0;
 }
 
@@ -808,8 +859,9 @@ static int resolve_op(pllgpu_ctx *c, const pllgpu_op_t &o, DevOp &d)
     else
     {
       d.id_site = c->ids[p] ? c->id_site[p].p : nullptr;
-      d.lsid = c->ids[o.left_clv] ? c->site_id[o.left_clv].p : nullptr;
-      d.rsid = c->ids[o.right_clv] ? c->site_id[o.right_clv].p : nullptr;
+      d.lsid = c->ids[o.left_clv] ? wide_map(c, o.left_clv) : nullptr;
+      d.rsid = c->ids[o.right_clv] ? wide_map(c, o.right_clv) : nullptr;
+      if ((c->ids[o.left_clv] && !d.lsid) || (c->ids[o.right_clv] && !d.rsid)) return fail(PLLGPU_EINVAL, "operation gathers through class maps that are not on the device");
     }
   }
   return 0;
@@ -2020,8 +2072,8 @@ extern "C" int pllgpu_edge_loglikelihood(pllgpu_ctx_t *c, const pllgpu_edge_t *e
   if (e.layout && !ed->gather) return fail(PLLGPU_EINVAL, "a class-compressed CLV met an evaluation without the gather flag");
   if (ed->gather)
   {
-    e.psid = c->ids[ed->parent_clv] ? c->site_id[ed->parent_clv].p : nullptr;
-    e.csid = c->ids[ed->child_clv] ? c->site_id[ed->child_clv].p : nullptr;
+    e.psid = c->ids[ed->parent_clv] ? wide_map(c, ed->parent_clv) : nullptr;
+    e.csid = c->ids[ed->child_clv] ? wide_map(c, ed->child_clv) : nullptr;
   }
   e.is_root = 0;
   if (held_p >= 0 || held_c >= 0)
@@ -2113,7 +2165,7 @@ extern "C" int pllgpu_root_loglikelihood(pllgpu_ctx_t *c, unsigned clv, int scal
   memset(&e, 0, sizeof e);
   e.parent = c->clv[clv].p;
   if (int rc = scaler_ptr(c, scaler, e.pscaler)) return rc;
-  if (gather) e.psid = c->ids[clv] ? c->site_id[clv].p : nullptr;
+  if (gather) e.psid = c->ids[clv] ? wide_map(c, clv) : nullptr;
   e.layout = c->clv_aos[clv] ? kAosParent : 0u;
   if (e.layout && !gather) return fail(PLLGPU_EINVAL, "a class-compressed CLV met an evaluation without the gather flag");
   e.is_root = 1;
@@ -2384,8 +2436,8 @@ extern "C" int pllgpu_update_sumtable(pllgpu_ctx_t *c, const pllgpu_sumtable_t *
   if (d.layout && !st->gather) return fail(PLLGPU_EINVAL, "a class-compressed CLV met a sumtable without the gather flag");
   if (st->gather)
   {
-    d.lsid = c->ids[st->left_clv] ? c->site_id[st->left_clv].p : nullptr;
-    d.rsid = c->ids[st->right_clv] ? c->site_id[st->right_clv].p : nullptr;
+    d.lsid = c->ids[st->left_clv] ? wide_map(c, st->left_clv) : nullptr;
+    d.rsid = c->ids[st->right_clv] ? wide_map(c, st->right_clv) : nullptr;
   }
   const unsigned kind = st->left_is_tip ? 1u : 0u;
   if (int rc = launch_partials(c, pack, 1, g.sites_alloc, kind, st->gather != 0)) return rc;
@@ -2693,117 +2745,263 @@ extern "C" int pllgpu_repeats_download(pllgpu_ctx_t *c, unsigned node, unsigned 
 {
   CHECK_CTX(c);
   const pllgpu_geometry_t &g = c->geo;
-  if (node >= g.nodes || !c->site_id[node].p || !c->id_site[node].p || ids > g.sites)
-    return fail(PLLGPU_EINVAL, "node %u has no class maps on the device", node);
-  HIP_TRY(hipMemcpyAsync(site_id, c->site_id[node].p, g.sites * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  const unsigned *wide = node < g.nodes ? wide_map(c, node) : nullptr;
+  if (!wide || !c->id_site[node].p || ids > g.sites) return fail(PLLGPU_EINVAL, "node %u has no class maps on the device", node);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(site_id, wide, g.sites * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
   if (ids) HIP_TRY(hipMemcpyAsync(id_site, c->id_site[node].p, ids * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
 
-extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops, unsigned count, unsigned *counts_out)
+// Class maps of a whole op list: every dependency level goes through k_rep_mark + k_rep_assign, the levels back to back,
+// and the host reads all class counts once at the end (kernels_repeats.h). What the host must know BEFORE a level's
+// counts exist - how large a table slice an op may need - comes from upper bounds: an op's classes are at most its
+// cells, its cells at most the product of its children's bounds, and a compressed parent's table is smaller than
+// lookup_size by the rule itself.
+extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops, unsigned count, unsigned lookup_size, unsigned *counts_out)
 {
   CHECK_CTX(c);
   const pllgpu_geometry_t &g = c->geo;
   const unsigned sites = g.sites;
-  const unsigned nblk = (sites + kRepBlock - 1) / kRepBlock, words = (sites + 31u) / 32u;
-  const size_t wstride = ((size_t)words + 32767u) & ~(size_t)32767u; // k_rep_scan works in whole chunks of 32768 words
-  const size_t table_cap = (size_t)64 << 20; // cells per batch (256 MB); a single larger op still gets its slice
-  unsigned done = 0;
-  while (done < count)
+  if (!count) return 0;
+  if (count > c->rep_host_cap) return fail(PLLGPU_EINVAL, "class maps of %u ops in one call (at most %u)", count, c->rep_host_cap);
+  const unsigned words = (sites + 31u) / 32u;
+  const size_t wstride = ((size_t)words + kRepScanChunk - 1u) / kRepScanChunk * kRepScanChunk;
+  const size_t table_cap = (size_t)64 << 20; // cells per launch (256 MB); a single larger op still gets its slice
+  const size_t melems = map_elems(c);
+  // How many of the levels to launch. The kernels decide by themselves which parents are compressed, but every level costs
+  // its launches even when none is; where compression ended the last time an op list of this length came is remembered,
+  // only the levels up to there are launched, and the rule (src/repeats.c:100-110) is evaluated HERE for the ops above,
+  // from the counts that came back: if it admits one of them after all, the whole call is repeated with every level.
+  unsigned ncut = count;
+  if (c->rep_hints && c->rep_hint_count == count)
   {
-    // batch: up to kRepOps ops whose table slices fit
-    unsigned n = 0;
-    size_t cells = 0;
-    while (done + n < count && n < (unsigned)kRepOps)
+    ncut = 0;
+    while (ncut < count && ops[ncut].level <= c->rep_hint_level && c->rep_hint_any) ++ncut;
+  }
+
+  // bounds, checks, buffers - everything that may allocate (and so synchronise) before the first launch
+  std::vector<unsigned long long> ub_cells(count);
+  std::vector<unsigned> ub_classes(count);
+  for (unsigned i = 0; i < count; ++i)
+  {
+    const pllgpu_repop_t &o = ops[i];
+    if (o.parent >= g.nodes || o.left >= g.nodes || o.right >= g.nodes) return fail(PLLGPU_EINVAL, "repeats op references a node out of range");
+    if (i && o.level < ops[i - 1].level) return fail(PLLGPU_EINVAL, "repeats ops are not sorted by level");
+    if ((o.lsrc >= 0 && ((unsigned)o.lsrc >= i || ops[o.lsrc].level >= o.level || ops[o.lsrc].parent != o.left)) ||
+        (o.rsrc >= 0 && ((unsigned)o.rsrc >= i || ops[o.rsrc].level >= o.level || ops[o.rsrc].parent != o.right)))
+      return fail(PLLGPU_EINVAL, "repeats op %u: a child's producer is not an op of a lower level", i);
+    const unsigned long long bl = o.lsrc >= 0 ? ub_classes[o.lsrc] : o.nleft, br = o.rsrc >= 0 ? ub_classes[o.rsrc] : o.nright;
+    unsigned long long cells = bl * br;
+    if (o.force)
     {
-      const pllgpu_repop_t &o = ops[done + n];
-      if (o.parent >= g.nodes || o.left >= g.nodes || o.right >= g.nodes) return fail(PLLGPU_EINVAL, "repeats op references a node out of range");
-      if (!o.nleft || !o.nright || !c->site_id[o.left].p || !c->site_id[o.right].p)
-        return fail(PLLGPU_EINVAL, "repeats op: children %u / %u have no class maps on the device", o.left, o.right);
-      const size_t need = (size_t)o.nleft * o.nright;
-      if (n && cells + need > table_cap) break;
-      cells += need;
-      ++n;
+      if (o.lsrc >= 0 || o.rsrc >= 0) return fail(PLLGPU_EINVAL, "repeats op %u: a decision taken by the host needs both children's counts", i);
+      if (!cells) return fail(PLLGPU_EINVAL, "repeats op: children %u / %u have no class maps on the device", o.left, o.right);
     }
-    if (cells >= 0x7FFFFFFFull) return fail(PLLGPU_EINVAL, "repeats table of %zu cells exceeds 31-bit addressing", cells);
-    if (int rc = c->rep_table.ensure(cells)) return rc;
-    if (int rc = c->rep_blocksum.ensure((size_t)kRepOps * 2u * wstride)) return rc; // per op: the bitmap, then the word prefixes
-    if (int rc = c->rep_counts.ensure(kRepOps)) return rc;
-    if (int rc = c->rep_ops.ensure((size_t)kRepOps * sizeof(RepOp))) return rc;
-    std::vector<RepOp> &rops = c->rep_ops_host;
-    rops.assign(n, RepOp());
-    size_t off = 0;
-    for (unsigned i = 0; i < n; ++i)
+    else if (cells >= lookup_size)
+      cells = lookup_size ? lookup_size - 1u : 0u;
+    if (cells >= 0x7FFFFFFFull) return fail(PLLGPU_EINVAL, "repeats table of %llu cells exceeds 31-bit addressing", cells);
+    ub_cells[i] = cells;
+    ub_classes[i] = (unsigned)std::min<unsigned long long>(cells, sites);
+    // children that come from outside the call: their maps in the form their class count asks for
+    const unsigned kid[2] = {o.left, o.right}, kn[2] = {o.nleft, o.nright};
+    const int ksrc[2] = {o.lsrc, o.rsrc};
+    for (int k = 0; k < 2 && cells && i < ncut; ++k)
     {
-      const pllgpu_repop_t &o = ops[done + i];
-      if (int rc = c->site_id[o.parent].ensure(g.sites_alloc)) return rc;
-      if (int rc = c->id_site[o.parent].ensure(g.sites_alloc)) return rc;
-      if (int rc = c->lent[o.parent].ensure(g.sites_alloc)) return rc;
-      if (int rc = c->rent[o.parent].ensure(g.sites_alloc)) return rc;
-      c->rep_left[o.parent] = (int)o.left;
-      c->rep_right[o.parent] = (int)o.right;
-      ++c->maps_epoch;
+      if (ksrc[k] >= 0 || !kn[k]) continue;
+      if (kn[k] <= kRepNarrow)
+      {
+        if (int rc = narrow_map(c, kid[k])) return rc;
+      }
+      else if (!wide_map(c, kid[k]))
+        return fail(PLLGPU_EINVAL, "repeats op: child %u has no class maps on the device", kid[k]);
+    }
+    if (!cells || i >= ncut) continue; // cannot be compressed / not launched: nothing to write
+    if (int rc = c->site_id8[o.parent].ensure(melems)) return rc;
+    if (ub_classes[i] > kRepNarrow)
+      if (int rc = c->site_id[o.parent].ensure(melems)) return rc;
+    if (int rc = c->id_site[o.parent].ensure(ub_classes[i])) return rc;
+    if (int rc = c->lent[o.parent].ensure(ub_classes[i])) return rc;
+    if (int rc = c->rent[o.parent].ensure(ub_classes[i])) return rc;
+  }
+  HIP_TRY(hipGetLastError());
+
+  // launches: the ops of a level, up to kRepOps and table_cap cells at a time
+  struct Launch
+  {
+    unsigned first, n, wgs, mark_lds, assign_lds;
+    bool rank; // some op's table may be a large one: k_rep_scan + k_rep_rank between k_rep_mark and k_rep_assign
+  };
+  std::vector<Launch> launches;
+  std::vector<RepOp> &rops = c->rep_ops_host;
+  rops.assign(ncut, RepOp());
+  size_t arena = 0;
+  for (unsigned done = 0; done < ncut;)
+  {
+    unsigned room = 0;
+    while (done + room < ncut && room < (unsigned)kRepOps && ops[done + room].level == ops[done].level) ++room;
+    // workgroups per op: ~1024 per launch (how they split into table parts and site ranges: k_rep_mark)
+    const unsigned wgs = c->rep_wgs ? c->rep_wgs : std::max(1u, std::min(64u, (1024u + room - 1u) / room));
+    Launch L = {done, 0, wgs, kRepSmallCells, 64, false};
+    size_t cells = 0;
+    for (unsigned k = 0; k < room; ++k)
+    {
+      const unsigned i = done + k;
+      const size_t ub = (size_t)ub_cells[i];
+      // all copies of the table (k_rep_mark): a small one has a copy per workgroup, a large one up to max_ranges - and only
+      // while its parts are fewer than the workgroups
+      const size_t slice = ub <= kRepSmallCells ? ub * wgs : std::max(ub, std::min(ub * c->rep_max_ranges, (size_t)kRepLdsCells * wgs));
+      if (ub > kRepSmallCells) L.rank = true;
+      if (k && cells + slice > table_cap) break;
       RepOp &r = rops[i];
-      r.lid = c->site_id[o.left].p;
-      r.rid = c->site_id[o.right].p;
-      r.psid = c->site_id[o.parent].p;
+      const pllgpu_repop_t &o = ops[i];
+      r.l8 = c->site_id8[o.left].p;
+      r.r8 = c->site_id8[o.right].p;
+      r.l32 = c->site_id[o.left].p;
+      r.r32 = c->site_id[o.right].p;
+      r.p8 = c->site_id8[o.parent].p;
+      r.p32 = c->site_id[o.parent].p;
       r.pids = c->id_site[o.parent].p;
       r.lent = c->lent[o.parent].p;
       r.rent = c->rent[o.parent].p;
-      r.bitmap = c->rep_blocksum.p + (size_t)i * 2u * wstride;
-      r.wprefix = r.bitmap + wstride;
+      r.table = reinterpret_cast<unsigned *>(cells); // offset for now: the arena may still grow
+      r.bitmap = reinterpret_cast<unsigned *>((size_t)k * 2u * wstride);
+      r.lsrc = o.lsrc;
+      r.rsrc = o.rsrc;
       r.nleft = o.nleft;
-      r.ncells = o.nleft * o.nright;
-      r.tab_off = (unsigned)off;
-      r.pad = 0;
-      off += (size_t)o.nleft * o.nright;
+      r.nright = o.nright;
+      r.slot = i;
+      r.force = o.force ? 1u : 0u;
+      r.slice = (unsigned)std::min<size_t>(slice, 0x7FFFFFFFu);
+      cells += slice;
+      L.mark_lds = std::max<unsigned>(L.mark_lds, (unsigned)std::min<size_t>(ub, kRepLdsCells));
+      L.assign_lds = std::max<unsigned>(L.assign_lds, (unsigned)std::min<size_t>(ub, kRepAssignLds));
+      ++L.n;
     }
-    RepPack pk;
-    memset(&pk, 0, sizeof pk);
-    // pageable source: staged before hipMemcpyAsync returns; ordered behind the previous batch's kernels
-    HIP_TRY(hipMemcpyAsync(c->rep_ops.p, rops.data(), n * sizeof(RepOp), hipMemcpyHostToDevice, c->stream));
-    pk.ops = reinterpret_cast<const RepOp *>(c->rep_ops.p);
-    pk.table = c->rep_table.p;
-    pk.counts = c->rep_counts.p;
-    pk.host_counts = c->rep_host_dev;
-    pk.host_seq = c->rep_host_dev + kRepOps;
-    pk.ticket = c->counter.p + 2; // [0]: log-likelihood / derivative reductions
-    pk.sequence = ++c->rep_seq;
-    pk.sites = sites;
-    pk.words = words;
-    pk.fenced = c->fenced;
-    HIP_TRY(hipMemsetAsync(c->rep_table.p, 0xFF, cells * sizeof(unsigned), c->stream));
-    HIP_TRY(hipMemsetAsync(c->rep_blocksum.p, 0, (size_t)n * 2u * wstride * sizeof(unsigned), c->stream));
-    unsigned maxcells = 0;
-    for (unsigned i = 0; i < n; ++i) maxcells = std::max(maxcells, rops[i].ncells);
-    const dim3 block(256), cgrid((maxcells + kRepBlock - 1) / kRepBlock, n);
-    // LDS for the largest slice that is reduced there (near the tips a few hundred bytes: more workgroups per CU)
-    unsigned lds_cells = 64;
-    for (unsigned i = 0; i < n; ++i)
-      lds_cells = std::max(lds_cells, rops[i].ncells <= kRepLdsCells ? rops[i].ncells : 2u * kRepFilter); // (the filter: 8 bytes per entry)
-    hipLaunchKernelGGL(k_rep_mark, dim3((sites + kRepMarkSites - 1) / kRepMarkSites, n), block, lds_cells * sizeof(unsigned), c->stream, pk);
-    hipLaunchKernelGGL(k_rep_bitmap, cgrid, block, 0, c->stream, pk);
-    hipLaunchKernelGGL(k_rep_scan, dim3(1, n), dim3(1024), 0, c->stream, pk);
-    hipLaunchKernelGGL(k_rep_rank_cells, cgrid, block, 0, c->stream, pk);
-    hipLaunchKernelGGL(k_rep_assign, dim3(nblk, n), block, 0, c->stream, pk);
-    HIP_TRY(hipGetLastError());
-    // the class counts arrive in mapped host memory as soon as k_rep_scan knows them (the last two kernels still run;
-    // whatever uses the maps is ordered behind it by the stream): poll the sequence word for a bounded time
+    arena = std::max(arena, cells);
+    launches.push_back(L);
+    done += L.n;
+  }
+  if (ncut)
+  {
+  if (int rc = c->rep_table.ensure(arena)) return rc;
+  {
+    // per op of a launch: the bitmap (zero between launches: k_rep_assign clears what k_rep_mark set), then the running counts
+    const size_t had = c->rep_blocksum.cap;
+    if (int rc = c->rep_blocksum.ensure((size_t)kRepOps * 2u * wstride)) return rc;
+    if (c->rep_blocksum.cap != had || c->rep_scratch_dirty) HIP_TRY(hipMemsetAsync(c->rep_blocksum.p, 0, c->rep_blocksum.cap * sizeof(unsigned), c->stream));
+    if (c->rep_scratch_dirty) HIP_TRY(hipMemsetAsync(c->rep_sync.p, 0, c->rep_sync.cap * sizeof(unsigned), c->stream));
+    c->rep_scratch_dirty = true; // until this call has gone through
+  }
+  if (int rc = c->rep_counts.ensure(count)) return rc;
+  if (int rc = c->rep_ops.ensure((size_t)count * sizeof(RepOp))) return rc;
+  for (unsigned i = 0; i < ncut; ++i)
+  {
+    rops[i].table = c->rep_table.p + reinterpret_cast<size_t>(rops[i].table);
+    rops[i].bitmap = c->rep_blocksum.p + reinterpret_cast<size_t>(rops[i].bitmap);
+  }
+  // pageable source: staged before hipMemcpyAsync returns; ordered behind the previous call's kernels
+  HIP_TRY(hipMemcpyAsync(c->rep_ops.p, rops.data(), (size_t)ncut * sizeof(RepOp), hipMemcpyHostToDevice, c->stream));
+  c->rep_host[c->rep_host_cap + 1u] = 0u;
+  RepPack pk;
+  memset(&pk, 0, sizeof pk);
+  pk.counts = c->rep_counts.p;
+  pk.tickets = c->rep_sync.p;
+  pk.launch_ticket = c->rep_sync.p + (size_t)kRepOps * kRepMaxParts;
+  pk.max_ranges = c->rep_max_ranges;
+  pk.host_counts = c->rep_host_dev;
+  pk.ncounts = ncut;
+  pk.host_cap = c->rep_host_cap;
+  pk.sites = sites;
+  pk.lookup = lookup_size;
+  pk.wstride = (unsigned)wstride;
+  pk.sequence = ++c->rep_seq;
+  pk.fenced = c->fenced;
+  for (size_t li = 0; li < launches.size(); ++li)
+  {
+    const Launch &L = launches[li];
+    pk.ops = reinterpret_cast<const RepOp *>(c->rep_ops.p) + L.first;
+    pk.nops = L.n;
+    pk.wgs = L.wgs;
+    const bool last = li + 1 == launches.size();
+    pk.has_rank = L.rank ? 1u : 0u;
+    pk.publish = last && !L.rank ? 1u : 0u;
+    pk.lds_cells = L.mark_lds;
+    const size_t mark_bytes = (size_t)L.mark_lds * sizeof(unsigned);
+    raise_lds_limit((const void *)k_rep_mark, c->device, mark_bytes);
+    hipLaunchKernelGGL(k_rep_mark, dim3((L.n + 7u) / 8u * 8u * L.wgs), dim3(kRepThreads), mark_bytes, c->stream, pk);
+    const unsigned n8 = (L.n + 7u) / 8u * 8u;
+    if (L.rank)
     {
-      volatile unsigned *seq = c->rep_host + kRepOps;
-      const auto t0 = std::chrono::steady_clock::now();
-      unsigned spins = 0;
-      while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != pk.sequence)
-        if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50))
-        {
-          HIP_TRY(hipStreamSynchronize(c->stream));
-          break;
-        }
-      if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != pk.sequence) return fail(PLLGPU_ERUNTIME, "class counts did not arrive");
-      for (unsigned i = 0; i < n; ++i) counts_out[done + i] = c->rep_host[i];
+      pk.publish = last ? 1u : 0u;
+      hipLaunchKernelGGL(k_rep_scan, dim3(L.n), dim3(kRepScanThreads), 0, c->stream, pk);
+      hipLaunchKernelGGL(k_rep_rank, dim3(n8 * kRepRankTiles), dim3(kRepRankThreads), 0, c->stream, pk);
     }
-    done += n;
+    pk.lds_cells = L.assign_lds;
+    pk.wgs = (sites + kRepAssignTile - 1u) / kRepAssignTile;
+    hipLaunchKernelGGL(k_rep_assign, dim3(n8 * pk.wgs), dim3(kRepAssignThreads), (size_t)L.assign_lds * sizeof(unsigned), c->stream, pk);
+  }
+  HIP_TRY(hipGetLastError());
+  // the class counts arrive in mapped host memory as soon as the last k_rep_mark knows them (its k_rep_assign still
+  // runs; whatever uses the maps is ordered behind it by the stream): poll the sequence word for a bounded time
+  {
+    volatile unsigned *seq = c->rep_host + c->rep_host_cap;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != pk.sequence)
+      if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50))
+      {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        break;
+      }
+    if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != pk.sequence) return fail(PLLGPU_ERUNTIME, "class counts did not arrive");
+    if (c->rep_host[c->rep_host_cap + 1u]) return fail(PLLGPU_ERUNTIME, "class maps: a table outgrew what the host had planned for it (%u)", c->rep_host[c->rep_host_cap + 1u]);
+  }
+  c->rep_scratch_dirty = false;
+  }
+  // the ops above the launched levels: the rule, from the counts below them
+  for (unsigned i = 0; i < ncut; ++i) counts_out[i] = c->rep_host[i];
+  for (unsigned i = ncut; i < count; ++i)
+  {
+    const pllgpu_repop_t &o = ops[i];
+    auto ids_of = [&](int src, unsigned given) -> unsigned long long {
+      if (src < 0) return given;
+      const unsigned w = counts_out[src], n = w & ~kRepFlag;
+      return (w & kRepFlag) && n < sites ? n : 0u;
+    };
+    const unsigned long long nl = ids_of(o.lsrc, o.nleft), nr = ids_of(o.rsrc, o.nright), cells = nl * nr;
+    if (o.force || (cells && cells < lookup_size && nl <= sites / 2u && nr <= sites / 2u))
+    {
+      c->rep_hint_count = 0; // the forecast was wrong: every level this time
+      return pllgpu_repeats_classes(c, ops, count, lookup_size, counts_out);
+    }
+    counts_out[i] = 0u;
+  }
+  c->rep_hint_count = count;
+  c->rep_hint_any = false;
+  c->rep_hint_level = 0;
+  for (unsigned i = 0; i < count; ++i)
+    if (counts_out[i] & kRepFlag)
+    {
+      c->rep_hint_any = true;
+      c->rep_hint_level = std::max(c->rep_hint_level, ops[i].level);
+    }
+  ++c->maps_epoch;
+  for (unsigned i = 0; i < count; ++i)
+  {
+    const unsigned word = counts_out[i], classes = word & ~kRepFlag;
+    const unsigned parent = ops[i].parent;
+    if (!(word & kRepFlag))
+    {
+      c->rep_left[parent] = c->rep_right[parent] = -1;
+      c->map_forms[parent] = 0;
+      continue;
+    }
+    if ((unsigned long long)classes > ub_cells[i]) return fail(PLLGPU_ERUNTIME, "class maps: op %u reports %u classes of at most %llu", i, classes, ub_cells[i]);
+    c->rep_left[parent] = (int)ops[i].left;
+    c->rep_right[parent] = (int)ops[i].right;
+    c->map_forms[parent] = classes <= kRepNarrow ? kMap8 : kMap32;
   }
   return 0;
 }

@@ -7,9 +7,11 @@
  * table that is wiped after use through a to-clean list (src/repeats.c:334-377).
  *
  * With a device context the class maps of inner nodes are computed ON the device
- * (pll_update_repeats_device -> kernels_repeats.h), dependency level by level; the host learns the
- * class counts (one small copy per level: allocation sizes and the enable_repeats callback need
- * them) and partition->repeats->pernode_site_id / pernode_id_site become a mirror that
+ * (pll_update_repeats_device -> kernels_repeats.h), all dependency levels of a list in one call; the
+ * host learns the class counts once, afterwards (its allocation sizes need them; the decision whether
+ * a parent is compressed is taken on the device by the reference's default rule - a caller-supplied
+ * enable_repeats callback is asked level by level instead) and
+ * partition->repeats->pernode_site_id / pernode_id_site become a mirror that
  * pll_get_site_id / pll_get_id_site / pll_gpu_sync_repeats refresh on demand. Tip maps are built on
  * the host while the sequence is parsed and uploaded. The sequential table walk below
  * (pll_update_repeats_host) only serves host-only shells (PLL_AMD_HOST_ONLY, CPU tests).
@@ -239,67 +241,161 @@ static void adopt_classes(pll_partition_t *p, const pll_operation_t *op, unsigne
   }
 }
 
+/* one piece of work for pllgpu_repeats_classes and what follows its counts */
+static int classes_call(pll_partition_t *p, pll_amd_ext_t *x, const pll_operation_t *ops, pllgpu_repop_t *rop,
+                        const unsigned int *idx, unsigned int n, unsigned int *counts)
+{
+  pll_repeats_t *r = p->repeats;
+  unsigned int k;
+  if (!n) return PLL_SUCCESS;
+  if (pllgpu_repeats_classes(x->ctx, rop, n, r->lookup_buffer_size, counts) != 0)
+  {
+    pll_set_gpu_error("pll_update_repeats");
+    return PLL_FAILURE;
+  }
+  for (k = 0; k < n; ++k)
+  {
+    const pll_operation_t *op = &ops[idx[k]];
+    const unsigned int parent = op->parent_clv_index;
+    const int enabled = (counts[k] & PLLGPU_REPEATS_COMPRESSED) != 0;
+    const unsigned int classes = counts[k] & ~PLLGPU_REPEATS_COMPRESSED;
+    adopt_classes(p, op, classes, enabled);
+    x->repeats_stale[parent] = enabled ? 1 : 0;
+    x->repeats_count[parent] = enabled ? classes : 0;
+    if (pllgpu_repeats_set_ids(x->ctx, parent, r->pernode_ids[parent]) != 0)
+    {
+      pll_set_gpu_error("pll_update_repeats");
+      return PLL_FAILURE;
+    }
+  }
+  return PLL_SUCCESS;
+}
+
+/* Class maps of an op list on the device. With the reference's own decision rule (pll_default_enable_repeats) the
+ * whole list goes down in one call: the rule is a function of the children's class counts, which the device holds
+ * before the host does, so the levels run back to back and the host reads all counts once (round 4: a blocking
+ * hand-off per level - the callback wanted the counts on the host). A caller-supplied enable_repeats keeps that form:
+ * the callback is asked level by level, with the counts of the levels below in pernode_ids as the reference has them.
+ * PLL_AMD_REP_LEVEL_SYNC=1 takes the level-by-level form for the default rule too (A/B, tests). */
 int pll_update_repeats_device(pll_partition_t *p, pll_amd_ext_t *x, const pll_operation_t *ops,
                               unsigned int count, const unsigned int *level, unsigned int nlevels)
 {
   x->fast_valid = 0;
   pll_repeats_t *r = p->repeats;
-  unsigned int l, i, k, n;
+  unsigned int l, i, n;
   int ok = PLL_FAILURE;
   if (!r->lookup_buffer) pll_resize_repeats_lookup(p, PLL_REPEATS_LOOKUP_SIZE); /* its SIZE bounds the pair table */
   pllgpu_repop_t *rop = (pllgpu_repop_t *)malloc(sizeof(pllgpu_repop_t) * count);
   unsigned int *idx = (unsigned int *)malloc(sizeof(unsigned int) * 2 * count);
-  if (!rop || !idx)
+  int *producer = (int *)malloc(sizeof(int) * (p->nodes ? p->nodes : 1));
+  if (!rop || !idx || !producer)
   {
     pll_set_error(PLL_ERROR_MEM_ALLOC, "Unable to allocate enough memory for repeats structure.");
     goto done;
   }
   unsigned int *counts = idx + count;
-  for (l = 0; l < nlevels; ++l)
+  static int level_sync = -1;
+  if (level_sync < 0)
   {
-    n = 0;
-    for (i = 0; i < count; ++i)
+    const char *v = getenv("PLL_AMD_REP_LEVEL_SYNC");
+    level_sync = (v && *v && *v != '0') ? 1 : 0;
+  }
+  if (r->enable_repeats == pll_default_enable_repeats && !level_sync && count <= PLLGPU_REPEATS_MAX_OPS)
+  {
+    /* order by level (stable); a child's producer is the latest earlier op of the LIST that writes it */
+    unsigned int *start = (unsigned int *)calloc(nlevels + 1, sizeof(unsigned int));
+    unsigned int *pos = (unsigned int *)malloc(sizeof(unsigned int) * count); /* op of the list -> its place in the call */
+    if (!start || !pos)
     {
-      if (level[i] != l) continue;
+      free(start);
+      free(pos);
+      pll_set_error(PLL_ERROR_MEM_ALLOC, "Unable to allocate enough memory for repeats structure.");
+      goto done;
+    }
+    for (i = 0; i < count; ++i) start[level[i] + 1]++;
+    for (l = 0; l < nlevels; ++l) start[l + 1] += start[l];
+    for (i = 0; i < count; ++i) pos[i] = start[level[i]]++;
+    for (i = 0; i < p->nodes; ++i) producer[i] = -1;
+    int failed = 0;
+    for (i = 0; i < count && !failed; ++i)
+    {
       const pll_operation_t *op = &ops[i];
       const unsigned int left = op->child1_clv_index, right = op->child2_clv_index, parent = op->parent_clv_index;
+      pllgpu_repop_t *o = &rop[pos[i]];
       x->repeats_dirty[parent] = 0;
-      if (!r->enable_repeats(p, left, right))
-      {
-        adopt_classes(p, op, 0, 0);
-        x->repeats_stale[parent] = 0;
-        x->repeats_count[parent] = 0;
-        if (pllgpu_repeats_set_ids(x->ctx, parent, 0) != 0) goto gpu_fail;
-        continue;
-      }
-      /* tips: host-built maps go up now; inner children were produced by an earlier level */
-      if (!pll_flush_repeats(p, x, left) || !pll_flush_repeats(p, x, right)) goto done;
-      rop[n].parent = parent;
-      rop[n].left = left;
-      rop[n].right = right;
-      rop[n].nleft = r->pernode_ids[left];
-      rop[n].nright = r->pernode_ids[right];
-      idx[n++] = i;
+      o->parent = parent;
+      o->left = left;
+      o->right = right;
+      o->lsrc = producer[left];
+      o->rsrc = producer[right];
+      o->nleft = o->lsrc >= 0 ? 0 : r->pernode_ids[left];
+      o->nright = o->rsrc >= 0 ? 0 : r->pernode_ids[right];
+      o->level = level[i];
+      o->force = 0;
+      idx[pos[i]] = i;
+      /* tips: host-built maps go up now */
+      if (o->lsrc < 0 && o->nleft && !pll_flush_repeats(p, x, left)) failed = 1;
+      if (o->rsrc < 0 && o->nright && !pll_flush_repeats(p, x, right)) failed = 1;
+      producer[parent] = (int)pos[i];
     }
-    if (!n) continue;
-    if (pllgpu_repeats_classes(x->ctx, rop, n, counts) != 0) goto gpu_fail;
-    for (k = 0; k < n; ++k)
+    free(start);
+    free(pos);
+    if (failed) goto done;
+    ok = classes_call(p, x, ops, rop, idx, count, counts);
+  }
+  else
+  {
+    ok = PLL_SUCCESS;
+    for (l = 0; l < nlevels && ok; ++l)
     {
-      const pll_operation_t *op = &ops[idx[k]];
-      adopt_classes(p, op, counts[k], 1);
-      x->repeats_stale[op->parent_clv_index] = 1;
-      x->repeats_count[op->parent_clv_index] = counts[k];
-      if (pllgpu_repeats_set_ids(x->ctx, op->parent_clv_index, r->pernode_ids[op->parent_clv_index]) != 0) goto gpu_fail;
+      n = 0;
+      for (i = 0; i < count && ok; ++i)
+      {
+        if (level[i] != l) continue;
+        const pll_operation_t *op = &ops[i];
+        const unsigned int left = op->child1_clv_index, right = op->child2_clv_index, parent = op->parent_clv_index;
+        x->repeats_dirty[parent] = 0;
+        if (!r->enable_repeats(p, left, right))
+        {
+          adopt_classes(p, op, 0, 0);
+          x->repeats_stale[parent] = 0;
+          x->repeats_count[parent] = 0;
+          if (pllgpu_repeats_set_ids(x->ctx, parent, 0) != 0) goto gpu_fail;
+          continue;
+        }
+        /* tips: host-built maps go up now; inner children were produced by an earlier level */
+        if (!pll_flush_repeats(p, x, left) || !pll_flush_repeats(p, x, right))
+        {
+          ok = PLL_FAILURE;
+          break;
+        }
+        rop[n].parent = parent;
+        rop[n].left = left;
+        rop[n].right = right;
+        rop[n].nleft = r->pernode_ids[left];
+        rop[n].nright = r->pernode_ids[right];
+        rop[n].lsrc = rop[n].rsrc = -1;
+        rop[n].level = 0;
+        rop[n].force = 1;
+        idx[n++] = i;
+        if (n == PLLGPU_REPEATS_MAX_OPS)
+        {
+          ok = classes_call(p, x, ops, rop, idx, n, counts);
+          n = 0;
+        }
+      }
+      if (ok) ok = classes_call(p, x, ops, rop, idx, n, counts);
     }
   }
-  ok = PLL_SUCCESS;
-  if (x->eager_mirror) ok = pll_gpu_sync_repeats(p, -1);
+  if (ok && x->eager_mirror) ok = pll_gpu_sync_repeats(p, -1);
   goto done;
 gpu_fail:
   pll_set_gpu_error("pll_update_repeats");
+  ok = PLL_FAILURE;
 done:
   free(rop);
   free(idx);
+  free(producer);
   return ok;
 }
 
