@@ -61,6 +61,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "libpll-2_amd"))
 sys.path.insert(0, ROOT)
 
+RCCL_LEG_HUNG_RC = 3   # exit status of every rank when the RCCL leg's watchdog fired
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # fp64 matrix pipe: 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz (v_mfma_f64_4x4x4: 512 flop / 16 clk).
 # The guide lists no fp64 row; tools/mfma_f64_probe.hip measures 70.6 TF on this part
@@ -80,6 +81,16 @@ CONFIGS = {
                desc="4-state DNA GTR+G4, 128 taxa, 1M sites, SITE_REPEATS"),
 }
 PINNED = os.path.join(ROOT, "tests", "golden", "section8d_lnl.json")
+
+# which calls a timed step is made of (config.step). Under PLL_ATTRIB_SITE_REPEATS `value` is timed with the class maps
+# of the first step re-used - what applications do between topology changes; the step as the reference's
+# pll_update_partials defines it (update_repeats = 1: class maps recomputed, src/partials.c:237-255) is timed beside it
+# and carried as ms_per_step_with_class_maps / value_with_class_maps.
+STEP_PLAIN = "pll_update_partials(full traversal) + pll_compute_edge_loglikelihood"
+STEP_REUSED = ("pll_update_partials_rep(full traversal, update_repeats = 0: the class maps of the first step re-used) "
+               "+ pll_compute_edge_loglikelihood")
+STEP_MAPS = ("pll_update_partials(full traversal) = pll_update_partials_rep(.., update_repeats = 1): class maps recomputed "
+             "by every step, the reference's default (src/partials.c:237-255) + pll_compute_edge_loglikelihood")
 
 
 def build_case(cfg, sites, attributes, tree="balanced", tips_as=None):
@@ -224,6 +235,48 @@ def cpu_baseline(case, api, driver, budget_s=4.0):
     return out, lnl
 
 
+def gpu_numa_node(index):
+    """NUMA node of the index-th AMD GPU as sysfs lists them (render nodes in PCI order = HIP's order with no
+    *_VISIBLE_DEVICES set), or None. No GPU call."""
+    import glob
+    cards = []
+    for dev in glob.glob("/sys/class/drm/renderD*/device"):
+        try:
+            if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
+                continue
+            cards.append((os.path.basename(os.path.realpath(dev)), int(open(os.path.join(dev, "numa_node")).read())))
+        except (OSError, ValueError):
+            continue
+    cards.sort()
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    if vis:
+        try:
+            index = [int(v) for v in vis.split(",")][index]
+        except (ValueError, IndexError):
+            return None
+    return cards[index][1] if index < len(cards) and cards[index][1] >= 0 else None
+
+
+def pin_near_gpu(index):
+    """sched_setaffinity of this process to the cores of its GPU's NUMA node (intersected with the cores it may
+    use). Returns what the line reports: {"numa_node", "cpus"} or a reason."""
+    node = gpu_numa_node(index)
+    if node is None:
+        return {"pinned": False, "why": "no NUMA node for this GPU in sysfs"}
+    try:
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return {"pinned": False, "numa_node": node, "why": "none of the node's cores is available to this process"}
+        os.sched_setaffinity(0, cpus)
+        return {"pinned": True, "numa_node": node, "cpus": len(cpus)}
+    except (OSError, ValueError) as exc:
+        return {"pinned": False, "numa_node": node, "why": f"{type(exc).__name__}: {exc}"}
+
+
 def free_port():
     import socket
     with socket.socket() as sk:
@@ -305,6 +358,9 @@ class Harness:
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
         self.same_device = os.environ.get("PLL_BENCH_SAME_DEVICE") == "1"
         os.environ.setdefault("PLL_AMD_DEVICE", "0" if self.same_device else str(self.local))
+        # every step ends in a host poll of mapped memory and, sharded, a shared-memory exchange: keep this rank's CPU
+        # next to its GPU (before anything touches the GPU or imports torch)
+        self.cpu_affinity = pin_near_gpu(0 if self.same_device else self.local) if self.world > 1 or os.environ.get("PLL_BENCH_PIN") == "1" else None
         self.dist = None
         self.torch = None
         self.backend = args.backend
@@ -374,6 +430,13 @@ class Harness:
         out = [self.torch.zeros_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t)
         return [[int(x) for x in o.tolist()] for o in out]
+
+    def gather_objects(self, obj):
+        if not self.dist:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
 
     def finish(self):
         if self.group:
@@ -478,6 +541,7 @@ class Runner:
         self.repeats = repeats
         self.upd = 1  # site repeats: class maps are computed by the first step and re-used, as applications do
         #               between topology changes: pll_update_partials_rep(..., update_repeats = 0)
+        self.every_step_maps = False  # timed_with_class_maps: update_repeats = 1 on EVERY step - the reference's pll_update_partials
         self.reduce = reduce if h.dist else None
         self.collective = self.reduce is not None  # this runner's steps are steps of ALL ranks (barriers, max over ranks)
         self.c_driver = c_driver
@@ -526,7 +590,7 @@ class Runner:
 
     def step(self):
         lib, sess, e, h = self.lib, self.sess, self.edge, self.h
-        sess.update_partials(update_repeats=self.upd)
+        sess.update_partials(update_repeats=1 if self.every_step_maps else self.upd)
         if self.repeats:
             self.upd = 0
         if self.reduce == "peer":
@@ -572,7 +636,7 @@ class Runner:
             grp = self.group if self.reduce == "peer" else None
             step_loop_fn()(fp(lib.pll_update_partials_rep), fp(lib.pll_compute_edge_loglikelihood),
                            fp(lib.pll_gpu_group_edge_loglikelihood), C.cast(sess.p, C.c_void_p), grp,
-                           C.cast(sess._op_arrays[0], C.c_void_p), len(self.case.op_batches[0]), self.upd, self.edge_c,
+                           C.cast(sess._op_arrays[0], C.c_void_p), len(self.case.op_batches[0]), 2 if self.every_step_maps else self.upd, self.edge_c,
                            self.api.uptr(self.fi), n, C.byref(lnl))
             if self.repeats:
                 self.upd = 0
@@ -584,7 +648,7 @@ class Runner:
             lnl = C.c_double(0.0)
             fn = _allreduce_loop_fn()
             fn(fp(lib.pll_update_partials_rep), fp(lib.pll_gpu_edge_loglikelihood_allreduce), C.cast(sess.p, C.c_void_p), self.rccl_comm,
-               C.cast(sess._op_arrays[0], C.c_void_p), len(self.case.op_batches[0]), self.upd, self.edge_c, self.api.uptr(self.fi), n, C.byref(lnl))
+               C.cast(sess._op_arrays[0], C.c_void_p), len(self.case.op_batches[0]), 2 if self.every_step_maps else self.upd, self.edge_c, self.api.uptr(self.fi), n, C.byref(lnl))
             if self.repeats:
                 self.upd = 0
             return lnl.value
@@ -611,6 +675,16 @@ class Runner:
             dt = time.perf_counter() - t0
             out.append(self.h.max_over_ranks(dt) if self.collective else dt)
         return out, lnl
+
+    def timed_with_class_maps(self, warmup, steps, blocks=1):
+        """the same timed blocks with the class maps recomputed by EVERY step: pll_update_partials as the reference
+        defines it on a SITE_REPEATS partition (src/partials.c:237-255: update_repeats = 1, pll_update_repeats inside
+        the op loop). Returns (block times, last lnL)."""
+        self.every_step_maps = True
+        try:
+            return self.timed(warmup, steps, blocks)
+        finally:
+            self.every_step_maps = False
 
     def repeats_update_ms(self, reps=5):
         """what the class maps cost when the topology changed: a full pll_update_partials_rep(.., 1) minus the
@@ -764,15 +838,30 @@ def roofline_leg(args, cfg, lib, api, runner, reps=20):
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source, kernel=kernel,
                         launches=launches, ops_in_those_launches=len(ii_ops), avg_launch_ms=round(per_launch_ms, 5),
                         algorithmic_bytes_per_launch=int(per_launch_bytes))
+    # what `frac` is made of: numerator = the launches' bytes AS GROUPED, reported by the library; checked against the PMC
+    # passes' HBM bytes of the same launch where a committed summary exists (traffic / numerator)
+    roofline["frac_numerator"] = ("algorithmic bytes of the timed launches as grouped - fused groups do not read their intermediate CLVs back - "
+                                  "reported by the library (pll_gpu_last_algorithmic_bytes)"
+                                  + (", checked against traffic = %.3f x" % (traffic / per_launch_bytes) if traffic else ", no PMC summary for this configuration"))
     roofline["unfused_equivalent"] = dict(
+        label="equivalent bandwidth, NOT a roofline fraction (fusion removes the child reads this accounting charges; it may exceed the peak)",
         note="the same ops priced at SURVEY 8d's per-update bytes (every op reads both children from HBM)",
         GBps=round(unfused_bytes / launches / (per_launch_ms * 1e-3) / 1e9, 1), bytes_per_launch=int(unfused_bytes / launches),
         frac_of_hbm_peak=round(unfused_bytes / launches / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
     roofline.update(full_traversal=dict(
-        launches=launches_full, ms=round(ms_full / reps, 5),
+        launches=launches_full, ms=round(ms_full / reps, 5), algorithmic_bytes=int(bytes_full or op_bytes(case, api, all_ops, entries)),
         algorithmic_GBps=round((bytes_full or op_bytes(case, api, all_ops, entries)) / (ms_full / reps * 1e-3) / 1e9, 1),
         update_partials_only_M_per_s=round(sites * nops / (ms_full / reps * 1e-3) / 1e6, 1)))
     return roofline, codes
+
+
+def step_roofline(roofline, ms_per_step):
+    """roofline.step: the WHOLE timed step - every update launch of the traversal as grouped plus the evaluation, whose
+    operands the last launch leaves behind - against the HBM peak: as-launched bytes / ms_per_step"""
+    b = roofline["full_traversal"]["algorithmic_bytes"]
+    gbps = b / (ms_per_step * 1e-3) / 1e9
+    roofline["step"] = dict(algorithmic_bytes=b, ms=round(ms_per_step, 5), GBps=round(gbps, 1), frac=round(gbps / HBM_PEAK_GBS, 4),
+                            note="as-launched bytes of all update launches of one step / ms_per_step (launch gaps, the evaluation's tail and the host hand-off included)")
 
 
 def tip_note(case, api, args):
@@ -815,6 +904,7 @@ def main_single(args, h):
     ms, ms_min, ms_max = block_stats(blocks_s, args.steps)
     value = total_sites * nops / (ms * 1e-3) / 1e6
     roofline, codes = roofline_leg(args, cfg, lib, api, runner)
+    step_roofline(roofline, ms)
     out = {
         "metric": "M site-CLV-updates/s", "value": round(value, 1), "unit": "M site-CLV-updates/s",
         "n_gpus": h.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
@@ -823,13 +913,20 @@ def main_single(args, h):
         "data": "synthetic (SURVEY 8d: xorshift64 alignment, seed 88172645463325252)",
         "config": {"workload": cfg["desc"] + tip_note(case, api, args),
                    "sites_per_gpu": total_sites, "ops_per_traversal": nops, "states": cfg["states"], "rate_cats": 4,
-                   "taxa": cfg["tips"], "step": "pll_update_partials(full traversal) + pll_compute_edge_loglikelihood",
+                   "taxa": cfg["tips"], "step": STEP_REUSED if cfg.get("repeats") else STEP_PLAIN,
                    "timed": f"median of {args.blocks} blocks of {args.steps} steps, each block between two device synchronises",
                    "driver": "C loop over the two C-ABI calls (csrc/workload/step_loop.c)" if args.driver == "c" and not h.dist else "Python ctypes loop",
                    "parallelism": "1 GPU"},
         "lnl": lnl, "roofline": roofline,
     }
     if cfg.get("repeats"):
+        # the step as the reference's pll_update_partials defines it: class maps recomputed by every step
+        bcm, lnl_cm = runner.timed_with_class_maps(args.warmup, args.steps, args.blocks)
+        ms_cm = block_stats(bcm, args.steps)[0]
+        out["config"]["step_with_class_maps"] = STEP_MAPS
+        out["ms_per_step_with_class_maps"] = round(ms_cm, 4)
+        out["value_with_class_maps"] = round(total_sites * nops / (ms_cm * 1e-3) / 1e6, 1)
+        out["lnl_with_class_maps"] = lnl_cm
         extra, full = runner.repeats_update_ms()
         out["repeats_update_ms"] = round(extra, 4)
         out["traversal_with_class_maps_ms"] = round(full, 4)
@@ -886,13 +983,18 @@ def main_strong(args, h):
             lib.pll_gpu_group_sum(runner.group, api.dptr(v), 1, api.dptr(o))
         exchange["peer_exchange_alone_us"] = round(h.max_over_ranks((time.perf_counter() - t0) / 2000 * 1e6), 3)
         exchange["peer_exchange_alone_note"] = "2000 group sums back to back through ctypes (~1-2 us of that is the Python call); tools/group_latency.c measures the C call"
+    # the same steps as the reference's pll_update_partials defines them: class maps recomputed by every step
+    bcm, lnl_cm = runner.timed_with_class_maps(args.warmup, args.steps, args.blocks)
+    tN_cm_ms = block_stats(bcm, args.steps)[0]
     rep_extra, rep_full = runner.repeats_update_ms()
     rep_extra = h.max_over_ranks(rep_extra)
     shard_levels = h.gather_ints(runner.level_entries())
     shard_sites = h.gather_ints([mine.sites])
+    affinities = h.gather_objects(h.cpu_affinity)  # per rank: the cores it was pinned to (next to its GPU)
     # roofline of the dominant kernel on this rank's shard (rank 0 reports)
     args.config = "c4"
     roofline, _ = roofline_leg(args, cfg, lib, api, runner)
+    step_roofline(roofline, tN_ms)
     h.barrier()
     out = None
     if h.rank == 0:
@@ -900,6 +1002,8 @@ def main_strong(args, h):
         solo = Runner(h, lib, api, driver, full, True, reduce=None, c_driver=args.driver == "c")
         b1, lnl1 = solo.timed(args.warmup, args.steps, args.blocks)
         t1_ms = block_stats(b1, args.steps)[0]
+        b1cm, _ = solo.timed_with_class_maps(args.warmup, args.steps, args.blocks)
+        t1_cm_ms = block_stats(b1cm, args.steps)[0]
         global_levels = solo.level_entries()
         rep1_extra, _ = solo.repeats_update_ms(reps=3)
         solo.close()
@@ -915,13 +1019,19 @@ def main_strong(args, h):
                        + tip_note(full, api, args),
                        "total_sites": total_sites, "patterns": full.sites, "sites_per_gpu": [s[0] for s in shard_sites],
                        "ops_per_traversal": nops, "states": 4, "rate_cats": 4, "taxa": cfg["tips"],
-                       "step": "pll_update_partials(full traversal) + edge log-likelihood + the one exchange: sum of the shard lnLs"
+                       "step_with_class_maps": STEP_MAPS.replace("pll_compute_edge_loglikelihood", "edge log-likelihood + the same exchange"),
+                       "step": "pll_update_partials_rep(full traversal, update_repeats = 0: the class maps of the first step re-used) + edge log-likelihood + the one exchange: sum of the shard lnLs"
                                + (" in rank order through shared host memory (pll_gpu_group_edge_loglikelihood)" if reduce == "peer" else " by one RCCL all-reduce on the device"),
                        "timed": f"median of {args.blocks} blocks of {args.steps} steps, each block between two barriers + device synchronises, max over ranks per block",
                        "driver": "C loop over the two C-ABI calls (csrc/workload/step_loop.c)" if args.driver == "c" and reduce == "peer" else "Python ctypes loop",
                        "parallelism": f"sites sharded x{h.world}, one sum of one double per step ({reduce}; control plane {h.backend})"},
             "lnl": lnl, "t1_ms": round(t1_ms, 4), "tN_ms": round(tN_ms, 4), "speedup": round(t1_ms / tN_ms, 3),
             "t1_value": round(total_sites * nops / (t1_ms * 1e-3) / 1e6, 1), "lnl_unsharded": lnl1,
+            "exchange_timed": reduce,  # which exchange `value` / tN_ms were timed with (never the other one's number)
+            "cpu_affinity": affinities,
+            "ms_per_step_with_class_maps": round(tN_cm_ms, 4), "value_with_class_maps": round(total_sites * nops / (tN_cm_ms * 1e-3) / 1e6, 1),
+            "t1_ms_with_class_maps": round(t1_cm_ms, 4), "speedup_with_class_maps": round(t1_cm_ms / tN_cm_ms, 3),
+            "lnl_with_class_maps": lnl_cm,
             "lnl_rel_err_vs_unsharded": abs(lnl - lnl1) / abs(lnl1), "exchange": exchange,
             "repeats_update_ms": round(rep_extra, 4), "repeats_update_ms_unsharded": round(rep1_extra, 4),
             "entries_per_level": {"unsharded": global_levels, "shards": shard_levels,
@@ -944,7 +1054,12 @@ def main_strong(args, h):
                 out["exchange"]["rccl_error"] = f"the RCCL leg did not finish within {limit:.0f} s; line printed by the watchdog"
                 line = (json.dumps(out) + "\n").encode()
                 os.write(h.real_stdout if h.real_stdout is not None else 1, line)
-            os._exit(0)
+            if h.group:  # the shared-memory segment of the peer exchange: leave it, so that its name is unlinked (host memory only)
+                h.group_lib.pll_gpu_group_leave(h.group)
+                h.group = None
+            # a collective that never completes is a hang on a process that holds the GPU: the line is out, the exit
+            # status says what happened (the launcher returns the worst rank's)
+            os._exit(RCCL_LEG_HUNG_RC)
 
         import threading
         dog = threading.Timer(limit, give_up)

@@ -36,15 +36,13 @@
 
 constexpr int kRepOps = 128;                // ops per launch
 constexpr unsigned kRepThreads = 512;       // k_rep_mark workgroup
-constexpr unsigned kRepLdsCells = 16384;    // cells of its table part (64 KB of LDS: two workgroups per CU)
+constexpr unsigned kRepLdsCells = 32768;    // cells of its part of a large table (128 KB of LDS: one workgroup per CU)
 constexpr unsigned kRepSmallCells = 1024;   // tables up to here are ranked by direct counting in LDS
-constexpr unsigned kRepSeedCells = 4096;    // tables up to here: a few sites seed the LDS table before the scan (rep_seed)
-constexpr unsigned kRepAssignLds = 8192;    // k_rep_assign copies tables up to this many cells into LDS
-constexpr unsigned kRepAssignThreads = 256;
-constexpr unsigned kRepAssignTile = kRepAssignThreads * 16u * 2u; // sites per workgroup of k_rep_assign
+constexpr unsigned kRepAssignLds = 65536;   // k_rep_assign keeps tables up to this many cells in LDS, 16 bits per cell
+constexpr unsigned kRepAssignThreads = 1024; // ... its workgroup: 16 sites per thread and round, RepPack::assign_iters rounds
 constexpr unsigned kRepScanThreads = 1024;                        // k_rep_scan workgroup
 constexpr unsigned kRepScanChunk = kRepScanThreads * 32u;         // bitmap words per round of its scan
-constexpr unsigned kRepMaxParts = 64;                             // tickets per op: parts of a table that has ranges (<= workgroups per op)
+constexpr unsigned kRepFoldThreads = 256, kRepFoldTiles = 64;     // k_rep_fold: workgroups per op (grid-stride over the cells)
 constexpr unsigned kRepRankThreads = 256, kRepRankTiles = 64;     // k_rep_rank: workgroups per op (grid-stride over the cells)
 constexpr unsigned kRepNarrow = 256;        // up to this many classes: site -> class map in bytes
 constexpr unsigned kRepEmpty = 0xFFFFFFFFu;
@@ -73,21 +71,24 @@ struct RepPack
 {
   const RepOp *ops;       // device array: this launch's ops
   unsigned *counts;       // [ncounts] per op of the CALL: kRepFlag | classes, or 0 (not compressed)
-  unsigned *tickets;      // [kRepOps][kRepMaxParts] arrivals per table part of the launch's ops (0 between launches)
+  unsigned *tickets;      // [kRepOps] arrivals of an op's workgroups (small tables; 0 between launches)
   unsigned *launch_ticket; // ops of the launch whose count is known (0 between launches)
   unsigned *host_counts;  // mapped host memory: counts[] for the host, then the sequence word, then an error word
   unsigned ncounts;       // ops in the call
   unsigned host_cap;      // entries before the sequence word
   unsigned nops;          // ops in this launch
-  unsigned wgs;           // workgroups per op
+  unsigned wgs;           // k_rep_assign: workgroups (tiles of sites) per op
+  unsigned mark_wgs;      // k_rep_mark: workgroups per op
+  unsigned mark_lds_cells; // ... and the cells of a large table's part (its LDS)
   unsigned sites;
   unsigned lookup;        // pll_repeats_t::lookup_buffer_size: the pair table a compressed parent may use
-  unsigned lds_cells;     // LDS cells per workgroup
+  unsigned lds_cells;     // k_rep_assign: tables up to this many cells go to LDS
+  unsigned assign_iters;  // ... rounds of 16384 sites per workgroup
   unsigned wstride;       // words per bitmap, a multiple of kRepScanChunk
   unsigned sequence;
   unsigned publish;       // the call's last kernel that produces counts: the op that reports last hands the counts to the host
-  unsigned has_rank;      // k_rep_scan + k_rep_rank follow this k_rep_mark (without them a large table is an error: 2)
-  unsigned max_ranges;    // site ranges per part of a large table
+  unsigned has_rank;      // k_rep_fold + k_rep_scan + k_rep_rank follow this k_rep_mark (without them a large table is an error: 2)
+  unsigned max_ranges;    // site ranges per part of a large table, at most
   int fenced;             // kernels_common.h: handoff_*
 };
 
@@ -169,10 +170,32 @@ __device__ __forceinline__ void rep_load16(const unsigned char *m8, const unsign
   rep_unpack16<NARROW>(rep_fetch16<NARROW>(m8, m32, s), v);
 }
 
+// sixteen sites against the table part in LDS. All sixteen looks first (a site outside the range or the part looks at
+// cell 0 and is dropped afterwards), then the few atomics: one wait for LDS per group instead of one per site. Two
+// sites of the group in one cell both see the state before the group - the atomic sorts them out.
+// WHOLE: the part is the whole table (no filter); FULL: all sixteen sites lie inside the range.
+template <bool WHOLE, bool FULL>
+__device__ __forceinline__ void rep_group(const unsigned (&l)[16], const unsigned (&r)[16], unsigned nleft, unsigned s, unsigned s1, unsigned lo, unsigned pcells, unsigned *lds)
+{
+  unsigned idx[16], seen[16];
+#pragma unroll
+  for (unsigned e = 0; e < 16u; ++e)
+  {
+    const unsigned i = WHOLE ? l[e] + r[e] * nleft : l[e] + r[e] * nleft - lo;
+    bool ok = WHOLE || i < pcells;
+    if (!FULL) ok = ok && s + e < s1;
+    idx[e] = ok ? i : kRepEmpty;
+    seen[e] = lds[ok ? i : 0u];
+  }
+#pragma unroll
+  for (unsigned e = 0; e < 16u; ++e)
+    if ((WHOLE && FULL || idx[e] != kRepEmpty) && seen[e] > s + e) atomicMin(&lds[idx[e]], s + e);
+}
+
 // sites [s0, s1) of one op against the table part [lo, lo + pcells) in LDS. Ascending sites per thread and a look
 // before the LDS atomic: after its first few sites a thread mostly finds a lower site already there. The next group's
 // maps are requested before this one is worked on.
-template <bool L8, bool R8>
+template <bool L8, bool R8, bool WHOLE>
 __device__ __forceinline__ void rep_scan(crepop_p o, unsigned nleft, unsigned s0, unsigned s1, unsigned lo, unsigned pcells, unsigned *lds)
 {
   const unsigned char *l8 = o->l8, *r8 = o->r8;
@@ -195,20 +218,8 @@ __device__ __forceinline__ void rep_scan(crepop_p o, unsigned nleft, unsigned s0
     unsigned l[16], r[16];
     rep_unpack16<L8>(lraw, l);
     rep_unpack16<R8>(rraw, r);
-    // all sixteen looks first (a site outside the range or the part looks at cell 0 and is dropped afterwards), then the
-    // few atomics: one wait for LDS per group instead of one per site. Two sites of the group in one cell both see the
-    // state before the group - the atomic sorts them out.
-    unsigned idx[16], seen[16];
-#pragma unroll
-    for (unsigned e = 0; e < 16u; ++e)
-    {
-      const unsigned i = l[e] + r[e] * nleft - lo;
-      idx[e] = (s + e < s1 && i < pcells) ? i : kRepEmpty;
-      seen[e] = lds[idx[e] != kRepEmpty ? idx[e] : 0u];
-    }
-#pragma unroll
-    for (unsigned e = 0; e < 16u; ++e)
-      if (idx[e] != kRepEmpty && seen[e] > s + e) atomicMin(&lds[idx[e]], s + e);
+    if (s + 16u <= s1) rep_group<WHOLE, true>(l, r, nleft, s, s1, lo, pcells, lds);
+    else rep_group<WHOLE, false>(l, r, nleft, s, s1, lo, pcells, lds);
     if (!more) return;
     lraw = lnext;
     rraw = rnext;
@@ -216,26 +227,14 @@ __device__ __forceinline__ void rep_scan(crepop_p o, unsigned nleft, unsigned s0
   }
 }
 
-// A few hundred sites from the front of the range, one per thread and round, before rep_scan: with an empty table every
-// look of rep_scan's first group fails and all sixteen sites of all threads go to the LDS atomic unit - 8192 atomics on
-// the handful of cells a table next to the tips has, which the unit takes one at a time (this was 20 us of every such
-// launch, whatever the number of sites). After these rounds the cells that occur at all are mostly there.
-template <bool L8, bool R8>
-__device__ __forceinline__ void rep_seed(crepop_p o, unsigned nleft, unsigned s0, unsigned s1, unsigned lo, unsigned pcells, unsigned *lds)
+template <bool WHOLE>
+__device__ __forceinline__ void rep_scan_forms(crepop_p o, const RepShape &sh, unsigned s0, unsigned s1, unsigned lo, unsigned pcells, unsigned *lds)
 {
-  const unsigned char *l8 = o->l8, *r8 = o->r8;
-  const unsigned *l32 = o->l32, *r32 = o->r32;
-  for (unsigned round = 0; round < 4u; ++round)
-  {
-    const unsigned s = s0 + round * kRepThreads + threadIdx.x;
-    if (s < s1)
-    {
-      const unsigned l = L8 ? l8[s] : l32[s], r = R8 ? r8[s] : r32[s];
-      const unsigned idx = l + r * nleft - lo;
-      if (idx < pcells && lds[idx] > s) atomicMin(&lds[idx], s);
-    }
-    __syncthreads();
-  }
+  const bool l8 = sh.nl <= kRepNarrow, r8 = sh.nr <= kRepNarrow;
+  if (l8 && r8) rep_scan<true, true, WHOLE>(o, sh.nl, s0, s1, lo, pcells, lds);
+  else if (l8) rep_scan<true, false, WHOLE>(o, sh.nl, s0, s1, lo, pcells, lds);
+  else if (r8) rep_scan<false, true, WHOLE>(o, sh.nl, s0, s1, lo, pcells, lds);
+  else rep_scan<false, false, WHOLE>(o, sh.nl, s0, s1, lo, pcells, lds);
 }
 
 __device__ __forceinline__ unsigned rep_coherent_load(const unsigned *p)
@@ -278,28 +277,28 @@ __device__ __forceinline__ void rep_store_count(const RepPack &p, crepop_p o, un
 }
 
 // the other workgroups' copies of a table part folded into this workgroup's own (still in LDS): `nranges` copies of
-// `ncells` cells each, the part is cells [lo, lo + pcells), `mine` is the copy to leave out. All requests of a round
-// first: every load is a trip to the coherent level.
+// `ncells` cells each, the part is cells [lo, lo + pcells), `mine` is the copy to leave out. The (copy, cell) pairs are
+// dealt out over the threads and a thread requests 32 of them before it looks at the first: every load is a trip to
+// the coherent level, and a loop over the copies made the tail of a launch as many trips long as an op had ranges
+// (32 ranges of a 16-cell table: 25 us of a 30 us launch).
 __device__ __forceinline__ void rep_fold_copies(const unsigned *table, unsigned ncells, unsigned nranges, unsigned mine, unsigned lo, unsigned pcells, unsigned *lds)
 {
-  for (unsigned base = 0; base < pcells; base += 16u * kRepThreads)
-    for (unsigned r = 0; r < nranges; ++r)
+  const unsigned total = nranges * pcells;
+  for (unsigned base = 0; base < total; base += 32u * kRepThreads)
+  {
+    unsigned t[32], cell[32];
+#pragma unroll
+    for (unsigned q = 0; q < 32u; ++q)
     {
-      if (r == mine) continue;
-      unsigned t[16];
-#pragma unroll
-      for (unsigned q = 0; q < 16u; ++q)
-      {
-        const unsigned c = base + q * kRepThreads + threadIdx.x;
-        t[q] = c < pcells ? rep_coherent_load(table + (size_t)r * ncells + lo + c) : kRepEmpty;
-      }
-#pragma unroll
-      for (unsigned q = 0; q < 16u; ++q)
-      {
-        const unsigned c = base + q * kRepThreads + threadIdx.x;
-        if (c < pcells && t[q] < lds[c]) lds[c] = t[q]; // (cell c of the part belongs to this thread alone)
-      }
+      const unsigned item = base + q * kRepThreads + threadIdx.x;
+      const unsigned r = item / pcells;
+      cell[q] = item - r * pcells;
+      t[q] = item < total && r != mine ? rep_coherent_load(table + (size_t)r * ncells + lo + cell[q]) : kRepEmpty;
     }
+#pragma unroll
+    for (unsigned q = 0; q < 32u; ++q)
+      if (t[q] != kRepEmpty && lds[cell[q]] > t[q]) atomicMin(&lds[cell[q]], t[q]);
+  }
 }
 
 // small table, complete in LDS: a cell's class = the cells with a lower first site. Returns the class count (every thread).
@@ -329,16 +328,50 @@ __device__ __forceinline__ unsigned rep_rank_small(crepop_p o, unsigned ncells, 
   return *s_count;
 }
 
-// Launch: a 1-D grid of (ops rounded up to eight) x wgs workgroups. Workgroups go to the XCDs round-robin by linear id:
-// the workgroups of one op are placed on ONE XCD (op = 8 * group + id % 8), so that the parts of an op's table, which
-// all scan the same two maps, find them in that XCD's L2.
+// (op, piece) of a workgroup in a 1-D grid of (ops rounded up to eight) x `per` workgroups: the workgroups of one op on
+// ONE XCD (workgroups go to the XCDs round-robin by linear id), so that what they share - the op's maps, its table, its
+// bitmap - is found in that XCD's L2
+__device__ __forceinline__ bool rep_place(unsigned nops, unsigned per, unsigned &opi, unsigned &piece)
+{
+  const unsigned j = blockIdx.x >> 3, grp = j / per;
+  piece = j - grp * per;
+  opi = grp * 8u + (blockIdx.x & 7u);
+  return opi < nops;
+}
+
+// How k_rep_mark's workgroups share an op: `parts` of the table (as few as LDS allows: every part scans the op's sites
+// again) x `ranges` of the sites, or - more parts than workgroups - the parts dealt out, one range.
+struct RepSplit
+{
+  unsigned nparts, nranges;
+  bool looped;
+};
+__device__ __forceinline__ RepSplit rep_split(const RepPack &p, crepop_p o, unsigned ncells)
+{
+  RepSplit sp;
+  const bool large = ncells > kRepSmallCells;
+  const unsigned lds_cells = large ? p.mark_lds_cells : kRepSmallCells;
+  sp.nparts = (ncells + lds_cells - 1u) / lds_cells;
+  sp.looped = sp.nparts >= p.mark_wgs;
+  sp.nranges = sp.looped ? 1u : p.mark_wgs / sp.nparts;
+  // a range is worth its copy of the table: a small table's is a few cells (folded by the op's last workgroup, which
+  // pays a trip to memory however few they are), a large one's is written and read once more by k_rep_fold
+  const unsigned per_range = large ? 32768u : 8192u;
+  const unsigned by_sites = (p.sites + per_range - 1u) / per_range;
+  if (sp.nranges > by_sites) sp.nranges = by_sites;
+  if (large && sp.nranges > p.max_ranges) sp.nranges = p.max_ranges;
+  if (sp.nranges > o->slice / ncells) sp.nranges = o->slice / ncells; // (>= 1: rep_shape; the host sizes the slice for all of them)
+  return sp;
+}
+
+// Launch: rep_place with mark_wgs workgroups per op.
 __global__ __launch_bounds__(kRepThreads) void k_rep_mark(const RepPack p)
 {
   extern __shared__ unsigned rep_lds[];
   __shared__ unsigned s_count;
   __shared__ unsigned s_last;
-  const unsigned j = blockIdx.x >> 3, grp = j / p.wgs, w = j - grp * p.wgs, opi = grp * 8u + (blockIdx.x & 7u);
-  if (opi >= p.nops) return;
+  unsigned opi, w;
+  if (!rep_place(p.nops, p.mark_wgs, opi, w)) return;
   crepop_p o = (crepop_p)(uintptr_t)p.ops + opi;
   const RepShape sh = rep_shape(p, o);
   const bool large = sh.ncells > kRepSmallCells;
@@ -347,89 +380,107 @@ __global__ __launch_bounds__(kRepThreads) void k_rep_mark(const RepPack p)
     if (w != 0u) return;
     const unsigned long long cells = (unsigned long long)sh.nl * sh.nr;
     // 1: a table the slice cannot hold although the rule admits it - the host's bound was wrong; 2: a large table in
-    // a launch that came without k_rep_scan / k_rep_rank - the host's forecast was wrong (it repeats the call with them)
+    // a launch that came without the kernels for it - the host's forecast was wrong
     const bool overflow = !sh.on && cells > (unsigned long long)o->slice && (o->force || (cells < (unsigned long long)p.lookup && sh.nl <= p.sites / 2u && sh.nr <= p.sites / 2u));
     rep_store_count(p, o, 0u, overflow ? 1u : sh.on ? 2u : 0u);
     if (!p.has_rank) rep_arrive(p);
     return;
   }
-  // parts x ranges: as few parts as LDS allows (every part scans the op's sites again), the other workgroups split the
-  // sites - as far as the copies stay cheap to fold: all of them for a small table, max_ranges for a large one
   const unsigned ncells = sh.ncells;
-  const unsigned nparts = (ncells + p.lds_cells - 1u) / p.lds_cells;
-  unsigned nranges = nparts < p.wgs ? p.wgs / nparts : 1u;
-  if (large && nranges > p.max_ranges) nranges = p.max_ranges;
-  if (nranges > (p.sites + 8191u) / 8192u) nranges = (p.sites + 8191u) / 8192u; // no range shorter than a pass of two workgroups
-  if (nranges > o->slice / ncells) nranges = o->slice / ncells; // (>= 1: rep_shape; the host sizes the slice for all of them)
-  const bool looped = nparts >= p.wgs || nparts > kRepMaxParts; // parts shared out over the workgroups, one range
-  if (looped) nranges = 1u;
-  const unsigned used = looped ? (nparts < p.wgs ? nparts : p.wgs) : nparts * nranges;
+  const RepSplit sp = rep_split(p, o, ncells);
+  const unsigned used = sp.looped ? (sp.nparts < p.mark_wgs ? sp.nparts : p.mark_wgs) : sp.nparts * sp.nranges;
   if (w >= used) return;
-  const unsigned pc = (ncells + nparts - 1u) / nparts; // cells per part (<= lds_cells)
-  const unsigned rs = ((p.sites + nranges - 1u) / nranges + 15u) & ~15u; // sites per range, whole groups of sixteen
-  const unsigned range = looped ? 0u : w / nparts;
+  const unsigned rs = ((p.sites + sp.nranges - 1u) / sp.nranges + 15u) & ~15u; // sites per range, whole groups of sixteen
+  const unsigned range = sp.looped ? 0u : w / sp.nparts;
   const unsigned s0 = range * rs < p.sites ? range * rs : p.sites, s1 = s0 + rs < p.sites ? s0 + rs : p.sites;
-  const bool l8 = sh.nl <= kRepNarrow, r8 = sh.nr <= kRepNarrow;
-  for (unsigned part = looped ? w : w % nparts; part < nparts; part += looped ? used : nparts)
+  if (!large)
   {
-    const unsigned lo = part * pc, pcells = lo + pc <= ncells ? pc : ncells - lo;
-    for (unsigned i = threadIdx.x; i < pcells; i += kRepThreads) rep_lds[i] = kRepEmpty;
+    // the whole table in LDS; the op's last workgroup folds the ranges and numbers the classes
+    for (unsigned i = threadIdx.x; i < ncells; i += kRepThreads) rep_lds[i] = kRepEmpty;
     __syncthreads();
-    if (ncells <= kRepSeedCells)
-    {
-      if (l8 && r8) rep_seed<true, true>(o, sh.nl, s0, s1, lo, pcells, rep_lds);
-      else if (l8) rep_seed<true, false>(o, sh.nl, s0, s1, lo, pcells, rep_lds);
-      else if (r8) rep_seed<false, true>(o, sh.nl, s0, s1, lo, pcells, rep_lds);
-      else rep_seed<false, false>(o, sh.nl, s0, s1, lo, pcells, rep_lds);
-    }
-    if (l8 && r8) rep_scan<true, true>(o, sh.nl, s0, s1, lo, pcells, rep_lds);
-    else if (l8) rep_scan<true, false>(o, sh.nl, s0, s1, lo, pcells, rep_lds);
-    else if (r8) rep_scan<false, true>(o, sh.nl, s0, s1, lo, pcells, rep_lds);
-    else rep_scan<false, false>(o, sh.nl, s0, s1, lo, pcells, rep_lds);
+    rep_scan_forms<true>(o, sh, s0, s1, 0u, ncells, rep_lds);
     __syncthreads();
-    if (nranges > 1u)
+    if (sp.nranges > 1u)
     {
-      // this workgroup's copy of the part: written through to the coherent level (kernels_common.h: partial_store);
-      // every wave's stores have been performed before the workgroup takes its ticket
-      unsigned *dst = o->table + (size_t)range * ncells + lo;
-      for (unsigned i = threadIdx.x; i < pcells; i += kRepThreads) __hip_atomic_store(dst + i, rep_lds[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // this workgroup's copy: written through to the coherent level (kernels_common.h: partial_store); every wave's
+      // stores have been performed before the workgroup takes its ticket
+      unsigned *dst = o->table + (size_t)range * ncells;
+      for (unsigned i = threadIdx.x; i < ncells; i += kRepThreads) __hip_atomic_store(dst + i, rep_lds[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (threadIdx.x == 0u)
       {
         if (p.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        unsigned *ticket = &p.tickets[opi * kRepMaxParts + part];
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == nranges - 1u) ? 1u : 0u;
+        const unsigned t = __hip_atomic_fetch_add(&p.tickets[opi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == sp.nranges - 1u) ? 1u : 0u;
         if (s_last)
         {
           handoff_after_last_ticket(p.fenced);
-          __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&p.tickets[opi], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       __syncthreads();
-      if (!s_last) return; // (a workgroup with ranges has this one part)
-      rep_fold_copies(o->table, ncells, nranges, range, lo, pcells, rep_lds);
+      if (!s_last) return;
+      rep_fold_copies(o->table, ncells, sp.nranges, range, 0u, ncells, rep_lds);
       __syncthreads();
     }
-    // the part's first sites are final, in LDS
-    if (!large)
-    {
-      const unsigned classes = rep_rank_small(o, ncells, sh.nl, rep_lds, &s_count); // (one part: the whole table)
-      rep_store_count(p, o, kRepFlag | classes, 0u);
-      if (!p.has_rank) rep_arrive(p);
-      return;
-    }
-    // large: the table for k_rep_rank (and the launches behind it: plain stores), the bits for k_rep_scan. The bitmap
-    // is shared by the op's parts: atomics at the coherent level.
-    unsigned *table = o->table + lo, *bitmap = o->bitmap;
-    for (unsigned i = threadIdx.x; i < pcells; i += kRepThreads)
-    {
-      const unsigned v = rep_lds[i];
-      table[i] = v;
-      if (v != kRepEmpty) __hip_atomic_fetch_or(&bitmap[v >> 5], 1u << (v & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    const unsigned classes = rep_rank_small(o, ncells, sh.nl, rep_lds, &s_count);
+    rep_store_count(p, o, kRepFlag | classes, 0u);
+    if (!p.has_rank) rep_arrive(p);
+    return;
+  }
+  // large: this workgroup's copy of its part(s) for k_rep_fold, plain stores
+  const unsigned pc = (ncells + sp.nparts - 1u) / sp.nparts; // cells per part (<= mark_lds_cells)
+  for (unsigned part = sp.looped ? w : w % sp.nparts; part < sp.nparts; part += sp.looped ? used : sp.nparts)
+  {
+    const unsigned lo = part * pc, pcells = lo + pc <= ncells ? pc : ncells - lo;
+    for (unsigned i = threadIdx.x; i < pcells; i += kRepThreads) rep_lds[i] = kRepEmpty;
+    __syncthreads();
+    if (sp.nparts == 1u) rep_scan_forms<true>(o, sh, s0, s1, 0u, ncells, rep_lds);
+    else rep_scan_forms<false>(o, sh, s0, s1, lo, pcells, rep_lds);
+    __syncthreads();
+    unsigned *dst = o->table + (size_t)range * ncells + lo;
+    for (unsigned i = threadIdx.x; i < pcells; i += kRepThreads) dst[i] = rep_lds[i];
     __syncthreads(); // rep_lds is reused by the next part
+  }
+}
+
+// Large tables, second step: the copies of the ranges folded - first[cell] = the lowest over them, left in copy 0 - and
+// bit first[cell] of the op's bitmap set (shared by the whole launch grid: atomics at the coherent level).
+// Launch: rep_place with kRepFoldTiles workgroups per op, which stride over the op's cells.
+__global__ __launch_bounds__(kRepFoldThreads) void k_rep_fold(const RepPack p)
+{
+  unsigned opi, tile;
+  if (!rep_place(p.nops, kRepFoldTiles, opi, tile)) return;
+  crepop_p o = (crepop_p)(uintptr_t)p.ops + opi;
+  const RepShape sh = rep_shape(p, o);
+  if (!sh.on || sh.ncells <= kRepSmallCells) return;
+  const unsigned ncells = sh.ncells;
+  const unsigned nranges = rep_split(p, o, ncells).nranges;
+  unsigned *__restrict__ table = o->table, *__restrict__ bitmap = o->bitmap;
+  for (unsigned base = tile * kRepFoldThreads * 4u; base < ncells; base += kRepFoldTiles * kRepFoldThreads * 4u)
+  {
+    unsigned v[4] = {kRepEmpty, kRepEmpty, kRepEmpty, kRepEmpty};
+    for (unsigned r = 0; r < nranges; ++r)
+    {
+      unsigned t[4];
+#pragma unroll
+      for (unsigned q = 0; q < 4u; ++q)
+      {
+        const unsigned c = base + q * kRepFoldThreads + threadIdx.x;
+        t[q] = c < ncells ? table[(size_t)r * ncells + c] : kRepEmpty;
+      }
+#pragma unroll
+      for (unsigned q = 0; q < 4u; ++q) v[q] = t[q] < v[q] ? t[q] : v[q];
+    }
+#pragma unroll
+    for (unsigned q = 0; q < 4u; ++q)
+    {
+      const unsigned c = base + q * kRepFoldThreads + threadIdx.x;
+      if (c >= ncells) continue;
+      if (nranges > 1u) table[c] = v[q];
+      if (v[q] != kRepEmpty) __hip_atomic_fetch_or(&bitmap[v[q] >> 5], 1u << (v[q] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -497,17 +548,6 @@ __global__ __launch_bounds__(kRepScanThreads) void k_rep_scan(const RepPack p)
   rep_arrive(p);
 }
 
-// (op, piece) of a workgroup in a 1-D grid of (ops rounded up to eight) x `per` workgroups: the workgroups of one op on
-// ONE XCD (workgroups go to the XCDs round-robin by linear id), so that what they share - the op's table, its maps, its
-// bitmap - is found in that XCD's L2
-__device__ __forceinline__ bool rep_place(unsigned nops, unsigned per, unsigned &opi, unsigned &piece)
-{
-  const unsigned j = blockIdx.x >> 3, grp = j / per;
-  piece = j - grp * per;
-  opi = grp * 8u + (blockIdx.x & 7u);
-  return opi < nops;
-}
-
 // Large tables, third step: every non-empty cell takes its class number - the first sites before its own.
 // Grid: rep_place with kRepRankTiles workgroups per op, which stride over the op's cells.
 __global__ __launch_bounds__(kRepRankThreads) void k_rep_rank(const RepPack p)
@@ -545,17 +585,20 @@ __global__ __launch_bounds__(kRepRankThreads) void k_rep_rank(const RepPack p)
   }
 }
 
-// site -> class. FIRSTS (large tables): the sites the bitmap marks as the first of their cell also write the class ->
-// first site / child entry maps - in site order, which is class order: neighbouring stores (the cells, which know the
-// same, would scatter them).
+// site -> class. The table sits in LDS as 16-bit class numbers when it has at most 65536 cells (a class number is
+// below the cell count) - looked up through global memory a scattered gather costs a cycle of the CU's address unit per
+// lane (C4's level 2: 16M look-ups, 52 us; in LDS a few cycles per wave). FIRSTS (large tables): the sites the bitmap
+// marks as the first of their cell also write the class -> first site / child entry maps - in site order, which is
+// class order: neighbouring stores (the cells, which know the same, would scatter them).
 template <bool L8, bool R8, bool P8, bool LDS, bool FIRSTS>
-__device__ __forceinline__ void rep_assign_tile(crepop_p o, unsigned nleft, const unsigned *tab, unsigned sites, unsigned tile)
+__device__ __forceinline__ void rep_assign_tile(const RepPack &p, crepop_p o, unsigned nleft, const unsigned short *lds, unsigned tile)
 {
   const unsigned char *l8 = o->l8, *r8 = o->r8;
   const unsigned *l32 = o->l32, *r32 = o->r32;
-  const unsigned tile0 = tile * kRepAssignTile;
-#pragma unroll
-  for (unsigned it = 0; it < kRepAssignTile / (kRepAssignThreads * 16u); ++it)
+  const unsigned *__restrict__ table = o->table;
+  const unsigned sites = p.sites;
+  const unsigned tile0 = tile * p.assign_iters * kRepAssignThreads * 16u;
+  for (unsigned it = 0; it < p.assign_iters; ++it)
   {
     const unsigned s = tile0 + it * kRepAssignThreads * 16u + threadIdx.x * 16u;
     if (s >= sites) continue;
@@ -565,14 +608,18 @@ __device__ __forceinline__ void rep_assign_tile(crepop_p o, unsigned nleft, cons
     unsigned firsts = 0;
     if (FIRSTS) firsts = (o->bitmap[s >> 5] >> (s & 16u)) & 0xFFFFu;
 #pragma unroll
-    for (unsigned e = 0; e < 16u; ++e) v[e] = tab[s + e < sites ? l[e] + r[e] * nleft : 0u]; // (the padding of the maps holds anything: cell 0, not stored beyond the map's padding)
+    for (unsigned e = 0; e < 16u; ++e)
+    {
+      const unsigned cell = s + e < sites ? l[e] + r[e] * nleft : 0u; // (the padding of the maps holds anything: cell 0, stored into the padding of the parent's)
+      v[e] = LDS ? (unsigned)lds[cell] : table[cell];
+    }
     if (P8)
     {
       uint4 out;
-      out.x = v[0] | v[1] << 8 | v[2] << 16 | v[3] << 24;
-      out.y = v[4] | v[5] << 8 | v[6] << 16 | v[7] << 24;
-      out.z = v[8] | v[9] << 8 | v[10] << 16 | v[11] << 24;
-      out.w = v[12] | v[13] << 8 | v[14] << 16 | v[15] << 24;
+      out.x = (v[0] & 255u) | (v[1] & 255u) << 8 | (v[2] & 255u) << 16 | v[3] << 24;
+      out.y = (v[4] & 255u) | (v[5] & 255u) << 8 | (v[6] & 255u) << 16 | v[7] << 24;
+      out.z = (v[8] & 255u) | (v[9] & 255u) << 8 | (v[10] & 255u) << 16 | v[11] << 24;
+      out.w = (v[12] & 255u) | (v[13] & 255u) << 8 | (v[14] & 255u) << 16 | v[15] << 24;
       *reinterpret_cast<uint4 *>(o->p8 + s) = out;
     }
     else
@@ -596,24 +643,30 @@ __device__ __forceinline__ void rep_assign_tile(crepop_p o, unsigned nleft, cons
 }
 
 template <bool L8, bool R8, bool P8>
-__device__ __forceinline__ void rep_assign_form(crepop_p o, unsigned nleft, unsigned ncells, unsigned lds_cells, unsigned *lds, unsigned sites, unsigned tile)
+__device__ __forceinline__ void rep_assign_form(const RepPack &p, crepop_p o, unsigned nleft, unsigned ncells, unsigned short *lds, unsigned tile)
 {
-  const unsigned *table = o->table;
-  if (ncells <= lds_cells)
+  if (ncells <= p.lds_cells)
   {
-    for (unsigned i = threadIdx.x; i < ncells; i += kRepAssignThreads) lds[i] = table[i];
+    const unsigned *__restrict__ table = o->table;
+    // (an empty cell: no site looks it up; the slices of the arena start at multiples of four cells and are padded to one)
+    for (unsigned i = threadIdx.x * 4u; i < ncells; i += kRepAssignThreads * 4u)
+    {
+      const uint4 t = *reinterpret_cast<const uint4 *>(table + i);
+      *reinterpret_cast<uint2 *>(lds + i) = make_uint2((t.x & 0xFFFFu) | t.y << 16, (t.z & 0xFFFFu) | t.w << 16);
+    }
     __syncthreads();
-    if (ncells > kRepSmallCells) rep_assign_tile<L8, R8, P8, true, true>(o, nleft, lds, sites, tile);
-    else rep_assign_tile<L8, R8, P8, true, false>(o, nleft, lds, sites, tile);
+    if (ncells > kRepSmallCells) rep_assign_tile<L8, R8, P8, true, true>(p, o, nleft, lds, tile);
+    else rep_assign_tile<L8, R8, P8, true, false>(p, o, nleft, lds, tile);
   }
   else
-    rep_assign_tile<L8, R8, P8, false, true>(o, nleft, table, sites, tile);
+    rep_assign_tile<L8, R8, P8, false, true>(p, o, nleft, lds, tile);
 }
 
-// Grid: rep_place with one workgroup per tile of kRepAssignTile sites
+// Grid: rep_place with one workgroup per assign_iters x 16384 sites
 __global__ __launch_bounds__(kRepAssignThreads) void k_rep_assign(const RepPack p)
 {
   extern __shared__ unsigned rep_lds[];
+  unsigned short *lds = reinterpret_cast<unsigned short *>(rep_lds);
   unsigned opi, tile;
   if (!rep_place(p.nops, p.wgs, opi, tile)) return;
   crepop_p o = (crepop_p)(uintptr_t)p.ops + opi;
@@ -623,22 +676,23 @@ __global__ __launch_bounds__(kRepAssignThreads) void k_rep_assign(const RepPack 
   const unsigned form = (sh.nl <= kRepNarrow ? 4u : 0u) | (sh.nr <= kRepNarrow ? 2u : 0u) | ((word & ~kRepFlag) <= kRepNarrow ? 1u : 0u);
   switch (form)
   {
-  case 7u: rep_assign_form<true, true, true>(o, sh.nl, sh.ncells, p.lds_cells, rep_lds, p.sites, tile); break;
-  case 6u: rep_assign_form<true, true, false>(o, sh.nl, sh.ncells, p.lds_cells, rep_lds, p.sites, tile); break;
-  case 5u: rep_assign_form<true, false, true>(o, sh.nl, sh.ncells, p.lds_cells, rep_lds, p.sites, tile); break;
-  case 4u: rep_assign_form<true, false, false>(o, sh.nl, sh.ncells, p.lds_cells, rep_lds, p.sites, tile); break;
-  case 3u: rep_assign_form<false, true, true>(o, sh.nl, sh.ncells, p.lds_cells, rep_lds, p.sites, tile); break;
-  case 2u: rep_assign_form<false, true, false>(o, sh.nl, sh.ncells, p.lds_cells, rep_lds, p.sites, tile); break;
-  case 1u: rep_assign_form<false, false, true>(o, sh.nl, sh.ncells, p.lds_cells, rep_lds, p.sites, tile); break;
-  default: rep_assign_form<false, false, false>(o, sh.nl, sh.ncells, p.lds_cells, rep_lds, p.sites, tile); break;
+  case 7u: rep_assign_form<true, true, true>(p, o, sh.nl, sh.ncells, lds, tile); break;
+  case 6u: rep_assign_form<true, true, false>(p, o, sh.nl, sh.ncells, lds, tile); break;
+  case 5u: rep_assign_form<true, false, true>(p, o, sh.nl, sh.ncells, lds, tile); break;
+  case 4u: rep_assign_form<true, false, false>(p, o, sh.nl, sh.ncells, lds, tile); break;
+  case 3u: rep_assign_form<false, true, true>(p, o, sh.nl, sh.ncells, lds, tile); break;
+  case 2u: rep_assign_form<false, true, false>(p, o, sh.nl, sh.ncells, lds, tile); break;
+  case 1u: rep_assign_form<false, false, true>(p, o, sh.nl, sh.ncells, lds, tile); break;
+  default: rep_assign_form<false, false, false>(p, o, sh.nl, sh.ncells, lds, tile); break;
   }
   if (sh.ncells > kRepSmallCells)
   {
     // the op's bitmap goes back to zero for the next launch that uses the slot: this tile's sites, once every thread
     // of the workgroup has read its bits
     __syncthreads();
-    const unsigned w0 = tile * (kRepAssignTile / 32u) + threadIdx.x * 4u;
-    if (threadIdx.x < kRepAssignTile / 128u && w0 < p.wstride) *reinterpret_cast<uint4 *>(o->bitmap + w0) = make_uint4(0u, 0u, 0u, 0u);
+    const unsigned tile_words = p.assign_iters * kRepAssignThreads / 2u; // 16 sites per thread and round
+    for (unsigned w = threadIdx.x * 4u; w < tile_words; w += kRepAssignThreads * 4u)
+      if (tile * tile_words + w < p.wstride) *reinterpret_cast<uint4 *>(o->bitmap + tile * tile_words + w) = make_uint4(0u, 0u, 0u, 0u);
   }
 }
 

@@ -131,7 +131,9 @@ struct pllgpu_ctx
   DevBuf<unsigned char> rep_ops;         // the op descriptors of one call
   std::vector<RepOp> rep_ops_host;
   unsigned rep_wgs = 0;                  // PLL_AMD_REP_WGS: workgroups per op of k_rep_mark (0: by the launch's size)
-  unsigned rep_max_ranges = 4;           // PLL_AMD_REP_RANGES: site ranges per part of a large table (kernels_repeats.h)
+  unsigned rep_max_ranges = 8;           // PLL_AMD_REP_RANGES: site ranges per part of a large table, at most (kernels_repeats.h)
+  unsigned rep_assign_iters = 0;         // PLL_AMD_REP_ASSIGN_ITERS: rounds per workgroup of k_rep_assign (0: by the launch's size)
+  unsigned rep_assign_lds = kRepAssignLds; // PLL_AMD_REP_ASSIGN_LDS: tables up to this many cells are looked up in LDS
   bool rep_hints = true;                 // PLL_AMD_REP_HINTS=0: every level of a class-map call is launched (A/B, tests)
   unsigned rep_hint_count = 0, rep_hint_level = 0; // the last call: its ops, the highest level with a compressed parent ...
   bool rep_hint_any = false;                       // ... if there was one
@@ -452,7 +454,7 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   if (c->pmat.ensure(c->pm_stride * (geo->prob_matrices + 2)) || c->freqs.ensure((size_t)geo->rate_matrices * geo->states_padded) ||
       c->rate_weights.ensure(geo->rate_cats) || c->prop_invar.ensure(geo->rate_matrices) ||
       c->pattern_weights.ensure(geo->sites_alloc) || c->persite.ensure(geo->sites_alloc) ||
-      c->block_sums.ensure(4096) || c->counter.ensure(4) || c->rep_sync.ensure((size_t)kRepOps * kRepMaxParts + 1))
+      c->block_sums.ensure(4096) || c->counter.ensure(4) || c->rep_sync.ensure((size_t)kRepOps + 1))
   {
     pllgpu_destroy(c);
     return nullptr;
@@ -463,6 +465,8 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   (void)hipMemsetAsync(c->counter.p, 0, c->counter.cap * sizeof(unsigned), c->stream);
   (void)hipMemsetAsync(c->rep_sync.p, 0, c->rep_sync.cap * sizeof(unsigned), c->stream);
   if (const char *v = getenv("PLL_AMD_REP_WGS")) c->rep_wgs = (unsigned)std::max(0, atoi(v));
+  if (const char *v = getenv("PLL_AMD_REP_ASSIGN_ITERS")) c->rep_assign_iters = (unsigned)std::max(0, atoi(v));
+  if (const char *v = getenv("PLL_AMD_REP_ASSIGN_LDS")) c->rep_assign_lds = (unsigned)std::min<int>(kRepAssignLds, std::max(0, atoi(v)));
   if (const char *v = getenv("PLL_AMD_REP_HINTS")) c->rep_hints = !(*v == '0');
   if (const char *v = getenv("PLL_AMD_REP_RANGES")) c->rep_max_ranges = (unsigned)std::max(1, atoi(v));
   return c;
@@ -2851,7 +2855,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
       const size_t ub = (size_t)ub_cells[i];
       // all copies of the table (k_rep_mark): a small one has a copy per workgroup, a large one up to max_ranges - and only
       // while its parts are fewer than the workgroups
-      const size_t slice = ub <= kRepSmallCells ? ub * wgs : std::max(ub, std::min(ub * c->rep_max_ranges, (size_t)kRepLdsCells * wgs));
+      const size_t slice = ((ub <= kRepSmallCells ? ub * wgs : std::max(ub, std::min(ub * c->rep_max_ranges, (size_t)kRepLdsCells * wgs))) + 3u) & ~(size_t)3u;
       if (ub > kRepSmallCells) L.rank = true;
       if (k && cells + slice > table_cap) break;
       RepOp &r = rops[i];
@@ -2876,7 +2880,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
       r.slice = (unsigned)std::min<size_t>(slice, 0x7FFFFFFFu);
       cells += slice;
       L.mark_lds = std::max<unsigned>(L.mark_lds, (unsigned)std::min<size_t>(ub, kRepLdsCells));
-      L.assign_lds = std::max<unsigned>(L.assign_lds, (unsigned)std::min<size_t>(ub, kRepAssignLds));
+      if (ub <= c->rep_assign_lds) L.assign_lds = std::max<unsigned>(L.assign_lds, (unsigned)((ub + 3u) & ~(size_t)3u));
       ++L.n;
     }
     arena = std::max(arena, cells);
@@ -2908,7 +2912,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
   memset(&pk, 0, sizeof pk);
   pk.counts = c->rep_counts.p;
   pk.tickets = c->rep_sync.p;
-  pk.launch_ticket = c->rep_sync.p + (size_t)kRepOps * kRepMaxParts;
+  pk.launch_ticket = c->rep_sync.p + kRepOps;
   pk.max_ranges = c->rep_max_ranges;
   pk.host_counts = c->rep_host_dev;
   pk.ncounts = ncut;
@@ -2923,24 +2927,32 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     const Launch &L = launches[li];
     pk.ops = reinterpret_cast<const RepOp *>(c->rep_ops.p) + L.first;
     pk.nops = L.n;
-    pk.wgs = L.wgs;
+    pk.mark_wgs = L.wgs;
+    pk.mark_lds_cells = L.mark_lds;
     const bool last = li + 1 == launches.size();
     pk.has_rank = L.rank ? 1u : 0u;
     pk.publish = last && !L.rank ? 1u : 0u;
-    pk.lds_cells = L.mark_lds;
     const size_t mark_bytes = (size_t)L.mark_lds * sizeof(unsigned);
     raise_lds_limit((const void *)k_rep_mark, c->device, mark_bytes);
     hipLaunchKernelGGL(k_rep_mark, dim3((L.n + 7u) / 8u * 8u * L.wgs), dim3(kRepThreads), mark_bytes, c->stream, pk);
     const unsigned n8 = (L.n + 7u) / 8u * 8u;
     if (L.rank)
     {
+      hipLaunchKernelGGL(k_rep_fold, dim3(n8 * kRepFoldTiles), dim3(kRepFoldThreads), 0, c->stream, pk);
       pk.publish = last ? 1u : 0u;
       hipLaunchKernelGGL(k_rep_scan, dim3(L.n), dim3(kRepScanThreads), 0, c->stream, pk);
       hipLaunchKernelGGL(k_rep_rank, dim3(n8 * kRepRankTiles), dim3(kRepRankThreads), 0, c->stream, pk);
     }
+    // k_rep_assign: a workgroup takes 1..4 rounds of 16384 sites - ~512 workgroups per launch, more rounds where a large
+    // table has to be brought into LDS first
     pk.lds_cells = L.assign_lds;
-    pk.wgs = (sites + kRepAssignTile - 1u) / kRepAssignTile;
-    hipLaunchKernelGGL(k_rep_assign, dim3(n8 * pk.wgs), dim3(kRepAssignThreads), (size_t)L.assign_lds * sizeof(unsigned), c->stream, pk);
+    const size_t assign_bytes = (size_t)L.assign_lds * sizeof(unsigned short);
+    const unsigned per_round = kRepAssignThreads * 16u, rounds = (sites + per_round - 1u) / per_round;
+    pk.assign_iters = std::max(1u, std::min(4u, rounds * L.n / (assign_bytes > 32768 ? 256u : 512u)));
+    if (c->rep_assign_iters) pk.assign_iters = c->rep_assign_iters;
+    pk.wgs = (rounds + pk.assign_iters - 1u) / pk.assign_iters;
+    raise_lds_limit((const void *)k_rep_assign, c->device, assign_bytes);
+    hipLaunchKernelGGL(k_rep_assign, dim3(n8 * pk.wgs), dim3(kRepAssignThreads), assign_bytes, c->stream, pk);
   }
   HIP_TRY(hipGetLastError());
   // the class counts arrive in mapped host memory as soon as the last k_rep_mark knows them (its k_rep_assign still

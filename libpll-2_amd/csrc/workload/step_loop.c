@@ -16,21 +16,23 @@ typedef double (*group_edge_fn)(void *partition, void *group, unsigned int paren
                                 const unsigned int *freqs_indices, double *persite);
 
 /* edge = {parent_clv, parent_scaler, child_clv, child_scaler, matrix}; group == NULL: the plain evaluation.
- * first_update_repeats applies to the first step only (class maps of a site-repeats partition are formed once
- * and re-used, update_repeats = 0, until the topology changes). Returns the seconds the K steps took on the
- * calling thread; *lnl = the last step's value. */
+ * first_update_repeats: 0 = every step with update_repeats = 0; 1 = the first step with update_repeats = 1, the
+ * others with 0 (class maps of a site-repeats partition formed once and re-used until the topology changes);
+ * 2 = EVERY step with update_repeats = 1, which is what the reference's pll_update_partials is
+ * (src/partials.c:237-242). Returns the seconds the K steps took on the calling thread; *lnl = the last step's
+ * value. */
 double pllwl_step_loop(update_fn update, edge_fn edge_lnl, group_edge_fn group_edge_lnl, void *partition, void *group,
                        const void *ops, unsigned int count, unsigned int first_update_repeats, const int *edge,
                        const unsigned int *freqs_indices, unsigned int steps, double *lnl)
 {
   struct timespec a, b;
   double v = 0.0;
-  unsigned int k, ur = first_update_repeats;
+  unsigned int k, ur = first_update_repeats ? 1u : 0u;
   clock_gettime(CLOCK_MONOTONIC, &a);
   for (k = 0; k < steps; ++k)
   {
     update(partition, ops, count, ur);
-    ur = first_update_repeats ? 0u : ur; /* 1 -> 0 after the first step; 0 stays 0 */
+    if (first_update_repeats == 1u) ur = 0u; /* 1 -> 0 after the first step; 0 stays 0, 2 stays 1 */
     v = group ? group_edge_lnl(partition, group, (unsigned int)edge[0], edge[1], (unsigned int)edge[2], edge[3], (unsigned int)edge[4], freqs_indices, 0)
               : edge_lnl(partition, (unsigned int)edge[0], edge[1], (unsigned int)edge[2], edge[3], (unsigned int)edge[4], freqs_indices, 0);
   }
@@ -51,12 +53,12 @@ double pllwl_step_loop_allreduce(update_fn update, allreduce_edge_fn allreduce_e
 {
   struct timespec a, b;
   double v = 0.0;
-  unsigned int k, ur = first_update_repeats;
+  unsigned int k, ur = first_update_repeats ? 1u : 0u;
   clock_gettime(CLOCK_MONOTONIC, &a);
   for (k = 0; k < steps; ++k)
   {
     update(partition, ops, count, ur);
-    ur = first_update_repeats ? 0u : ur;
+    if (first_update_repeats == 1u) ur = 0u;
     v = allreduce_edge_lnl(partition, nccl_comm, (unsigned int)edge[0], edge[1], (unsigned int)edge[2], edge[3], (unsigned int)edge[4], freqs_indices);
   }
   clock_gettime(CLOCK_MONOTONIC, &b);

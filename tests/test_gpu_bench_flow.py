@@ -12,11 +12,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*argv, env=None, timeout=900):
+def run_bench(*argv, env=None, timeout=900, rc=0):
     e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     e.update(env or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=e, capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.returncode == rc, (r.returncode, r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout  # ONE JSON line
     return json.loads(lines[0])
@@ -32,6 +32,12 @@ def test_gpus_2_starts_two_ranks_and_runs_the_strong_scaling_flow(cut):
     assert len(out["config"]["sites_per_gpu"]) == 2 and sum(out["config"]["sites_per_gpu"]) == out["config"]["patterns"]
     assert out["value"] > 0 and out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
     assert "roofline" in out and out["t1_ms"] > 0
+    # which call is timed, and the step as the reference's pll_update_partials defines it beside it
+    assert "update_repeats = 0" in out["config"]["step"] and "update_repeats = 1" in out["config"]["step_with_class_maps"]
+    assert out["ms_per_step_with_class_maps"] > out["ms_per_step"] and out["t1_ms_with_class_maps"] > out["t1_ms"]
+    assert out["speedup_with_class_maps"] > 0 and out["value_with_class_maps"] > 0
+    assert abs(out["lnl_with_class_maps"] - out["lnl"]) <= 1e-12 * abs(out["lnl"])
+    assert out["exchange_timed"] == "peer" and len(out["cpu_affinity"]) == 2
 
 
 @pytest.mark.parametrize("reduce", ["rccl", "peer"])
@@ -54,13 +60,24 @@ def test_the_rccl_form_of_the_exchange_runs_through_the_librarys_entry_point(red
 
 def test_a_stuck_rccl_leg_does_not_cost_the_line():
     """the RCCL form of the exchange is the line's LAST leg and runs under a watchdog: when it does not come back in
-    time (here: a limit it cannot meet) rank 0 still prints the one line, complete but for that leg, and exits 0"""
+    time (here: a limit it cannot meet) rank 0 still prints the one line, complete but for that leg - and every rank
+    exits NON-ZERO: a collective that never completes is a hang, not a result"""
     out = run_bench("--gpus", "1", "--backend", "nccl", "--reduce", "peer", "--sites", "200000", "--steps", "3", "--blocks", "2", "--warmup", "2",
-                    env={"PLL_BENCH_FORCE_DIST": "1", "PLL_BENCH_FORCE_STRONG": "1", "PLL_BENCH_RCCL_LEG_TIMEOUT_S": "0.02"})
+                    env={"PLL_BENCH_FORCE_DIST": "1", "PLL_BENCH_FORCE_STRONG": "1", "PLL_BENCH_RCCL_LEG_TIMEOUT_S": "0.02"}, rc=3)
     ex = out["exchange"]
     assert "watchdog" in ex["rccl_error"] and "rccl_ms_per_step" not in ex
     assert out["scaling"] == "strong" and out["t1_ms"] > 0 and out["speedup"] > 0 and "roofline" in out
     assert out["lnl_rel_err_vs_unsharded"] <= 1e-12
+
+
+def test_repeats_line_times_both_forms_of_the_step():
+    """a SITE_REPEATS line says which call its `value` is timed with and carries the step with the class maps
+    recomputed - pll_update_partials as the reference defines it - as a second timed figure"""
+    out = run_bench("--config", "c4", "--sites", "100000", "--steps", "3", "--blocks", "2", "--warmup", "2", "--no-cpu")
+    assert "update_repeats = 0" in out["config"]["step"] and "update_repeats = 1" in out["config"]["step_with_class_maps"]
+    assert out["ms_per_step_with_class_maps"] > out["ms_per_step"] > 0
+    assert 0 < out["value_with_class_maps"] < out["value"]
+    assert abs(out["lnl_with_class_maps"] - out["lnl"]) <= 1e-12 * abs(out["lnl"])
 
 
 def test_default_line_carries_the_contract_fields():
@@ -70,6 +87,8 @@ def test_default_line_carries_the_contract_fields():
     rf, cb = out["roofline"], out["cpu_baseline"]
     assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and rf["achieved"] > 0
     assert (rf["traffic"] is None) == (rf["traffic_source"] is None)
+    assert 0 < rf["step"]["frac"] < 1 and abs(rf["step"]["ms"] - out["ms_per_step"]) < 1e-3 and "library" in rf["frac_numerator"]
+    assert "NOT a roofline fraction" in rf["unfused_equivalent"]["label"]
     assert cb["kind"] == "reference" and len(cb["samples"]) == 3 and cb["one_core"]["cores"] == 1 and cb["pattern_tip"]["value"] > 0
 
 
