@@ -88,6 +88,7 @@ struct RepPack
   unsigned sequence;
   unsigned publish;       // the call's last kernel that produces counts: the op that reports last hands the counts to the host
   unsigned has_rank;      // k_rep_fold + k_rep_scan + k_rep_rank follow this k_rep_mark (without them a large table is an error: 2)
+  unsigned has_narrow, has_general; // which builds of k_rep_mark this level's launch consists of
   unsigned max_ranges;    // site ranges per part of a large table, at most
   int fenced;             // kernels_common.h: handoff_*
 };
@@ -174,12 +175,12 @@ __device__ __forceinline__ void rep_load16(const unsigned char *m8, const unsign
 // cell 0 and is dropped afterwards), then the few atomics: one wait for LDS per group instead of one per site. Two
 // sites of the group in one cell both see the state before the group - the atomic sorts them out.
 // WHOLE: the part is the whole table (no filter); FULL: all sixteen sites lie inside the range.
-template <bool WHOLE, bool FULL>
-__device__ __forceinline__ void rep_group(const unsigned (&l)[16], const unsigned (&r)[16], unsigned nleft, unsigned s, unsigned s1, unsigned lo, unsigned pcells, unsigned *lds)
+template <bool WHOLE, bool FULL, unsigned N>
+__device__ __forceinline__ void rep_group(const unsigned (&l)[N], const unsigned (&r)[N], unsigned nleft, unsigned s, unsigned s1, unsigned lo, unsigned pcells, unsigned *lds)
 {
-  unsigned idx[16], seen[16];
+  unsigned idx[N], seen[N];
 #pragma unroll
-  for (unsigned e = 0; e < 16u; ++e)
+  for (unsigned e = 0; e < N; ++e)
   {
     const unsigned i = WHOLE ? l[e] + r[e] * nleft : l[e] + r[e] * nleft - lo;
     bool ok = WHOLE || i < pcells;
@@ -188,8 +189,28 @@ __device__ __forceinline__ void rep_group(const unsigned (&l)[16], const unsigne
     seen[e] = lds[ok ? i : 0u];
   }
 #pragma unroll
-  for (unsigned e = 0; e < 16u; ++e)
-    if ((WHOLE && FULL || idx[e] != kRepEmpty) && seen[e] > s + e) atomicMin(&lds[idx[e]], s + e);
+  for (unsigned e = 0; e < N; ++e)
+    if (((WHOLE && FULL) || idx[e] != kRepEmpty) && seen[e] > s + e) atomicMin(&lds[idx[e]], s + e);
+}
+
+// the same for sixteen sites whose maps are both bytes, in two halves straight from the loaded words: half the
+// registers (k_rep_mark_narrow is built for 64)
+template <bool WHOLE, bool FULL>
+__device__ __forceinline__ void rep_group_bytes(const uint4 &lq, const uint4 &rq, unsigned nleft, unsigned s, unsigned s1, unsigned lo, unsigned pcells, unsigned *lds)
+{
+#pragma unroll
+  for (unsigned h = 0; h < 2u; ++h)
+  {
+    const unsigned lw[2] = {h ? lq.z : lq.x, h ? lq.w : lq.y}, rw[2] = {h ? rq.z : rq.x, h ? rq.w : rq.y};
+    unsigned l[8], r[8];
+#pragma unroll
+    for (unsigned e = 0; e < 8u; ++e)
+    {
+      l[e] = (lw[e >> 2] >> (8u * (e & 3u))) & 255u;
+      r[e] = (rw[e >> 2] >> (8u * (e & 3u))) & 255u;
+    }
+    rep_group<WHOLE, FULL, 8>(l, r, nleft, s + 8u * h, s1, lo, pcells, lds);
+  }
 }
 
 // sites [s0, s1) of one op against the table part [lo, lo + pcells) in LDS. Ascending sites per thread and a look
@@ -215,11 +236,19 @@ __device__ __forceinline__ void rep_scan(crepop_p o, unsigned nleft, unsigned s0
       lnext = rep_fetch16<L8>(l8, l32, sn);
       rnext = rep_fetch16<R8>(r8, r32, sn);
     }
-    unsigned l[16], r[16];
-    rep_unpack16<L8>(lraw, l);
-    rep_unpack16<R8>(rraw, r);
-    if (s + 16u <= s1) rep_group<WHOLE, true>(l, r, nleft, s, s1, lo, pcells, lds);
-    else rep_group<WHOLE, false>(l, r, nleft, s, s1, lo, pcells, lds);
+    if (L8 && R8)
+    {
+      if (s + 16u <= s1) rep_group_bytes<WHOLE, true>(lraw.q[0], rraw.q[0], nleft, s, s1, lo, pcells, lds);
+      else rep_group_bytes<WHOLE, false>(lraw.q[0], rraw.q[0], nleft, s, s1, lo, pcells, lds);
+    }
+    else
+    {
+      unsigned l[16], r[16];
+      rep_unpack16<L8>(lraw, l);
+      rep_unpack16<R8>(rraw, r);
+      if (s + 16u <= s1) rep_group<WHOLE, true, 16>(l, r, nleft, s, s1, lo, pcells, lds);
+      else rep_group<WHOLE, false, 16>(l, r, nleft, s, s1, lo, pcells, lds);
+    }
     if (!more) return;
     lraw = lnext;
     rraw = rnext;
@@ -278,17 +307,18 @@ __device__ __forceinline__ void rep_store_count(const RepPack &p, crepop_p o, un
 
 // the other workgroups' copies of a table part folded into this workgroup's own (still in LDS): `nranges` copies of
 // `ncells` cells each, the part is cells [lo, lo + pcells), `mine` is the copy to leave out. The (copy, cell) pairs are
-// dealt out over the threads and a thread requests 32 of them before it looks at the first: every load is a trip to
+// dealt out over the threads and a thread requests BATCH of them before it looks at the first: every load is a trip to
 // the coherent level, and a loop over the copies made the tail of a launch as many trips long as an op had ranges
 // (32 ranges of a 16-cell table: 25 us of a 30 us launch).
+template <unsigned BATCH>
 __device__ __forceinline__ void rep_fold_copies(const unsigned *table, unsigned ncells, unsigned nranges, unsigned mine, unsigned lo, unsigned pcells, unsigned *lds)
 {
   const unsigned total = nranges * pcells;
-  for (unsigned base = 0; base < total; base += 32u * kRepThreads)
+  for (unsigned base = 0; base < total; base += BATCH * kRepThreads)
   {
-    unsigned t[32], cell[32];
+    unsigned t[BATCH], cell[BATCH];
 #pragma unroll
-    for (unsigned q = 0; q < 32u; ++q)
+    for (unsigned q = 0; q < BATCH; ++q)
     {
       const unsigned item = base + q * kRepThreads + threadIdx.x;
       const unsigned r = item / pcells;
@@ -296,7 +326,7 @@ __device__ __forceinline__ void rep_fold_copies(const unsigned *table, unsigned 
       t[q] = item < total && r != mine ? rep_coherent_load(table + (size_t)r * ncells + lo + cell[q]) : kRepEmpty;
     }
 #pragma unroll
-    for (unsigned q = 0; q < 32u; ++q)
+    for (unsigned q = 0; q < BATCH; ++q)
       if (t[q] != kRepEmpty && lds[cell[q]] > t[q]) atomicMin(&lds[cell[q]], t[q]);
   }
 }
@@ -364,10 +394,16 @@ __device__ __forceinline__ RepSplit rep_split(const RepPack &p, crepop_p o, unsi
   return sp;
 }
 
-// Launch: rep_place with mark_wgs workgroups per op.
-__global__ __launch_bounds__(kRepThreads) void k_rep_mark(const RepPack p)
+// k_rep_mark comes in two builds. Where all sites x ops of the work are - next to the tips - the tables are small and
+// both children's maps are bytes: that form alone needs few registers, and built by itself (k_rep_mark_narrow, at most 64
+// VGPRs) FOUR of its workgroups fit a CU instead of two: the whole grid is resident at once (a launch of 1024
+// workgroups took two rounds of them: 23 us for a 10 us chain on a 125k-site shard) and the VALU-bound scan has twice
+// the waves to issue from. Everything else - 32-bit maps, large tables - is the general build. A level's launch
+// consists of the builds its ops may need (the host knows bounds); an op is taken by the build its actual counts ask
+// for; parents that stay uncompressed are reported by the general build if it is there.
+template <bool NARROW>
+__device__ __forceinline__ void rep_mark(const RepPack &p, unsigned *rep_lds)
 {
-  extern __shared__ unsigned rep_lds[];
   __shared__ unsigned s_count;
   __shared__ unsigned s_last;
   unsigned opi, w;
@@ -375,17 +411,20 @@ __global__ __launch_bounds__(kRepThreads) void k_rep_mark(const RepPack p)
   crepop_p o = (crepop_p)(uintptr_t)p.ops + opi;
   const RepShape sh = rep_shape(p, o);
   const bool large = sh.ncells > kRepSmallCells;
+  const bool publishes = !p.has_rank; // no k_rep_scan behind this launch: the counts are handed over here
   if (!sh.on || (large && !p.has_rank))
   {
-    if (w != 0u) return;
+    if (w != 0u || NARROW != !p.has_general) return;
     const unsigned long long cells = (unsigned long long)sh.nl * sh.nr;
     // 1: a table the slice cannot hold although the rule admits it - the host's bound was wrong; 2: a large table in
     // a launch that came without the kernels for it - the host's forecast was wrong
     const bool overflow = !sh.on && cells > (unsigned long long)o->slice && (o->force || (cells < (unsigned long long)p.lookup && sh.nl <= p.sites / 2u && sh.nr <= p.sites / 2u));
     rep_store_count(p, o, 0u, overflow ? 1u : sh.on ? 2u : 0u);
-    if (!p.has_rank) rep_arrive(p);
+    if (publishes) rep_arrive(p);
     return;
   }
+  const bool narrow_op = !large && sh.nl <= kRepNarrow && sh.nr <= kRepNarrow;
+  if (NARROW ? !narrow_op : (narrow_op && p.has_narrow)) return; // the other build's
   const unsigned ncells = sh.ncells;
   const RepSplit sp = rep_split(p, o, ncells);
   const unsigned used = sp.looped ? (sp.nparts < p.mark_wgs ? sp.nparts : p.mark_wgs) : sp.nparts * sp.nranges;
@@ -398,7 +437,8 @@ __global__ __launch_bounds__(kRepThreads) void k_rep_mark(const RepPack p)
     // the whole table in LDS; the op's last workgroup folds the ranges and numbers the classes
     for (unsigned i = threadIdx.x; i < ncells; i += kRepThreads) rep_lds[i] = kRepEmpty;
     __syncthreads();
-    rep_scan_forms<true>(o, sh, s0, s1, 0u, ncells, rep_lds);
+    if (NARROW) rep_scan<true, true, true>(o, sh.nl, s0, s1, 0u, ncells, rep_lds);
+    else rep_scan_forms<true>(o, sh, s0, s1, 0u, ncells, rep_lds);
     __syncthreads();
     if (sp.nranges > 1u)
     {
@@ -421,14 +461,15 @@ __global__ __launch_bounds__(kRepThreads) void k_rep_mark(const RepPack p)
       }
       __syncthreads();
       if (!s_last) return;
-      rep_fold_copies(o->table, ncells, sp.nranges, range, 0u, ncells, rep_lds);
+      rep_fold_copies<NARROW ? 8 : 32>(o->table, ncells, sp.nranges, range, 0u, ncells, rep_lds);
       __syncthreads();
     }
     const unsigned classes = rep_rank_small(o, ncells, sh.nl, rep_lds, &s_count);
     rep_store_count(p, o, kRepFlag | classes, 0u);
-    if (!p.has_rank) rep_arrive(p);
+    if (publishes) rep_arrive(p);
     return;
   }
+  if (NARROW) return; // (not reached: a large table is never the narrow build's)
   // large: this workgroup's copy of its part(s) for k_rep_fold, plain stores
   const unsigned pc = (ncells + sp.nparts - 1u) / sp.nparts; // cells per part (<= mark_lds_cells)
   for (unsigned part = sp.looped ? w : w % sp.nparts; part < sp.nparts; part += sp.looped ? used : sp.nparts)
@@ -443,6 +484,19 @@ __global__ __launch_bounds__(kRepThreads) void k_rep_mark(const RepPack p)
     for (unsigned i = threadIdx.x; i < pcells; i += kRepThreads) dst[i] = rep_lds[i];
     __syncthreads(); // rep_lds is reused by the next part
   }
+}
+
+// Launch: rep_place with mark_wgs workgroups per op.
+__global__ __launch_bounds__(kRepThreads, 8) void k_rep_mark_narrow(const RepPack p)
+{
+  extern __shared__ unsigned rep_lds[];
+  rep_mark<true>(p, rep_lds);
+}
+
+__global__ __launch_bounds__(kRepThreads) void k_rep_mark(const RepPack p)
+{
+  extern __shared__ unsigned rep_lds[];
+  rep_mark<false>(p, rep_lds);
 }
 
 // Large tables, second step: the copies of the ranges folded - first[cell] = the lowest over them, left in copy 0 - and

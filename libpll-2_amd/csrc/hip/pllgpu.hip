@@ -172,7 +172,10 @@ struct pllgpu_ctx
   DevBuf<unsigned char> chain_dev;  // its descriptors
   // level-scheduled lists: the launches of a planned list are kept (descriptor packs by value) and replayed
   // as they are when the same list comes again while nothing they point at has moved (LevelPlan below)
-  unsigned long long maps_epoch = 1; // bumped whenever class maps / class counts of a node change
+  unsigned long long maps_epoch = 1; // bumped whenever the SHAPE of the class maps changes: a node's class count, the children its entry maps
+                                     // were built for, the form of its site -> class map (cached launches carry counts and pointers)
+  unsigned long long maps_version = 1; // bumped whenever class maps are written at all (data derived from their CONTENTS: k_sub_pack)
+  std::vector<unsigned char> map_widened; // per node: a launch reads the 32-bit form although the class kernels write bytes (wide_map)
   std::vector<struct LevelPlan *> level_plans;
   struct LevelPlan *recording = nullptr;
   int launch_rc = 0;                // a launch helper that failed inside emit()
@@ -196,7 +199,7 @@ struct pllgpu_ctx
   std::vector<SubItem> sub_cache, sub_build; // ... and what that array holds / the list being planned
   unsigned long long sub_epoch = 0;
   DevBuf<unsigned long long> sub_packed; // k_sub_pack: per sub-tree op and entry, the tip codes below it
-  bool sub_pack_valid = false;           // ... formed for the descriptors on the device, the class maps (maps_epoch) ...
+  bool sub_pack_valid = false;           // ... formed for the descriptors on the device, the class maps (maps_version) ...
   unsigned long long sub_pack_maps = 0, sub_pack_tips = 0, tips_epoch = 1; // ... and the tip data (tips_epoch) of now
 };
 
@@ -446,6 +449,7 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   c->id_site.resize(geo->nodes);
   c->site_id8.resize(geo->nodes);
   c->map_forms.assign(geo->nodes, 0);
+  c->map_widened.assign(geo->nodes, 0);
   c->lent.resize(geo->nodes);
   c->rent.resize(geo->nodes);
   c->rep_left.assign(geo->nodes, -1);
@@ -745,6 +749,8 @@ extern "C" int pllgpu_repeats_upload(pllgpu_ctx_t *c, unsigned node, const unsig
   if (node >= c->geo.nodes) return fail(PLLGPU_EINVAL, "node %u out of range", node);
   c->ids[node] = ids;
   ++c->maps_epoch;
+  ++c->maps_version;
+  c->map_widened[node] = 0;
   c->rep_left[node] = c->rep_right[node] = -1; // host-built maps: no entry-indexed child maps
   c->map_forms[node] = 0;
   if (!ids) return 0;
@@ -768,6 +774,7 @@ static const unsigned *wide_map(pllgpu_ctx *c, unsigned node)
   const unsigned n = (unsigned)map_elems(c);
   hipLaunchKernelGGL(k_rep_widen, dim3((n / 16u + 255u) / 256u), dim3(256), 0, c->stream, c->site_id8[node].p, c->site_id[node].p, n);
   c->map_forms[node] |= kMap32;
+  c->map_widened[node] = 1; // from now on the class kernels' bytes are followed by this form again (pllgpu_repeats_classes)
   return c->site_id[node].p;
 }
 
@@ -2739,7 +2746,11 @@ extern "C" int pllgpu_repeats_set_ids(pllgpu_ctx_t *c, unsigned node, unsigned i
 {
   CHECK_CTX(c);
   if (node >= c->geo.nodes) return fail(PLLGPU_EINVAL, "node %u out of range", node);
-  if (c->ids[node] != ids) ++c->maps_epoch;
+  if (c->ids[node] != ids)
+  {
+    ++c->maps_epoch;
+    ++c->maps_version;
+  }
   c->ids[node] = ids;
   if (!ids) c->rep_left[node] = c->rep_right[node] = -1;
   return 0;
@@ -2835,7 +2846,8 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
   struct Launch
   {
     unsigned first, n, wgs, mark_lds, assign_lds;
-    bool rank; // some op's table may be a large one: k_rep_scan + k_rep_rank between k_rep_mark and k_rep_assign
+    bool rank; // some op's table may be a large one: k_rep_fold + k_rep_scan + k_rep_rank between k_rep_mark and k_rep_assign
+    bool narrow, general; // the builds of k_rep_mark its ops may need (kernels_repeats.h)
   };
   std::vector<Launch> launches;
   std::vector<RepOp> &rops = c->rep_ops_host;
@@ -2845,9 +2857,10 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
   {
     unsigned room = 0;
     while (done + room < ncut && room < (unsigned)kRepOps && ops[done + room].level == ops[done].level) ++room;
-    // workgroups per op: ~1024 per launch (how they split into table parts and site ranges: k_rep_mark)
-    const unsigned wgs = c->rep_wgs ? c->rep_wgs : std::max(1u, std::min(64u, (1024u + room - 1u) / room));
-    Launch L = {done, 0, wgs, kRepSmallCells, 64, false};
+    // workgroups per op: ~512 per launch - all resident at once, and on a 125k-site shard measurably better than 1024
+    // (how they split into table parts and site ranges: k_rep_mark)
+    const unsigned wgs = c->rep_wgs ? c->rep_wgs : std::max(1u, std::min(64u, (512u + room - 1u) / room));
+    Launch L = {done, 0, wgs, kRepSmallCells, 64, false, false, false};
     size_t cells = 0;
     for (unsigned k = 0; k < room; ++k)
     {
@@ -2857,6 +2870,12 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
       // while its parts are fewer than the workgroups
       const size_t slice = ((ub <= kRepSmallCells ? ub * wgs : std::max(ub, std::min(ub * c->rep_max_ranges, (size_t)kRepLdsCells * wgs))) + 3u) & ~(size_t)3u;
       if (ub > kRepSmallCells) L.rank = true;
+      {
+        const unsigned long long bl = ops[i].lsrc >= 0 ? ub_classes[ops[i].lsrc] : ops[i].nleft, br = ops[i].rsrc >= 0 ? ub_classes[ops[i].rsrc] : ops[i].nright;
+        // the narrow build for the ops that are its for sure; an op that only may turn out so goes with the general build
+        if (bl <= kRepNarrow && br <= kRepNarrow && ub <= kRepSmallCells) L.narrow = true;
+        else L.general = true;
+      }
       if (k && cells + slice > table_cap) break;
       RepOp &r = rops[i];
       const pllgpu_repop_t &o = ops[i];
@@ -2932,10 +2951,16 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     const bool last = li + 1 == launches.size();
     pk.has_rank = L.rank ? 1u : 0u;
     pk.publish = last && !L.rank ? 1u : 0u;
-    const size_t mark_bytes = (size_t)L.mark_lds * sizeof(unsigned);
-    raise_lds_limit((const void *)k_rep_mark, c->device, mark_bytes);
-    hipLaunchKernelGGL(k_rep_mark, dim3((L.n + 7u) / 8u * 8u * L.wgs), dim3(kRepThreads), mark_bytes, c->stream, pk);
     const unsigned n8 = (L.n + 7u) / 8u * 8u;
+    pk.has_narrow = L.narrow ? 1u : 0u;
+    pk.has_general = L.general || !L.narrow ? 1u : 0u;
+    if (pk.has_narrow) hipLaunchKernelGGL(k_rep_mark_narrow, dim3(n8 * L.wgs), dim3(kRepThreads), kRepSmallCells * sizeof(unsigned), c->stream, pk);
+    if (pk.has_general)
+    {
+      const size_t mark_bytes = (size_t)L.mark_lds * sizeof(unsigned);
+      raise_lds_limit((const void *)k_rep_mark, c->device, mark_bytes);
+      hipLaunchKernelGGL(k_rep_mark, dim3(n8 * L.wgs), dim3(kRepThreads), mark_bytes, c->stream, pk);
+    }
     if (L.rank)
     {
       hipLaunchKernelGGL(k_rep_fold, dim3(n8 * kRepFoldTiles), dim3(kRepFoldThreads), 0, c->stream, pk);
@@ -2999,21 +3024,36 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
       c->rep_hint_any = true;
       c->rep_hint_level = std::max(c->rep_hint_level, ops[i].level);
     }
-  ++c->maps_epoch;
+  // cached launches (LevelPlan) carry class counts and pointers, not contents: they stay valid when this call found what the
+  // last one found - the re-evaluation of one tree, again and again, with the reference's pll_update_partials
+  bool reshaped = false;
   for (unsigned i = 0; i < count; ++i)
   {
     const unsigned word = counts_out[i], classes = word & ~kRepFlag;
     const unsigned parent = ops[i].parent;
     if (!(word & kRepFlag))
     {
+      reshaped = reshaped || c->rep_left[parent] != -1 || c->rep_right[parent] != -1 || c->map_forms[parent] != 0;
       c->rep_left[parent] = c->rep_right[parent] = -1;
       c->map_forms[parent] = 0;
+      c->map_widened[parent] = 0;
       continue;
     }
     if ((unsigned long long)classes > ub_cells[i]) return fail(PLLGPU_ERUNTIME, "class maps: op %u reports %u classes of at most %llu", i, classes, ub_cells[i]);
+    const unsigned char form = classes <= kRepNarrow ? kMap8 : kMap32;
+    reshaped = reshaped || c->rep_left[parent] != (int)ops[i].left || c->rep_right[parent] != (int)ops[i].right || !(c->map_forms[parent] & form);
     c->rep_left[parent] = (int)ops[i].left;
     c->rep_right[parent] = (int)ops[i].right;
-    c->map_forms[parent] = classes <= kRepNarrow ? kMap8 : kMap32;
+    c->map_forms[parent] = form;
+    if (form == kMap8 && c->map_widened[parent])
+    {
+      // a cached launch reads this node's 32-bit form: bring it up to date behind the bytes
+      c->map_widened[parent] = 0;
+      if (!wide_map(c, parent)) return fail(PLLGPU_ENOMEM, "class maps: no room for the 32-bit form of node %u", parent);
+    }
   }
+  if (reshaped) ++c->maps_epoch;
+  ++c->maps_version;
+  HIP_TRY(hipGetLastError());
   return 0;
 }

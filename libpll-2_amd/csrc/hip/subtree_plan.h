@@ -144,7 +144,7 @@ static unsigned launch_subtrees(pllgpu_ctx *c, unsigned nsub)
 {
   const SubItem *items = reinterpret_cast<const SubItem *>(c->sub_dev.p);
   unsigned launches = 0;
-  const bool stale = !c->sub_pack_valid || c->sub_pack_maps != c->maps_epoch || c->sub_pack_tips != c->tips_epoch;
+  const bool stale = !c->sub_pack_valid || c->sub_pack_maps != c->maps_version || c->sub_pack_tips != c->tips_epoch;
   for (unsigned first = 0; first < nsub; first += (unsigned)kSubItemsPerLaunch, ++launches)
   {
     const unsigned n = std::min(nsub - first, (unsigned)kSubItemsPerLaunch);
@@ -165,7 +165,7 @@ static unsigned launch_subtrees(pllgpu_ctx *c, unsigned nsub)
       hipLaunchKernelGGL(k_partials_dna_sub<1>, grid, block, 0, c->stream, items + first, tiles, n);
   }
   c->sub_pack_valid = true;
-  c->sub_pack_maps = c->maps_epoch;
+  c->sub_pack_maps = c->maps_version;
   c->sub_pack_tips = c->tips_epoch;
   return launches;
 }

@@ -147,7 +147,27 @@ void pll_update_partials_rep(pll_partition_t *p, const pll_operation_t *ops, uns
       fail_loudly("pll_update_partials");
       return;
     }
-  if (x->fast_valid && count == x->fast_count && !(update_repeats && pll_repeats_enabled(p)) && !x->always_upload && !x->eager_mirror &&
+  const int rep = pll_repeats_enabled(p);
+  unsigned int *level = NULL;
+  int *war = NULL;
+  unsigned int nlevels = 0;
+  if (rep && update_repeats)
+  {
+    /* site-repeats class maps first: a parent's classes derive from its children's (src/partials.c:256-257) - on the
+     * device, every dependency level in one call. When they come out as they were (the same tree evaluated again with
+     * the reference's pll_update_partials), the list classified by the last whole pass is still right: fast path below */
+    if (!grow_scratch(p, x, count))
+    {
+      pll_set_error(PLL_ERROR_MEM_ALLOC, "pll_update_partials: out of memory");
+      fail_loudly("pll_update_partials");
+      return;
+    }
+    level = (unsigned int *)(x->gops + count); /* second half of the scratch block */
+    war = (int *)(level + count);
+    nlevels = assign_levels(p, x, ops, count, level, war);
+    if (!pll_update_repeats_device(p, x, ops, count, level, nlevels)) BAIL();
+  }
+  if (x->fast_valid && count == x->fast_count && !x->always_upload && !x->eager_mirror &&
       memcmp(ops, x->fast_ops, (size_t)count * sizeof *ops) == 0 && nothing_dirty(p, x))
   {
     if (pllgpu_update_partials(x->ctx, x->gops, count) != 0)
@@ -167,14 +187,12 @@ void pll_update_partials_rep(pll_partition_t *p, const pll_operation_t *ops, uns
     return;
   }
 
-  unsigned int *level = (unsigned int *)(x->gops + count); /* second half of the scratch block */
-  int *war = (int *)(level + count);
-  const unsigned int nlevels = assign_levels(p, x, ops, count, level, war);
-
-  /* 1. site-repeats class maps: a parent's classes derive from its children's
-   *    (src/partials.c:256-257) - on the device, one dependency level at a time */
-  const int rep = pll_repeats_enabled(p);
-  if (rep && update_repeats && !pll_update_repeats_device(p, x, ops, count, level, nlevels)) BAIL();
+  if (!level)
+  {
+    level = (unsigned int *)(x->gops + count); /* second half of the scratch block */
+    war = (int *)(level + count);
+    nlevels = assign_levels(p, x, ops, count, level, war);
+  }
 
   /* 2. bring inputs up to date on the device */
   if (!pll_flush_model(p, x)) BAIL();

@@ -243,7 +243,7 @@ static void adopt_classes(pll_partition_t *p, const pll_operation_t *op, unsigne
 
 /* one piece of work for pllgpu_repeats_classes and what follows its counts */
 static int classes_call(pll_partition_t *p, pll_amd_ext_t *x, const pll_operation_t *ops, pllgpu_repop_t *rop,
-                        const unsigned int *idx, unsigned int n, unsigned int *counts)
+                        const unsigned int *idx, unsigned int n, unsigned int *counts, int *changed)
 {
   pll_repeats_t *r = p->repeats;
   unsigned int k;
@@ -259,6 +259,10 @@ static int classes_call(pll_partition_t *p, pll_amd_ext_t *x, const pll_operatio
     const unsigned int parent = op->parent_clv_index;
     const int enabled = (counts[k] & PLLGPU_REPEATS_COMPRESSED) != 0;
     const unsigned int classes = counts[k] & ~PLLGPU_REPEATS_COMPRESSED;
+    /* the same classes as before (a re-evaluation of the same tree): what pll_update_partials classified stays right */
+    if (x->repeats_count[parent] != (enabled ? classes : 0) || r->pernode_ids[parent] != (enabled && classes < p->sites ? classes : 0) ||
+        r->pernode_allocated_clvs[parent] != (enabled ? classes : p->sites))
+      *changed = 1;
     adopt_classes(p, op, classes, enabled);
     x->repeats_stale[parent] = enabled ? 1 : 0;
     x->repeats_count[parent] = enabled ? classes : 0;
@@ -280,11 +284,17 @@ static int classes_call(pll_partition_t *p, pll_amd_ext_t *x, const pll_operatio
 int pll_update_repeats_device(pll_partition_t *p, pll_amd_ext_t *x, const pll_operation_t *ops,
                               unsigned int count, const unsigned int *level, unsigned int nlevels)
 {
+  const int was_fast = x->fast_valid;
+  int changed = 0;
   x->fast_valid = 0;
   pll_repeats_t *r = p->repeats;
   unsigned int l, i, n;
   int ok = PLL_FAILURE;
-  if (!r->lookup_buffer) pll_resize_repeats_lookup(p, PLL_REPEATS_LOOKUP_SIZE); /* its SIZE bounds the pair table */
+  if (!r->lookup_buffer)
+  {
+    pll_resize_repeats_lookup(p, PLL_REPEATS_LOOKUP_SIZE); /* its SIZE bounds the pair table */
+    changed = 1;
+  }
   pllgpu_repop_t *rop = (pllgpu_repop_t *)malloc(sizeof(pllgpu_repop_t) * count);
   unsigned int *idx = (unsigned int *)malloc(sizeof(unsigned int) * 2 * count);
   int *producer = (int *)malloc(sizeof(int) * (p->nodes ? p->nodes : 1));
@@ -341,7 +351,7 @@ int pll_update_repeats_device(pll_partition_t *p, pll_amd_ext_t *x, const pll_op
     free(start);
     free(pos);
     if (failed) goto done;
-    ok = classes_call(p, x, ops, rop, idx, count, counts);
+    ok = classes_call(p, x, ops, rop, idx, count, counts, &changed);
   }
   else
   {
@@ -357,6 +367,7 @@ int pll_update_repeats_device(pll_partition_t *p, pll_amd_ext_t *x, const pll_op
         x->repeats_dirty[parent] = 0;
         if (!r->enable_repeats(p, left, right))
         {
+          if (x->repeats_count[parent] || r->pernode_ids[parent] || r->pernode_allocated_clvs[parent] != p->sites) changed = 1;
           adopt_classes(p, op, 0, 0);
           x->repeats_stale[parent] = 0;
           x->repeats_count[parent] = 0;
@@ -380,14 +391,17 @@ int pll_update_repeats_device(pll_partition_t *p, pll_amd_ext_t *x, const pll_op
         idx[n++] = i;
         if (n == PLLGPU_REPEATS_MAX_OPS)
         {
-          ok = classes_call(p, x, ops, rop, idx, n, counts);
+          ok = classes_call(p, x, ops, rop, idx, n, counts, &changed);
           n = 0;
         }
       }
-      if (ok) ok = classes_call(p, x, ops, rop, idx, n, counts);
+      if (ok) ok = classes_call(p, x, ops, rop, idx, n, counts, &changed);
     }
   }
   if (ok && x->eager_mirror) ok = pll_gpu_sync_repeats(p, -1);
+  /* every class count as it was: the classified list of the last whole pll_update_partials (partials.c: fast path) is
+   * still the right one */
+  if (ok && !changed) x->fast_valid = was_fast;
   goto done;
 gpu_fail:
   pll_set_gpu_error("pll_update_repeats");
