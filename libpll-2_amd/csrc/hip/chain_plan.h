@@ -368,7 +368,7 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
         return rc;
       }
   {
-    std::stable_sort(groups.begin(), groups.end(), [](const FusedGroup &x, const FusedGroup &y) { return x.level < y.level; });
+    sort_groups_by_level(groups); // (ga / gb of the fifteen-op groups are indices into this list: they move with it)
     if (int rc = build_cc_launches(c, ops, groups, 0, groups.size(), pl->cc))
     {
       delete pl;

@@ -18,6 +18,28 @@ struct FusedGroup
   bool absorbed = false;                  // a complete 8-tip group that a fifteen-op group evaluates: not launched on its own
 };
 
+// the group list ordered by level (stable), with the group indices some groups hold (ga / gb) following their groups
+static void sort_groups_by_level(std::vector<FusedGroup> &groups)
+{
+  if (std::is_sorted(groups.begin(), groups.end(), [](const FusedGroup &x, const FusedGroup &y) { return x.level < y.level; })) return;
+  std::vector<size_t> order(groups.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return groups[x].level < groups[y].level; });
+  std::vector<int> now_at(groups.size());
+  std::vector<FusedGroup> sorted(groups.size());
+  for (size_t i = 0; i < order.size(); ++i)
+  {
+    now_at[order[i]] = (int)i;
+    sorted[i] = groups[order[i]];
+  }
+  for (FusedGroup &g : sorted)
+  {
+    if (g.ga >= 0) g.ga = now_at[g.ga];
+    if (g.gb >= 0) g.gb = now_at[g.gb];
+  }
+  groups.swap(sorted);
+}
+
 static int child_kind(const pllgpu_op_t &prod)
 {
   const bool lt = prod.flags & PLLGPU_OP_LEFT_TIP, rt = prod.flags & PLLGPU_OP_RIGHT_TIP;

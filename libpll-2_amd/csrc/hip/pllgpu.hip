@@ -1432,7 +1432,7 @@ static int plan_and_launch_levels(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigne
   }
   size_t gi_sorted = 0;
   if (!groups.empty())
-    std::stable_sort(groups.begin(), groups.end(), [](const FusedGroup &x, const FusedGroup &y) { return x.level < y.level; });
+    sort_groups_by_level(groups);
   unsigned i = 0;
   unsigned level = 0;
   const unsigned last_level = count ? ops[count - 1].level : 0;

@@ -2,11 +2,11 @@
  * updates, :1295-1414 log-likelihoods; bodies in src/core_partials.c and src/core_likelihood.c).
  *
  * The reference's partition-level functions call these with pointers into the partition; a caller
- * that uses them directly hands over raw HOST arrays. Each call here wraps the arrays in a throw-away
- * partition (layout from the PLL_ATTRIB_ARCH_* bits of `attrib`, scaler mode from
- * PLL_ATTRIB_RATE_SCALERS), runs the same device path as the partition-level API and copies the result
- * back. Functionally complete; priced at an allocation and a PCIe round trip per call - the
- * partition-level entry points are the ones to use for speed.
+ * that uses them directly hands over raw HOST arrays. Each call here wraps the arrays in a partition of
+ * the call's shape (layout from the PLL_ATTRIB_ARCH_* bits of `attrib`, scaler mode from
+ * PLL_ATTRIB_RATE_SCALERS; kept per thread and shape: seam_open), runs the same device path as the
+ * partition-level API and copies the result back. Functionally complete; priced at a PCIe round trip
+ * per call - the partition-level entry points are the ones to use for speed.
  *
  * Tip children (the `ti` / `tt` forms) arrive as encoded characters: their 0/1 indicator vectors are
  * formed on the host and the update runs as inner x inner - the same arithmetic (a tip's vector is what
@@ -21,26 +21,116 @@ typedef struct
 {
   pll_partition_t *p;
   unsigned int span; /* doubles per entry in the caller's layout */
+  int slot;          /* where the partition lives in this thread's cache, or -1: destroyed by seam_close */
 } seam_t;
+
+/* A caller that loops over these entry points - the reference's own partition-level functions do, once per operation -
+ * comes with the same shapes again and again: the partition behind a call (device context, stream, buffers) is kept,
+ * per thread, and the next call of the same shape finds it (round 4 paid an allocation, a stream and their release
+ * per call). A few shapes at a time (update + evaluation + derivative calls of one loop); PLL_AMD_SEAM_CACHE=0: none.
+ * A thread's partitions are destroyed when it exits; the main thread's stay until the process ends. */
+#include <pthread.h>
+#define SEAM_SLOTS 6
+typedef struct
+{
+  pll_partition_t *p;
+  unsigned int key[7];
+  unsigned long long used;
+  int busy;
+} seam_slot_t;
+static __thread seam_slot_t seam_slots[SEAM_SLOTS];
+static __thread unsigned long long seam_clock;
+static pthread_key_t seam_key;
+static pthread_once_t seam_once = PTHREAD_ONCE_INIT;
+
+static void seam_thread_exit(void *slots_)
+{
+  seam_slot_t *slots = (seam_slot_t *)slots_;
+  for (int i = 0; i < SEAM_SLOTS; ++i)
+    if (slots[i].p && !slots[i].busy)
+    {
+      pll_partition_destroy(slots[i].p);
+      slots[i].p = NULL;
+    }
+}
+static void seam_make_key(void) { (void)pthread_key_create(&seam_key, seam_thread_exit); }
+
+static int seam_cache_on(void)
+{
+  static int on = -1;
+  if (on < 0)
+  {
+    const char *v = getenv("PLL_AMD_SEAM_CACHE");
+    on = !(v && *v == '0');
+  }
+  return on;
+}
 
 static int seam_open(seam_t *s, unsigned int states, unsigned int entries, unsigned int rate_cats, unsigned int clvs,
                      unsigned int matrices, unsigned int freq_sets, unsigned int attrib)
 {
   const unsigned int attrs = (attrib & PLL_ATTRIB_ARCH_MASK) | (attrib & PLL_ATTRIB_RATE_SCALERS);
+  const unsigned int key[7] = {states, entries, rate_cats, clvs, matrices, freq_sets ? freq_sets : 1, attrs};
+  s->slot = -1;
+  s->p = NULL;
+  if (seam_cache_on())
+    for (int i = 0; i < SEAM_SLOTS; ++i)
+      if (seam_slots[i].p && !seam_slots[i].busy && memcmp(seam_slots[i].key, key, sizeof key) == 0)
+      {
+        pll_partition_t *p = seam_slots[i].p;
+        /* what a former call may have left behind and this one may not set: no invariant sites, no invariant
+         * proportion, pattern weights of one */
+        if (p->invariant)
+        {
+          free(p->invariant);
+          p->invariant = NULL;
+          pll_gpu_invalidate(p, PLL_GPU_DIRTY_INVARIANT, -1);
+        }
+        for (unsigned int f = 0; f < p->rate_matrices; ++f) p->prop_invar[f] = 0.0;
+        for (unsigned int k = 0; k < p->sites; ++k) p->pattern_weights[k] = 1;
+        pll_gpu_invalidate(p, PLL_GPU_DIRTY_FREQS | PLL_GPU_DIRTY_PATTERN_WEIGHTS, -1);
+        seam_slots[i].busy = 1;
+        seam_slots[i].used = ++seam_clock;
+        s->p = p;
+        s->slot = i;
+        s->span = p->states_padded * rate_cats;
+        return 1;
+      }
   /* one (unused) tip: CLV k of the seam is clv[k + 1] of the partition, scale buffer k is scale_buffer[k] */
-  s->p = pll_partition_create(1, clvs, states, entries, freq_sets ? freq_sets : 1, matrices, rate_cats, clvs, attrs);
+  s->p = pll_partition_create(1, clvs, states, entries, key[5], matrices, rate_cats, clvs, attrs);
   if (!s->p)
   {
     fprintf(stderr, "libpll_amd: pll_core_*: [%d] %s\n", pll_errno, pll_errmsg);
     return 0;
   }
   s->span = s->p->states_padded * rate_cats;
+  if (seam_cache_on())
+  {
+    /* a free slot, or the least recently used idle one */
+    int at = -1;
+    for (int i = 0; i < SEAM_SLOTS; ++i)
+      if (!seam_slots[i].busy && (at < 0 || !seam_slots[i].p || (seam_slots[at].p && seam_slots[i].used < seam_slots[at].used))) at = i;
+    if (at >= 0)
+    {
+      if (seam_slots[at].p) pll_partition_destroy(seam_slots[at].p);
+      seam_slots[at].p = s->p;
+      memcpy(seam_slots[at].key, key, sizeof key);
+      seam_slots[at].busy = 1;
+      seam_slots[at].used = ++seam_clock;
+      s->slot = at;
+      pthread_once(&seam_once, seam_make_key);
+      (void)pthread_setspecific(seam_key, seam_slots);
+    }
+  }
   return 1;
 }
 
 static void seam_close(seam_t *s)
 {
-  if (s->p) pll_partition_destroy(s->p);
+  if (s->p && s->slot >= 0)
+    seam_slots[s->slot].busy = 0;
+  else if (s->p)
+    pll_partition_destroy(s->p);
   s->p = NULL;
 }
 

@@ -224,7 +224,10 @@ void pll_gpu_group_leave(pll_gpu_group_t *g)
   if (!g) return;
   /* the last rank to leave removes the name (unless the segment was given up: then the name is gone already, and a
    * later run may own it); a killed run leaves it behind, for the next run under the name to find stale and replace */
-  if (__atomic_add_fetch(&g->hdr->left, 1u, __ATOMIC_ACQ_REL) >= g->size && !__atomic_load_n(&g->hdr->poisoned, __ATOMIC_ACQUIRE))
+  /* "removed exactly once": whoever flips `poisoned` first owns the unlink - the last leaver here, or a rank of a later
+   * run that found the segment stale (group_poison). Decided with ONE atomic: a read of the flag followed by the unlink
+   * let a later run poison, unlink and re-create the name in between, and this call then removed the NEW segment's name */
+  if (__atomic_add_fetch(&g->hdr->left, 1u, __ATOMIC_ACQ_REL) >= g->size && __atomic_exchange_n(&g->hdr->poisoned, 1u, __ATOMIC_ACQ_REL) == 0u)
     shm_unlink(g->name);
   group_unmap(g);
   free(g);
@@ -308,12 +311,15 @@ double pll_gpu_group_edge_loglikelihood(pll_partition_t *p, pll_gpu_group_t *g, 
  * derivatives of ITS sites' log-likelihood at the same branch length; the whole alignment's are their sums
  * (src/core_derivatives.c:643-849 accumulates over sites exactly like the log-likelihood does). Added in rank order, so
  * every rank holds the same bits and takes the same Newton step: the ranks' branch lengths cannot drift apart by an
- * ulp, which an arrival-order reduction would allow. A rank whose evaluation failed brings NaN. */
+ * ulp, which an arrival-order reduction would allow. A rank whose evaluation failed says so in a third value. */
 int pll_gpu_group_likelihood_derivatives(pll_partition_t *p, pll_gpu_group_t *g, int parent_scaler_index, int child_scaler_index,
                                          double branch_length, const unsigned int *params_indices, const double *sumtable,
                                          double *d_f, double *dd_f)
 {
-  double mine[2] = {NAN, NAN}, all[2] = {NAN, NAN};
+  /* {d_f, dd_f, failed}: the third value counts the ranks whose evaluation failed - an explicit word, not a NaN in the
+   * sums: a derivative that IS NaN on one shard (a site of zero likelihood) is a result, and every rank shall see it as
+   * one instead of "another rank failed" */
+  double mine[3] = {0.0, 0.0, 0.0}, all[3] = {NAN, NAN, 0.0};
   const int ok = pll_compute_likelihood_derivatives(p, parent_scaler_index, child_scaler_index, branch_length, params_indices, sumtable,
                                                     &mine[0], &mine[1]);
   if (!g)
@@ -322,14 +328,14 @@ int pll_gpu_group_likelihood_derivatives(pll_partition_t *p, pll_gpu_group_t *g,
     return ok;
   }
   const int my_errno = pll_errno;
-  if (!ok) mine[0] = mine[1] = NAN;
-  if (!pll_gpu_group_sum(g, mine, 2, all)) return PLL_FAILURE;
+  if (!ok) mine[0] = mine[1] = 0.0, mine[2] = 1.0;
+  if (!pll_gpu_group_sum(g, mine, 3, all)) return PLL_FAILURE;
   if (!ok)
   {
     pll_errno = my_errno;
     return PLL_FAILURE;
   }
-  if (isnan(all[0]) || isnan(all[1]))
+  if (all[2] != 0.0)
   {
     pll_set_error(PLL_ERROR_GPU_RUNTIME, "pll_gpu_group_likelihood_derivatives: another rank's evaluation failed");
     return PLL_FAILURE;
@@ -434,7 +440,8 @@ int pll_gpu_allreduce_prepare(pll_partition_t *p, void *comm)
 {
   pll_amd_ext_t *x = reduce_ctx(p, comm, "pll_gpu_allreduce_prepare");
   if (!x) return PLL_FAILURE;
-  if (x->reduce_comm == comm && x->reduce_pair) return PLL_SUCCESS;
+  /* (always asked again, also for the communicator prepared last: a new ncclComm_t may live at the address of a destroyed
+   * one with another number of ranks - the per-step entry point only comes here when it has nothing prepared) */
   int ranks = 0;
   const int rc = g_rccl.count(comm, &ranks);
   if (rc != 0 || ranks < 1)

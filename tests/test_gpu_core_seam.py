@@ -440,3 +440,54 @@ def test_root_loglikelihood_repeats_generic(amd_lib, ref_lib):
         out[tag] = (f(states, n, rates, dp(clv), up(site_id), up(scaler), fr, dp(rate_w), up(weights), None, None, up(fidx), dp(per)), per)
     assert out["amd"][0] == pytest.approx(out["ref"][0], rel=RTOL)
     assert np.allclose(out["amd"][1], out["ref"][1], rtol=RTOL, atol=0)
+
+
+def test_a_loop_over_the_flat_update_reuses_its_partition(amd_lib, ref_lib):
+    """a caller that loops over pll_core_update_partial_ii (src/pll.h:1049-1177) must not pay an allocation,
+    a stream and their release per call: the partition of a shape is kept per thread (core_seam.c: seam_open). 1000
+    calls at 1k sites, the last one's result against the reference's, the mean time per call, and results that do
+    not depend on what an earlier call of the same shape left behind (pattern weights, invariant sites)."""
+    import time
+    states, rates, n, arch = 4, 4, 1000, api.ARCH_AVX2
+    sp = sp_of(states, arch)
+    rng = np.random.default_rng(5)
+    lm, freqs = pmat(states, rates, sp, 0.1, 1)
+    rm, _ = pmat(states, rates, sp, 0.23, 2)
+    f = amd_lib.dll.pll_core_update_partial_ii
+    f.restype = None
+    f.argtypes = [C.c_uint] * 3 + [D, U, D, D, D, D, U, U, C.c_uint]
+    pc = aligned(np.zeros((n, rates, sp)))
+    ps = np.zeros((n, 1), dtype=np.uint32)
+    l = rand_clv(rng, n, rates, states, sp)
+    r = rand_clv(rng, n, rates, states, sp)
+    for _ in range(5):
+        f(states, n, rates, dp(pc), up(ps), dp(l), dp(r), dp(lm), dp(rm), None, None, arch)
+    t0 = time.perf_counter()
+    for i in range(1000):
+        f(states, n, rates, dp(pc), up(ps), dp(l), dp(r), dp(lm), dp(rm), None, None, arch)
+    per_call_us = (time.perf_counter() - t0) / 1000 * 1e6
+    g = ref_lib.dll.pll_core_update_partial_ii
+    g.restype = None
+    g.argtypes = f.argtypes
+    pc2 = aligned(np.zeros((n, rates, sp)))
+    ps2 = np.zeros((n, 1), dtype=np.uint32)
+    g(states, n, rates, dp(pc2), up(ps2), dp(l), dp(r), dp(lm), dp(rm), None, None, arch)
+    np.testing.assert_allclose(pc[..., :states], pc2[..., :states], rtol=RTOL, atol=0)
+    assert (ps == ps2).all()
+    print("pll_core_update_partial_ii, 1k sites, cached partition: %.1f us per call" % per_call_us)
+    assert per_call_us < 150.0, per_call_us  # (round 4: ~1.5 ms per call; the PCIe round trips of one call are ~40 us)
+    # an evaluation with pattern weights and invariant sites, then one without: the second must not see the first's
+    e = amd_lib.dll.pll_core_edge_loglikelihood_ii
+    e.restype = C.c_double
+    e.argtypes = [C.c_uint] * 3 + [D, U, D, U, D, DP, D, U, D, I, U, D, C.c_uint]
+    fp, keep = freq_ptrs(freqs, sp, 1)
+    rw = aligned(np.full(rates, 1.0 / rates))
+    fi = np.zeros(rates, dtype=np.uint32)
+    ones = np.ones(n, dtype=np.uint32)
+    heavy = np.ascontiguousarray(rng.integers(1, 9, size=n).astype(np.uint32))
+    inv = np.ascontiguousarray(rng.integers(-1, 4, size=n).astype(np.int32))
+    pinv0, pinv = np.zeros(1), np.array([0.3])
+    plain = e(states, n, rates, dp(l), None, dp(r), None, dp(lm), fp, dp(rw), up(ones), dp(pinv0), None, up(fi), None, arch)
+    other = e(states, n, rates, dp(l), None, dp(r), None, dp(lm), fp, dp(rw), up(heavy), dp(pinv), inv.ctypes.data_as(I), up(fi), None, arch)
+    again = e(states, n, rates, dp(l), None, dp(r), None, dp(lm), fp, dp(rw), up(ones), dp(pinv0), None, up(fi), None, arch)
+    assert other != plain and again == plain

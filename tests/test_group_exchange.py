@@ -159,7 +159,7 @@ def test_a_rank_seated_twice_is_an_error_not_a_hang():
 
 def test_sharded_derivatives_with_failing_ranks_return_instead_of_waiting():
     """pll_gpu_group_likelihood_derivatives when EVERY rank's evaluation fails (host-only shells here): each rank still
-    takes part in the exchange (NaN operands), gets PLL_FAILURE with its own error and nobody waits for a time-out"""
+    takes part in the exchange (its failure is counted in a third value), gets PLL_FAILURE with its own error and nobody waits for a time-out"""
     import time
     name = "/pllamd-test-" + uuid.uuid4().hex[:12]
     code = r'''
