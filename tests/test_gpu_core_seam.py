@@ -475,7 +475,23 @@ def test_a_loop_over_the_flat_update_reuses_its_partition(amd_lib, ref_lib):
     np.testing.assert_allclose(pc[..., :states], pc2[..., :states], rtol=RTOL, atol=0)
     assert (ps == ps2).all()
     print("pll_core_update_partial_ii, 1k sites, cached partition: %.1f us per call" % per_call_us)
-    assert per_call_us < 150.0, per_call_us  # (round 4: ~1.5 ms per call; the PCIe round trips of one call are ~40 us)
+    # (what remains are the call's own transfers: two CLVs and two matrices up, CLV and scaler vector back, each an
+    # API call of 10-20 us on this stack; without the kept partition a call is the creation and release of a device
+    # context on top: measured below through the A/B switch, in a child process - the switch is read once)
+    import subprocess, sys, os
+    code = ("import os,sys,time,ctypes as C,numpy as np;sys.path[:0]=[%r,%r];import test_gpu_core_seam as T;from pllamd import api;"
+            "lib=api.PllLib();f=lib.dll.pll_core_update_partial_ii;f.restype=None;f.argtypes=[C.c_uint]*3+[T.D,T.U,T.D,T.D,T.D,T.D,T.U,T.U,C.c_uint];"
+            "rng=np.random.default_rng(5);sp=4;lm,_=T.pmat(4,4,sp,0.1,1);rm,_=T.pmat(4,4,sp,0.23,2);pc=T.aligned(np.zeros((1000,4,sp)));ps=np.zeros((1000,1),dtype=np.uint32);"
+            "l=T.rand_clv(rng,1000,4,4,sp);r=T.rand_clv(rng,1000,4,4,sp);\n"
+            "for _ in range(3): f(4,1000,4,T.dp(pc),T.up(ps),T.dp(l),T.dp(r),T.dp(lm),T.dp(rm),None,None,api.ARCH_AVX2)\n"
+            "t0=time.perf_counter()\n"
+            "for _ in range(50): f(4,1000,4,T.dp(pc),T.up(ps),T.dp(l),T.dp(r),T.dp(lm),T.dp(rm),None,None,api.ARCH_AVX2)\n"
+            "print((time.perf_counter()-t0)/50*1e6)") % (os.path.dirname(os.path.abspath(__file__)), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libpll-2_amd"))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PLL_AMD_SEAM_CACHE="0"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    uncached_us = float(out.stdout.strip().splitlines()[-1])
+    print("the same without the kept partition (PLL_AMD_SEAM_CACHE=0): %.1f us per call" % uncached_us)
+    assert per_call_us < 400.0 and per_call_us * 3.0 < uncached_us, (per_call_us, uncached_us)
     # an evaluation with pattern weights and invariant sites, then one without: the second must not see the first's
     e = amd_lib.dll.pll_core_edge_loglikelihood_ii
     e.restype = C.c_double
