@@ -181,7 +181,7 @@ def cpu_baseline(case, api, driver, budget_s=4.0):
     ref = api.PllLib(O.REF_LIB)
     rep_mode = bool(case.attributes & api.SITE_REPEATS)
 
-    def leg(cores, extra_attr, samples, budget):
+    def leg(cores, extra_attr, samples, budget, maps_every_step=False):
         c2 = case
         if extra_attr:
             kw = {f: getattr(case, f) for f in case.__dataclass_fields__}
@@ -202,7 +202,7 @@ def cpu_baseline(case, api, driver, budget_s=4.0):
 
         def work(i):
             for _ in range(reps):
-                shards[i].update_partials(update_repeats=0 if rep_mode else 1)
+                shards[i].update_partials(update_repeats=0 if rep_mode and not maps_every_step else 1)
             lnls[i] = shards[i].edge_lnl(c2.edges[0], persite=False)[0]
 
         vals, walls = [], []
@@ -230,6 +230,11 @@ def cpu_baseline(case, api, driver, budget_s=4.0):
         v2, r2, w2, _ = leg(cores, api.PATTERN_TIP, 3, budget_s * 0.75)
         out["pattern_tip"] = dict(value=round(float(np.median(v2)), 2), cores=cores, samples=[round(v, 2) for v in v2],
                                   sample=f"the same with | PLL_ATTRIB_PATTERN_TIP, {r2} traversals per sample, {w2:.1f} s wall")
+    if rep_mode:
+        # the same step as the reference's pll_update_partials defines it: class maps recomputed by every traversal
+        v3, r3, w3, _ = leg(cores, 0, 3, budget_s * 0.75, maps_every_step=True)
+        out["with_class_maps"] = dict(value=round(float(np.median(v3)), 2), cores=cores, samples=[round(v, 2) for v in v3],
+                                      sample=f"the same with update_repeats = 1 on every traversal (pll_update_partials), {r3} traversals per sample, {w3:.1f} s wall")
     v1, r1, w1, _ = leg(1, 0, 1, budget_s)
     out["one_core"] = dict(value=round(v1[0], 3), cores=1, sample=f"{r1} traversals of the whole alignment on one thread, {w1:.1f} s wall")
     return out, lnl

@@ -1,13 +1,9 @@
 #!/bin/bash
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
-export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r5
-mkdir -p $O
-timeout -k 10 900 python -m pytest tests/test_gpu_walk.py -x -q > $O/t_gpu.txt 2>&1 || { tail -40 $O/t_gpu.txt; exit 1; }
-tail -3 $O/t_gpu.txt
-for v in 0 1 0 1; do PLL_AMD_NO_WALK=$v timeout -k 10 300 python bench.py --config c3 --no-cpu --steps 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('NO_WALK=$v', d['value'], d['ms_per_step'], d['roofline']['full_traversal'])"; done
-cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -- python3 $R/bench.py --config c3 --no-cpu --steps 10 > $O/prof_c3.log 2>&1
-cd $R; python tools/kstats.py $O/prof_c3
+mkdir -p gpurun_out/r5
+bash tools/pmc_sets.sh r5/pmc_c3 k_partials_mfma_cc -- --config c3 > gpurun_out/r5/pmc_c3.txt 2>&1
+tail -45 gpurun_out/r5/pmc_c3.txt
+bash tools/pmc_sets.sh r5/pmc_c5 k_partials_mfma -- --config c5 > gpurun_out/r5/pmc_c5.txt 2>&1
+tail -80 gpurun_out/r5/pmc_c5.txt
+find gpurun_out/r5/pmc_c3 gpurun_out/r5/pmc_c5 -name "*.csv" -size +5M -delete
