@@ -231,3 +231,95 @@ def test_packed_subtree_lookups_follow_maps_and_tips(amd_lib):
             assert np.array_equal(s.read_clv(case_a.edges[0][0]), fresh[tag][1]), tag
             s.update_partials(update_repeats=0)  # the cached plan and the packed words as they are
             assert s.edge_lnl(case_a.edges[0], persite=False)[0] == v
+
+
+@pytest.mark.parametrize("env", [{"PLL_AMD_REP_LEVEL_SYNC": "1"}, {"PLL_AMD_REP_HINTS": "0"}, {"PLL_AMD_REP_WGS": "1"}, {"PLL_AMD_REP_WGS": "64"},
+                                 {"PLL_AMD_REP_RANGES": "1"}, {"PLL_AMD_REP_RANGES": "16", "PLL_AMD_REP_WGS": "64"}, {"PLL_AMD_FENCED_HANDOFF": "1"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+@pytest.mark.parametrize("kw", [dict(states=4, tips=64, sites=70000, mutate_pct=4, seed=81),     # small and large tables, several ranges and parts
+                                dict(states=4, tips=16, sites=300, mutate_pct=30, seed=82)],
+                         ids=lambda k: "t%d-n%d" % (k["tips"], k["sites"]))
+def test_class_maps_do_not_depend_on_how_the_launches_are_cut(amd_lib, ref_lib, monkeypatch, kw, env):
+    """round 5: all levels in one call with the decisions on the device, against the level-by-level form with the
+    decisions on the host (PLL_AMD_REP_LEVEL_SYNC=1), without the level forecast, with other numbers of workgroups per
+    op and of site ranges per table part, with the in-model hand-off: the same maps as the reference's table walk"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    case = W.make_case("rep", attributes=api.SITE_REPEATS, **kw)
+    ops = api.make_ops(case.op_batches[0])
+    res = {}
+    for lib in (amd_lib, ref_lib):
+        with driver.Session(lib, case, api.ARCH_AVX2) as s:
+            lib.pll_update_partials(s.p, ops, len(case.op_batches[0]))
+            lib.pll_update_partials(s.p, ops, len(case.op_batches[0]))  # (the forecast of the first call, the cached launches)
+            res[lib.is_amd] = (_maps(lib, s, case.sites, through_accessors=True), s.edge_lnl(case.edges[0], persite=False)[0])
+    for node, (a, b) in enumerate(zip(res[True][0], res[False][0])):
+        assert a[0] == b[0] and a[3] == b[3] and a[4] == b[4], (node, a[0], b[0])
+        if a[0]:
+            assert (a[1] == b[1]).all() and (a[2] == b[2]).all(), node
+    assert abs(res[True][1] - res[False][1]) <= 1e-10 * abs(res[False][1])
+
+
+def test_a_wrong_level_forecast_is_repaired(amd_lib, ref_lib):
+    """the levels a class-map call launches follow where compression ended the last time (pllgpu_repeats_classes);
+    sequences that compress deeper than the last ones did must still get the reference's maps - the call notices that
+    the rule admits a parent above the launched levels and runs every level - and so must going back"""
+    import ctypes
+    shallow = W.make_case("fc", 4, tips=64, sites=4000, attributes=api.SITE_REPEATS, mutate_pct=45, seed=91)
+    deep = W.make_case("fc", 4, tips=64, sites=4000, attributes=api.SITE_REPEATS, mutate_pct=1, seed=92)
+    ops = api.make_ops(shallow.op_batches[0])
+    n = len(shallow.op_batches[0])
+    want = {}
+    for tag, c in (("shallow", shallow), ("deep", deep)):
+        with driver.Session(ref_lib, c, api.ARCH_AVX2) as s:
+            ref_lib.pll_update_partials(s.p, ops, n)
+            want[tag] = [s.part.repeats.contents.pernode_ids[i] for i in range(s.part.nodes)]
+    assert sum(1 for v in want["deep"][64:] if v) > sum(1 for v in want["shallow"][64:] if v)  # the second tree compresses further up
+    with driver.Session(amd_lib, shallow, api.ARCH_AVX2) as s:
+        cmap = (ctypes.c_ulonglong * 256)(*[int(x) for x in shallow.charmap])
+        for tag, c in (("shallow", shallow), ("deep", deep), ("shallow", shallow), ("deep", deep)):
+            for t, seq in enumerate(c.sequences):
+                assert amd_lib.pll_set_tip_states(s.p, t, cmap, seq)
+            amd_lib.pll_update_partials(s.p, ops, n)
+            got = [s.part.repeats.contents.pernode_ids[i] for i in range(s.part.nodes)]
+            assert got == want[tag], tag
+            assert np.isfinite(s.edge_lnl(shallow.edges[0], persite=False)[0])
+
+
+def test_a_callers_enable_repeats_callback_is_asked_level_by_level(amd_lib, ref_lib):
+    """pll_repeats_t::enable_repeats supplied by the caller (src/pll.h:292-297): the decision stays with the callback -
+    it sees the class counts of the levels below in pernode_ids, as in the reference's op loop - and the maps are the
+    reference's under the same callback; pll_no_enable_repeats switches compression off altogether"""
+    case = W.make_case("cb", 4, tips=32, sites=3000, attributes=api.SITE_REPEATS, mutate_pct=4, seed=95)
+    ops = api.make_ops(case.op_batches[0])
+    n = len(case.op_batches[0])
+    asked = {True: [], False: []}
+
+    def make_cb(is_amd):
+        @C.CFUNCTYPE(C.c_uint, C.POINTER(api.Partition), C.c_uint, C.c_uint)
+        def cb(p, left, right):
+            ids = p.contents.repeats.contents.pernode_ids
+            asked[is_amd].append((left, right, ids[left], ids[right]))
+            return 1 if (0 < ids[left] <= 40 and 0 < ids[right] <= 40) else 0  # an own rule: small children only
+        return cb
+
+    res = {}
+    for lib in (amd_lib, ref_lib):
+        with driver.Session(lib, case, api.ARCH_AVX2) as s:
+            cb = make_cb(lib.is_amd)
+            s.part.repeats.contents.enable_repeats = C.cast(cb, C.c_void_p).value
+            lib.pll_update_partials(s.p, ops, n)
+            res[lib.is_amd] = (_maps(lib, s, case.sites, through_accessors=True), s.edge_lnl(case.edges[0], persite=False)[0])
+    assert sorted(asked[True]) == sorted(asked[False]) and len(asked[True]) == n  # the same questions, with the same counts
+    for node, (a, b) in enumerate(zip(res[True][0], res[False][0])):
+        assert a[0] == b[0] and a[3] == b[3], (node, a[0], b[0])
+        if a[0]:
+            assert (a[1] == b[1]).all() and (a[2] == b[2]).all(), node
+    assert any(r[0] for r in res[True][0][case.tips:]) and not all(r[0] for r in res[True][0][case.tips:])
+    assert abs(res[True][1] - res[False][1]) <= 1e-10 * abs(res[False][1])
+    # the library's own "never" callback
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.part.repeats.contents.enable_repeats = C.cast(amd_lib.dll.pll_no_enable_repeats, C.c_void_p).value
+        amd_lib.pll_update_partials(s.p, ops, n)
+        assert not any(s.part.repeats.contents.pernode_ids[i] for i in range(case.tips, s.part.nodes))
+        assert abs(s.edge_lnl(case.edges[0], persite=False)[0] - res[False][1]) <= 1e-10 * abs(res[False][1])
