@@ -4,22 +4,25 @@
 // A parent's classes are the distinct pairs (left class, right class) of its sites, numbered in order of first
 // occurrence; id_site[class] is that first site. The reference walks the sites sequentially through a direct-address
 // table (cell = lid + rid * ids_left). The same numbering without the sequential walk, two launches per dependency
-// level (four where a level may hold large tables), every op of the level in each, NO host round trip between levels:
+// level (five where a level may hold large tables), every op of the level in each, NO host round trip between levels:
 //
 //   k_rep_mark    first[cell] = the lowest site of the cell. A workgroup owns a PART of the op's table (in LDS) and a
-//                 RANGE of its sites; what it finds goes to its own copy of the part in the op's slice of the arena
-//                 with plain write-through stores - no atomics on the table, nothing to clear beforehand (round 4 spent
-//                 62 % of the update on device-scope atomicMin). The workgroup that finishes a part LAST (a ticket per
-//                 part) takes the minimum over the ranges. Then the classes are numbered: a cell's class is the count
-//                 of cells with a lower first site.
+//                 RANGE of its sites; what it finds goes to its own copy of the part in the op's slice of the arena -
+//                 no atomics on the table, nothing to clear beforehand (round 4 spent 62 % of the update on
+//                 device-scope atomicMin). Two builds: k_rep_mark_narrow for small tables over byte maps (few
+//                 registers: four workgroups per CU), k_rep_mark for everything else.
 //                   small tables (<= kRepSmallCells cells: the levels next to the tips, where ops x sites is largest):
-//                     counted directly, in LDS, by that same workgroup - the op is finished inside this launch;
-//                   large tables: through a bitmap over the sites (bit s = site s is the first of its cell) and its
-//                     running bit count: the part's last workgroup sets the bits, k_rep_scan (one workgroup per op)
-//                     counts, k_rep_rank (cells in parallel) looks every cell's class up.
-//                 Either way the op leaves table[cell] = class, the class -> first site / child entry maps (the cell
-//                 index IS the pair), and its class count for the levels above.
-//   k_rep_assign  site_id[site] = table[cell(site)].
+//                     the copies are written through to the coherent level; the op's LAST workgroup (a ticket) folds
+//                     them and numbers the classes - a cell's class is the count of cells with a lower first site -
+//                     by direct counting in LDS: the op is finished inside this launch;
+//                   large tables: plain stores, and three launches follow:
+//   k_rep_fold      first[cell] = the minimum over the ranges' copies; bit first[cell] of a bitmap over the sites set
+//   k_rep_scan      one workgroup per op: the running bit count per 32-site word; the class count = all set bits
+//   k_rep_rank      a cell's class = the set bits before its first site.
+//                 Either way the op leaves table[cell] = class and its class count for the levels above.
+//   k_rep_assign  site_id[site] = table[cell(site)] (the table as 16-bit entries in LDS up to 65536 cells); large
+//                 tables: the sites the bitmap marks as first also write the class -> first site / child entry maps,
+//                 in site order = class order (small tables: the op's last workgroup wrote them).
 //
 // Whether a parent is compressed at all is decided HERE, by the reference's default rule, from the children's class
 // counts as the launches of the levels below left them in device memory: the host enqueues all levels back to back
