@@ -525,7 +525,12 @@ constexpr unsigned kCcAmbiguous = 255u; // column index of a code that is neithe
 
 template <int NG> struct CcGeo
 {
-  static constexpr unsigned LD = 4 * NG;              // row stride (doubles) of a staged matrix
+  static constexpr unsigned LD = 4 * NG + 1;          // row stride (doubles) of a staged matrix: ODD. A lane reads the tip column of ITS site's
+                                                      // code - row (column index) x LD + state - so what must not share banks are the ROWS: with 4 NG = 20
+                                                      // the 21 rows fall on 8 bank groups and lanes with different codes wait for each other (round-5 counters:
+                                                      // 40.9 M conflict cycles against 9 M cycles of active LDS instructions in C3's launch); 21 is coprime to
+                                                      // the 32 eight-byte banks. The A-operand reads (row = 4 jg + k, 16 distinct addresses) pay a two-way
+                                                      // conflict on three of them instead.
   static constexpr unsigned rows = 4 * NG + 1;        // PT rows j < S, zero rows up to 4 NG, then the row sums
   static constexpr unsigned mat = rows * LD;          // doubles per matrix
   static constexpr unsigned gap_col = 4 * NG;
