@@ -46,6 +46,8 @@ constexpr unsigned kRepAssignThreads = 1024; // ... its workgroup: 16 sites per 
 constexpr unsigned kRepScanThreads = 1024;                        // k_rep_scan workgroup
 constexpr unsigned kRepScanChunk = kRepScanThreads * 32u;         // bitmap words per round of its scan
 constexpr unsigned kRepFoldThreads = 256, kRepFoldTiles = 64;     // k_rep_fold: workgroups per op (grid-stride over the cells)
+constexpr unsigned kRepBitsCells = 1u << 18;                      // tables up to here: bitmap through k_rep_bits (no atomics on memory)
+constexpr unsigned kRepBitsMaxRanges = 32;                        // ... its workgroups per op, at most
 constexpr unsigned kRepRankThreads = 256, kRepRankTiles = 64;     // k_rep_rank: workgroups per op (grid-stride over the cells)
 constexpr unsigned kRepNarrow = 256;        // up to this many classes: site -> class map in bytes
 constexpr unsigned kRepEmpty = 0xFFFFFFFFu;
@@ -93,6 +95,7 @@ struct RepPack
   unsigned has_rank;      // k_rep_fold + k_rep_scan + k_rep_rank follow this k_rep_mark (without them a large table is an error: 2)
   unsigned has_narrow, has_general; // which builds of k_rep_mark this level's launch consists of
   unsigned max_ranges;    // site ranges per part of a large table, at most
+  unsigned bit_ranges, bit_words; // k_rep_bits follows k_rep_fold: its workgroups per op and their bitmap words each (0: k_rep_scan)
   int fenced;             // kernels_common.h: handoff_*
 };
 
@@ -502,8 +505,9 @@ __global__ __launch_bounds__(kRepThreads) void k_rep_mark(const RepPack p)
   rep_mark<false>(p, rep_lds);
 }
 
-// Large tables, second step: the copies of the ranges folded - first[cell] = the lowest over them, left in copy 0 - and
-// bit first[cell] of the op's bitmap set (shared by the whole launch grid: atomics at the coherent level).
+// Large tables, second step: the copies of the ranges folded - first[cell] = the lowest over them, left in copy 0 - and,
+// where k_rep_scan follows (tables too large for k_rep_bits' passes over the cells), bit first[cell] of the op's
+// bitmap set (shared by the whole launch grid: atomics at the coherent level).
 // Launch: rep_place with kRepFoldTiles workgroups per op, which stride over the op's cells.
 __global__ __launch_bounds__(kRepFoldThreads) void k_rep_fold(const RepPack p)
 {
@@ -536,9 +540,116 @@ __global__ __launch_bounds__(kRepFoldThreads) void k_rep_fold(const RepPack p)
       const unsigned c = base + q * kRepFoldThreads + threadIdx.x;
       if (c >= ncells) continue;
       if (nranges > 1u) table[c] = v[q];
-      if (v[q] != kRepEmpty) __hip_atomic_fetch_or(&bitmap[v[q] >> 5], 1u << (v[q] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!p.bit_ranges && v[q] != kRepEmpty) __hip_atomic_fetch_or(&bitmap[v[q] >> 5], 1u << (v[q] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+// Large tables, the bitmap WITHOUT atomics on memory (tables up to kRepBitsCells cells): workgroup b of an op owns the
+// sites of `bit_words` bitmap words, reads the first site of EVERY cell of the op (from that XCD's L2: the workgroups
+// of an op share it) and sets the bits of the first sites in its range in LDS; then the running bit count of its words
+// (from the range's start) and its total. The op's last workgroup (a ticket) turns the totals into the ranges' starting
+// counts and knows the class count. Replaces the device-scope atomicOr of k_rep_fold (0.6 M of them in C4's level 2: 37 us
+// at 1M sites, 18 us on a shard - as much as everything else at that level) and k_rep_scan's single workgroup per op.
+// Launch: rep_place with bit_ranges workgroups per op; LDS bit_words words. Every op of the launch passes here.
+__global__ __launch_bounds__(kRepScanThreads) void k_rep_bits(const RepPack p)
+{
+  extern __shared__ unsigned rep_lds[];
+  __shared__ unsigned wsum[kRepScanThreads / 64u];
+  __shared__ unsigned s_last;
+  unsigned opi, b;
+  if (!rep_place(p.nops, p.bit_ranges, opi, b)) return;
+  crepop_p o = (crepop_p)(uintptr_t)p.ops + opi;
+  const RepShape sh = rep_shape(p, o);
+  if (!sh.on || sh.ncells <= kRepSmallCells)
+  {
+    if (b == 0u) rep_arrive(p); // (its count was left by k_rep_mark)
+    return;
+  }
+  const unsigned ncells = sh.ncells, words = (p.sites + 31u) / 32u;
+  const unsigned w0 = b * p.bit_words, w1 = w0 + p.bit_words < words ? w0 + p.bit_words : words; // (w0 may lie beyond the last word: an empty range)
+  const unsigned nw = w1 > w0 ? w1 - w0 : 0u;
+  const unsigned *__restrict__ table = o->table;
+  unsigned *__restrict__ bitmap = o->bitmap, *__restrict__ wprefix = o->bitmap + p.wstride;
+  unsigned *totals = o->bitmap + 2u * (size_t)p.wstride; // [bit_ranges] totals, then [bit_ranges] starting counts
+  for (unsigned w = threadIdx.x; w < p.bit_words; w += kRepScanThreads) rep_lds[w] = 0u;
+  __syncthreads();
+  for (unsigned base = 0; base < ncells; base += 16u * kRepScanThreads)
+  {
+    unsigned v[16];
+#pragma unroll
+    for (unsigned q = 0; q < 16u; ++q)
+    {
+      const unsigned c = base + q * kRepScanThreads + threadIdx.x;
+      v[q] = c < ncells ? table[c] : kRepEmpty;
+    }
+#pragma unroll
+    for (unsigned q = 0; q < 16u; ++q)
+    {
+      const unsigned w = v[q] >> 5;
+      if (v[q] != kRepEmpty && w >= w0 && w < w1) atomicOr(&rep_lds[w - w0], 1u << (v[q] & 31u));
+    }
+  }
+  __syncthreads();
+  // running count: bit_words / 1024 consecutive words per thread (bit_words is a multiple of 1024)
+  const unsigned per = p.bit_words / kRepScanThreads, t0 = threadIdx.x * per;
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  unsigned n = 0;
+  for (unsigned q = 0; q < per; ++q) n += __popc(rep_lds[t0 + q]);
+  unsigned inc = n;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1)
+  {
+    const unsigned t = __shfl_up(inc, off, 64);
+    if ((int)lane >= off) inc += t;
+  }
+  if (lane == 63u) wsum[wave] = inc;
+  __syncthreads();
+  unsigned before = 0, total = 0;
+  for (unsigned w = 0; w < kRepScanThreads / 64u; ++w)
+  {
+    before += w < wave ? wsum[w] : 0u;
+    total += wsum[w];
+  }
+  unsigned run = before + inc - n;
+  for (unsigned q = 0; q < per; ++q)
+  {
+    const unsigned w = t0 + q, bits = rep_lds[w];
+    if (w < nw)
+    {
+      bitmap[w0 + w] = bits;
+      wprefix[w0 + w] = run;
+    }
+    run += __popc(bits);
+  }
+  // the range's total for the op's last workgroup
+  if (threadIdx.x == 0u)
+  {
+    __hip_atomic_store(&totals[b], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    handoff_before_ticket(p.fenced);
+    const unsigned t = __hip_atomic_fetch_add(&p.tickets[opi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == p.bit_ranges - 1u) ? 1u : 0u;
+    if (s_last)
+    {
+      handoff_after_last_ticket(p.fenced);
+      __hip_atomic_store(&p.tickets[opi], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0u)
+  {
+    unsigned classes = 0;
+    for (unsigned r = 0; r < p.bit_ranges; ++r)
+    {
+      totals[p.bit_ranges + r] = classes; // (plain: read by the next launch)
+      classes += rep_coherent_load(&totals[r]);
+    }
+    s_last = classes;
+  }
+  __syncthreads();
+  rep_store_count(p, o, kRepFlag | s_last, 0u);
+  rep_arrive(p);
 }
 
 // Large tables, second step: ONE workgroup per op of the launch: wprefix[w] = set bits in the words before w, the
@@ -616,10 +727,11 @@ __global__ __launch_bounds__(kRepRankThreads) void k_rep_rank(const RepPack p)
   if (!sh.on || sh.ncells <= kRepSmallCells) return;
   unsigned *__restrict__ table = o->table;
   const unsigned *__restrict__ bitmap = o->bitmap, *__restrict__ wprefix = o->bitmap + p.wstride;
+  const unsigned *__restrict__ starts = o->bitmap + 2u * (size_t)p.wstride + p.bit_ranges; // k_rep_bits: classes before each range
   const unsigned ncells = sh.ncells;
   for (unsigned base = tile * kRepRankThreads * 4u; base < ncells; base += kRepRankTiles * kRepRankThreads * 4u)
   {
-    unsigned v[4], pre[4], bits[4];
+    unsigned v[4], pre[4], bits[4], start[4];
 #pragma unroll
     for (unsigned q = 0; q < 4u; ++q)
     {
@@ -632,12 +744,14 @@ __global__ __launch_bounds__(kRepRankThreads) void k_rep_rank(const RepPack p)
       const unsigned w = v[q] != kRepEmpty ? v[q] >> 5 : 0u;
       pre[q] = wprefix[w];
       bits[q] = bitmap[w];
+      // (after k_rep_bits the running counts start anew in every range: + the classes of the ranges before)
+      start[q] = p.bit_ranges ? starts[w / p.bit_words] : 0u;
     }
 #pragma unroll
     for (unsigned q = 0; q < 4u; ++q)
     {
       const unsigned c = base + q * kRepRankThreads + threadIdx.x;
-      if (c < ncells && v[q] != kRepEmpty) table[c] = pre[q] + __popc(bits[q] & ((1u << (v[q] & 31u)) - 1u));
+      if (c < ncells && v[q] != kRepEmpty) table[c] = start[q] + pre[q] + __popc(bits[q] & ((1u << (v[q] & 31u)) - 1u));
     }
   }
 }

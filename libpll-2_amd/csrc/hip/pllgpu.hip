@@ -134,6 +134,7 @@ struct pllgpu_ctx
   unsigned rep_max_ranges = 8;           // PLL_AMD_REP_RANGES: site ranges per part of a large table, at most (kernels_repeats.h)
   unsigned rep_assign_iters = 0;         // PLL_AMD_REP_ASSIGN_ITERS: rounds per workgroup of k_rep_assign (0: by the launch's size)
   unsigned rep_assign_lds = kRepAssignLds; // PLL_AMD_REP_ASSIGN_LDS: tables up to this many cells are looked up in LDS
+  bool rep_bits = true;                  // PLL_AMD_REP_BITS=0: the bitmap of first sites by atomics + k_rep_scan for every table size (A/B)
   bool rep_hints = true;                 // PLL_AMD_REP_HINTS=0: every level of a class-map call is launched (A/B, tests)
   unsigned rep_hint_count = 0, rep_hint_level = 0; // the last call: its ops, the highest level with a compressed parent ...
   bool rep_hint_any = false;                       // ... if there was one
@@ -471,6 +472,7 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   if (const char *v = getenv("PLL_AMD_REP_WGS")) c->rep_wgs = (unsigned)std::max(0, atoi(v));
   if (const char *v = getenv("PLL_AMD_REP_ASSIGN_ITERS")) c->rep_assign_iters = (unsigned)std::max(0, atoi(v));
   if (const char *v = getenv("PLL_AMD_REP_ASSIGN_LDS")) c->rep_assign_lds = (unsigned)std::min<int>(kRepAssignLds, std::max(0, atoi(v)));
+  if (const char *v = getenv("PLL_AMD_REP_BITS")) c->rep_bits = !(*v == '0');
   if (const char *v = getenv("PLL_AMD_REP_HINTS")) c->rep_hints = !(*v == '0');
   if (const char *v = getenv("PLL_AMD_REP_RANGES")) c->rep_max_ranges = (unsigned)std::max(1, atoi(v));
   return c;
@@ -2783,6 +2785,10 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
   if (count > c->rep_host_cap) return fail(PLLGPU_EINVAL, "class maps of %u ops in one call (at most %u)", count, c->rep_host_cap);
   const unsigned words = (sites + 31u) / 32u;
   const size_t wstride = ((size_t)words + kRepScanChunk - 1u) / kRepScanChunk * kRepScanChunk;
+  // k_rep_bits: 4 ... 32 ranges of the sites per op, each a multiple of 1024 bitmap words (its LDS)
+  const unsigned bit_ranges = std::max(4u, std::min(kRepBitsMaxRanges, (words + 2047u) / 2048u));
+  const unsigned bit_words = ((words + bit_ranges - 1u) / bit_ranges + kRepScanThreads - 1u) / kRepScanThreads * kRepScanThreads;
+  const size_t op_scratch = 2u * wstride + 2u * kRepBitsMaxRanges; // per op of a launch: bitmap, running counts, the ranges' totals and starts
   const size_t table_cap = (size_t)64 << 20; // cells per launch (256 MB); a single larger op still gets its slice
   const size_t melems = map_elems(c);
   // How many of the levels to launch. The kernels decide by themselves which parents are compressed, but every level costs
@@ -2848,6 +2854,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     unsigned first, n, wgs, mark_lds, assign_lds;
     bool rank; // some op's table may be a large one: k_rep_fold + k_rep_scan + k_rep_rank between k_rep_mark and k_rep_assign
     bool narrow, general; // the builds of k_rep_mark its ops may need (kernels_repeats.h)
+    size_t max_cells;     // the largest table an op of the launch may have
   };
   std::vector<Launch> launches;
   std::vector<RepOp> &rops = c->rep_ops_host;
@@ -2860,7 +2867,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     // workgroups per op: ~512 per launch - all resident at once, and on a 125k-site shard measurably better than 1024
     // (how they split into table parts and site ranges: k_rep_mark)
     const unsigned wgs = c->rep_wgs ? c->rep_wgs : std::max(1u, std::min(64u, (512u + room - 1u) / room));
-    Launch L = {done, 0, wgs, kRepSmallCells, 64, false, false, false};
+    Launch L = {done, 0, wgs, kRepSmallCells, 64, false, false, false, 0};
     size_t cells = 0;
     for (unsigned k = 0; k < room; ++k)
     {
@@ -2870,6 +2877,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
       // while its parts are fewer than the workgroups
       const size_t slice = ((ub <= kRepSmallCells ? ub * wgs : std::max(ub, std::min(ub * c->rep_max_ranges, (size_t)kRepLdsCells * wgs))) + 3u) & ~(size_t)3u;
       if (ub > kRepSmallCells) L.rank = true;
+      L.max_cells = std::max(L.max_cells, ub);
       {
         const unsigned long long bl = ops[i].lsrc >= 0 ? ub_classes[ops[i].lsrc] : ops[i].nleft, br = ops[i].rsrc >= 0 ? ub_classes[ops[i].rsrc] : ops[i].nright;
         // the narrow build for the ops that are its for sure; an op that only may turn out so goes with the general build
@@ -2889,7 +2897,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
       r.lent = c->lent[o.parent].p;
       r.rent = c->rent[o.parent].p;
       r.table = reinterpret_cast<unsigned *>(cells); // offset for now: the arena may still grow
-      r.bitmap = reinterpret_cast<unsigned *>((size_t)k * 2u * wstride);
+      r.bitmap = reinterpret_cast<unsigned *>((size_t)k * op_scratch);
       r.lsrc = o.lsrc;
       r.rsrc = o.rsrc;
       r.nleft = o.nleft;
@@ -2912,7 +2920,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
   {
     // per op of a launch: the bitmap (zero between launches: k_rep_assign clears what k_rep_mark set), then the running counts
     const size_t had = c->rep_blocksum.cap;
-    if (int rc = c->rep_blocksum.ensure((size_t)kRepOps * 2u * wstride)) return rc;
+    if (int rc = c->rep_blocksum.ensure((size_t)kRepOps * op_scratch)) return rc;
     if (c->rep_blocksum.cap != had || c->rep_scratch_dirty) HIP_TRY(hipMemsetAsync(c->rep_blocksum.p, 0, c->rep_blocksum.cap * sizeof(unsigned), c->stream));
     if (c->rep_scratch_dirty) HIP_TRY(hipMemsetAsync(c->rep_sync.p, 0, c->rep_sync.cap * sizeof(unsigned), c->stream));
     c->rep_scratch_dirty = true; // until this call has gone through
@@ -2963,9 +2971,17 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     }
     if (L.rank)
     {
+      // the bitmap of first sites: in LDS per (op, range of sites) where the tables are small enough for every range's
+      // workgroup to read all cells (k_rep_bits), else by atomics in k_rep_fold and one workgroup per op (k_rep_scan)
+      const bool bits = c->rep_bits && L.max_cells <= kRepBitsCells;
+      pk.bit_ranges = bits ? bit_ranges : 0u;
+      pk.bit_words = bits ? bit_words : 0u;
       hipLaunchKernelGGL(k_rep_fold, dim3(n8 * kRepFoldTiles), dim3(kRepFoldThreads), 0, c->stream, pk);
       pk.publish = last ? 1u : 0u;
-      hipLaunchKernelGGL(k_rep_scan, dim3(L.n), dim3(kRepScanThreads), 0, c->stream, pk);
+      if (bits)
+        hipLaunchKernelGGL(k_rep_bits, dim3(n8 * bit_ranges), dim3(kRepScanThreads), (size_t)bit_words * sizeof(unsigned), c->stream, pk);
+      else
+        hipLaunchKernelGGL(k_rep_scan, dim3(L.n), dim3(kRepScanThreads), 0, c->stream, pk);
       hipLaunchKernelGGL(k_rep_rank, dim3(n8 * kRepRankTiles), dim3(kRepRankThreads), 0, c->stream, pk);
     }
     // k_rep_assign: a workgroup takes 1..4 rounds of 16384 sites - ~512 workgroups per launch, more rounds where a large
