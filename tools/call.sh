@@ -5,14 +5,9 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r5
 mkdir -p $O
-timeout -k 10 900 python -m pytest tests/test_gpu_repeats.py tests/test_gpu_c4_sharded.py tests/test_gpu_fuzz.py -x -q > $O/t_gpu.txt 2>&1 || { tail -40 $O/t_gpu.txt; exit 1; }
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -k "tail_fusion" > $O/t_gpu.txt 2>&1 || { tail -60 $O/t_gpu.txt; exit 1; }
 tail -3 $O/t_gpu.txt
-S="'' PLL_AMD_REP_BITS=0"
-eval timeout -k 10 300 python tools/rep_ab.py 1000000 bench $S > $O/ab_1m.txt 2>&1; cat $O/ab_1m.txt
-eval timeout -k 10 300 python tools/rep_ab.py 125000 bench $S > $O/ab_125k.txt 2>&1; cat $O/ab_125k.txt
-eval timeout -k 10 300 python tools/rep_ab.py 125000 mutated $S > $O/ab_125k_mut.txt 2>&1; cat $O/ab_125k_mut.txt
-eval timeout -k 10 300 python tools/rep_ab.py 1000000 mutated $S > $O/ab_1m_mut.txt 2>&1; cat $O/ab_1m_mut.txt
+for v in 0 1 0 1 0 1; do PLL_AMD_NO_TAIL_FUSION=$v timeout -k 10 300 python bench.py --config c3 --no-cpu --steps 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('NO_TAIL_FUSION=$v', d['value'], d['ms_per_step'], d['lnl'])"; done
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c4 -- python3 $R/tools/rep_ab.py 1000000 bench > $O/prof_c4.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c4s -- python3 $R/tools/rep_ab.py 125000 bench > $O/prof_c4s.log 2>&1
-find $O -name "*kernel_trace.csv" -size +30M -delete
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -- python3 $R/bench.py --config c3 --no-cpu --steps 10 > $O/prof_c3.log 2>&1
+cd $R; python tools/kstats.py $O/prof_c3
