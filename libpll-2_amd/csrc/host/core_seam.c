@@ -79,16 +79,27 @@ static int seam_open(seam_t *s, unsigned int states, unsigned int entries, unsig
       {
         pll_partition_t *p = seam_slots[i].p;
         /* what a former call may have left behind and this one may not set: no invariant sites, no invariant
-         * proportion, pattern weights of one */
+         * proportion, pattern weights of one - touched (and sent to the device again) only where they are not so */
         if (p->invariant)
         {
           free(p->invariant);
           p->invariant = NULL;
           pll_gpu_invalidate(p, PLL_GPU_DIRTY_INVARIANT, -1);
         }
-        for (unsigned int f = 0; f < p->rate_matrices; ++f) p->prop_invar[f] = 0.0;
-        for (unsigned int k = 0; k < p->sites; ++k) p->pattern_weights[k] = 1;
-        pll_gpu_invalidate(p, PLL_GPU_DIRTY_FREQS | PLL_GPU_DIRTY_PATTERN_WEIGHTS, -1);
+        unsigned int what = 0;
+        for (unsigned int f = 0; f < p->rate_matrices; ++f)
+          if (p->prop_invar[f] != 0.0)
+          {
+            p->prop_invar[f] = 0.0;
+            what |= PLL_GPU_DIRTY_FREQS;
+          }
+        for (unsigned int k = 0; k < p->sites; ++k)
+          if (p->pattern_weights[k] != 1)
+          {
+            p->pattern_weights[k] = 1;
+            what |= PLL_GPU_DIRTY_PATTERN_WEIGHTS;
+          }
+        if (what) pll_gpu_invalidate(p, what, -1);
         seam_slots[i].busy = 1;
         seam_slots[i].used = ++seam_clock;
         s->p = p;

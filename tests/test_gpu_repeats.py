@@ -237,7 +237,9 @@ def test_packed_subtree_lookups_follow_maps_and_tips(amd_lib):
                                  {"PLL_AMD_REP_RANGES": "1"}, {"PLL_AMD_REP_RANGES": "16", "PLL_AMD_REP_WGS": "64"}, {"PLL_AMD_FENCED_HANDOFF": "1"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 @pytest.mark.parametrize("kw", [dict(states=4, tips=64, sites=70000, mutate_pct=4, seed=81),     # small and large tables, several ranges and parts
-                                dict(states=4, tips=16, sites=300, mutate_pct=30, seed=82)],
+                                dict(states=4, tips=16, sites=300, mutate_pct=30, seed=82),
+                                dict(states=4, tips=90, sites=33333, mutate_pct=2, seed=83, tree="random"),       # levels of mixed table sizes and map forms
+                                dict(states=20, tips=120, sites=5000, mutate_pct=1, seed=84, tree="caterpillar")],  # (tip, inner) all the way: one op per level
                          ids=lambda k: "t%d-n%d" % (k["tips"], k["sites"]))
 def test_class_maps_do_not_depend_on_how_the_launches_are_cut(amd_lib, ref_lib, monkeypatch, kw, env):
     """round 5: all levels in one call with the decisions on the device, against the level-by-level form with the
