@@ -5,5 +5,5 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r5
 mkdir -p $O
-timeout -k 10 900 python -m pytest tests/test_gpu_repeats.py tests/test_gpu_core_seam.py -x -q -s > $O/t_gpu.txt 2>&1 || { tail -60 $O/t_gpu.txt; exit 1; }
-grep "us per call" $O/t_gpu.txt; tail -3 $O/t_gpu.txt
+( timeout -k 10 250 python tools/rep_stress.py 40000 300000 bench; timeout -k 10 250 python tools/rep_stress.py 30000 125000 mutated; PLL_AMD_REP_WGS=64 PLL_AMD_REP_RANGES=16 timeout -k 10 250 python tools/rep_stress.py 15000 200000 mutated ) > $O/rep_stress.txt 2>&1
+cat $O/rep_stress.txt
