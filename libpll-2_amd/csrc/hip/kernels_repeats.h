@@ -15,8 +15,13 @@
 //                     the copies are written through to the coherent level; the op's LAST workgroup (a ticket) folds
 //                     them and numbers the classes - a cell's class is the count of cells with a lower first site -
 //                     by direct counting in LDS: the op is finished inside this launch;
-//                   large tables: plain stores, and three launches follow:
-//   k_rep_fold      first[cell] = the minimum over the ranges' copies; bit first[cell] of a bitmap over the sites set
+//                   large tables: plain stores, and three launches (fold, bits | scan, rank) follow:
+//   k_rep_fold      first[cell] = the minimum over the ranges' copies
+//   k_rep_bits      tables up to kRepBitsCells cells: a workgroup per (op, range of the op's SITES) gathers the folded
+//                   table's first sites that fall into its range as a bitmap in LDS, stores its words and their running
+//                   bit counts; the op's last workgroup (a ticket) turns the ranges' totals into starts and the class
+//                   count - nothing but LDS atomics. Larger tables: the fold sets bit first[cell] with device-scope
+//                   atomicOr, and
 //   k_rep_scan      one workgroup per op: the running bit count per 32-site word; the class count = all set bits
 //   k_rep_rank      a cell's class = the set bits before its first site.
 //                 Either way the op leaves table[cell] = class and its class count for the levels above.
