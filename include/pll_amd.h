@@ -591,6 +591,9 @@ int pll_gpu_timer_start(pll_partition_t *partition);
 double pll_gpu_timer_stop(pll_partition_t *partition);
 /* number of kernel launches issued by the last pll_update_partials call (bench bookkeeping) */
 unsigned int pll_gpu_last_launch_count(const pll_partition_t *partition);
+/* 1 if the last pll_update_partials call found its operation list, and everything its classification rests on, as the
+ * call before left them and went straight to the launches (a re-evaluation of one tree); 0 if it took the whole path */
+int pll_gpu_last_update_replayed(const pll_partition_t *partition);
 /* HBM bytes the kernels of the last pll_update_partials call had to move by construction: child
  * reads + parent and scaler writes of every launch AS IT WAS GROUPED (an op evaluated together with
  * the producers of its children does not read those children back) - bench.py's roofline numerator */

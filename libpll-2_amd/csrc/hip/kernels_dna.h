@@ -1267,8 +1267,14 @@ __device__ __forceinline__ void dna_sub_fetch(const SubItem *items, const SubTil
 // entry's tip codes as one 64-bit word (launched by the host when maps, tips or descriptors changed); the evaluation
 // then starts from one coalesced load. (C4's shard: a workgroup lived 12 us, 60 % of it waiting in that chain; the
 // launch 35 us for 30 MB of output. Two tiles per workgroup with the second tile's chain in flight was slower: 44 us.)
-__global__ __launch_bounds__(256) void k_sub_pack(const SubItem *items, const SubTiles tiles, unsigned nitems, unsigned total_tiles)
+// `changed` / `since` (class maps rewritten, by the class kernels alone, since the words were formed): the words stand unless one
+// of those calls - their sequence numbers start at `since` - left a class -> child entry map other than it found it
+// (kernels_repeats.h: RepPack::changed). The reference's pll_update_partials recomputes the class maps of the tree it
+// re-evaluates on every call; they come out as they were.
+__global__ __launch_bounds__(256) void k_sub_pack(const SubItem *items, const SubTiles tiles, unsigned nitems, unsigned total_tiles, const unsigned *changed,
+                                                  unsigned since)
 {
+  if (changed && (int)(*changed - since) < 0) return;
   const unsigned gtile = blockIdx.x * 4u + (threadIdx.x >> 6);
   if (gtile >= total_tiles) return;
   SubFetch f;

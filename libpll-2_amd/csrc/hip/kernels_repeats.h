@@ -101,6 +101,8 @@ struct RepPack
   unsigned has_narrow, has_general; // which builds of k_rep_mark this level's launch consists of
   unsigned max_ranges;    // site ranges per part of a large table, at most
   unsigned bit_ranges, bit_words; // k_rep_bits follows k_rep_fold: its workgroups per op and their bitmap words each (0: k_rep_scan)
+  unsigned *changed;      // one word: `sequence` of the last call that left a class -> child entry map other than it found it
+                          // (what is derived from the CONTENTS of those maps - k_sub_pack - is redone only then)
   int fenced;             // kernels_common.h: handoff_*
 };
 
@@ -343,14 +345,22 @@ __device__ __forceinline__ void rep_fold_copies(const unsigned *table, unsigned 
 }
 
 // small table, complete in LDS: a cell's class = the cells with a lower first site. Returns the class count (every thread).
-__device__ __forceinline__ unsigned rep_rank_small(crepop_p o, unsigned ncells, unsigned nl, const unsigned *lds, unsigned *s_count)
+// `moved`: nonzero where this thread's entries of the class -> child entry maps differ from what stood there before (read
+// ahead of the stores, looked at by the caller once the count is on its way: RepPack::changed).
+static_assert(kRepSmallCells <= 2u * kRepThreads, "rep_rank_small: two cells per thread");
+__device__ __forceinline__ unsigned rep_rank_small(crepop_p o, unsigned ncells, unsigned nl, const unsigned *lds, unsigned *s_count, unsigned &moved)
 {
   unsigned *table = o->table;
-  unsigned *__restrict__ pids = o->pids, *__restrict__ lent = o->lent, *__restrict__ rent = o->rent;
+  unsigned *pids = o->pids, *lent = o->lent, *rent = o->rent;
   if (threadIdx.x == 0u) *s_count = 0u;
   __syncthreads();
-  for (unsigned c = threadIdx.x; c < ncells; c += kRepThreads)
+  unsigned was[2][2], is[2][2];
+#pragma unroll
+  for (unsigned k = 0; k < 2u; ++k)
   {
+    was[k][0] = was[k][1] = is[k][0] = is[k][1] = 0u;
+    const unsigned c = threadIdx.x + k * kRepThreads;
+    if (c >= ncells) continue;
     const unsigned v = lds[c];
     if (v == kRepEmpty)
     {
@@ -361,11 +371,14 @@ __device__ __forceinline__ unsigned rep_rank_small(crepop_p o, unsigned ncells, 
     for (unsigned j = 0; j < ncells; ++j) rank += lds[j] < v ? 1u : 0u; // (an empty cell is never lower)
     table[c] = rank;
     pids[rank] = v;
-    lent[rank] = c % nl;
-    rent[rank] = c / nl;
+    was[k][0] = lent[rank];
+    was[k][1] = rent[rank];
+    lent[rank] = is[k][0] = c % nl;
+    rent[rank] = is[k][1] = c / nl;
     atomicAdd(s_count, 1u);
   }
   __syncthreads();
+  moved = (was[0][0] ^ is[0][0]) | (was[0][1] ^ is[0][1]) | (was[1][0] ^ is[1][0]) | (was[1][1] ^ is[1][1]);
   return *s_count;
 }
 
@@ -475,9 +488,11 @@ __device__ __forceinline__ void rep_mark(const RepPack &p, unsigned *rep_lds)
       rep_fold_copies<NARROW ? 8 : 32>(o->table, ncells, sp.nranges, range, 0u, ncells, rep_lds);
       __syncthreads();
     }
-    const unsigned classes = rep_rank_small(o, ncells, sh.nl, rep_lds, &s_count);
+    unsigned moved;
+    const unsigned classes = rep_rank_small(o, ncells, sh.nl, rep_lds, &s_count, moved);
     rep_store_count(p, o, kRepFlag | classes, 0u);
     if (publishes) rep_arrive(p);
+    if (moved) *p.changed = p.sequence; // (every writer of the call stores the same word)
     return;
   }
   if (NARROW) return; // (not reached: a large table is never the narrow build's)
@@ -805,15 +820,18 @@ __device__ __forceinline__ void rep_assign_tile(const RepPack &p, crepop_p o, un
     }
     if (FIRSTS && firsts)
     {
-      unsigned *__restrict__ pids = o->pids, *__restrict__ lent = o->lent, *__restrict__ rent = o->rent;
+      unsigned *pids = o->pids, *lent = o->lent, *rent = o->rent;
+      unsigned moved = 0u;
 #pragma unroll
       for (unsigned e = 0; e < 16u; ++e)
         if (firsts >> e & 1u)
         {
           pids[v[e]] = s + e;
+          moved |= (lent[v[e]] ^ l[e]) | (rent[v[e]] ^ r[e]);
           lent[v[e]] = l[e];
           rent[v[e]] = r[e];
         }
+      if (moved) *p.changed = p.sequence;
     }
   }
 }

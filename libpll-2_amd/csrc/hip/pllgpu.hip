@@ -134,6 +134,7 @@ struct pllgpu_ctx
   unsigned rep_max_ranges = 8;           // PLL_AMD_REP_RANGES: site ranges per part of a large table, at most (kernels_repeats.h)
   unsigned rep_assign_iters = 0;         // PLL_AMD_REP_ASSIGN_ITERS: rounds per workgroup of k_rep_assign (0: by the launch's size)
   unsigned rep_assign_lds = kRepAssignLds; // PLL_AMD_REP_ASSIGN_LDS: tables up to this many cells are looked up in LDS
+  bool sub_pack_always = false;          // PLL_AMD_SUB_PACK_ALWAYS=1: k_sub_pack after every class-map call, whatever it reported (A/B)
   bool rep_bits = true;                  // PLL_AMD_REP_BITS=0: the bitmap of first sites by atomics + k_rep_scan for every table size (A/B)
   bool rep_hints = true;                 // PLL_AMD_REP_HINTS=0: every level of a class-map call is launched (A/B, tests)
   unsigned rep_hint_count = 0, rep_hint_level = 0; // the last call: its ops, the highest level with a compressed parent ...
@@ -202,6 +203,9 @@ struct pllgpu_ctx
   DevBuf<unsigned long long> sub_packed; // k_sub_pack: per sub-tree op and entry, the tip codes below it
   bool sub_pack_valid = false;           // ... formed for the descriptors on the device, the class maps (maps_version) ...
   unsigned long long sub_pack_maps = 0, sub_pack_tips = 0, tips_epoch = 1; // ... and the tip data (tips_epoch) of now
+  unsigned long long maps_foreign = 1, sub_pack_foreign = 0; // maps written by anything but the class kernels (uploads, count changes)
+  unsigned sub_pack_since = 0;           // the class-map calls from this sequence number on came after the packed words
+  DevBuf<unsigned> rep_changed;          // RepPack::changed
 };
 
 // what pllgpu_update_partials did for one op list through the level scheduler: its launches, in order, with
@@ -459,7 +463,7 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   if (c->pmat.ensure(c->pm_stride * (geo->prob_matrices + 2)) || c->freqs.ensure((size_t)geo->rate_matrices * geo->states_padded) ||
       c->rate_weights.ensure(geo->rate_cats) || c->prop_invar.ensure(geo->rate_matrices) ||
       c->pattern_weights.ensure(geo->sites_alloc) || c->persite.ensure(geo->sites_alloc) ||
-      c->block_sums.ensure(4096) || c->counter.ensure(4) || c->rep_sync.ensure((size_t)kRepOps + 1))
+      c->block_sums.ensure(4096) || c->counter.ensure(4) || c->rep_sync.ensure((size_t)kRepOps + 1) || c->rep_changed.ensure(1))
   {
     pllgpu_destroy(c);
     return nullptr;
@@ -469,10 +473,12 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   (void)hipMemsetAsync(c->prop_invar.p, 0, c->prop_invar.cap * sizeof(double), c->stream);
   (void)hipMemsetAsync(c->counter.p, 0, c->counter.cap * sizeof(unsigned), c->stream);
   (void)hipMemsetAsync(c->rep_sync.p, 0, c->rep_sync.cap * sizeof(unsigned), c->stream);
+  (void)hipMemsetAsync(c->rep_changed.p, 0, sizeof(unsigned), c->stream);
   if (const char *v = getenv("PLL_AMD_REP_WGS")) c->rep_wgs = (unsigned)std::max(0, atoi(v));
   if (const char *v = getenv("PLL_AMD_REP_ASSIGN_ITERS")) c->rep_assign_iters = (unsigned)std::max(0, atoi(v));
   if (const char *v = getenv("PLL_AMD_REP_ASSIGN_LDS")) c->rep_assign_lds = (unsigned)std::min<int>(kRepAssignLds, std::max(0, atoi(v)));
   if (const char *v = getenv("PLL_AMD_REP_BITS")) c->rep_bits = !(*v == '0');
+  if (const char *v = getenv("PLL_AMD_SUB_PACK_ALWAYS")) c->sub_pack_always = *v && *v != '0';
   if (const char *v = getenv("PLL_AMD_REP_HINTS")) c->rep_hints = !(*v == '0');
   if (const char *v = getenv("PLL_AMD_REP_RANGES")) c->rep_max_ranges = (unsigned)std::max(1, atoi(v));
   return c;
@@ -525,6 +531,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->rep_blocksum.release();
   c->rep_counts.release();
   c->rep_sync.release();
+  c->rep_changed.release();
   c->rates.release();
   c->diag.release();
   for (auto &b : c->sumtable) b.release();
@@ -752,6 +759,7 @@ extern "C" int pllgpu_repeats_upload(pllgpu_ctx_t *c, unsigned node, const unsig
   c->ids[node] = ids;
   ++c->maps_epoch;
   ++c->maps_version;
+  ++c->maps_foreign;
   c->map_widened[node] = 0;
   c->rep_left[node] = c->rep_right[node] = -1; // host-built maps: no entry-indexed child maps
   c->map_forms[node] = 0;
@@ -2752,6 +2760,7 @@ extern "C" int pllgpu_repeats_set_ids(pllgpu_ctx_t *c, unsigned node, unsigned i
   {
     ++c->maps_epoch;
     ++c->maps_version;
+    ++c->maps_foreign;
   }
   c->ids[node] = ids;
   if (!ids) c->rep_left[node] = c->rep_right[node] = -1;
@@ -2940,6 +2949,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
   pk.counts = c->rep_counts.p;
   pk.tickets = c->rep_sync.p;
   pk.launch_ticket = c->rep_sync.p + kRepOps;
+  pk.changed = c->rep_changed.p;
   pk.max_ranges = c->rep_max_ranges;
   pk.host_counts = c->rep_host_dev;
   pk.ncounts = ncut;

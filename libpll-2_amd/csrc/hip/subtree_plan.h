@@ -144,7 +144,11 @@ static unsigned launch_subtrees(pllgpu_ctx *c, unsigned nsub)
 {
   const SubItem *items = reinterpret_cast<const SubItem *>(c->sub_dev.p);
   unsigned launches = 0;
-  const bool stale = !c->sub_pack_valid || c->sub_pack_maps != c->maps_version || c->sub_pack_tips != c->tips_epoch;
+  // formed anew when descriptors, tip data or host-built maps changed; when only the class kernels have rewritten maps
+  // since, the launch looks at what they reported (k_sub_pack)
+  const bool stale = !c->sub_pack_valid || c->sub_pack_foreign != c->maps_foreign || c->sub_pack_tips != c->tips_epoch;
+  const bool rewritten = c->sub_pack_maps != c->maps_version;
+  const unsigned *changed = stale || c->sub_pack_always ? nullptr : c->rep_changed.p;
   for (unsigned first = 0; first < nsub; first += (unsigned)kSubItemsPerLaunch, ++launches)
   {
     const unsigned n = std::min(nsub - first, (unsigned)kSubItemsPerLaunch);
@@ -158,7 +162,7 @@ static unsigned launch_subtrees(pllgpu_ctx *c, unsigned nsub)
     for (unsigned i = n; i <= (unsigned)kSubItemsPerLaunch; ++i) tiles.first[i] = t;
     dim3 grid(t), block(256);
     // the entries' tip codes, packed: once per set of class maps, tip data and descriptors (kernels_dna.h: k_sub_pack)
-    if (stale) hipLaunchKernelGGL(k_sub_pack, dim3((t + 3u) / 4u), block, 0, c->stream, items + first, tiles, n, t);
+    if (stale || rewritten) hipLaunchKernelGGL(k_sub_pack, dim3((t + 3u) / 4u), block, 0, c->stream, items + first, tiles, n, t, changed, c->sub_pack_since);
     if (c->gg.scale_mode == 2)
       hipLaunchKernelGGL(k_partials_dna_sub<2>, grid, block, 0, c->stream, items + first, tiles, n);
     else
@@ -166,6 +170,8 @@ static unsigned launch_subtrees(pllgpu_ctx *c, unsigned nsub)
   }
   c->sub_pack_valid = true;
   c->sub_pack_maps = c->maps_version;
+  c->sub_pack_foreign = c->maps_foreign;
   c->sub_pack_tips = c->tips_epoch;
+  c->sub_pack_since = c->rep_seq + 1u; // the next class-map call's sequence number
   return launches;
 }

@@ -101,7 +101,11 @@ static int nothing_dirty(const pll_partition_t *p, const pll_amd_ext_t *x)
     if (x->pmatrix_dirty[i] && !x->pmatrix_stale[i]) return 0;
   if (memchr(x->tipchars_dirty, 1, p->tips)) return 0;
   if (pll_repeats_enabled(p) && memchr(x->repeats_dirty, 1, p->nodes)) return 0;
-  if (memchr(x->clv_side, SIDE_HOST, p->nodes)) return 0;
+  /* a tip the device reads as one-byte codes keeps its indicator CLV in the host mirror for good (tips.c): what the
+   * device needs of it is covered by tipchars_dirty above */
+  for (i = 0; i < p->tips; ++i)
+    if (x->clv_side[i] == SIDE_HOST && !pll_tip_by_codes(p, i)) return 0;
+  if (p->nodes > p->tips && memchr(x->clv_side + p->tips, SIDE_HOST, p->nodes - p->tips)) return 0;
   if (p->scale_buffers && memchr(x->scaler_side, SIDE_HOST, p->scale_buffers)) return 0;
   return 1;
 }
@@ -177,9 +181,11 @@ void pll_update_partials_rep(pll_partition_t *p, const pll_operation_t *ops, uns
       return;
     }
     mark_results(p, x, ops, count);
+    x->fast_taken = 1;
     return;
   }
   x->fast_valid = 0;
+  x->fast_taken = 0;
   if (!grow_scratch(p, x, count))
   {
     pll_set_error(PLL_ERROR_MEM_ALLOC, "pll_update_partials: out of memory");

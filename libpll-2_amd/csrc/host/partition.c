@@ -890,6 +890,12 @@ double pll_gpu_last_algorithmic_bytes(const pll_partition_t *p)
   return (x && x->ctx) ? pllgpu_last_algorithmic_bytes(x->ctx) : 0.0;
 }
 
+int pll_gpu_last_update_replayed(const pll_partition_t *p)
+{
+  const pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
+  return x ? x->fast_taken : 0;
+}
+
 unsigned int pll_gpu_last_launch_count(const pll_partition_t *p)
 {
   pll_amd_ext_t *x = p ? pll_ext(p) : NULL;

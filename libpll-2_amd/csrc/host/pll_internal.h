@@ -81,6 +81,7 @@ typedef struct pll_amd_ext
    * class counts or caller-written arrays change), goes straight to the device layer */
   pll_operation_t *fast_ops;
   unsigned int fast_count, fast_cap, fast_lo, fast_hi;
+  int fast_taken; /* the last pll_update_partials went straight to the launches (pll_gpu_last_update_replayed) */
   int fast_valid;
   double reduce_step;           /* collective evaluations issued so far (group.c: the ranks count in step) */
   /* what pll_gpu_allreduce_prepare established for the communicator last used with this partition: everything that

@@ -259,12 +259,19 @@ static int classes_call(pll_partition_t *p, pll_amd_ext_t *x, const pll_operatio
     const unsigned int parent = op->parent_clv_index;
     const int enabled = (counts[k] & PLLGPU_REPEATS_COMPRESSED) != 0;
     const unsigned int classes = counts[k] & ~PLLGPU_REPEATS_COMPRESSED;
-    /* the same classes as before (a re-evaluation of the same tree): what pll_update_partials classified stays right */
-    if (x->repeats_count[parent] != (enabled ? classes : 0) || r->pernode_ids[parent] != (enabled && classes < p->sites ? classes : 0) ||
-        r->pernode_allocated_clvs[parent] != (enabled ? classes : p->sites))
-      *changed = 1;
-    adopt_classes(p, op, classes, enabled);
+    /* the same classes as before (a re-evaluation of the same tree): what pll_update_partials classified stays right,
+     * and with the default callback nothing below would change a thing - the host's time between the counts and the
+     * first launch that uses the maps is the device's idle time on a small alignment */
+    const int same = x->repeats_count[parent] == (enabled ? classes : 0) && r->pernode_ids[parent] == (enabled && classes < p->sites ? classes : 0) &&
+                     r->pernode_allocated_clvs[parent] == (enabled ? classes : p->sites);
     x->repeats_stale[parent] = enabled ? 1 : 0;
+    if (same && r->reallocate_repeats == pll_default_reallocate_repeats)
+    {
+      if (op->parent_scaler_index != PLL_SCALE_BUFFER_NONE) r->perscale_ids[op->parent_scaler_index] = r->pernode_ids[parent];
+      continue;
+    }
+    if (!same) *changed = 1;
+    adopt_classes(p, op, classes, enabled);
     x->repeats_count[parent] = enabled ? classes : 0;
     if (pllgpu_repeats_set_ids(x->ctx, parent, r->pernode_ids[parent]) != 0)
     {

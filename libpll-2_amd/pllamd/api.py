@@ -174,6 +174,7 @@ _GPU_PROTOS = {
     "pll_gpu_timer_start": (C.c_int, [PartitionP]),
     "pll_gpu_timer_stop": (C.c_double, [PartitionP]),
     "pll_gpu_last_launch_count": (C.c_uint, [PartitionP]),
+    "pll_gpu_last_update_replayed": (C.c_int, [PartitionP]),
     "pll_gpu_group_join": (C.c_void_p, [C.c_char_p, C.c_uint, C.c_uint, C.c_int]),
     "pll_gpu_group_leave": (None, [C.c_void_p]),
     "pll_gpu_group_rank": (C.c_uint, [C.c_void_p]),

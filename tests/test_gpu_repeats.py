@@ -205,11 +205,15 @@ def test_matrix_pipe_gather_kernel_against_the_fma_kernel(amd_lib, monkeypatch, 
         assert sum(int(v.sum()) for v in fma["scaler"].values()) > 0  # the case does rescale
 
 
-def test_packed_subtree_lookups_follow_maps_and_tips(amd_lib):
+@pytest.mark.parametrize("always", ["0", "1"], ids=["as-reported", "always"])
+def test_packed_subtree_lookups_follow_maps_and_tips(amd_lib, monkeypatch, always):
     """the all-tip subtrees are evaluated from per-entry words of packed tip codes that k_sub_pack forms once per set
     of class maps, tip data and descriptors: new tip sequences in a living partition (class maps recomputed) must give
-    what a fresh partition gives, and so must going back"""
+    what a fresh partition gives, and so must going back. Class maps recomputed over unchanged tips (the reference's
+    pll_update_partials on every call) leave the words standing - the class kernels report whether an entry map moved
+    (PLL_AMD_SUB_PACK_ALWAYS=1: formed anew after every class-map call)"""
     import ctypes
+    monkeypatch.setenv("PLL_AMD_SUB_PACK_ALWAYS", always)
     case_a = W.make_case("pk", 4, tips=32, sites=4000, attributes=api.SITE_REPEATS, mutate_pct=4, seed=61)
     case_b = W.make_case("pk", 4, tips=32, sites=4000, attributes=api.SITE_REPEATS, mutate_pct=4, seed=62)
     case_b.pmatrix, case_b.freqs = case_a.pmatrix, case_a.freqs  # the same model and tree, other sequences
@@ -231,6 +235,10 @@ def test_packed_subtree_lookups_follow_maps_and_tips(amd_lib):
             assert np.array_equal(s.read_clv(case_a.edges[0][0]), fresh[tag][1]), tag
             s.update_partials(update_repeats=0)  # the cached plan and the packed words as they are
             assert s.edge_lnl(case_a.edges[0], persite=False)[0] == v
+            for _ in range(2):  # the maps again, as they were
+                s.update_partials(update_repeats=1)
+                assert s.edge_lnl(case_a.edges[0], persite=False)[0] == v
+                assert np.array_equal(s.read_clv(case_a.edges[0][0]), fresh[tag][1]), tag
 
 
 @pytest.mark.parametrize("env", [{"PLL_AMD_REP_LEVEL_SYNC": "1"}, {"PLL_AMD_REP_HINTS": "0"}, {"PLL_AMD_REP_WGS": "1"}, {"PLL_AMD_REP_WGS": "64"},
@@ -325,3 +333,31 @@ def test_a_callers_enable_repeats_callback_is_asked_level_by_level(amd_lib, ref_
         amd_lib.pll_update_partials(s.p, ops, n)
         assert not any(s.part.repeats.contents.pernode_ids[i] for i in range(case.tips, s.part.nodes))
         assert abs(s.edge_lnl(case.edges[0], persite=False)[0] - res[False][1]) <= 1e-10 * abs(res[False][1])
+
+
+@pytest.mark.parametrize("attributes", [api.SITE_REPEATS, 0, api.PATTERN_TIP], ids=["site-repeats", "plain", "pattern-tip"])
+def test_the_same_list_again_goes_straight_to_the_launches(amd_lib, attributes):
+    """a re-evaluation of one tree - the same operation list, nothing edited in between - skips levels, flushes and
+    classification (partials.c: nothing_dirty). Tips the device reads as one-byte codes keep their indicator CLV in
+    the host mirror for good; that must not look like a pending upload (it did until round 5: every partition without
+    PLL_ATTRIB_PATTERN_TIP took the whole path on every call). With site repeats the class maps recomputed by the call
+    (update_repeats = 1) leave the short path standing as long as they come out as they were."""
+    case = W.make_case("again", 4, tips=32, sites=3000, attributes=attributes, mutate_pct=3, seed=91)
+    with driver.Session(amd_lib, case, api.ARCH_AVX2) as s:
+        s.update_partials()
+        assert amd_lib.pll_gpu_last_update_replayed(s.p) == 0
+        first = s.edge_lnl(case.edges[0], persite=False)[0]
+        for update_repeats in ((0, 1, 1, 0) if attributes & api.SITE_REPEATS else (1, 1)):
+            s.update_partials(update_repeats=update_repeats)
+            assert amd_lib.pll_gpu_last_update_replayed(s.p) == 1, update_repeats
+            assert s.edge_lnl(case.edges[0], persite=False)[0] == first
+        # an edit in between: the whole path once, then the short one again
+        import ctypes
+        cmap = (ctypes.c_ulonglong * 256)(*[int(x) for x in case.charmap])
+        assert amd_lib.pll_set_tip_states(s.p, 3, cmap, case.sequences[3])
+        s.update_partials()
+        assert amd_lib.pll_gpu_last_update_replayed(s.p) == 0
+        assert s.edge_lnl(case.edges[0], persite=False)[0] == first
+        s.update_partials()
+        assert amd_lib.pll_gpu_last_update_replayed(s.p) == 1
+        assert s.edge_lnl(case.edges[0], persite=False)[0] == first

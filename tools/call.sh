@@ -1,9 +1,7 @@
-#!/bin/bash
-set -o pipefail
-cd "$GRAFT_REPO_ROOT" || exit 1
-export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r5
-mkdir -p $O
-( timeout -k 10 250 python tools/rep_stress.py 40000 300000 bench; timeout -k 10 250 python tools/rep_stress.py 30000 125000 mutated; PLL_AMD_REP_WGS=64 PLL_AMD_REP_RANGES=16 timeout -k 10 250 python tools/rep_stress.py 15000 200000 mutated ) > $O/rep_stress.txt 2>&1
-cat $O/rep_stress.txt
+set -e
+mkdir -p gpurun_out/r5
+python -m pytest tests/test_gpu_repeats.py tests/test_gpu_c4_sharded.py tests/test_gpu_fullsize.py -x -q -m gpu > gpurun_out/r5/t2.log 2>&1 || { tail -30 gpurun_out/r5/t2.log; exit 1; }
+tail -2 gpurun_out/r5/t2.log
+python3 tools/rep_ab.py 125000 bench ""
+python3 tools/rep_ab.py 1000000 bench ""
+python tools/c4_projection.py > gpurun_out/r5/c4_proj_fast2.json 2> gpurun_out/r5/c4_proj_fast2.err
