@@ -98,6 +98,10 @@ int pllgpu_scaler_upload(pllgpu_ctx_t *ctx, unsigned int index, const unsigned i
                          unsigned int entries);
 int pllgpu_scaler_download(pllgpu_ctx_t *ctx, unsigned int index, unsigned int *host,
                            unsigned int entries);
+/* on = 1: CLV and scaler downloads of up to 2 MB are enqueued and return before their bytes have arrived; on = 0: one
+ * wait for all of them, after which every `host` buffer handed over since holds its data (a caller that wants a CLV and
+ * its scaler vector pays one wait instead of two). Larger downloads wait as always. */
+int pllgpu_download_defer(pllgpu_ctx_t *ctx, int on);
 int pllgpu_tipchars_upload(pllgpu_ctx_t *ctx, unsigned int tip, const unsigned char *host,
                            unsigned int count);
 /* code -> state mask table; NULL selects "code is the mask" (4-state, src/pll.c:875-910) */

@@ -614,3 +614,34 @@ __global__ __launch_bounds__(256) void k_tiled_to_aos(const double *__restrict__
     if (ent < entries) aos[(ent * R + k) * SP + j] = j < S ? tiled[((tile * R + k) * S + j) * 64 + lane] : 0.0;
   }
 }
+
+// The same two with the entry-major side in HOST memory (small transfers: pllgpu.hip, stage_take): one thread per element of
+// THAT side, so that what crosses the bus are whole consecutive lines, each once - host memory is not cached on the device, and
+// indexed by the tiled side every 8-byte read would fetch its own line (sixteen times the bytes at 4 states x 4 rates).
+__global__ __launch_bounds__(256) void k_host_aos_to_tiled(const double *__restrict__ aos, double *__restrict__ tiled,
+                                                           unsigned entries, unsigned S, unsigned SP, unsigned R)
+{
+  const size_t padded = (size_t)((entries + 63u) / 64u) * 64u, total = padded * R * SP;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256)
+  {
+    const unsigned j = idx % SP;
+    size_t r = idx / SP;
+    const unsigned k = r % R;
+    const size_t ent = r / R;
+    if (j < S) tiled[(((ent >> 6) * R + k) * S + j) * 64 + (ent & 63u)] = ent < entries ? aos[idx] : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_host_tiled_to_aos(const double *__restrict__ tiled, double *__restrict__ aos,
+                                                           unsigned entries, unsigned S, unsigned SP, unsigned R)
+{
+  const size_t total = (size_t)entries * R * SP;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256)
+  {
+    const unsigned j = idx % SP;
+    size_t r = idx / SP;
+    const unsigned k = r % R;
+    const size_t ent = r / R;
+    aos[idx] = j < S ? tiled[(((ent >> 6) * R + k) * S + j) * 64 + (ent & 63u)] : 0.0;
+  }
+}

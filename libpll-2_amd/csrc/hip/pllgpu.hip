@@ -206,6 +206,19 @@ struct pllgpu_ctx
   unsigned long long maps_foreign = 1, sub_pack_foreign = 0; // maps written by anything but the class kernels (uploads, count changes)
   unsigned sub_pack_since = 0;           // the class-map calls from this sequence number on came after the packed words
   DevBuf<unsigned> rep_changed;          // RepPack::changed
+  // small transfers go through one block of pinned, device-visible host memory (stage_take below)
+  unsigned char *ring_host = nullptr, *ring_dev = nullptr;
+  size_t ring_cap = 0, ring_off = 0;
+  bool ring_failed = false;
+  // downloads through the block that have been enqueued but not waited for (pllgpu_download_defer)
+  struct PendingDown
+  {
+    void *host;
+    const unsigned char *ring;
+    size_t bytes;
+  };
+  std::vector<PendingDown> pending_down;
+  bool defer_down = false;
 };
 
 // what pllgpu_update_partials did for one op list through the level scheduler: its launches, in order, with
@@ -479,6 +492,7 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   if (const char *v = getenv("PLL_AMD_REP_ASSIGN_LDS")) c->rep_assign_lds = (unsigned)std::min<int>(kRepAssignLds, std::max(0, atoi(v)));
   if (const char *v = getenv("PLL_AMD_REP_BITS")) c->rep_bits = !(*v == '0');
   if (const char *v = getenv("PLL_AMD_SUB_PACK_ALWAYS")) c->sub_pack_always = *v && *v != '0';
+  if (const char *v = getenv("PLL_AMD_PINNED_STAGING")) c->ring_failed = *v == '0'; // 0: every transfer from / to pageable memory as the runtime does it (A/B)
   if (const char *v = getenv("PLL_AMD_REP_HINTS")) c->rep_hints = !(*v == '0');
   if (const char *v = getenv("PLL_AMD_REP_RANGES")) c->rep_max_ranges = (unsigned)std::max(1, atoi(v));
   return c;
@@ -539,6 +553,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->invariant.release();
   if (c->result_host) (void)hipHostFree(c->result_host);
   if (c->rep_host) (void)hipHostFree(c->rep_host);
+  if (c->ring_host) (void)hipHostFree(c->ring_host);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -560,6 +575,92 @@ static int flush_deferred(pllgpu_ctx *c);
   if (!(c)->deferred.empty() || (c)->chain_held)       \
     if (int rc_ = flush_deferred(c)) return rc_
 
+// Small transfers. hipMemcpyAsync from or to pageable memory is a blocking trip through the runtime's own staging (10-25 us
+// whatever the size; the flat pll_core_* seam made six of them per call): a transfer of up to kRingMax bytes goes through
+// the context's block of pinned host memory instead - up: the caller's bytes are copied there and the device reads them
+// from there (a copy enqueued from pinned memory, or the layout kernel straight out of host memory); down: the device
+// writes there, one wait, the bytes are copied out. A piece of the block belongs to its transfer until the stream has
+// been waited for; the block is handed out front to back and starts over after a wait (stream_wait).
+constexpr size_t kRingCap = (size_t)8 << 20, kRingMax = (size_t)2 << 20;
+
+// the stream has just been waited for: everything that read or wrote the block has completed
+static void ring_drained(pllgpu_ctx *c)
+{
+  for (const auto &d : c->pending_down) memcpy(d.host, d.ring, d.bytes);
+  c->pending_down.clear();
+  c->ring_off = 0;
+}
+
+static hipError_t stream_wait(pllgpu_ctx *c)
+{
+  const hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) ring_drained(c);
+  return e;
+}
+
+// `bytes` of the block: the host address, and the address the device knows the same memory by. nullptr: not this way
+// (too large, or no pinned memory to be had) - the caller takes the pageable path.
+static unsigned char *stage_take(pllgpu_ctx *c, size_t bytes, unsigned char **dev)
+{
+  if (bytes > kRingMax || c->ring_failed) return nullptr;
+  if (!c->ring_host)
+  {
+    void *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, kRingCap, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess)
+    {
+      if (h) (void)hipHostFree(h);
+      (void)hipGetLastError();
+      c->ring_failed = true;
+      return nullptr;
+    }
+    c->ring_host = (unsigned char *)h;
+    c->ring_dev = (unsigned char *)d;
+    c->ring_cap = kRingCap;
+    c->ring_off = 0;
+  }
+  const size_t need = (bytes + 255u) & ~(size_t)255u;
+  if (c->ring_off + need > c->ring_cap && stream_wait(c) != hipSuccess) return nullptr;
+  unsigned char *h = c->ring_host + c->ring_off;
+  *dev = c->ring_dev + c->ring_off;
+  c->ring_off += need;
+  return h;
+}
+
+// host -> device, `bytes` from pageable caller memory
+static hipError_t copy_up(pllgpu_ctx *c, void *dst, const void *host, size_t bytes)
+{
+  unsigned char *dev = nullptr;
+  if (unsigned char *h = stage_take(c, bytes, &dev))
+  {
+    memcpy(h, host, bytes);
+    return hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, c->stream);
+  }
+  return hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, c->stream);
+}
+
+// device -> host and wait
+static hipError_t copy_down(pllgpu_ctx *c, void *host, const void *src, size_t bytes)
+{
+  unsigned char *dev = nullptr;
+  if (unsigned char *h = stage_take(c, bytes, &dev))
+  {
+    hipError_t e = hipMemcpyAsync(h, src, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess) return e;
+    c->pending_down.push_back({host, h, bytes});
+    return c->defer_down ? hipSuccess : stream_wait(c);
+  }
+  const hipError_t e = hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, c->stream);
+  return e == hipSuccess ? stream_wait(c) : e;
+}
+
+extern "C" int pllgpu_download_defer(pllgpu_ctx_t *c, int on)
+{
+  CHECK_CTX_KEEP(c);
+  c->defer_down = on != 0;
+  if (!on && !c->pending_down.empty()) HIP_TRY(stream_wait(c));
+  return 0;
+}
+
 extern "C" int pllgpu_clv_reserve(pllgpu_ctx_t *c, unsigned node, unsigned entries)
 {
   CHECK_CTX(c);
@@ -574,7 +675,18 @@ extern "C" int pllgpu_clv_upload(pllgpu_ctx_t *c, unsigned node, const double *h
   c->clv_aos[node] = aos_entries(c, entries) ? 1 : 0;
   if (!c->tiled || c->clv_aos[node])
   {
-    HIP_TRY(hipMemcpyAsync(c->clv[node].p, host, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(copy_up(c, c->clv[node].p, host, bytes));
+    return 0;
+  }
+  unsigned char *dev = nullptr;
+  if (unsigned char *h = stage_take(c, bytes, &dev))
+  {
+    // the layout kernel reads the caller's entries out of host memory
+    memcpy(h, host, bytes);
+    const unsigned blocks = (unsigned)std::min<size_t>(1024, ((size_t)(entries + 63u) * c->span + 255u) / 256u);
+    hipLaunchKernelGGL(k_host_aos_to_tiled, dim3(blocks), dim3(256), 0, c->stream, reinterpret_cast<const double *>(dev), c->clv[node].p, entries,
+                       c->gg.S, c->gg.SP, c->gg.R);
+    HIP_TRY(hipGetLastError());
     return 0;
   }
   if (int rc = c->scratch.ensure((size_t)entries * c->span)) return rc;
@@ -594,14 +706,25 @@ extern "C" int pllgpu_clv_download(pllgpu_ctx_t *c, unsigned node, double *host,
   const double *src = c->clv[node].p;
   if (c->tiled && !c->clv_aos[node])
   {
+    unsigned char *dev = nullptr;
+    if (unsigned char *h = stage_take(c, bytes, &dev))
+    {
+      // the layout kernel writes the entries into host memory
+      const unsigned blocks = (unsigned)std::min<size_t>(1024, ((size_t)entries * c->span + 255u) / 256u);
+      hipLaunchKernelGGL(k_host_tiled_to_aos, dim3(blocks), dim3(256), 0, c->stream, c->clv[node].p, reinterpret_cast<double *>(dev), entries,
+                         c->gg.S, c->gg.SP, c->gg.R);
+      HIP_TRY(hipGetLastError());
+      c->pending_down.push_back({host, h, bytes});
+      if (!c->defer_down) HIP_TRY(stream_wait(c));
+      return 0;
+    }
     if (int rc = c->scratch.ensure((size_t)entries * c->span)) return rc;
     hipLaunchKernelGGL(k_tiled_to_aos, dim3(1024), dim3(256), 0, c->stream, c->clv[node].p, c->scratch.p, entries,
                        c->gg.S, c->gg.SP, c->gg.R);
     HIP_TRY(hipGetLastError());
     src = c->scratch.p;
   }
-  HIP_TRY(hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(copy_down(c, host, src, bytes));
   return 0;
 }
 
@@ -620,8 +743,7 @@ extern "C" int pllgpu_scaler_reserve(pllgpu_ctx_t *c, unsigned index, unsigned e
 extern "C" int pllgpu_scaler_upload(pllgpu_ctx_t *c, unsigned index, const unsigned *host, unsigned entries)
 {
   if (int rc = pllgpu_scaler_reserve(c, index, entries)) return rc;
-  HIP_TRY(hipMemcpyAsync(c->scaler[index].p, host, scaler_elems(c, entries) * sizeof(unsigned),
-                         hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(copy_up(c, c->scaler[index].p, host, scaler_elems(c, entries) * sizeof(unsigned)));
   return 0;
 }
 
@@ -630,9 +752,7 @@ extern "C" int pllgpu_scaler_download(pllgpu_ctx_t *c, unsigned index, unsigned 
   CHECK_CTX(c);
   if (index >= c->geo.scale_buffers || scaler_elems(c, entries) > c->scaler[index].cap)
     return fail(PLLGPU_EINVAL, "scale buffer %u: download exceeds the device buffer", index);
-  HIP_TRY(hipMemcpyAsync(host, c->scaler[index].p, scaler_elems(c, entries) * sizeof(unsigned),
-                         hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(copy_down(c, host, c->scaler[index].p, scaler_elems(c, entries) * sizeof(unsigned)));
   return 0;
 }
 
@@ -673,19 +793,27 @@ static int upload_matrices(pllgpu_ctx *c, unsigned first, unsigned count, const 
   if (first + count > limit) return fail(PLLGPU_EINVAL, "matrix range [%u,%u) out of range", first, first + count);
   const unsigned S = g.states, SP = g.states_padded, R = g.rate_cats, SPT = c->gg.SPT;
   const size_t host_stride = (size_t)R * S * SP;
-  // the previous async copy may still be reading the staging vector
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  c->stage.assign(c->pm_stride * count, 0.0);
+  // the device's layout is formed in pinned memory where the block fits (no wait), else in the staging vector
+  const size_t doubles = c->pm_stride * count;
+  unsigned char *dev = nullptr;
+  double *stage = reinterpret_cast<double *>(stage_take(c, doubles * sizeof(double), &dev));
+  if (stage)
+    memset(stage, 0, doubles * sizeof(double));
+  else
+  {
+    HIP_TRY(stream_wait(c)); // the previous async copy may still be reading the staging vector
+    c->stage.assign(doubles, 0.0);
+    stage = c->stage.data();
+  }
   for (unsigned m = 0; m < count; ++m)
     for (unsigned k = 0; k < R; ++k)
       for (unsigned i = 0; i < S; ++i)
       {
         const double *row = host + m * host_stride + ((size_t)k * S + i) * SP;
-        double *dst = c->stage.data() + m * c->pm_stride + (size_t)k * S * SPT + i;
+        double *dst = stage + m * c->pm_stride + (size_t)k * S * SPT + i;
         for (unsigned j = 0; j < S; ++j) dst[(size_t)j * SPT] = row[j];
       }
-  HIP_TRY(hipMemcpyAsync(c->pmat.p + (size_t)first * c->pm_stride, c->stage.data(),
-                         c->stage.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->pmat.p + (size_t)first * c->pm_stride, stage, doubles * sizeof(double), hipMemcpyHostToDevice, c->stream));
   for (unsigned m = first; m < first + count && m < c->pm_version.size(); ++m) ++c->pm_version[m];
   return 0;
 }
@@ -2352,7 +2480,7 @@ extern "C" int pllgpu_reduce_fetch(pllgpu_ctx_t *c, double expected_sequence, do
 extern "C" int pllgpu_set_stream(pllgpu_ctx_t *c, void *s)
 {
   CHECK_CTX(c);
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(stream_wait(c));
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   c->stream = (hipStream_t)s;
   c->own_stream = false;

@@ -152,7 +152,26 @@ static void seam_put_clv(seam_t *s, unsigned int idx, const double *clv, const u
                          const unsigned int *outer /* entry -> site or NULL */, const unsigned int *inner /* site -> source entry or NULL */)
 {
   pll_partition_t *p = s->p;
+  pll_amd_ext_t *x = pll_ext(p);
   const size_t sw = scaler_words(p);
+  if (!outer && !inner && x && x->ctx && entries == pll_get_sites_number(p, idx + 1))
+  {
+    /* the caller's arrays as they are: straight to the device, the partition's host mirror left out (a 128 KB CLV
+     * copied into the mirror and from there to where the device reads it was a fifth of a call at 1k sites) */
+    if (pllgpu_clv_upload(x->ctx, idx + 1, clv, entries) == 0 &&
+        (!scaler || pllgpu_scaler_upload(x->ctx, idx, scaler, entries) == 0))
+    {
+      x->clv_side[idx + 1] = SIDE_DEVICE;
+      x->fast_valid = 0;
+      if (scaler)
+      {
+        x->scaler_side[idx] = SIDE_DEVICE;
+        x->scaler_entries[idx] = entries;
+      }
+      return;
+    }
+    /* (an error of the device layer: the mirror path below reports it) */
+  }
   for (unsigned int e = 0; e < entries; ++e)
   {
     unsigned int src = outer ? outer[e] : e;
@@ -202,13 +221,17 @@ static void seam_update(seam_t *s, double *parent_clv, unsigned int *parent_scal
   op.child2_scaler_index = rscal ? 2 : PLL_SCALE_BUFFER_NONE;
   pll_errno = 0;
   pll_update_partials(p, &op, 1);
-  if (pll_errno || !pll_gpu_sync_clv(p, 1) || (parent_scaler && !pll_gpu_sync_scaler(p, 0)))
+  /* the CLV and its scaler vector come back behind ONE wait, into the caller's arrays */
+  pll_amd_ext_t *x = pll_ext(p);
+  int ok = !pll_errno && x && x->ctx && pllgpu_download_defer(x->ctx, 1) == 0;
+  ok = ok && pllgpu_clv_download(x->ctx, 1, parent_clv, entries) == 0 &&
+       (!parent_scaler || pllgpu_scaler_download(x->ctx, 0, parent_scaler, entries) == 0);
+  if (x && x->ctx && pllgpu_download_defer(x->ctx, 0) != 0) ok = 0;
+  if (!ok)
   {
+    if (!pll_errno) pll_set_gpu_error("pll_core_update_partial_*");
     fprintf(stderr, "libpll_amd: pll_core_update_partial_*: [%d] %s\n", pll_errno, pll_errmsg);
-    return;
   }
-  memcpy(parent_clv, p->clv[1], (size_t)entries * s->span * sizeof(double));
-  if (parent_scaler) memcpy(parent_scaler, p->scale_buffer[0], (size_t)entries * scaler_words(p) * sizeof(unsigned int));
 }
 
 void pll_core_update_partial_ii(unsigned int states, unsigned int sites, unsigned int rate_cats, double *parent_clv,

@@ -783,8 +783,16 @@ int pll_gpu_sync_all(pll_partition_t *p)
   int ok = PLL_SUCCESS;
   ok &= pll_gpu_sync_pmatrix(p, -1);
   ok &= pll_gpu_sync_repeats(p, -1);
+  /* small CLVs and scaler vectors: enqueued one after another, waited for together */
+  pll_amd_ext_t *x = pll_ext(p);
+  if (x && x->ctx) (void)pllgpu_download_defer(x->ctx, 1);
   for (i = 0; i < p->nodes; ++i) ok &= pll_gpu_sync_clv(p, i);
   for (i = 0; i < p->scale_buffers; ++i) ok &= pll_gpu_sync_scaler(p, i);
+  if (x && x->ctx && pllgpu_download_defer(x->ctx, 0) != 0)
+  {
+    pll_set_gpu_error("pll_gpu_sync_all");
+    ok = PLL_FAILURE;
+  }
   return ok;
 }
 

@@ -28,11 +28,12 @@ def main():
     ps = np.zeros((n, 1), dtype=np.uint32)
     l = T.rand_clv(rng, n, 4, 4, sp)
     r = T.rand_clv(rng, n, 4, 4, sp)
+    args = (4, n, 4, T.dp(pc), T.up(ps), T.dp(l), T.dp(r), T.dp(lm), T.dp(rm), None, None, api.ARCH_AVX2)  # (the pointers once: numpy's ctypes views cost a microsecond each)
     for _ in range(5):
-        f(4, n, 4, T.dp(pc), T.up(ps), T.dp(l), T.dp(r), T.dp(lm), T.dp(rm), None, None, api.ARCH_AVX2)
+        f(*args)
     t0 = time.perf_counter()
     for _ in range(calls):
-        f(4, n, 4, T.dp(pc), T.up(ps), T.dp(l), T.dp(r), T.dp(lm), T.dp(rm), None, None, api.ARCH_AVX2)
+        f(*args)
     print("pll_core_update_partial_ii, %d sites: %.1f us per call (%d calls), checksum %.17g" % (n, (time.perf_counter() - t0) / calls * 1e6, calls, float(pc.sum())))
 
 
