@@ -67,6 +67,8 @@ struct RepOp
   unsigned *pids;               // out: class -> first site
   unsigned *lent, *rent;        // out: class -> entry of the left / right child (what the gather kernels want)
   unsigned *table;              // this op's slice of the arena: ranges x cells while marking, then cell -> class
+  unsigned *keep;               // large tables: the node's bitmap of first sites as k_rep_bits last left it + one word: 1 while that is
+                                // what the node's maps derive from (RepPack::changed); or null
   unsigned *bitmap;             // large tables: [wstride] bitmap over the sites (ZERO between launches), then [wstride] running bit counts
   int lsrc, rsrc;               // op of this call that produces the child (index into counts[]), or -1: nleft / nright are given
   unsigned nleft, nright;
@@ -493,6 +495,7 @@ __device__ __forceinline__ void rep_mark(const RepPack &p, unsigned *rep_lds)
     rep_store_count(p, o, kRepFlag | classes, 0u);
     if (publishes) rep_arrive(p);
     if (moved) *p.changed = p.sequence; // (every writer of the call stores the same word)
+    if (threadIdx.x == 0u && o->keep) o->keep[(p.sites + 31u) / 32u] = 0u; // (not what k_rep_bits left any more)
     return;
   }
   if (NARROW) return; // (not reached: a large table is never the narrow build's)
@@ -592,22 +595,33 @@ __global__ __launch_bounds__(kRepScanThreads) void k_rep_bits(const RepPack p)
   const unsigned *__restrict__ table = o->table;
   unsigned *__restrict__ bitmap = o->bitmap, *__restrict__ wprefix = o->bitmap + p.wstride;
   unsigned *totals = o->bitmap + 2u * (size_t)p.wstride; // [bit_ranges] totals, then [bit_ranges] starting counts
+  unsigned *__restrict__ keep = o->keep;
+  unsigned moved = keep && keep[words] == 1u ? 0u : 1u; // (the word: written by launches before this one)
   for (unsigned w = threadIdx.x; w < p.bit_words; w += kRepScanThreads) rep_lds[w] = 0u;
   __syncthreads();
-  for (unsigned base = 0; base < ncells; base += 16u * kRepScanThreads)
+  // every cell of the op: sixteen 16-byte loads per thread in flight (65536 cells per round - a round is a trip to memory,
+  // and with four cells per trip a 125k-site shard's launch was four of them long: 14 us); the slices of the arena
+  // start at multiples of four cells and are padded to one
+  for (unsigned base = 0; base < ncells; base += 64u * kRepScanThreads)
   {
-    unsigned v[16];
+    uint4 v[16];
 #pragma unroll
     for (unsigned q = 0; q < 16u; ++q)
     {
-      const unsigned c = base + q * kRepScanThreads + threadIdx.x;
-      v[q] = c < ncells ? table[c] : kRepEmpty;
+      const unsigned c = base + (q * kRepScanThreads + threadIdx.x) * 4u;
+      v[q] = c < ncells ? *reinterpret_cast<const uint4 *>(table + c) : make_uint4(kRepEmpty, kRepEmpty, kRepEmpty, kRepEmpty);
     }
 #pragma unroll
     for (unsigned q = 0; q < 16u; ++q)
     {
-      const unsigned w = v[q] >> 5;
-      if (v[q] != kRepEmpty && w >= w0 && w < w1) atomicOr(&rep_lds[w - w0], 1u << (v[q] & 31u));
+      const unsigned c = base + (q * kRepScanThreads + threadIdx.x) * 4u;
+      const unsigned f[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+      for (unsigned e = 0; e < 4u; ++e)
+      {
+        const unsigned w = f[e] >> 5;
+        if (c + e < ncells && f[e] != kRepEmpty && w >= w0 && w < w1) atomicOr(&rep_lds[w - w0], 1u << (f[e] & 31u));
+      }
     }
   }
   __syncthreads();
@@ -639,9 +653,16 @@ __global__ __launch_bounds__(kRepScanThreads) void k_rep_bits(const RepPack p)
     {
       bitmap[w0 + w] = bits;
       wprefix[w0 + w] = run;
+      // the node's first sites as the last call left them: other ones = other class -> first site / child entry maps
+      if (keep)
+      {
+        moved |= keep[w0 + w] ^ bits;
+        keep[w0 + w] = bits;
+      }
     }
     run += __popc(bits);
   }
+  if (moved) *p.changed = p.sequence;
   // the range's total for the op's last workgroup
   if (threadIdx.x == 0u)
   {
@@ -666,6 +687,7 @@ __global__ __launch_bounds__(kRepScanThreads) void k_rep_bits(const RepPack p)
       classes += rep_coherent_load(&totals[r]);
     }
     s_last = classes;
+    if (keep) keep[words] = 1u;
   }
   __syncthreads();
   rep_store_count(p, o, kRepFlag | s_last, 0u);
@@ -686,6 +708,12 @@ __global__ __launch_bounds__(kRepScanThreads) void k_rep_scan(const RepPack p)
     unsigned *__restrict__ wprefix = o->bitmap + p.wstride;
     const unsigned words = (p.sites + 31u) / 32u;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0u)
+    {
+      // (this path keeps no bitmap to compare with: the node's maps count as other ones than before)
+      *p.changed = p.sequence;
+      if (o->keep) o->keep[words] = 0u;
+    }
     unsigned carried = 0; // set bits in the chunks before
     // chunks of 1024 threads x 32 consecutive words (1M sites): eight 16-byte loads per thread, all in flight together
     // (the buffers are allocated in whole chunks, zero beyond the last site)
@@ -820,18 +848,15 @@ __device__ __forceinline__ void rep_assign_tile(const RepPack &p, crepop_p o, un
     }
     if (FIRSTS && firsts)
     {
-      unsigned *pids = o->pids, *lent = o->lent, *rent = o->rent;
-      unsigned moved = 0u;
+      unsigned *__restrict__ pids = o->pids, *__restrict__ lent = o->lent, *__restrict__ rent = o->rent;
 #pragma unroll
       for (unsigned e = 0; e < 16u; ++e)
         if (firsts >> e & 1u)
         {
           pids[v[e]] = s + e;
-          moved |= (lent[v[e]] ^ l[e]) | (rent[v[e]] ^ r[e]);
           lent[v[e]] = l[e];
           rent[v[e]] = r[e];
         }
-      if (moved) *p.changed = p.sequence;
     }
   }
 }

@@ -206,6 +206,7 @@ struct pllgpu_ctx
   unsigned long long maps_foreign = 1, sub_pack_foreign = 0; // maps written by anything but the class kernels (uploads, count changes)
   unsigned sub_pack_since = 0;           // the class-map calls from this sequence number on came after the packed words
   DevBuf<unsigned> rep_changed;          // RepPack::changed
+  std::vector<DevBuf<unsigned>> rep_keep; // per node: RepOp::keep
   // small transfers go through one block of pinned, device-visible host memory (stage_take below)
   unsigned char *ring_host = nullptr, *ring_dev = nullptr;
   size_t ring_cap = 0, ring_off = 0;
@@ -466,6 +467,7 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   c->site_id.resize(geo->nodes);
   c->id_site.resize(geo->nodes);
   c->site_id8.resize(geo->nodes);
+  c->rep_keep.resize(geo->nodes);
   c->map_forms.assign(geo->nodes, 0);
   c->map_widened.assign(geo->nodes, 0);
   c->lent.resize(geo->nodes);
@@ -520,6 +522,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   for (auto &b : c->site_id) b.release();
   for (auto &b : c->id_site) b.release();
   for (auto &b : c->site_id8) b.release();
+  for (auto &b : c->rep_keep) b.release();
   for (auto &b : c->lent) b.release();
   for (auto &b : c->rent) b.release();
   c->tipmap.release();
@@ -3035,6 +3038,16 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
       r.rent = c->rent[o.parent].p;
       r.table = reinterpret_cast<unsigned *>(cells); // offset for now: the arena may still grow
       r.bitmap = reinterpret_cast<unsigned *>((size_t)k * op_scratch);
+      r.keep = nullptr;
+      if (ub > kRepSmallCells)
+      {
+        // (zeroed when it is new: its last word says whether the rest is what the node's maps derive from)
+        DevBuf<unsigned> &kb = c->rep_keep[o.parent];
+        const size_t had = kb.cap;
+        if (int rc = kb.ensure((size_t)words + 1u)) return rc;
+        if (kb.cap != had) HIP_TRY(hipMemsetAsync(kb.p, 0, kb.cap * sizeof(unsigned), c->stream));
+        r.keep = kb.p;
+      }
       r.lsrc = o.lsrc;
       r.rsrc = o.rsrc;
       r.nleft = o.nleft;

@@ -1,6 +1,11 @@
 set -e
-python3 tools/seam_loop.py 2000 1000
-PLL_AMD_PINNED_STAGING=0 python3 tools/seam_loop.py 2000 1000
-python3 tools/seam_loop.py 2000 1000
-PLL_AMD_PINNED_STAGING=0 python3 tools/seam_loop.py 2000 1000
-python -m pytest tests -x -q -m gpu > gpurun_out/r5/full2.log 2>&1; tail -3 gpurun_out/r5/full2.log
+python -m pytest tests/test_gpu_repeats.py tests/test_gpu_c4_sharded.py -x -q -m gpu 2>&1 | tail -2
+python3 tools/rep_ab.py 125000 bench "" PLL_AMD_SUB_PACK_ALWAYS=1 "" PLL_AMD_SUB_PACK_ALWAYS=1
+python3 tools/rep_ab.py 1000000 bench "" PLL_AMD_SUB_PACK_ALWAYS=1 "" PLL_AMD_SUB_PACK_ALWAYS=1
+mkdir -p gpurun_out/r5/tl125 gpurun_out/r5/tl1m
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r5/tl125 -o t -- python3 $GRAFT_REPO_ROOT/tools/rep_ab.py 125000 bench "" > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r5/tl1m -o t -- python3 $GRAFT_REPO_ROOT/tools/rep_ab.py 1000000 bench "" > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+python3 tools/rep_timeline.py gpurun_out/r5/tl125 | head -11
+python3 tools/rep_timeline.py gpurun_out/r5/tl1m | head -11
