@@ -67,6 +67,7 @@ struct RepOp
   unsigned *pids;               // out: class -> first site
   unsigned *lent, *rent;        // out: class -> entry of the left / right child (what the gather kernels want)
   unsigned *table;              // this op's slice of the arena: ranges x cells while marking, then cell -> class
+  unsigned *final;              // where cell -> class is left: `table`, or - kRepDeferred - a place that outlives the next launches
   unsigned *keep;               // large tables: the node's bitmap of first sites as k_rep_bits last left it + one word: 1 while that is
                                 // what the node's maps derive from (RepPack::changed); or null
   unsigned *bitmap;             // large tables: [wstride] bitmap over the sites (ZERO between launches), then [wstride] running bit counts
@@ -75,13 +76,20 @@ struct RepOp
   unsigned slot;                // this op's index in counts[]
   unsigned force;               // 1: the host decided to compress (enable_repeats callback); 0: the default rule, here
   unsigned slice;               // cells in `table`
-  unsigned pad;
+  unsigned flags;               // kRepFuseLeft | kRepFuseRight | kRepDeferred
 };
 typedef const RepOp __attribute__((address_space(4))) *crepop_p;
+// A child's site -> class pass inside its parent's mark launch. A child X with a table of at most kRepFuseCells cells over
+// byte maps, produced by this call and read by ONE op P of it: k_rep_assign leaves X out (kRepDeferred); P's workgroups -
+// which read X's map anyway - form it from X's own children's maps and X's table (bytes in LDS) as they go, and write it
+// for whoever comes later (kRepFuseLeft / kRepFuseRight on P). Two launches and one pass over the maps less per level.
+constexpr unsigned kRepFuseLeft = 1u, kRepFuseRight = 2u, kRepDeferred = 4u;
+constexpr unsigned kRepFuseCells = 256;
 
 struct RepPack
 {
   const RepOp *ops;       // device array: this launch's ops
+  const RepOp *all_ops;   // ... the call's (RepOp::lsrc / rsrc index it)
   unsigned *counts;       // [ncounts] per op of the CALL: kRepFlag | classes, or 0 (not compressed)
   unsigned *tickets;      // [kRepOps] arrivals of an op's workgroups (small tables; 0 between launches)
   unsigned *launch_ticket; // ops of the launch whose count is known (0 between launches)
@@ -271,6 +279,112 @@ __device__ __forceinline__ void rep_scan(crepop_p o, unsigned nleft, unsigned s0
   }
 }
 
+// A fused child (kRepFuseLeft / Right): what the scan needs of it.
+struct RepFused
+{
+  const unsigned char *a8, *b8; // the child's own children's maps
+  unsigned char *out8;          // the child's map, written here (null: another workgroup of the op writes these sites)
+  const unsigned char *tab;     // LDS: the child's cell -> class
+  unsigned nl;                  // its left child's classes
+};
+
+// sixteen sites of a fused child: its class per site from its children's maps, as the bytes its map holds
+__device__ __forceinline__ uint4 rep_fused16(const RepFused &f, const uint4 &a, const uint4 &b, unsigned s)
+{
+  const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+  unsigned ow[4];
+#pragma unroll
+  for (unsigned q = 0; q < 4u; ++q)
+  {
+    unsigned w = 0u;
+#pragma unroll
+    for (unsigned e = 0; e < 4u; ++e)
+    {
+      // (the padding behind the last site holds anything: kept inside the table, stored into the padding of the child's map)
+      const unsigned cell = (((aw[q] >> (8u * e)) & 255u) + ((bw[q] >> (8u * e)) & 255u) * f.nl) & (kRepFuseCells - 1u);
+      w |= (unsigned)f.tab[cell] << (8u * e);
+    }
+    ow[q] = w;
+  }
+  const uint4 out = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+  if (f.out8) *reinterpret_cast<uint4 *>(f.out8 + s) = out;
+  return out;
+}
+
+// rep_scan for two byte maps of which one or both are fused children
+template <bool LF, bool RF, bool WHOLE>
+__device__ __forceinline__ void rep_scan_fused(crepop_p o, const RepFused &fl, const RepFused &fr, unsigned nleft, unsigned s0, unsigned s1, unsigned lo, unsigned pcells,
+                                               unsigned *lds)
+{
+  const unsigned char *la = LF ? fl.a8 : o->l8, *lb = fl.b8, *ra = RF ? fr.a8 : o->r8, *rb = fr.b8;
+  unsigned s = s0 + threadIdx.x * 16u;
+  if (s >= s1) return;
+  uint4 la_q = *reinterpret_cast<const uint4 *>(la + s), ra_q = *reinterpret_cast<const uint4 *>(ra + s);
+  uint4 lb_q = la_q, rb_q = ra_q;
+  if (LF) lb_q = *reinterpret_cast<const uint4 *>(lb + s);
+  if (RF) rb_q = *reinterpret_cast<const uint4 *>(rb + s);
+  for (;;)
+  {
+    const unsigned sn = s + kRepThreads * 16u;
+    const bool more = sn < s1;
+    uint4 la_n = la_q, lb_n = lb_q, ra_n = ra_q, rb_n = rb_q;
+    if (more)
+    {
+      la_n = *reinterpret_cast<const uint4 *>(la + sn);
+      ra_n = *reinterpret_cast<const uint4 *>(ra + sn);
+      if (LF) lb_n = *reinterpret_cast<const uint4 *>(lb + sn);
+      if (RF) rb_n = *reinterpret_cast<const uint4 *>(rb + sn);
+    }
+    const uint4 lq = LF ? rep_fused16(fl, la_q, lb_q, s) : la_q;
+    const uint4 rq = RF ? rep_fused16(fr, ra_q, rb_q, s) : ra_q;
+    if (s + 16u <= s1) rep_group_bytes<WHOLE, true>(lq, rq, nleft, s, s1, lo, pcells, lds);
+    else rep_group_bytes<WHOLE, false>(lq, rq, nleft, s, s1, lo, pcells, lds);
+    if (!more) return;
+    la_q = la_n;
+    lb_q = lb_n;
+    ra_q = ra_n;
+    rb_q = rb_n;
+    s = sn;
+  }
+}
+
+template <bool WHOLE>
+__device__ __forceinline__ void rep_scan_fused_forms(crepop_p o, const RepFused &fl, const RepFused &fr, unsigned flags, unsigned nleft, unsigned s0, unsigned s1, unsigned lo,
+                                                     unsigned pcells, unsigned *lds)
+{
+  if ((flags & kRepFuseLeft) && (flags & kRepFuseRight)) rep_scan_fused<true, true, WHOLE>(o, fl, fr, nleft, s0, s1, lo, pcells, lds);
+  else if (flags & kRepFuseLeft) rep_scan_fused<true, false, WHOLE>(o, fl, fr, nleft, s0, s1, lo, pcells, lds);
+  else rep_scan_fused<false, true, WHOLE>(o, fl, fr, nleft, s0, s1, lo, pcells, lds);
+}
+
+// the maps of an op's fused children alone, sites [s0, s1): the op itself stays uncompressed
+__device__ __forceinline__ void rep_fused_only(const RepFused &f, unsigned s0, unsigned s1)
+{
+  for (unsigned s = s0 + threadIdx.x * 16u; s < s1; s += kRepThreads * 16u)
+    (void)rep_fused16(f, *reinterpret_cast<const uint4 *>(f.a8 + s), *reinterpret_cast<const uint4 *>(f.b8 + s), s);
+}
+
+// what P's workgroup needs of its fused child `side`: the child's table as bytes in `tab` (LDS; the caller's barrier
+// follows). live = false: nothing to do for this side (not fused, or the child has no maps).
+__device__ __forceinline__ bool rep_fused_open(const RepPack &p, crepop_p o, bool right, unsigned char *tab, RepFused &f)
+{
+  f.a8 = f.b8 = nullptr;
+  f.out8 = nullptr;
+  f.tab = tab;
+  f.nl = 0u;
+  if (!(o->flags & (right ? kRepFuseRight : kRepFuseLeft))) return false;
+  crepop_p x = (crepop_p)(uintptr_t)p.all_ops + (right ? o->rsrc : o->lsrc);
+  if (!rep_ids(p.counts[x->slot], p.sites)) return false; // (uniform) the child is not compressed: no map
+  const RepShape xs = rep_shape(p, x);
+  f.a8 = x->l8;
+  f.b8 = x->r8;
+  f.out8 = x->p8;
+  f.nl = xs.nl;
+  const unsigned *__restrict__ final = x->final;
+  for (unsigned i = threadIdx.x; i < xs.ncells && i < kRepFuseCells; i += kRepThreads) tab[i] = (unsigned char)final[i];
+  return true;
+}
+
 template <bool WHOLE>
 __device__ __forceinline__ void rep_scan_forms(crepop_p o, const RepShape &sh, unsigned s0, unsigned s1, unsigned lo, unsigned pcells, unsigned *lds)
 {
@@ -352,7 +466,7 @@ __device__ __forceinline__ void rep_fold_copies(const unsigned *table, unsigned 
 static_assert(kRepSmallCells <= 2u * kRepThreads, "rep_rank_small: two cells per thread");
 __device__ __forceinline__ unsigned rep_rank_small(crepop_p o, unsigned ncells, unsigned nl, const unsigned *lds, unsigned *s_count, unsigned &moved)
 {
-  unsigned *table = o->table;
+  unsigned *table = o->final;
   unsigned *pids = o->pids, *lent = o->lent, *rent = o->rent;
   if (threadIdx.x == 0u) *s_count = 0u;
   __syncthreads();
@@ -427,20 +541,34 @@ __device__ __forceinline__ RepSplit rep_split(const RepPack &p, crepop_p o, unsi
 // the waves to issue from. Everything else - 32-bit maps, large tables - is the general build. A level's launch
 // consists of the builds its ops may need (the host knows bounds); an op is taken by the build its actual counts ask
 // for; parents that stay uncompressed are reported by the general build if it is there.
-template <bool NARROW>
+template <bool NARROW, bool FUSED>
 __device__ __forceinline__ void rep_mark(const RepPack &p, unsigned *rep_lds)
 {
   __shared__ unsigned s_count;
   __shared__ unsigned s_last;
+  __shared__ unsigned char s_tab[2][kRepFuseCells];
   unsigned opi, w;
   if (!rep_place(p.nops, p.mark_wgs, opi, w)) return;
   crepop_p o = (crepop_p)(uintptr_t)p.ops + opi;
   const RepShape sh = rep_shape(p, o);
   const bool large = sh.ncells > kRepSmallCells;
   const bool publishes = !p.has_rank; // no k_rep_scan behind this launch: the counts are handed over here
+  const unsigned fuse = FUSED ? o->flags & (kRepFuseLeft | kRepFuseRight) : 0u; // (a launch with fused children takes the builds that know them)
+  RepFused fl = {}, fr = {};
   if (!sh.on || (large && !p.has_rank))
   {
-    if (w != 0u || NARROW != !p.has_general) return;
+    if (NARROW != !p.has_general) return;
+    if (fuse)
+    {
+      // the maps of its fused children are still this op's to write: its workgroups share the sites
+      const bool lv = rep_fused_open(p, o, false, s_tab[0], fl), rv = rep_fused_open(p, o, true, s_tab[1], fr);
+      __syncthreads();
+      const unsigned rs = ((p.sites + p.mark_wgs - 1u) / p.mark_wgs + 15u) & ~15u;
+      const unsigned s0 = w * rs < p.sites ? w * rs : p.sites, s1 = s0 + rs < p.sites ? s0 + rs : p.sites;
+      if (lv) rep_fused_only(fl, s0, s1);
+      if (rv) rep_fused_only(fr, s0, s1);
+    }
+    if (w != 0u) return;
     const unsigned long long cells = (unsigned long long)sh.nl * sh.nr;
     // 1: a table the slice cannot hold although the rule admits it - the host's bound was wrong; 2: a large table in
     // a launch that came without the kernels for it - the host's forecast was wrong
@@ -458,12 +586,19 @@ __device__ __forceinline__ void rep_mark(const RepPack &p, unsigned *rep_lds)
   const unsigned rs = ((p.sites + sp.nranges - 1u) / sp.nranges + 15u) & ~15u; // sites per range, whole groups of sixteen
   const unsigned range = sp.looped ? 0u : w / sp.nparts;
   const unsigned s0 = range * rs < p.sites ? range * rs : p.sites, s1 = s0 + rs < p.sites ? s0 + rs : p.sites;
+  if (fuse)
+  {
+    // (an op that is compressed has compressed children: both fused sides are live; the barriers below come before the scan)
+    (void)rep_fused_open(p, o, false, s_tab[0], fl);
+    (void)rep_fused_open(p, o, true, s_tab[1], fr);
+  }
   if (!large)
   {
     // the whole table in LDS; the op's last workgroup folds the ranges and numbers the classes
     for (unsigned i = threadIdx.x; i < ncells; i += kRepThreads) rep_lds[i] = kRepEmpty;
     __syncthreads();
-    if (NARROW) rep_scan<true, true, true>(o, sh.nl, s0, s1, 0u, ncells, rep_lds);
+    if (fuse) rep_scan_fused_forms<true>(o, fl, fr, fuse, sh.nl, s0, s1, 0u, ncells, rep_lds);
+    else if (NARROW) rep_scan<true, true, true>(o, sh.nl, s0, s1, 0u, ncells, rep_lds);
     else rep_scan_forms<true>(o, sh, s0, s1, 0u, ncells, rep_lds);
     __syncthreads();
     if (sp.nranges > 1u)
@@ -501,12 +636,21 @@ __device__ __forceinline__ void rep_mark(const RepPack &p, unsigned *rep_lds)
   if (NARROW) return; // (not reached: a large table is never the narrow build's)
   // large: this workgroup's copy of its part(s) for k_rep_fold, plain stores
   const unsigned pc = (ncells + sp.nparts - 1u) / sp.nparts; // cells per part (<= mark_lds_cells)
+  unsigned char *const lout = fl.out8, *const rout = fr.out8;
   for (unsigned part = sp.looped ? w : w % sp.nparts; part < sp.nparts; part += sp.looped ? used : sp.nparts)
   {
     const unsigned lo = part * pc, pcells = lo + pc <= ncells ? pc : ncells - lo;
     for (unsigned i = threadIdx.x; i < pcells; i += kRepThreads) rep_lds[i] = kRepEmpty;
     __syncthreads();
-    if (sp.nparts == 1u) rep_scan_forms<true>(o, sh, s0, s1, 0u, ncells, rep_lds);
+    if (fuse)
+    {
+      // every part scans the range's sites; the fused children's maps are written along with part 0
+      fl.out8 = part == 0u ? lout : nullptr;
+      fr.out8 = part == 0u ? rout : nullptr;
+      if (sp.nparts == 1u) rep_scan_fused_forms<true>(o, fl, fr, fuse, sh.nl, s0, s1, 0u, ncells, rep_lds);
+      else rep_scan_fused_forms<false>(o, fl, fr, fuse, sh.nl, s0, s1, lo, pcells, rep_lds);
+    }
+    else if (sp.nparts == 1u) rep_scan_forms<true>(o, sh, s0, s1, 0u, ncells, rep_lds);
     else rep_scan_forms<false>(o, sh, s0, s1, lo, pcells, rep_lds);
     __syncthreads();
     unsigned *dst = o->table + (size_t)range * ncells + lo;
@@ -519,13 +663,20 @@ __device__ __forceinline__ void rep_mark(const RepPack &p, unsigned *rep_lds)
 __global__ __launch_bounds__(kRepThreads, 8) void k_rep_mark_narrow(const RepPack p)
 {
   extern __shared__ unsigned rep_lds[];
-  rep_mark<true>(p, rep_lds);
+  rep_mark<true, false>(p, rep_lds);
+}
+
+// ... with fused children (twice the maps in flight: 85 registers, three workgroups per CU - still the whole grid at once)
+__global__ __launch_bounds__(kRepThreads, 6) void k_rep_mark_narrow_fused(const RepPack p)
+{
+  extern __shared__ unsigned rep_lds[];
+  rep_mark<true, true>(p, rep_lds);
 }
 
 __global__ __launch_bounds__(kRepThreads) void k_rep_mark(const RepPack p)
 {
   extern __shared__ unsigned rep_lds[];
-  rep_mark<false>(p, rep_lds);
+  rep_mark<false, true>(p, rep_lds);
 }
 
 // Large tables, second step: the copies of the ranges folded - first[cell] = the lowest over them, left in copy 0 - and,
@@ -814,7 +965,7 @@ __device__ __forceinline__ void rep_assign_tile(const RepPack &p, crepop_p o, un
 {
   const unsigned char *l8 = o->l8, *r8 = o->r8;
   const unsigned *l32 = o->l32, *r32 = o->r32;
-  const unsigned *__restrict__ table = o->table;
+  const unsigned *__restrict__ table = o->final;
   const unsigned sites = p.sites;
   const unsigned tile0 = tile * p.assign_iters * kRepAssignThreads * 16u;
   for (unsigned it = 0; it < p.assign_iters; ++it)
@@ -866,7 +1017,7 @@ __device__ __forceinline__ void rep_assign_form(const RepPack &p, crepop_p o, un
 {
   if (ncells <= p.lds_cells)
   {
-    const unsigned *__restrict__ table = o->table;
+    const unsigned *__restrict__ table = o->final;
     // (an empty cell: no site looks it up; the slices of the arena start at multiples of four cells and are padded to one)
     for (unsigned i = threadIdx.x * 4u; i < ncells; i += kRepAssignThreads * 4u)
     {
@@ -891,6 +1042,7 @@ __global__ __launch_bounds__(kRepAssignThreads) void k_rep_assign(const RepPack 
   crepop_p o = (crepop_p)(uintptr_t)p.ops + opi;
   const unsigned word = p.counts[o->slot];
   if (!(word & kRepFlag)) return; // not compressed: no maps
+  if (o->flags & kRepDeferred) return; // its parent's k_rep_mark writes the map
   const RepShape sh = rep_shape(p, o);
   const unsigned form = (sh.nl <= kRepNarrow ? 4u : 0u) | (sh.nr <= kRepNarrow ? 2u : 0u) | ((word & ~kRepFlag) <= kRepNarrow ? 1u : 0u);
   switch (form)

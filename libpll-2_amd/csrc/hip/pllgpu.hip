@@ -207,6 +207,8 @@ struct pllgpu_ctx
   unsigned sub_pack_since = 0;           // the class-map calls from this sequence number on came after the packed words
   DevBuf<unsigned> rep_changed;          // RepPack::changed
   std::vector<DevBuf<unsigned>> rep_keep; // per node: RepOp::keep
+  DevBuf<unsigned> rep_final;            // RepOp::final of the deferred ops of a call (kRepFuseCells cells each)
+  bool rep_fuse = true;                  // PLL_AMD_REP_FUSE=0: every op's site -> class pass in k_rep_assign (A/B)
   // small transfers go through one block of pinned, device-visible host memory (stage_take below)
   unsigned char *ring_host = nullptr, *ring_dev = nullptr;
   size_t ring_cap = 0, ring_off = 0;
@@ -494,6 +496,7 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   if (const char *v = getenv("PLL_AMD_REP_ASSIGN_LDS")) c->rep_assign_lds = (unsigned)std::min<int>(kRepAssignLds, std::max(0, atoi(v)));
   if (const char *v = getenv("PLL_AMD_REP_BITS")) c->rep_bits = !(*v == '0');
   if (const char *v = getenv("PLL_AMD_SUB_PACK_ALWAYS")) c->sub_pack_always = *v && *v != '0';
+  if (const char *v = getenv("PLL_AMD_REP_FUSE")) c->rep_fuse = !(*v == '0');
   if (const char *v = getenv("PLL_AMD_PINNED_STAGING")) c->ring_failed = *v == '0'; // 0: every transfer from / to pageable memory as the runtime does it (A/B)
   if (const char *v = getenv("PLL_AMD_REP_HINTS")) c->rep_hints = !(*v == '0');
   if (const char *v = getenv("PLL_AMD_REP_RANGES")) c->rep_max_ranges = (unsigned)std::max(1, atoi(v));
@@ -549,6 +552,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   c->rep_counts.release();
   c->rep_sync.release();
   c->rep_changed.release();
+  c->rep_final.release();
   c->rates.release();
   c->diag.release();
   for (auto &b : c->sumtable) b.release();
@@ -2995,10 +2999,43 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     bool rank; // some op's table may be a large one: k_rep_fold + k_rep_scan + k_rep_rank between k_rep_mark and k_rep_assign
     bool narrow, general; // the builds of k_rep_mark its ops may need (kernels_repeats.h)
     size_t max_cells;     // the largest table an op of the launch may have
+    bool fused;           // some op has fused children
+    bool assign;          // some op's site -> class pass is k_rep_assign's (not every one deferred to the parent's k_rep_mark)
   };
   std::vector<Launch> launches;
   std::vector<RepOp> &rops = c->rep_ops_host;
   rops.assign(ncut, RepOp());
+  // A child's site -> class pass inside its parent's k_rep_mark (kernels_repeats.h: kRepFuseLeft): for a child X of the call
+  // whose table is small for sure, over byte maps, read by exactly one launched op P whose children's maps are both bytes
+  std::vector<unsigned> fuse(ncut, 0u);
+  std::vector<int> final_slot(ncut, -1);
+  unsigned ndeferred = 0;
+  if (c->rep_fuse)
+  {
+    std::vector<unsigned> readers(ncut, 0u);
+    for (unsigned i = 0; i < ncut; ++i)
+    {
+      if (ops[i].lsrc >= 0) ++readers[ops[i].lsrc];
+      if (ops[i].rsrc >= 0) ++readers[ops[i].rsrc];
+    }
+    auto bytes = [&](int src, unsigned given) { return (src >= 0 ? ub_classes[src] : given) <= kRepNarrow; };
+    for (unsigned i = 0; i < ncut; ++i)
+    {
+      const pllgpu_repop_t &o = ops[i];
+      if (o.force || !bytes(o.lsrc, o.nleft) || !bytes(o.rsrc, o.nright) || (o.lsrc >= 0 && o.lsrc == o.rsrc)) continue;
+      const int kid[2] = {o.lsrc, o.rsrc};
+      for (int k = 0; k < 2; ++k)
+      {
+        const int x = kid[k];
+        if (x < 0 || readers[x] != 1u || ops[x].force || !ub_cells[x] || ub_cells[x] > kRepFuseCells) continue;
+        if (!bytes(ops[x].lsrc, ops[x].nleft) || !bytes(ops[x].rsrc, ops[x].nright)) continue;
+        fuse[i] |= k ? kRepFuseRight : kRepFuseLeft;
+        fuse[x] |= kRepDeferred;
+        final_slot[x] = (int)ndeferred++;
+      }
+    }
+    if (int rc = c->rep_final.ensure((size_t)std::max(1u, ndeferred) * kRepFuseCells)) return rc;
+  }
   size_t arena = 0;
   for (unsigned done = 0; done < ncut;)
   {
@@ -3007,7 +3044,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     // workgroups per op: ~512 per launch - all resident at once, and on a 125k-site shard measurably better than 1024
     // (how they split into table parts and site ranges: k_rep_mark)
     const unsigned wgs = c->rep_wgs ? c->rep_wgs : std::max(1u, std::min(64u, (512u + room - 1u) / room));
-    Launch L = {done, 0, wgs, kRepSmallCells, 64, false, false, false, 0};
+    Launch L = {done, 0, wgs, kRepSmallCells, 64, false, false, false, 0, false, false};
     size_t cells = 0;
     for (unsigned k = 0; k < room; ++k)
     {
@@ -3055,6 +3092,9 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
       r.slot = i;
       r.force = o.force ? 1u : 0u;
       r.slice = (unsigned)std::min<size_t>(slice, 0x7FFFFFFFu);
+      r.flags = fuse[i];
+      if (fuse[i] & (kRepFuseLeft | kRepFuseRight)) L.fused = true;
+      if (!(fuse[i] & kRepDeferred) && ub) L.assign = true;
       cells += slice;
       L.mark_lds = std::max<unsigned>(L.mark_lds, (unsigned)std::min<size_t>(ub, kRepLdsCells));
       if (ub <= c->rep_assign_lds) L.assign_lds = std::max<unsigned>(L.assign_lds, (unsigned)((ub + 3u) & ~(size_t)3u));
@@ -3081,6 +3121,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
   {
     rops[i].table = c->rep_table.p + reinterpret_cast<size_t>(rops[i].table);
     rops[i].bitmap = c->rep_blocksum.p + reinterpret_cast<size_t>(rops[i].bitmap);
+    rops[i].final = final_slot[i] >= 0 ? c->rep_final.p + (size_t)final_slot[i] * kRepFuseCells : rops[i].table;
   }
   // pageable source: staged before hipMemcpyAsync returns; ordered behind the previous call's kernels
   HIP_TRY(hipMemcpyAsync(c->rep_ops.p, rops.data(), (size_t)ncut * sizeof(RepOp), hipMemcpyHostToDevice, c->stream));
@@ -3091,6 +3132,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
   pk.tickets = c->rep_sync.p;
   pk.launch_ticket = c->rep_sync.p + kRepOps;
   pk.changed = c->rep_changed.p;
+  pk.all_ops = reinterpret_cast<const RepOp *>(c->rep_ops.p);
   pk.max_ranges = c->rep_max_ranges;
   pk.host_counts = c->rep_host_dev;
   pk.ncounts = ncut;
@@ -3113,7 +3155,10 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     const unsigned n8 = (L.n + 7u) / 8u * 8u;
     pk.has_narrow = L.narrow ? 1u : 0u;
     pk.has_general = L.general || !L.narrow ? 1u : 0u;
-    if (pk.has_narrow) hipLaunchKernelGGL(k_rep_mark_narrow, dim3(n8 * L.wgs), dim3(kRepThreads), kRepSmallCells * sizeof(unsigned), c->stream, pk);
+    if (pk.has_narrow && L.fused)
+      hipLaunchKernelGGL(k_rep_mark_narrow_fused, dim3(n8 * L.wgs), dim3(kRepThreads), kRepSmallCells * sizeof(unsigned), c->stream, pk);
+    else if (pk.has_narrow)
+      hipLaunchKernelGGL(k_rep_mark_narrow, dim3(n8 * L.wgs), dim3(kRepThreads), kRepSmallCells * sizeof(unsigned), c->stream, pk);
     if (pk.has_general)
     {
       const size_t mark_bytes = (size_t)L.mark_lds * sizeof(unsigned);
@@ -3144,7 +3189,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     if (c->rep_assign_iters) pk.assign_iters = c->rep_assign_iters;
     pk.wgs = (rounds + pk.assign_iters - 1u) / pk.assign_iters;
     raise_lds_limit((const void *)k_rep_assign, c->device, assign_bytes);
-    hipLaunchKernelGGL(k_rep_assign, dim3(n8 * pk.wgs), dim3(kRepAssignThreads), assign_bytes, c->stream, pk);
+    if (L.assign) hipLaunchKernelGGL(k_rep_assign, dim3(n8 * pk.wgs), dim3(kRepAssignThreads), assign_bytes, c->stream, pk);
   }
   HIP_TRY(hipGetLastError());
   // the class counts arrive in mapped host memory as soon as the last k_rep_mark knows them (its k_rep_assign still

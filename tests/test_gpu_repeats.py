@@ -242,7 +242,8 @@ def test_packed_subtree_lookups_follow_maps_and_tips(amd_lib, monkeypatch, alway
 
 
 @pytest.mark.parametrize("env", [{"PLL_AMD_REP_LEVEL_SYNC": "1"}, {"PLL_AMD_REP_HINTS": "0"}, {"PLL_AMD_REP_WGS": "1"}, {"PLL_AMD_REP_WGS": "64"},
-                                 {"PLL_AMD_REP_RANGES": "1"}, {"PLL_AMD_REP_RANGES": "16", "PLL_AMD_REP_WGS": "64"}, {"PLL_AMD_FENCED_HANDOFF": "1"}],
+                                 {"PLL_AMD_REP_RANGES": "1"}, {"PLL_AMD_REP_RANGES": "16", "PLL_AMD_REP_WGS": "64"}, {"PLL_AMD_FENCED_HANDOFF": "1"},
+                                 {"PLL_AMD_REP_FUSE": "0"}, {"PLL_AMD_REP_BITS": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 @pytest.mark.parametrize("kw", [dict(states=4, tips=64, sites=70000, mutate_pct=4, seed=81),     # small and large tables, several ranges and parts
                                 dict(states=4, tips=16, sites=300, mutate_pct=30, seed=82),
