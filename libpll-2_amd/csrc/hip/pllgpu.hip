@@ -207,6 +207,8 @@ struct pllgpu_ctx
   unsigned sub_pack_since = 0;           // the class-map calls from this sequence number on came after the packed words
   DevBuf<unsigned> rep_changed;          // RepPack::changed
   std::vector<DevBuf<unsigned>> rep_keep; // per node: RepOp::keep
+  std::vector<unsigned char> rep_ops_sent; // the descriptors the device array holds (bytes), and where
+  const void *rep_ops_sent_at = nullptr;
   DevBuf<unsigned> rep_final;            // RepOp::final of the deferred ops of a call (kRepFuseCells cells each)
   bool rep_fuse = true;                  // PLL_AMD_REP_FUSE=0: every op's site -> class pass in k_rep_assign (A/B)
   // small transfers go through one block of pinned, device-visible host memory (stage_take below)
@@ -3123,8 +3125,16 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     rops[i].bitmap = c->rep_blocksum.p + reinterpret_cast<size_t>(rops[i].bitmap);
     rops[i].final = final_slot[i] >= 0 ? c->rep_final.p + (size_t)final_slot[i] * kRepFuseCells : rops[i].table;
   }
-  // pageable source: staged before hipMemcpyAsync returns; ordered behind the previous call's kernels
-  HIP_TRY(hipMemcpyAsync(c->rep_ops.p, rops.data(), (size_t)ncut * sizeof(RepOp), hipMemcpyHostToDevice, c->stream));
+  // the descriptors go up unless the device array holds exactly these (the same list over the same buffers: the re-evaluation
+  // of one tree - a copy of 14 KB is 5 us on the stream, ahead of the first launch)
+  if (c->rep_ops_sent.size() != (size_t)ncut * sizeof(RepOp) || c->rep_ops_sent_at != c->rep_ops.p ||
+      memcmp(c->rep_ops_sent.data(), rops.data(), c->rep_ops_sent.size()) != 0)
+  {
+    // pageable source: staged before hipMemcpyAsync returns; ordered behind the previous call's kernels
+    HIP_TRY(hipMemcpyAsync(c->rep_ops.p, rops.data(), (size_t)ncut * sizeof(RepOp), hipMemcpyHostToDevice, c->stream));
+    c->rep_ops_sent.assign(reinterpret_cast<const unsigned char *>(rops.data()), reinterpret_cast<const unsigned char *>(rops.data() + ncut));
+    c->rep_ops_sent_at = c->rep_ops.p;
+  }
   c->rep_host[c->rep_host_cap + 1u] = 0u;
   RepPack pk;
   memset(&pk, 0, sizeof pk);

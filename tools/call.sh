@@ -1,11 +1,5 @@
 set -e
-python -m pytest tests/test_gpu_repeats.py tests/test_gpu_c4_sharded.py tests/test_gpu_fullsize.py -x -q -m gpu 2>&1 | tail -4
-python3 tools/rep_ab.py 125000 bench "" PLL_AMD_REP_FUSE=0 "" PLL_AMD_REP_FUSE=0
-python3 tools/rep_ab.py 1000000 bench "" PLL_AMD_REP_FUSE=0 "" PLL_AMD_REP_FUSE=0
-mkdir -p gpurun_out/r5/tl125 gpurun_out/r5/tl1m
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r5/tl125 -o t -- python3 $GRAFT_REPO_ROOT/tools/rep_ab.py 125000 bench "" > /dev/null 2>&1
-rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r5/tl1m -o t -- python3 $GRAFT_REPO_ROOT/tools/rep_ab.py 1000000 bench "" > /dev/null 2>&1
-cd $GRAFT_REPO_ROOT
-python3 tools/rep_timeline.py gpurun_out/r5/tl125 | head -9
-python3 tools/rep_timeline.py gpurun_out/r5/tl1m | head -9
+python3 tools/rep_ab.py 125000 bench "" PLL_AMD_REP_FUSE=0
+python3 tools/rep_ab.py 1000000 bench ""
+python tools/c4_projection.py > gpurun_out/r5/c4_proj_f3.json 2> gpurun_out/r5/c4_proj_f3.err
+python -m pytest tests -x -q -m gpu > gpurun_out/r5/full3.log 2>&1; tail -3 gpurun_out/r5/full3.log
