@@ -29,6 +29,9 @@
 //                 tables: the sites the bitmap marks as first also write the class -> first site / child entry maps,
 //                 in site order = class order (small tables: the op's last workgroup wrote them).
 //
+// A small child's site -> class pass runs inside its parent's k_rep_mark instead (kRepFuseLeft, below); what is derived from
+// the CONTENTS of the maps is told whether they moved (RepPack::changed).
+//
 // Whether a parent is compressed at all is decided HERE, by the reference's default rule, from the children's class
 // counts as the launches of the levels below left them in device memory: the host enqueues all levels back to back
 // and reads every count once at the end (round 4: one blocking hand-off per level). A caller-supplied
