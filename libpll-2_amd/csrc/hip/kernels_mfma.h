@@ -174,7 +174,7 @@ template <int NG, bool LTIP, bool RTIP, bool GATHER>
 __global__ __launch_bounds__(256, NG > 8 ? 2 : 4) void k_partials_mfma(const OpPack pack, const GenGeo g,
                                                           const unsigned long long *__restrict__ tipmap,
                                                           unsigned items_per_wave, unsigned char *__restrict__ flagbuf,
-                                                          unsigned flag_stride /* bytes per (op, rate) */)
+                                                          unsigned flag_stride /* bytes per (op, rate) */, unsigned xcd_nx, unsigned xcd_ny)
 {
   extern __shared__ double lds[];
   typedef MfmaGeo<NG> MG;
@@ -183,15 +183,26 @@ __global__ __launch_bounds__(256, NG > 8 ? 2 : 4) void k_partials_mfma(const OpP
   double *PR = lds + MG::frag_array;
   double *RS = lds + MG::rowsum_off; // row sums of P_left [4 NG], P_right [4 NG]
 
-  const DevOp &op = pack.ops[blockIdx.y];
+  // xcd_nx != 0: a 1-D grid in the XCD-aware order of the store-bound launches (kernels_common.h: xcd_linear) - every XCD
+  // a contiguous run of (op, rate, item blocks); else the (item blocks, ops, rates) grid as launched
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (xcd_nx)
+  {
+    const unsigned l = xcd_linear(xcd_nx * xcd_ny * g.R, 1u);
+    if (l == ~0u) return;
+    bx = l % xcd_nx;
+    bz = (l / xcd_nx) % g.R;
+    by = l / (xcd_nx * g.R);
+  }
+  const DevOp &op = pack.ops[by];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned row = lane >> 4;   // k on the input side, i on the output side
   const unsigned col = lane & 15u;  // site within a 16-site group
   const unsigned S = g.S;
-  const unsigned k = blockIdx.z;
+  const unsigned k = bz;
   const unsigned nitems = (op.entries + 31u) / 32u;
-  if (blockIdx.x * 4u * items_per_wave >= nitems) return; // whole workgroup
+  if (bx * 4u * items_per_wave >= nitems) return; // whole workgroup
   const int mode = op.pscaler ? g.scale_mode : 0;
   const unsigned fragoff = (row * 4u + (lane & 3u));
   const unsigned long long full = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(256, NG > 8 ? 2 : 4) void k_partials_mfma(const OpP
     __syncthreads();
   }
 
-  const unsigned item0 = (blockIdx.x * 4u + wave) * items_per_wave;
+  const unsigned item0 = (bx * 4u + wave) * items_per_wave;
   if (item0 >= nitems) return; // no barriers below
   const unsigned nmine = min(items_per_wave, nitems - item0);
 
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(256, NG > 8 ? 2 : 4) void k_partials_mfma(const OpP
         s &= __shfl_xor(s, 16, 64);
         s &= __shfl_xor(s, 32, 64);
         if (row == 0 && cur.valid[sg])
-          flagbuf[((size_t)blockIdx.y * g.R + k) * flag_stride + cur.e[sg]] = (unsigned char)s;
+          flagbuf[((size_t)by * g.R + k) * flag_stride + cur.e[sg]] = (unsigned char)s;
       }
     }
     cur = nxt;

@@ -134,6 +134,7 @@ struct pllgpu_ctx
   unsigned rep_max_ranges = 8;           // PLL_AMD_REP_RANGES: site ranges per part of a large table, at most (kernels_repeats.h)
   unsigned rep_assign_iters = 0;         // PLL_AMD_REP_ASSIGN_ITERS: rounds per workgroup of k_rep_assign (0: by the launch's size)
   unsigned rep_assign_lds = kRepAssignLds; // PLL_AMD_REP_ASSIGN_LDS: tables up to this many cells are looked up in LDS
+  bool mfma_tt_xcd = false;              // PLL_AMD_MFMA_TT_XCD=1: plain tip x tip launches of the matrix-pipe kernel in XCD-aware order (A/B)
   bool sub_pack_always = false;          // PLL_AMD_SUB_PACK_ALWAYS=1: k_sub_pack after every class-map call, whatever it reported (A/B)
   bool rep_bits = true;                  // PLL_AMD_REP_BITS=0: the bitmap of first sites by atomics + k_rep_scan for every table size (A/B)
   bool rep_hints = true;                 // PLL_AMD_REP_HINTS=0: every level of a class-map call is launched (A/B, tests)
@@ -499,6 +500,7 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   if (const char *v = getenv("PLL_AMD_REP_BITS")) c->rep_bits = !(*v == '0');
   if (const char *v = getenv("PLL_AMD_SUB_PACK_ALWAYS")) c->sub_pack_always = *v && *v != '0';
   if (const char *v = getenv("PLL_AMD_REP_FUSE")) c->rep_fuse = !(*v == '0');
+  if (const char *v = getenv("PLL_AMD_MFMA_TT_XCD")) c->mfma_tt_xcd = *v && *v != '0';
   if (const char *v = getenv("PLL_AMD_PINNED_STAGING")) c->ring_failed = *v == '0'; // 0: every transfer from / to pageable memory as the runtime does it (A/B)
   if (const char *v = getenv("PLL_AMD_REP_HINTS")) c->rep_hints = !(*v == '0');
   if (const char *v = getenv("PLL_AMD_REP_RANGES")) c->rep_max_ranges = (unsigned)std::max(1, atoi(v));
@@ -1204,6 +1206,9 @@ static int launch_mfma_t(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsig
   unsigned ipw = (unsigned)(((size_t)items * nops * R + want - 1) / want);
   ipw = std::max(1u, std::min(ipw, NG > 8 ? ~0u : 8u));
   dim3 grid((items + 4 * ipw - 1) / (4 * ipw), nops, R), block(256);
+  // plain tip x tip levels are store traffic and nothing else (C5's: 625 MB): PLL_AMD_MFMA_TT_XCD=1 runs them in the
+  // XCD-aware order of the other store-bound launches (A/B; profiles/README.md)
+  const bool xcd = c->mfma_tt_xcd && kind == 2 && !gather;
   const size_t lds = MfmaGeo<NG>::lds_doubles * sizeof(double);
   const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
   bool scaling = false;
@@ -1216,7 +1221,7 @@ static int launch_mfma_t(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsig
   do                                                                                                            \
   {                                                                                                             \
     raise_lds_limit((const void *)k_partials_mfma<NG, LT, RT, GA>, c->device, lds);                             \
-    hipLaunchKernelGGL((k_partials_mfma<NG, LT, RT, GA>), grid, block, lds, c->stream, pack, c->gg, tm, ipw, fb, fstride); \
+    hipLaunchKernelGGL((k_partials_mfma<NG, LT, RT, GA>), xcd ? xcd_grid(grid.x, nops, R) : grid, block, lds, c->stream, pack, c->gg, tm, ipw, fb, fstride, xcd ? grid.x : 0u, nops); \
   } while (0)
   if (kind == 0)
   {
