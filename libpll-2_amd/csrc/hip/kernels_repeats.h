@@ -3,7 +3,7 @@
 //
 // A parent's classes are the distinct pairs (left class, right class) of its sites, numbered in order of first
 // occurrence; id_site[class] is that first site. The reference walks the sites sequentially through a direct-address
-// table (cell = lid + rid * ids_left). The same numbering without the sequential walk, two launches per dependency
+// table (cell = lid + rid * ids_left). The same numbering without the sequential walk, one or two launches per dependency
 // level (five where a level may hold large tables), every op of the level in each, NO host round trip between levels:
 //
 //   k_rep_mark    first[cell] = the lowest site of the cell. A workgroup owns a PART of the op's table (in LDS) and a
