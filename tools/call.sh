@@ -1,5 +1,8 @@
 set -e
-mkdir -p gpurun_out/r5
-python -m pytest tests -x -q -m gpu > gpurun_out/r5/full4.log 2>&1; tail -3 gpurun_out/r5/full4.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
-python bench.py > gpurun_out/r5/bench_default.json 2> gpurun_out/r5/bench_default.err; python3 -c "import json; d=json.loads(open('gpurun_out/r5/bench_default.json').readline()); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['step']['frac'], d['cpu_baseline']['value'])"
+mkdir -p gpurun_out/r5/tl1m gpurun_out/r5/tl125
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r5/tl1m -o t -- python3 $GRAFT_REPO_ROOT/tools/rep_ab.py 1000000 bench "" > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r5/tl125 -o t -- python3 $GRAFT_REPO_ROOT/tools/rep_ab.py 125000 bench "" > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+python3 tools/rep_timeline.py gpurun_out/r5/tl1m | head -3
+python3 tools/rep_timeline.py gpurun_out/r5/tl125 | head -3
