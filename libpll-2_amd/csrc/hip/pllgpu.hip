@@ -617,7 +617,7 @@ static unsigned char *stage_take(pllgpu_ctx *c, size_t bytes, unsigned char **de
   if (!c->ring_host)
   {
     void *h = nullptr, *d = nullptr;
-    if (hipHostMalloc(&h, kRingCap, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess)
+    if (hipHostMalloc(&h, kRingCap, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess)
     {
       if (h) (void)hipHostFree(h);
       (void)hipGetLastError();
@@ -681,6 +681,7 @@ extern "C" int pllgpu_clv_reserve(pllgpu_ctx_t *c, unsigned node, unsigned entri
 
 extern "C" int pllgpu_clv_upload(pllgpu_ctx_t *c, unsigned node, const double *host, unsigned entries)
 {
+  CHECK_CTX(c); // (the context's device for the copies and the layout kernel below, not only for the reservation)
   if (int rc = pllgpu_clv_reserve(c, node, entries)) return rc;
   const size_t bytes = (size_t)entries * c->span * sizeof(double);
   c->clv_aos[node] = aos_entries(c, entries) ? 1 : 0;
@@ -753,6 +754,7 @@ extern "C" int pllgpu_scaler_reserve(pllgpu_ctx_t *c, unsigned index, unsigned e
 
 extern "C" int pllgpu_scaler_upload(pllgpu_ctx_t *c, unsigned index, const unsigned *host, unsigned entries)
 {
+  CHECK_CTX(c);
   if (int rc = pllgpu_scaler_reserve(c, index, entries)) return rc;
   HIP_TRY(copy_up(c, c->scaler[index].p, host, scaler_elems(c, entries) * sizeof(unsigned)));
   return 0;
