@@ -1,1 +1,1 @@
-python -m pytest tests/test_gpu_repeats.py -x -q -m gpu -k "class_maps_match" 2>&1 | tail -12
+PLL_FUZZ_SEEDS=96 python -m pytest tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -4
