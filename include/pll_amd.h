@@ -274,10 +274,13 @@ double pll_compute_root_loglikelihood(pll_partition_t *partition, unsigned int c
  * src/core_partials.c:48-1210, src/core_likelihood.c:24-1496) ----------------------------------
  * Same signatures as the reference: raw HOST arrays in the layout `attrib` describes (PLL_ATTRIB_ARCH_*
  * -> states_padded; PLL_ATTRIB_RATE_SCALERS -> [entry][rate] scalers). Every call wraps its arrays in a
- * throw-away partition and runs the device path (csrc/host/core_seam.c): complete, but priced at an
- * allocation and a PCIe round trip per call - use the partition-level functions above for speed.
+ * partition of the call's shape and runs the device path (csrc/host/core_seam.c): complete, but priced at a
+ * PCIe round trip per call - use the partition-level functions above for speed. Small shapes are kept per
+ * thread, shape and device for the next call (at most 32 MB each, 128 MB together, least recently used out
+ * first; PLL_AMD_SEAM_CACHE=0: none); pll_core_seam_release() gives the calling thread's back at once.
  * The lookup table of pll_core_create_lookup is private to its pair with pll_core_update_partial_tt,
  * as in the reference (there: products per pair of tip states; here: the two matrices). */
+void pll_core_seam_release(void); /* (no counterpart in the reference, whose core functions hold no state) */
 void pll_core_create_lookup(unsigned int states, unsigned int rate_cats, double *lookup, const double *left_matrix,
                             const double *right_matrix, const pll_state_t *tipmap, unsigned int tipmap_size, unsigned int attrib);
 void pll_core_create_lookup_4x4(unsigned int rate_cats, double *lookup, const double *left_matrix, const double *right_matrix);
@@ -484,6 +487,14 @@ int pll_gpu_sync_all(pll_partition_t *partition);
 #define PLL_GPU_DIRTY_TIPCHARS 128u
 #define PLL_GPU_DIRTY_REPEATS 256u
 #define PLL_GPU_DIRTY_EIGEN 512u /* eigenvecs / inv_eigenvecs / eigenvals / rates written directly */
+/* Site repeats: pll_update_repeats / pll_update_partials keep, per node, what the class map standing on the device was
+ * computed from (the two children, the versions of their maps, the lookup size) and launch nothing for an op whose
+ * inputs have not moved - the maps are a function of the children's maps alone (src/repeats.c:299-382), so a
+ * re-evaluation of the same tree after new branch lengths recomputes none and a topology move only the ancestors of
+ * the moved edge. FORGET_REPEATS drops that knowledge for node `index` (-1: every node) without marking any host map
+ * as newer: the next update computes the maps derived from it again (benchmarks of the recomputation itself; callers
+ * that changed pernode_ids or a map behind the library's back use PLL_GPU_DIRTY_REPEATS, which implies it). */
+#define PLL_GPU_FORGET_REPEATS 1024u
 void pll_gpu_invalidate(pll_partition_t *partition, unsigned int what, int index);
 /* download the device sumtable that stands for this host buffer into it (reference layout) */
 int pll_gpu_sync_sumtable(pll_partition_t *partition, double *sumtable);
@@ -591,6 +602,9 @@ int pll_gpu_timer_start(pll_partition_t *partition);
 double pll_gpu_timer_stop(pll_partition_t *partition);
 /* number of kernel launches issued by the last pll_update_partials call (bench bookkeeping) */
 unsigned int pll_gpu_last_launch_count(const pll_partition_t *partition);
+/* site repeats: class-map operations computed on the device (launches = 0) / class kernels launched (launches != 0)
+ * since the partition was created. An unchanged tree adds nothing, a topology move the ops of its partial traversal */
+unsigned long long pll_gpu_class_map_work(const pll_partition_t *partition, int launches);
 /* 1 if the last pll_update_partials call found its operation list, and everything its classification rests on, as the
  * call before left them and went straight to the launches (a re-evaluation of one tree); 0 if it took the whole path */
 int pll_gpu_last_update_replayed(const pll_partition_t *partition);

@@ -83,6 +83,13 @@ typedef struct pllgpu_edge
 } pllgpu_edge_t;
 
 int pllgpu_device_count(void);
+/* the device a context created now with device = -1 would live on (PLL_AMD_DEVICE=<n>, else the calling thread's
+ * current HIP device); -2: any of them in turn (PLL_AMD_DEVICE=auto); and the device a context does live on */
+/* site repeats, since the context was created: class-map ops handed to the device (launches = 0) or class kernels
+ * launched (launches = 1) - what the version stamps of repeats.c save is visible here */
+unsigned long long pllgpu_class_map_work(const pllgpu_ctx_t *ctx, int launches);
+int pllgpu_default_device(void);
+int pllgpu_context_device(const pllgpu_ctx_t *ctx);
 const char *pllgpu_last_error(void);
 
 pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device);

@@ -138,7 +138,8 @@ struct pllgpu_ctx
   bool sub_pack_always = false;          // PLL_AMD_SUB_PACK_ALWAYS=1: k_sub_pack after every class-map call, whatever it reported (A/B)
   bool rep_bits = true;                  // PLL_AMD_REP_BITS=0: the bitmap of first sites by atomics + k_rep_scan for every table size (A/B)
   bool rep_hints = true;                 // PLL_AMD_REP_HINTS=0: every level of a class-map call is launched (A/B, tests)
-  unsigned rep_hint_count = 0, rep_hint_level = 0; // the last call: its ops, the highest level with a compressed parent ...
+  unsigned long long rep_hint_key = 0;   // the last call: a hash of its (parent, left, right, level) records ...
+  unsigned rep_hint_count = 0, rep_hint_level = 0; // ... their number, the highest level with a compressed parent ...
   bool rep_hint_any = false;                       // ... if there was one
   bool rep_scratch_dirty = false;        // a class-map call did not complete: its bitmaps and tickets are cleared before the next
   DevBuf<double> sumtable[PLLGPU_SUMTABLE_SLOTS]; // device-resident sumtables (tiled like a CLV), allocated on first use
@@ -156,6 +157,7 @@ struct pllgpu_ctx
   DevBuf<double> reduce;         // {lnL, sequence}: the operand of a caller's all-reduce (pllgpu_reduce_buffer)
   std::vector<double> stage;     // host staging for the P-matrix re-layout
   unsigned last_launches = 0;
+  unsigned long long rep_ops_total = 0, rep_launches_total = 0; // class-map ops handed to the device / class kernels launched, ever
   double last_bytes = 0.0;       // algorithmic HBM bytes of the last update_partials call
   bool no_tip_columns = false;   // PLL_AMD_NO_TIP_COLUMNS=1: tips always through the FMA contraction
   bool no_par_lds = false;       // PLL_AMD_NO_PARENT_LDS=1 (A/B): entry-contiguous parents stored 8 bytes per lane
@@ -302,6 +304,22 @@ extern "C" int pllgpu_device_count(void)
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+
+extern "C" int pllgpu_default_device(void)
+{
+  const char *env = getenv("PLL_AMD_DEVICE");
+  int device = 0;
+  if (env && strcmp(env, "auto") == 0) return -2;
+  if (env) return atoi(env);
+  if (hipGetDevice(&device) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    device = 0;
+  }
+  return device;
+}
+
+extern "C" int pllgpu_context_device(const pllgpu_ctx_t *c) { return c ? c->device : -1; }
 
 static void derive_geometry(pllgpu_ctx *c)
 {
@@ -606,6 +624,14 @@ static hipError_t stream_wait(pllgpu_ctx *c)
 {
   const hipError_t e = hipStreamSynchronize(c->stream);
   if (e == hipSuccess) ring_drained(c);
+  else
+  {
+    // the downloads that were waiting for this did not happen: their host pointers (a caller's arrays, perhaps out of
+    // scope by the next wait) are forgotten, and the block is not handed out again - what the device still does with
+    // it is unknown
+    c->pending_down.clear();
+    c->ring_failed = true;
+  }
   return e;
 }
 
@@ -2546,6 +2572,7 @@ extern "C" double pllgpu_timer_stop(pllgpu_ctx_t *c)
 }
 
 extern "C" unsigned pllgpu_last_launch_count(const pllgpu_ctx_t *c) { return c ? c->last_launches : 0; }
+extern "C" unsigned long long pllgpu_class_map_work(const pllgpu_ctx_t *c, int launches) { return !c ? 0ull : launches ? c->rep_launches_total : c->rep_ops_total; }
 
 // ---- branch-length derivatives ------------------------------------------------------------------
 extern "C" int pllgpu_eigenvals_upload(pllgpu_ctx_t *c, unsigned index, const double *host)
@@ -2949,7 +2976,11 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
   // only the levels up to there are launched, and the rule (src/repeats.c:100-110) is evaluated HERE for the ops above,
   // from the counts that came back: if it admits one of them after all, the whole call is repeated with every level.
   unsigned ncut = count;
-  if (c->rep_hints && c->rep_hint_count == count)
+  unsigned long long key = 1469598103934665603ull; // FNV-1a over what identifies the list (two lists of one length differ in where compression ends)
+  for (unsigned i = 0; i < count; ++i)
+    for (unsigned w : {ops[i].parent, ops[i].left, ops[i].right, ops[i].level})
+      key = (key ^ w) * 1099511628211ull;
+  if (c->rep_hints && c->rep_hint_count == count && c->rep_hint_key == key)
   {
     ncut = 0;
     while (ncut < count && ops[ncut].level <= c->rep_hint_level && c->rep_hint_any) ++ncut;
@@ -3115,6 +3146,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
   }
   if (ncut)
   {
+  c->rep_ops_total += ncut;
   if (int rc = c->rep_table.ensure(arena)) return rc;
   {
     // per op of a launch: the bitmap (zero between launches: k_rep_assign clears what k_rep_mark set), then the running counts
@@ -3172,6 +3204,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     const unsigned n8 = (L.n + 7u) / 8u * 8u;
     pk.has_narrow = L.narrow ? 1u : 0u;
     pk.has_general = L.general || !L.narrow ? 1u : 0u;
+    c->rep_launches_total += (pk.has_narrow ? 1u : 0u) + (pk.has_general ? 1u : 0u) + (L.rank ? 3u : 0u) + (L.assign ? 1u : 0u);
     if (pk.has_narrow && L.fused)
       hipLaunchKernelGGL(k_rep_mark_narrow_fused, dim3(n8 * L.wgs), dim3(kRepThreads), kRepSmallCells * sizeof(unsigned), c->stream, pk);
     else if (pk.has_narrow)
@@ -3245,6 +3278,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     counts_out[i] = 0u;
   }
   c->rep_hint_count = count;
+  c->rep_hint_key = key;
   c->rep_hint_any = false;
   c->rep_hint_level = 0;
   for (unsigned i = 0; i < count; ++i)

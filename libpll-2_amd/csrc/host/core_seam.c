@@ -28,14 +28,23 @@ typedef struct
  * comes with the same shapes again and again: the partition behind a call (device context, stream, buffers) is kept,
  * per thread, and the next call of the same shape finds it (round 4 paid an allocation, a stream and their release
  * per call). A few shapes at a time (update + evaluation + derivative calls of one loop); PLL_AMD_SEAM_CACHE=0: none.
- * A thread's partitions are destroyed when it exits; the main thread's stay until the process ends. */
+ * A thread's partitions are destroyed when it exits or calls pll_core_seam_release(); the main thread's otherwise stay
+ * until the process ends. What is kept is BOUNDED BY BYTES, not only by count (round-5 advice: the API looks stateless,
+ * and a 1M-site call would have left several GB of host mirror, HBM and pinned memory behind): a partition above
+ * SEAM_KEEP_ONE is never kept, the idle ones together stay within SEAM_KEEP_ALL (least recently used out first). A
+ * kept partition is bound to the device it was created on, so the device a new one WOULD get (PLL_AMD_DEVICE / the
+ * thread's current device) is part of the match. */
 #include <pthread.h>
 #define SEAM_SLOTS 6
+#define SEAM_KEEP_ONE ((size_t)32 << 20)
+#define SEAM_KEEP_ALL ((size_t)128 << 20)
 typedef struct
 {
   pll_partition_t *p;
   unsigned int key[7];
   unsigned long long used;
+  size_t bytes;
+  int device;
   int busy;
 } seam_slot_t;
 static __thread seam_slot_t seam_slots[SEAM_SLOTS];
@@ -73,9 +82,11 @@ static int seam_open(seam_t *s, unsigned int states, unsigned int entries, unsig
   const unsigned int key[7] = {states, entries, rate_cats, clvs, matrices, freq_sets ? freq_sets : 1, attrs};
   s->slot = -1;
   s->p = NULL;
+  const int want = pllgpu_default_device(); /* -2: any (PLL_AMD_DEVICE=auto) */
   if (seam_cache_on())
     for (int i = 0; i < SEAM_SLOTS; ++i)
-      if (seam_slots[i].p && !seam_slots[i].busy && memcmp(seam_slots[i].key, key, sizeof key) == 0)
+      if (seam_slots[i].p && !seam_slots[i].busy && memcmp(seam_slots[i].key, key, sizeof key) == 0 &&
+          (want == -2 || seam_slots[i].device == want))
       {
         pll_partition_t *p = seam_slots[i].p;
         /* what a former call may have left behind and this one may not set: no invariant sites, no invariant
@@ -115,8 +126,25 @@ static int seam_open(seam_t *s, unsigned int states, unsigned int entries, unsig
     return 0;
   }
   s->span = s->p->states_padded * rate_cats;
-  if (seam_cache_on())
+  /* host mirror + HBM of the CLVs and scalers (what grows with the call's size; the context's pinned block is 8 MB) */
+  const size_t bytes = 2u * (size_t)(clvs + 1u) * entries * ((size_t)s->span * sizeof(double) + rate_cats * sizeof(unsigned int)) + ((size_t)8 << 20);
+  if (seam_cache_on() && bytes <= SEAM_KEEP_ONE)
   {
+    /* within the byte bound: idle partitions go, least recently used first, until this one fits */
+    for (;;)
+    {
+      size_t held = bytes;
+      int lru = -1;
+      for (int i = 0; i < SEAM_SLOTS; ++i)
+      {
+        if (!seam_slots[i].p) continue;
+        held += seam_slots[i].bytes;
+        if (!seam_slots[i].busy && (lru < 0 || seam_slots[i].used < seam_slots[lru].used)) lru = i;
+      }
+      if (held <= SEAM_KEEP_ALL || lru < 0) break;
+      pll_partition_destroy(seam_slots[lru].p);
+      seam_slots[lru].p = NULL;
+    }
     /* a free slot, or the least recently used idle one */
     int at = -1;
     for (int i = 0; i < SEAM_SLOTS; ++i)
@@ -125,6 +153,8 @@ static int seam_open(seam_t *s, unsigned int states, unsigned int entries, unsig
     {
       if (seam_slots[at].p) pll_partition_destroy(seam_slots[at].p);
       seam_slots[at].p = s->p;
+      seam_slots[at].bytes = bytes;
+      seam_slots[at].device = pllgpu_context_device(pll_ext(s->p)->ctx);
       memcpy(seam_slots[at].key, key, sizeof key);
       seam_slots[at].busy = 1;
       seam_slots[at].used = ++seam_clock;
@@ -134,6 +164,17 @@ static int seam_open(seam_t *s, unsigned int states, unsigned int entries, unsig
     }
   }
   return 1;
+}
+
+/* the calling thread's kept partitions (host mirrors, HBM, streams, pinned blocks) are given back now */
+void pll_core_seam_release(void)
+{
+  for (int i = 0; i < SEAM_SLOTS; ++i)
+    if (seam_slots[i].p && !seam_slots[i].busy)
+    {
+      pll_partition_destroy(seam_slots[i].p);
+      seam_slots[i].p = NULL;
+    }
 }
 
 static void seam_close(seam_t *s)

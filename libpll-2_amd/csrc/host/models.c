@@ -272,7 +272,55 @@ int pll_update_prob_matrices(pll_partition_t *p, const unsigned int *params_indi
       return PLL_FAILURE;
     }
   if (!pll_flush_eigen(p, x)) return PLL_FAILURE;
-  if (pllgpu_update_pmatrices(x->ctx, params_indices, matrix_indices, branch_lengths, count) != 0)
+  /* The reference forms the matrices one after another (src/core_pmatrix.c:62), so an index that comes twice ends with
+   * the LAST of its branch lengths - and lists like that are what callers hand over (an SPR's three changed branches plus
+   * a re-optimised one next to it: found by tests/test_gpu_tree_search.py, the device wrote both in one launch and either
+   * could win). Only the last occurrence of an index goes to the device. */
+  unsigned int *uidx = NULL;
+  double *ubl = NULL;
+  unsigned int ucount = count;
+  {
+    int dup = 0;
+    if (count <= 32)
+    {
+      for (b = 1; b < count && !dup; ++b)
+        for (n = 0; n < b; ++n)
+          if (matrix_indices[n] == matrix_indices[b])
+          {
+            dup = 1;
+            break;
+          }
+    }
+    else
+      dup = -1; /* not looked at yet: the marks below tell */
+    if (dup)
+    {
+      unsigned int *last = (unsigned int *)malloc(sizeof(unsigned int) * (p->prob_matrices ? p->prob_matrices : 1));
+      uidx = (unsigned int *)malloc(sizeof(unsigned int) * count);
+      ubl = (double *)malloc(sizeof(double) * count);
+      if (!last || !uidx || !ubl)
+      {
+        free(last);
+        free(uidx);
+        free(ubl);
+        pll_set_error(PLL_ERROR_MEM_ALLOC, "pll_update_prob_matrices: out of memory");
+        return PLL_FAILURE;
+      }
+      for (b = 0; b < count; ++b) last[matrix_indices[b]] = b;
+      ucount = 0;
+      for (b = 0; b < count; ++b)
+        if (last[matrix_indices[b]] == b)
+        {
+          uidx[ucount] = matrix_indices[b];
+          ubl[ucount++] = branch_lengths[b];
+        }
+      free(last);
+    }
+  }
+  const int rc = pllgpu_update_pmatrices(x->ctx, params_indices, uidx ? uidx : matrix_indices, ubl ? ubl : branch_lengths, ucount);
+  free(uidx);
+  free(ubl);
+  if (rc != 0)
   {
     pll_set_gpu_error("pll_update_prob_matrices");
     return PLL_FAILURE;

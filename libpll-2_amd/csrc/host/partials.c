@@ -75,6 +75,29 @@ static unsigned int assign_levels(const pll_partition_t *p, pll_amd_ext_t *x, co
   return nlevels;
 }
 
+/* Site repeats: the class maps of a whole list are computed before its first CLV kernel runs, and the list is classified
+ * with the class counts the maps END with. That is the reference's op-by-op order (src/partials.c:253-257: maps, then
+ * the CLV, per op) only while no op overwrites a node an earlier op of the list has read or written - true of every
+ * traversal for ONE evaluation, not of two traversals handed over as one list (the three records of an inner node share
+ * a clv_index: the second may turn round a CLV the first has read - found by tests/test_gpu_tree_search.py). Returns the
+ * index of the first op that does so, 0 if none: the caller runs the list in two pieces, one after the other. */
+static unsigned int first_overwrite(const pll_partition_t *p, pll_amd_ext_t *x, const pll_operation_t *ops, unsigned int count)
+{
+  unsigned int i;
+  for (i = 0; i < p->nodes; ++i) x->lvl_clv_w[i] = 0;
+  for (i = 0; i < p->scale_buffers; ++i) x->lvl_sc_w[i] = 0;
+  for (i = 0; i < count; ++i)
+  {
+    const pll_operation_t *o = &ops[i];
+    if (x->lvl_clv_w[o->parent_clv_index] || (o->parent_scaler_index >= 0 && x->lvl_sc_w[o->parent_scaler_index])) return i;
+    x->lvl_clv_w[o->parent_clv_index] = x->lvl_clv_w[o->child1_clv_index] = x->lvl_clv_w[o->child2_clv_index] = 1;
+    if (o->parent_scaler_index >= 0) x->lvl_sc_w[o->parent_scaler_index] = 1;
+    if (o->child1_scaler_index >= 0) x->lvl_sc_w[o->child1_scaler_index] = 1;
+    if (o->child2_scaler_index >= 0) x->lvl_sc_w[o->child2_scaler_index] = 1;
+  }
+  return 0;
+}
+
 static void fail_loudly(const char *what)
 {
   fprintf(stderr, "libpll_amd: %s: [%d] %s\n", what, pll_errno, pll_errmsg);
@@ -134,6 +157,7 @@ void pll_update_partials_rep(pll_partition_t *p, const pll_operation_t *ops, uns
 {
   pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
   unsigned int i;
+  if (x) x->fast_taken = 0; /* pll_gpu_last_update_replayed() speaks of THIS call, also when it returns early */
   if (!count) return;
   if (!x || !x->ctx)
   {
@@ -164,6 +188,13 @@ void pll_update_partials_rep(pll_partition_t *p, const pll_operation_t *ops, uns
     {
       pll_set_error(PLL_ERROR_MEM_ALLOC, "pll_update_partials: out of memory");
       fail_loudly("pll_update_partials");
+      return;
+    }
+    const unsigned int cut = count > 1 ? first_overwrite(p, x, ops, count) : 0;
+    if (cut)
+    {
+      pll_update_partials_rep(p, ops, cut, update_repeats);
+      pll_update_partials_rep(p, ops + cut, count - cut, update_repeats);
       return;
     }
     level = (unsigned int *)(x->gops + count); /* second half of the scratch block */

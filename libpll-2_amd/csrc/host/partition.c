@@ -99,6 +99,8 @@ static void free_ext(pll_amd_ext_t *x)
   free(x->pmatrix_version);
   free(x->repeats_stale);
   free(x->repeats_count);
+  free(x->map_version);
+  free(x->map_stamp);
   free(x->aux_params);
   free(x->gops);
   free(x->lvl_clv_w);
@@ -359,6 +361,13 @@ pll_partition_t *pll_partition_create(unsigned int tips, unsigned int clv_buffer
   x->repeats_stale = (unsigned char *)calloc(p->nodes ? p->nodes : 1, 1);
   x->repeats_count = (unsigned int *)calloc(p->nodes ? p->nodes : 1, sizeof(unsigned int));
   NEED(x->repeats_stale && x->repeats_count);
+  x->map_version = (unsigned long long *)calloc(p->nodes ? p->nodes : 1, sizeof(unsigned long long));
+  x->map_stamp = (pll_map_stamp_t *)calloc(p->nodes ? p->nodes : 1, sizeof(pll_map_stamp_t));
+  NEED(x->map_version && x->map_stamp);
+  {
+    const char *v = getenv("PLL_AMD_REP_STAMPS");
+    x->map_stamps = !(v && *v == '0');
+  }
   x->aux_params = (unsigned int *)malloc(sizeof(unsigned int) * rate_cats);
   NEED(x->clv_side && x->scaler_side && x->scaler_entries && x->tipchars_dirty && x->repeats_dirty &&
        x->pmatrix_dirty && x->freqs_dirty && x->eigen_dirty && x->aux_params);
@@ -785,14 +794,26 @@ int pll_gpu_sync_all(pll_partition_t *p)
   ok &= pll_gpu_sync_repeats(p, -1);
   /* small CLVs and scaler vectors: enqueued one after another, waited for together */
   pll_amd_ext_t *x = pll_ext(p);
-  if (x && x->ctx) (void)pllgpu_download_defer(x->ctx, 1);
+  /* ... so a mirror is only in step once that wait has succeeded: what was marked on the way is taken back otherwise */
+  unsigned char *was = (x && x->ctx) ? (unsigned char *)malloc((size_t)p->nodes + p->scale_buffers + 1) : NULL;
+  if (was)
+  {
+    memcpy(was, x->clv_side, p->nodes);
+    memcpy(was + p->nodes, x->scaler_side, p->scale_buffers);
+    (void)pllgpu_download_defer(x->ctx, 1);
+  }
   for (i = 0; i < p->nodes; ++i) ok &= pll_gpu_sync_clv(p, i);
   for (i = 0; i < p->scale_buffers; ++i) ok &= pll_gpu_sync_scaler(p, i);
-  if (x && x->ctx && pllgpu_download_defer(x->ctx, 0) != 0)
+  if (was && pllgpu_download_defer(x->ctx, 0) != 0)
   {
     pll_set_gpu_error("pll_gpu_sync_all");
+    for (i = 0; i < p->nodes; ++i)
+      if (was[i] == SIDE_DEVICE) x->clv_side[i] = SIDE_DEVICE;
+    for (i = 0; i < p->scale_buffers; ++i)
+      if (was[p->nodes + i] == SIDE_DEVICE) x->scaler_side[i] = SIDE_DEVICE;
     ok = PLL_FAILURE;
   }
+  free(was);
   return ok;
 }
 
@@ -842,7 +863,12 @@ void pll_gpu_invalidate(pll_partition_t *p, unsigned int what, int index)
     MARK(tipchars_dirty, p->tips, 1);
     x->tipmap_dirty = 1;
   }
-  if (what & PLL_GPU_DIRTY_REPEATS) MARK(repeats_dirty, p->nodes, 1);
+  if (what & PLL_GPU_DIRTY_REPEATS)
+  {
+    MARK(repeats_dirty, p->nodes, 1);
+    pll_maps_touched(x, p, index);
+  }
+  if (what & PLL_GPU_FORGET_REPEATS) pll_maps_touched(x, p, index);
   if (what & PLL_GPU_DIRTY_EIGEN)
   {
     MARK(eigen_dirty, p->rate_matrices, 1);
@@ -902,6 +928,12 @@ int pll_gpu_last_update_replayed(const pll_partition_t *p)
 {
   const pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
   return x ? x->fast_taken : 0;
+}
+
+unsigned long long pll_gpu_class_map_work(const pll_partition_t *p, int launches)
+{
+  pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
+  return (x && x->ctx) ? pllgpu_class_map_work(x->ctx, launches) : 0ull;
 }
 
 unsigned int pll_gpu_last_launch_count(const pll_partition_t *p)

@@ -65,6 +65,14 @@ typedef struct pll_amd_ext
   unsigned int *pmatrix_version; /* [prob_matrices][rate_cats] */
   unsigned char *repeats_stale; /* [nodes] class maps computed on the device, host mirror not refreshed */
   unsigned int *repeats_count;  /* [nodes] classes the device found (kept even when the node stays uncompressed) */
+  /* A node's class map is a function of its children's maps and the enable rule alone (src/repeats.c:299-382) - not of
+   * branch lengths or the model. map_version[node] moves whenever the node's map is (or may have been) written;
+   * map_stamp[node] records what the map standing on the device was computed FROM. pll_update_repeats for an op whose
+   * stamp still describes its inputs launches nothing and leaves the version alone (repeats.c: stamp_holds) */
+  unsigned long long *map_version; /* [nodes] */
+  struct pll_map_stamp *map_stamp; /* [nodes] */
+  unsigned long long map_clock;
+  int map_stamps;                  /* PLL_AMD_REP_STAMPS=0: every call recomputes every map (bit-identity control) */
   int rates_dirty;
   unsigned int eigen_version;   /* bumped whenever an eigensystem or frequency vector changes */
   unsigned int aux_version;     /* eigen_version the device contraction matrices were built from */
@@ -96,6 +104,14 @@ typedef struct pll_amd_ext
   int *lvl_clv_w, *lvl_clv_r, *lvl_sc_w, *lvl_sc_r;
 } pll_amd_ext_t;
 
+typedef struct pll_map_stamp
+{
+  unsigned int left, right;         /* the children the map was computed from, in the op's order ... */
+  unsigned long long lver, rver;    /* ... and the versions of their maps at that moment */
+  unsigned int lookup;              /* lookup_buffer_size of the enable rule (src/repeats.c:100-110) */
+  int valid;
+} pll_map_stamp_t;
+
 static inline pll_amd_ext_t *pll_ext(const pll_partition_t *p)
 {
   pll_amd_ext_t *x = (pll_amd_ext_t *)(p + 1);
@@ -119,6 +135,9 @@ int pll_update_repeats_device(pll_partition_t *p, pll_amd_ext_t *x, const pll_op
                               unsigned int count, const unsigned int *level, unsigned int nlevels);
 int pll_flush_pmatrix(pll_partition_t *p, pll_amd_ext_t *x, unsigned int first, unsigned int last);
 int pll_flush_repeats(pll_partition_t *p, pll_amd_ext_t *x, unsigned int node);
+/* the class map of `node` (all nodes: node < 0) was written by something other than the class kernels, or must be
+ * taken as such: whatever was derived from it is computed again by the next pll_update_repeats */
+void pll_maps_touched(pll_amd_ext_t *x, const pll_partition_t *p, int node);
 int pll_is_pattern_tip(const pll_partition_t *p, unsigned int clv_index);
 /* the device reads this node as tip codes (PATTERN_TIP tip, or a compact indicator tip) */
 int pll_tip_by_codes(const pll_partition_t *p, unsigned int clv_index);

@@ -135,6 +135,45 @@ void pll_disable_bclv(pll_partition_t *p)
   p->repeats->bclv_buffer = NULL;
 }
 
+/* ---- which class maps still stand (pll_internal.h: map_version / map_stamp) ------------------------------------
+ * The reference recomputes a parent's map on every pll_update_partials (src/partials.c:253-255) although the map is a
+ * function of the two children's maps and the enable rule only. Here every write of a node's map gives the node a new
+ * version, and a parent remembers the (child, version) pairs it was computed from: while they are what they were the
+ * parent's map - and its version - stand, so the question "did anything move" costs a comparison per op and an
+ * unchanged tree costs no launch at all. */
+void pll_maps_touched(pll_amd_ext_t *x, const pll_partition_t *p, int node)
+{
+  unsigned int i;
+  if (!x || !x->map_version) return;
+  for (i = 0; i < p->nodes; ++i)
+    if (node < 0 || i == (unsigned int)node)
+    {
+      x->map_version[i] = ++x->map_clock;
+      x->map_stamp[i].valid = 0;
+    }
+}
+
+static int stamp_holds(const pll_amd_ext_t *x, const pll_repeats_t *r, const pll_operation_t *op)
+{
+  const pll_map_stamp_t *s = &x->map_stamp[op->parent_clv_index];
+  return s->valid && s->left == op->child1_clv_index && s->right == op->child2_clv_index &&
+         s->lver == x->map_version[op->child1_clv_index] && s->rver == x->map_version[op->child2_clv_index] &&
+         s->lookup == r->lookup_buffer_size;
+}
+
+/* the parent's map is about to be computed from the children's maps as they are now */
+static void stamp_set(pll_amd_ext_t *x, const pll_repeats_t *r, const pll_operation_t *op)
+{
+  pll_map_stamp_t *s = &x->map_stamp[op->parent_clv_index];
+  s->left = op->child1_clv_index;
+  s->right = op->child2_clv_index;
+  s->lver = x->map_version[op->child1_clv_index];
+  s->rver = x->map_version[op->child2_clv_index];
+  s->lookup = r->lookup_buffer_size;
+  s->valid = 1;
+  x->map_version[op->parent_clv_index] = ++x->map_clock;
+}
+
 /* classes of a tip = distinct state masks of its sequence (src/repeats.c:189-254) */
 int pll_update_repeats_tips(pll_partition_t *p, unsigned int tip, const pll_state_t *map, const char *seq)
 {
@@ -192,6 +231,7 @@ int pll_update_repeats_tips(pll_partition_t *p, unsigned int tip, const pll_stat
     x->repeats_dirty[tip] = 1;
     x->repeats_stale[tip] = 0;
     x->repeats_count[tip] = next;
+    pll_maps_touched(x, p, (int)tip);
   }
   return PLL_SUCCESS;
 }
@@ -319,23 +359,38 @@ int pll_update_repeats_device(pll_partition_t *p, pll_amd_ext_t *x, const pll_op
   }
   if (r->enable_repeats == pll_default_enable_repeats && !level_sync && count <= PLLGPU_REPEATS_MAX_OPS)
   {
-    /* order by level (stable); a child's producer is the latest earlier op of the LIST that writes it */
+    /* which ops have anything to compute: in list order, so that a parent sees the versions its children's maps have
+     * when ITS turn comes (a child written by an earlier op of the list that is computed again has a new one) */
+    unsigned char *keep = (unsigned char *)malloc(count);
     unsigned int *start = (unsigned int *)calloc(nlevels + 1, sizeof(unsigned int));
     unsigned int *pos = (unsigned int *)malloc(sizeof(unsigned int) * count); /* op of the list -> its place in the call */
-    if (!start || !pos)
+    if (!keep || !start || !pos)
     {
+      free(keep);
       free(start);
       free(pos);
       pll_set_error(PLL_ERROR_MEM_ALLOC, "Unable to allocate enough memory for repeats structure.");
       goto done;
     }
-    for (i = 0; i < count; ++i) start[level[i] + 1]++;
+    const int stamps = x->map_stamps && r->reallocate_repeats == pll_default_reallocate_repeats;
+    unsigned int kept = 0;
+    for (i = 0; i < count; ++i)
+    {
+      keep[i] = !(stamps && stamp_holds(x, r, &ops[i]));
+      if (!keep[i]) continue;
+      stamp_set(x, r, &ops[i]);
+      start[level[i] + 1]++;
+      ++kept;
+    }
+    /* order by level (stable); a child's producer is the latest earlier op of the CALL that writes it */
     for (l = 0; l < nlevels; ++l) start[l + 1] += start[l];
-    for (i = 0; i < count; ++i) pos[i] = start[level[i]]++;
+    for (i = 0; i < count; ++i)
+      if (keep[i]) pos[i] = start[level[i]]++;
     for (i = 0; i < p->nodes; ++i) producer[i] = -1;
     int failed = 0;
     for (i = 0; i < count && !failed; ++i)
     {
+      if (!keep[i]) continue;
       const pll_operation_t *op = &ops[i];
       const unsigned int left = op->child1_clv_index, right = op->child2_clv_index, parent = op->parent_clv_index;
       pllgpu_repop_t *o = &rop[pos[i]];
@@ -357,12 +412,18 @@ int pll_update_repeats_device(pll_partition_t *p, pll_amd_ext_t *x, const pll_op
     }
     free(start);
     free(pos);
+    if (!failed) ok = classes_call(p, x, ops, rop, idx, kept, counts, &changed);
+    if (!ok) /* whatever the device left of these maps is not what their stamps say */
+      for (i = 0; i < count; ++i)
+        if (keep[i]) pll_maps_touched(x, p, (int)ops[i].parent_clv_index);
+    free(keep);
     if (failed) goto done;
-    ok = classes_call(p, x, ops, rop, idx, count, counts, &changed);
   }
   else
   {
     ok = PLL_SUCCESS;
+    /* level by level with the decisions on the host: no stamps kept (a caller's rule may depend on anything) */
+    for (i = 0; i < count; ++i) pll_maps_touched(x, p, (int)ops[i].parent_clv_index);
     for (l = 0; l < nlevels && ok; ++l)
     {
       n = 0;
@@ -486,7 +547,11 @@ static void pll_update_repeats_host(pll_partition_t *p, const pll_operation_t *o
     r->lookup_buffer[r->toclean_buffer[s]] = EMPTY;
   }
   pll_amd_ext_t *x = pll_ext(p);
-  if (x) x->repeats_dirty[parent] = 1;
+  if (x)
+  {
+    x->repeats_dirty[parent] = 1;
+    pll_maps_touched(x, p, (int)parent);
+  }
 }
 
 /* ---- scaler utilities for class-compressed operands (src/repeats.c:392-540) ----------------------

@@ -28,6 +28,7 @@ SCALE_BUFFER_NONE = -1
 DIRTY_PMATRIX, DIRTY_FREQS, DIRTY_RATE_WEIGHTS, DIRTY_PATTERN_WEIGHTS = 1, 2, 4, 8
 DIRTY_INVARIANT, DIRTY_CLV, DIRTY_SCALER, DIRTY_TIPCHARS, DIRTY_REPEATS = 16, 32, 64, 128, 256
 DIRTY_EIGEN = 512
+FORGET_REPEATS = 1024
 
 
 class Repeats(C.Structure):
@@ -175,6 +176,8 @@ _GPU_PROTOS = {
     "pll_gpu_timer_stop": (C.c_double, [PartitionP]),
     "pll_gpu_last_launch_count": (C.c_uint, [PartitionP]),
     "pll_gpu_last_update_replayed": (C.c_int, [PartitionP]),
+    "pll_gpu_class_map_work": (C.c_ulonglong, [PartitionP, C.c_int]),
+    "pll_core_seam_release": (None, []),
     "pll_gpu_group_join": (C.c_void_p, [C.c_char_p, C.c_uint, C.c_uint, C.c_int]),
     "pll_gpu_group_leave": (None, [C.c_void_p]),
     "pll_gpu_group_rank": (C.c_uint, [C.c_void_p]),

@@ -41,9 +41,11 @@ def test_device_prob_matrices_match_reference(amd_lib, ref_lib, states, arch, ca
     for lib in (ref_lib, amd_lib):
         p = _partition(lib, states, exch, freqs, cats, len(brlens), arch, pinv, rates)
         pi = np.zeros(cats, dtype=np.uint32)
-        # matrices out of order, one of them written twice: the last value must win
+        # matrices out of order, one of them written twice with DIFFERENT lengths: the last one must win (the reference
+        # forms them one after another; a tree search hands over such lists - tests/test_gpu_tree_search.py)
         mi = np.array([6, 5, 4, 3, 2, 1, 0, 3], dtype=np.uint32)
         bl = np.concatenate([brlens[::-1], [brlens[3]]])
+        bl[3] = 1.234
         assert lib.pll_update_prob_matrices(p, api.uptr(pi), api.uptr(mi), api.dptr(np.ascontiguousarray(bl)), len(mi)), lib.errmsg()
         out[lib.is_amd] = _read(lib, p, len(brlens), cats, states)
         assert p.contents.eigen_decomp_valid[0] == 1
