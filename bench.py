@@ -89,8 +89,12 @@ PINNED = os.path.join(ROOT, "tests", "golden", "section8d_lnl.json")
 STEP_PLAIN = "pll_update_partials(full traversal) + pll_compute_edge_loglikelihood"
 STEP_REUSED = ("pll_update_partials_rep(full traversal, update_repeats = 0: the class maps of the first step re-used) "
                "+ pll_compute_edge_loglikelihood")
-STEP_MAPS = ("pll_update_partials(full traversal) = pll_update_partials_rep(.., update_repeats = 1): class maps recomputed "
-             "by every step, the reference's default (src/partials.c:237-255) + pll_compute_edge_loglikelihood")
+STEP_MAPS = ("pll_gpu_invalidate(PLL_GPU_FORGET_REPEATS) + pll_update_partials(full traversal): EVERY class map of the traversal "
+             "computed again by every step - what the reference does on every call (src/partials.c:237-255) and what a step after "
+             "a change of every tip costs - + pll_compute_edge_loglikelihood")
+STEP_DEFAULT = ("pll_update_partials(full traversal) = pll_update_partials_rep(.., update_repeats = 1), the reference's default call, on "
+                "an UNCHANGED tree: the library finds every class map's inputs as they were (version stamps, csrc/host/repeats.c) and "
+                "computes none + pll_compute_edge_loglikelihood")
 
 
 def build_case(cfg, sites, attributes, tree="balanced", tips_as=None):
@@ -472,7 +476,7 @@ def step_loop_fn():
         fn = dll.pllwl_step_loop
         fn.restype = C.c_double
         fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint,
-                       C.POINTER(C.c_int), C.POINTER(C.c_uint), C.c_uint, C.POINTER(C.c_double)]
+                       C.POINTER(C.c_int), C.POINTER(C.c_uint), C.c_uint, C.POINTER(C.c_double), C.c_void_p]
         _STEP_LOOP = fn
     return _STEP_LOOP
 
@@ -528,7 +532,7 @@ def _allreduce_loop_fn():
         fn = dll.pllwl_step_loop_allreduce
         fn.restype = C.c_double
         fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint,
-                       C.POINTER(C.c_int), C.POINTER(C.c_uint), C.c_uint, C.POINTER(C.c_double)]
+                       C.POINTER(C.c_int), C.POINTER(C.c_uint), C.c_uint, C.POINTER(C.c_double), C.c_void_p]
         _ALLREDUCE_LOOP = fn
     return _ALLREDUCE_LOOP
 
@@ -546,7 +550,9 @@ class Runner:
         self.repeats = repeats
         self.upd = 1  # site repeats: class maps are computed by the first step and re-used, as applications do
         #               between topology changes: pll_update_partials_rep(..., update_repeats = 0)
-        self.every_step_maps = False  # timed_with_class_maps: update_repeats = 1 on EVERY step - the reference's pll_update_partials
+        # timed_with_class_maps: None = as above; "default" = update_repeats = 1 on EVERY step (the reference's
+        # pll_update_partials) on the unchanged tree; "forced" = the same with PLL_GPU_FORGET_REPEATS ahead of every step
+        self.maps_mode = None
         self.reduce = reduce if h.dist else None
         self.collective = self.reduce is not None  # this runner's steps are steps of ALL ranks (barriers, max over ranks)
         self.c_driver = c_driver
@@ -595,7 +601,9 @@ class Runner:
 
     def step(self):
         lib, sess, e, h = self.lib, self.sess, self.edge, self.h
-        sess.update_partials(update_repeats=1 if self.every_step_maps else self.upd)
+        if self.maps_mode == "forced":
+            lib.pll_gpu_invalidate(sess.p, self.api.FORGET_REPEATS, -1)
+        sess.update_partials(update_repeats=1 if self.maps_mode else self.upd)
         if self.repeats:
             self.upd = 0
         if self.reduce == "peer":
@@ -629,6 +637,10 @@ class Runner:
             v = float(self.red[0].item())
         return v
 
+    def loop_mode(self):
+        """first_update_repeats of csrc/workload/step_loop.c"""
+        return {"forced": 3, "default": 2}.get(self.maps_mode, self.upd)
+
     def steps(self, n):
         """n steps; returns the last log-likelihood. The C loop serves every mode whose step is two C-ABI calls."""
         if n <= 0:
@@ -641,8 +653,8 @@ class Runner:
             grp = self.group if self.reduce == "peer" else None
             step_loop_fn()(fp(lib.pll_update_partials_rep), fp(lib.pll_compute_edge_loglikelihood),
                            fp(lib.pll_gpu_group_edge_loglikelihood), C.cast(sess.p, C.c_void_p), grp,
-                           C.cast(sess._op_arrays[0], C.c_void_p), len(self.case.op_batches[0]), 2 if self.every_step_maps else self.upd, self.edge_c,
-                           self.api.uptr(self.fi), n, C.byref(lnl))
+                           C.cast(sess._op_arrays[0], C.c_void_p), len(self.case.op_batches[0]), self.loop_mode(), self.edge_c,
+                           self.api.uptr(self.fi), n, C.byref(lnl), fp(lib.pll_gpu_invalidate))
             if self.repeats:
                 self.upd = 0
             return lnl.value
@@ -653,7 +665,8 @@ class Runner:
             lnl = C.c_double(0.0)
             fn = _allreduce_loop_fn()
             fn(fp(lib.pll_update_partials_rep), fp(lib.pll_gpu_edge_loglikelihood_allreduce), C.cast(sess.p, C.c_void_p), self.rccl_comm,
-               C.cast(sess._op_arrays[0], C.c_void_p), len(self.case.op_batches[0]), 2 if self.every_step_maps else self.upd, self.edge_c, self.api.uptr(self.fi), n, C.byref(lnl))
+               C.cast(sess._op_arrays[0], C.c_void_p), len(self.case.op_batches[0]), self.loop_mode(), self.edge_c, self.api.uptr(self.fi), n, C.byref(lnl),
+               fp(lib.pll_gpu_invalidate))
             if self.repeats:
                 self.upd = 0
             return lnl.value
@@ -681,15 +694,17 @@ class Runner:
             out.append(self.h.max_over_ranks(dt) if self.collective else dt)
         return out, lnl
 
-    def timed_with_class_maps(self, warmup, steps, blocks=1):
-        """the same timed blocks with the class maps recomputed by EVERY step: pll_update_partials as the reference
-        defines it on a SITE_REPEATS partition (src/partials.c:237-255: update_repeats = 1, pll_update_repeats inside
-        the op loop). Returns (block times, last lnL)."""
-        self.every_step_maps = True
+    def timed_with_class_maps(self, warmup, steps, blocks=1, mode="forced"):
+        """the same timed blocks with pll_update_partials as the reference defines it on a SITE_REPEATS partition
+        (src/partials.c:237-255: update_repeats = 1, pll_update_repeats inside the op loop) in EVERY step. mode "forced":
+        every map is computed again by every step (PLL_GPU_FORGET_REPEATS first - the reference's own cost model, and the
+        figure the scaling claim is made on); mode "default": the call as it is, on the unchanged tree - the library
+        recognises that no map's inputs moved. Returns (block times, last lnL)."""
+        self.maps_mode = mode
         try:
             return self.timed(warmup, steps, blocks)
         finally:
-            self.every_step_maps = False
+            self.maps_mode = None
 
     def repeats_update_ms(self, reps=5):
         """what the class maps cost when the topology changed: a full pll_update_partials_rep(.., 1) minus the
@@ -701,6 +716,8 @@ class Runner:
             lib.pll_gpu_synchronize(sess.p)
             t0 = time.perf_counter()
             for _ in range(reps):
+                if ur:
+                    lib.pll_gpu_invalidate(sess.p, self.api.FORGET_REPEATS, -1)
                 sess.update_partials(update_repeats=ur)
             lib.pll_gpu_synchronize(sess.p)
             out.append((time.perf_counter() - t0) / reps * 1e3)
@@ -925,8 +942,15 @@ def main_single(args, h):
         "lnl": lnl, "roofline": roofline,
     }
     if cfg.get("repeats"):
-        # the step as the reference's pll_update_partials defines it: class maps recomputed by every step
-        bcm, lnl_cm = runner.timed_with_class_maps(args.warmup, args.steps, args.blocks)
+        # THREE timed figures of the same blocks x steps: maps re-used (value, above); the reference's default call on the
+        # unchanged tree; every class map forced to be computed again by every step
+        bdc, lnl_dc = runner.timed_with_class_maps(args.warmup, args.steps, args.blocks, mode="default")
+        ms_dc = block_stats(bdc, args.steps)[0]
+        out["config"]["step_default_call"] = STEP_DEFAULT
+        out["ms_per_step_default_call"] = round(ms_dc, 4)
+        out["value_default_call"] = round(total_sites * nops / (ms_dc * 1e-3) / 1e6, 1)
+        out["lnl_default_call"] = lnl_dc
+        bcm, lnl_cm = runner.timed_with_class_maps(args.warmup, args.steps, args.blocks, mode="forced")
         ms_cm = block_stats(bcm, args.steps)[0]
         out["config"]["step_with_class_maps"] = STEP_MAPS
         out["ms_per_step_with_class_maps"] = round(ms_cm, 4)
@@ -988,8 +1012,11 @@ def main_strong(args, h):
             lib.pll_gpu_group_sum(runner.group, api.dptr(v), 1, api.dptr(o))
         exchange["peer_exchange_alone_us"] = round(h.max_over_ranks((time.perf_counter() - t0) / 2000 * 1e6), 3)
         exchange["peer_exchange_alone_note"] = "2000 group sums back to back through ctypes (~1-2 us of that is the Python call); tools/group_latency.c measures the C call"
-    # the same steps as the reference's pll_update_partials defines them: class maps recomputed by every step
-    bcm, lnl_cm = runner.timed_with_class_maps(args.warmup, args.steps, args.blocks)
+    # the same steps with the reference's default call on the unchanged tree, and with every class map forced to be
+    # computed again by every step (speedup_with_class_maps is defined on the FORCED figure)
+    bdc, lnl_dc = runner.timed_with_class_maps(args.warmup, args.steps, args.blocks, mode="default")
+    tN_dc_ms = block_stats(bdc, args.steps)[0]
+    bcm, lnl_cm = runner.timed_with_class_maps(args.warmup, args.steps, args.blocks, mode="forced")
     tN_cm_ms = block_stats(bcm, args.steps)[0]
     rep_extra, rep_full = runner.repeats_update_ms()
     rep_extra = h.max_over_ranks(rep_extra)
@@ -1007,7 +1034,9 @@ def main_strong(args, h):
         solo = Runner(h, lib, api, driver, full, True, reduce=None, c_driver=args.driver == "c")
         b1, lnl1 = solo.timed(args.warmup, args.steps, args.blocks)
         t1_ms = block_stats(b1, args.steps)[0]
-        b1cm, _ = solo.timed_with_class_maps(args.warmup, args.steps, args.blocks)
+        b1dc, _ = solo.timed_with_class_maps(args.warmup, args.steps, args.blocks, mode="default")
+        t1_dc_ms = block_stats(b1dc, args.steps)[0]
+        b1cm, _ = solo.timed_with_class_maps(args.warmup, args.steps, args.blocks, mode="forced")
         t1_cm_ms = block_stats(b1cm, args.steps)[0]
         global_levels = solo.level_entries()
         rep1_extra, _ = solo.repeats_update_ms(reps=3)
@@ -1025,6 +1054,7 @@ def main_strong(args, h):
                        "total_sites": total_sites, "patterns": full.sites, "sites_per_gpu": [s[0] for s in shard_sites],
                        "ops_per_traversal": nops, "states": 4, "rate_cats": 4, "taxa": cfg["tips"],
                        "step_with_class_maps": STEP_MAPS.replace("pll_compute_edge_loglikelihood", "edge log-likelihood + the same exchange"),
+                       "step_default_call": STEP_DEFAULT.replace("pll_compute_edge_loglikelihood", "edge log-likelihood + the same exchange"),
                        "step": "pll_update_partials_rep(full traversal, update_repeats = 0: the class maps of the first step re-used) + edge log-likelihood + the one exchange: sum of the shard lnLs"
                                + (" in rank order through shared host memory (pll_gpu_group_edge_loglikelihood)" if reduce == "peer" else " by one RCCL all-reduce on the device"),
                        "timed": f"median of {args.blocks} blocks of {args.steps} steps, each block between two barriers + device synchronises, max over ranks per block",
@@ -1037,6 +1067,8 @@ def main_strong(args, h):
             "ms_per_step_with_class_maps": round(tN_cm_ms, 4), "value_with_class_maps": round(total_sites * nops / (tN_cm_ms * 1e-3) / 1e6, 1),
             "t1_ms_with_class_maps": round(t1_cm_ms, 4), "speedup_with_class_maps": round(t1_cm_ms / tN_cm_ms, 3),
             "lnl_with_class_maps": lnl_cm,
+            "ms_per_step_default_call": round(tN_dc_ms, 4), "value_default_call": round(total_sites * nops / (tN_dc_ms * 1e-3) / 1e6, 1),
+            "t1_ms_default_call": round(t1_dc_ms, 4), "speedup_default_call": round(t1_dc_ms / tN_dc_ms, 3), "lnl_default_call": lnl_dc,
             "lnl_rel_err_vs_unsharded": abs(lnl - lnl1) / abs(lnl1), "exchange": exchange,
             "repeats_update_ms": round(rep_extra, 4), "repeats_update_ms_unsharded": round(rep1_extra, 4),
             "entries_per_level": {"unsharded": global_levels, "shards": shard_levels,

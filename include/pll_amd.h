@@ -605,6 +605,9 @@ unsigned int pll_gpu_last_launch_count(const pll_partition_t *partition);
 /* site repeats: class-map operations computed on the device (launches = 0) / class kernels launched (launches != 0)
  * since the partition was created. An unchanged tree adds nothing, a topology move the ops of its partial traversal */
 unsigned long long pll_gpu_class_map_work(const pll_partition_t *partition, int launches);
+/* pll_update_partials calls whose launches came from a plan the partition's device context had kept, since it was
+ * created. A context's plans depend on ITS device blocks only: other partitions coming, growing and going leave them */
+unsigned long long pll_gpu_plan_replays(const pll_partition_t *partition);
 /* 1 if the last pll_update_partials call found its operation list, and everything its classification rests on, as the
  * call before left them and went straight to the launches (a re-evaluation of one tree); 0 if it took the whole path */
 int pll_gpu_last_update_replayed(const pll_partition_t *partition);

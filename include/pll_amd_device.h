@@ -88,6 +88,8 @@ int pllgpu_device_count(void);
 /* site repeats, since the context was created: class-map ops handed to the device (launches = 0) or class kernels
  * launched (launches = 1) - what the version stamps of repeats.c save is visible here */
 unsigned long long pllgpu_class_map_work(const pllgpu_ctx_t *ctx, int launches);
+/* op lists launched from a plan the context had kept (the same list over blocks that have not moved), ever */
+unsigned long long pllgpu_plan_replays(const pllgpu_ctx_t *ctx);
 int pllgpu_default_device(void);
 int pllgpu_context_device(const pllgpu_ctx_t *ctx);
 const char *pllgpu_last_error(void);

@@ -337,10 +337,11 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
 {
   used = false;
   if (!c->chains || !c->fuse || count < 4 || c->any_aos) return 0; // up to three ops the level scheduler + tail kernel is as fast (tools/path_latency.py)
-  if (c->plan && c->plan->epoch == g_alloc_epoch.load(std::memory_order_relaxed) && c->plan->key.size() == count &&
+  if (c->plan && c->plan->epoch == c->alloc_epoch && c->plan->key.size() == count &&
       memcmp(c->plan->key.data(), ops, count * sizeof(pllgpu_op_t)) == 0)
   {
     used = true;
+    ++c->plan_replays;
     return launch_chain_plan(c, *c->plan, c->defer_tail);
   }
   const unsigned entries = ops[0].parent_entries;
@@ -561,7 +562,7 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
     }
   }
   pl->key.assign(ops, ops + count);
-  pl->epoch = g_alloc_epoch.load(std::memory_order_relaxed);
+  pl->epoch = c->alloc_epoch;
   drop_chain_plan(c);
   c->plan = pl;
   used = true;

@@ -47,8 +47,83 @@ static int fail(int code, const char *fmt, ...)
                   #call, hipGetErrorString(e_));                                                 \
   } while (0)
 
-// bumped whenever a device block is (re)allocated or freed: cached launch plans hold raw pointers
-static std::atomic<unsigned long long> g_alloc_epoch{1};
+// Cached launch plans hold raw device pointers: whenever one of a context's blocks is (re)allocated or freed, THAT
+// context's epoch moves (pllgpu_ctx::alloc_epoch) and its plans are planned again. Round 5 kept one counter for the
+// whole process, so a partition created, grown or destroyed anywhere - the usual shape of a multi-partition caller, or a
+// flat pll_core_* call beside a partition - dropped every other partition's plans. A DevBuf does not know its owner:
+// the entry point that is running says whose blocks are being touched (DeviceScope sets t_epoch; a context is used by
+// one thread at a time, so the counter is plain).
+static unsigned long long g_orphan_epoch = 1; // blocks touched outside any entry point (none today)
+static thread_local unsigned long long *t_epoch = &g_orphan_epoch;
+
+// Device blocks a context has let go of are kept for its next request instead of going back to the runtime: hipFree
+// waits for the whole device (35 us on average, 0.5 ms at worst, measured under a tree search on a site-repeats partition
+// - every move re-orients nodes whose class counts, and so their CLV / map buffers, change size: 9 pairs of hipFree +
+// hipMalloc per move, 330 us of a 450 us move; profiles/r6_tree_search.json). Everything a context does is ordered by its
+// one stream, so a block may serve its next owner at once: whatever was enqueued to read the old contents runs before
+// whatever is enqueued to write the new ones. Sizes are rounded up to four significant bits (at most 1/8 more), so that
+// blocks of nearly the same size are interchangeable; what is held idle is bounded (kPoolIdleMax, and a failed
+// hipMalloc gives everything back and tries again); pllgpu_destroy returns it all.
+struct BlockPool
+{
+  std::multimap<size_t, void *> idle; // bytes -> block
+  size_t idle_bytes = 0;
+  void trim(size_t keep)
+  {
+    while (idle_bytes > keep && !idle.empty())
+    {
+      auto it = std::prev(idle.end()); // the largest first
+      (void)hipFree(it->second);
+      idle_bytes -= it->first;
+      idle.erase(it);
+    }
+  }
+};
+constexpr size_t kPoolIdleMax = (size_t)8 << 30;
+static thread_local BlockPool *t_pool = nullptr; // the running entry point's context (DeviceScope), like t_epoch
+
+static inline size_t block_bytes(size_t bytes)
+{
+  if (bytes <= 4096) return 4096;
+  int top = 63 - __builtin_clzll((unsigned long long)bytes);
+  const size_t step = (size_t)1 << (top - 3);
+  return (bytes + step - 1) & ~(step - 1);
+}
+
+static hipError_t block_take(size_t bytes, void **out)
+{
+  if (t_pool)
+  {
+    auto it = t_pool->idle.find(bytes);
+    if (it != t_pool->idle.end())
+    {
+      *out = it->second;
+      t_pool->idle_bytes -= it->first;
+      t_pool->idle.erase(it);
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e == hipErrorOutOfMemory && t_pool && !t_pool->idle.empty())
+  {
+    (void)hipGetLastError();
+    t_pool->trim(0);
+    e = hipMalloc(out, bytes);
+  }
+  return e;
+}
+
+static void block_give(void *p, size_t bytes)
+{
+  if (!t_pool)
+  {
+    (void)hipFree(p);
+    return;
+  }
+  t_pool->idle.emplace(bytes, p);
+  t_pool->idle_bytes += bytes;
+  if (t_pool->idle_bytes > kPoolIdleMax) t_pool->trim(kPoolIdleMax / 2);
+}
 
 template <typename T>
 struct DevBuf
@@ -58,21 +133,27 @@ struct DevBuf
   int ensure(size_t n)
   {
     if (n <= cap) return 0;
-    g_alloc_epoch.fetch_add(1, std::memory_order_relaxed);
+    ++*t_epoch;
     if (p)
     {
-      HIP_TRY(hipFree(p)); // hipFree synchronises: no kernel still uses the old block
+      block_give(p, cap * sizeof(T)); // (its readers and writers so far are ahead of the next owner's on the stream)
       p = nullptr;
       cap = 0;
     }
-    HIP_TRY(hipMalloc(&p, n * sizeof(T)));
-    cap = n;
+    const size_t bytes = block_bytes(n * sizeof(T));
+    void *q = nullptr;
+    HIP_TRY(block_take(bytes, &q));
+    p = static_cast<T *>(q);
+    cap = bytes / sizeof(T);
     return 0;
   }
   void release()
   {
-    if (p) (void)hipFree(p);
-    if (p) g_alloc_epoch.fetch_add(1, std::memory_order_relaxed);
+    if (p)
+    {
+      block_give(p, cap * sizeof(T));
+      ++*t_epoch;
+    }
     p = nullptr;
     cap = 0;
   }
@@ -86,6 +167,8 @@ constexpr unsigned char kMap8 = 1, kMap32 = 2;
 
 struct pllgpu_ctx
 {
+  unsigned long long alloc_epoch = 1; // moves whenever one of this context's device blocks is (re)allocated or freed
+  BlockPool pool;                     // device blocks this context has let go of (DevBuf)
   pllgpu_geometry_t geo;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -186,6 +269,7 @@ struct pllgpu_ctx
   int launch_rc = 0;                // a launch helper that failed inside emit()
   int fenced = 0;                   // PLL_AMD_FENCED_HANDOFF=1 (kernels_common.h: handoff_*)
   unsigned long long plan_stamp = 0;
+  unsigned long long plan_replays = 0; // op lists that were launched from a kept plan (chain or level), ever
   bool plan_cache = true;           // PLL_AMD_NO_PLAN_CACHE=1 plans every call afresh
   DevBuf<unsigned char> cherry_bits; // k_cherry_bits: which cherry entries are rescaled, [slot][rate][pair of tip codes]
   struct CherrySlot
@@ -231,7 +315,7 @@ struct pllgpu_ctx
 
 // what pllgpu_update_partials did for one op list through the level scheduler: its launches, in order, with
 // their descriptor packs captured by value; the ops it held back for the log-likelihood kernel; the CLV layout
-// flags resolve_op() left behind. Valid while no device block has been (re)allocated (g_alloc_epoch) and no
+// flags resolve_op() left behind. Valid while no device block has been (re)allocated (pllgpu_ctx::alloc_epoch) and no
 // class map has changed (maps_epoch).
 struct LevelPlan
 {
@@ -266,14 +350,20 @@ static inline int use(pllgpu_ctx *c)
 struct DeviceScope
 {
   int prev = -1, rc = 0;
-  explicit DeviceScope(pllgpu_ctx *c)
+  unsigned long long *prev_epoch;
+  BlockPool *prev_pool;
+  explicit DeviceScope(pllgpu_ctx *c) : prev_epoch(t_epoch), prev_pool(t_pool)
   {
+    t_epoch = &c->alloc_epoch; // whose blocks this entry point may move (entry points nest: put back on the way out)
+    t_pool = &c->pool;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != c->device) rc = use(c);
     else prev = -1; // nothing to restore
   }
   ~DeviceScope()
   {
+    t_epoch = prev_epoch;
+    t_pool = prev_pool;
     if (prev >= 0) (void)hipSetDevice(prev);
   }
 };
@@ -580,6 +670,7 @@ extern "C" void pllgpu_destroy(pllgpu_ctx_t *c)
   for (auto &b : c->sumtable) b.release();
   c->pattern_weights.release();
   c->invariant.release();
+  c->pool.trim(0); // everything above went to the context's idle blocks: back to the runtime now
   if (c->result_host) (void)hipHostFree(c->result_host);
   if (c->rep_host) (void)hipHostFree(c->rep_host);
   if (c->ring_host) (void)hipHostFree(c->ring_host);
@@ -1787,7 +1878,7 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
   }
   if (c->plan_cache)
   {
-    const unsigned long long epoch = g_alloc_epoch.load(std::memory_order_relaxed);
+    const unsigned long long epoch = c->alloc_epoch;
     for (LevelPlan *lp : c->level_plans)
       if (lp->alloc_epoch == epoch && lp->maps_epoch == c->maps_epoch && lp->key.size() == count &&
           memcmp(lp->key.data(), ops, count * sizeof(pllgpu_op_t)) == 0)
@@ -1798,6 +1889,7 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
         c->deferred = lp->deferred;
         c->launch_rc = 0;
         for (const auto &fn : lp->launches) fn();
+        ++c->plan_replays;
         c->last_launches = lp->nlaunches;
         c->last_bytes = lp->bytes;
         lp->used = ++c->plan_stamp;
@@ -1818,7 +1910,7 @@ extern "C" int pllgpu_update_partials(pllgpu_ctx_t *c, const pllgpu_op_t *ops, u
     return rc;
   }
   lp->key.assign(ops, ops + count);
-  lp->alloc_epoch = g_alloc_epoch.load(std::memory_order_relaxed); // after the planning: it may have allocated
+  lp->alloc_epoch = c->alloc_epoch; // after the planning: it may have allocated
   lp->maps_epoch = c->maps_epoch;
   lp->deferred = c->deferred;
   for (unsigned i = 0; i < count; ++i) lp->aos.emplace_back(ops[i].parent_clv, c->clv_aos[ops[i].parent_clv]);
@@ -2572,6 +2664,7 @@ extern "C" double pllgpu_timer_stop(pllgpu_ctx_t *c)
 }
 
 extern "C" unsigned pllgpu_last_launch_count(const pllgpu_ctx_t *c) { return c ? c->last_launches : 0; }
+extern "C" unsigned long long pllgpu_plan_replays(const pllgpu_ctx_t *c) { return c ? c->plan_replays : 0ull; }
 extern "C" unsigned long long pllgpu_class_map_work(const pllgpu_ctx_t *c, int launches) { return !c ? 0ull : launches ? c->rep_launches_total : c->rep_ops_total; }
 
 // ---- branch-length derivatives ------------------------------------------------------------------
@@ -2934,7 +3027,15 @@ extern "C" int pllgpu_repeats_set_ids(pllgpu_ctx_t *c, unsigned node, unsigned i
     ++c->maps_foreign;
   }
   c->ids[node] = ids;
-  if (!ids) c->rep_left[node] = c->rep_right[node] = -1;
+  if (!ids)
+  {
+    // (the host may settle a parent that cannot be compressed without a class-map call: what such a call leaves behind
+    // for an uncompressed parent is left behind here)
+    if (c->rep_left[node] != -1 || c->rep_right[node] != -1 || c->map_forms[node] != 0) ++c->maps_epoch;
+    c->rep_left[node] = c->rep_right[node] = -1;
+    c->map_forms[node] = 0;
+    c->map_widened[node] = 0;
+  }
   return 0;
 }
 

@@ -128,14 +128,14 @@ static int plan_subtrees(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count, 
 static int upload_subtrees(pllgpu_ctx *c, const std::vector<SubItem> &items)
 {
   const size_t nbytes = items.size() * sizeof(SubItem);
-  const unsigned long long epoch = g_alloc_epoch.load(std::memory_order_relaxed);
+  const unsigned long long epoch = c->alloc_epoch;
   if (c->sub_epoch == epoch && c->sub_cache.size() == items.size() && memcmp(c->sub_cache.data(), items.data(), nbytes) == 0) return 0;
   if (int rc = c->sub_dev.ensure(nbytes)) return rc;
   // pageable source: staged before hipMemcpyAsync returns; ordered behind the kernels that read the old array
   HIP_TRY(hipMemcpyAsync(c->sub_dev.p, items.data(), nbytes, hipMemcpyHostToDevice, c->stream));
   c->sub_pack_valid = false; // other descriptors: their packed codes have to be formed
   c->sub_cache = items;
-  c->sub_epoch = g_alloc_epoch.load(std::memory_order_relaxed);
+  c->sub_epoch = c->alloc_epoch;
   return 0;
 }
 

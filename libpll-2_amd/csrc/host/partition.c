@@ -822,7 +822,9 @@ void pll_gpu_invalidate(pll_partition_t *p, unsigned int what, int index)
   pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
   unsigned int i;
   if (!x) return;
-  x->fast_valid = 0; /* the caller wrote something: the next traversal takes the whole path again */
+  /* the caller wrote something: the next traversal takes the whole path again (forgetting what the class maps were
+   * computed from writes nothing: if they come out as they were, the classified list stands - repeats.c) */
+  if (what & ~PLL_GPU_FORGET_REPEATS) x->fast_valid = 0;
 #define MARK(arr, n, val)                                             \
   do                                                                  \
   {                                                                   \
@@ -928,6 +930,12 @@ int pll_gpu_last_update_replayed(const pll_partition_t *p)
 {
   const pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
   return x ? x->fast_taken : 0;
+}
+
+unsigned long long pll_gpu_plan_replays(const pll_partition_t *p)
+{
+  pll_amd_ext_t *x = p ? pll_ext(p) : NULL;
+  return (x && x->ctx) ? pllgpu_plan_replays(x->ctx) : 0ull;
 }
 
 unsigned long long pll_gpu_class_map_work(const pll_partition_t *p, int launches)

@@ -281,44 +281,48 @@ static void adopt_classes(pll_partition_t *p, const pll_operation_t *op, unsigne
   }
 }
 
+/* what follows an op's count word (PLLGPU_REPEATS_COMPRESSED | classes, or 0: the parent stays uncompressed) on the host */
+static int follow_count(pll_partition_t *p, pll_amd_ext_t *x, const pll_operation_t *op, unsigned int word, int *changed)
+{
+  pll_repeats_t *r = p->repeats;
+  const unsigned int parent = op->parent_clv_index;
+  const int enabled = (word & PLLGPU_REPEATS_COMPRESSED) != 0;
+  const unsigned int classes = word & ~PLLGPU_REPEATS_COMPRESSED;
+  /* the same classes as before (a re-evaluation of the same tree): what pll_update_partials classified stays right,
+   * and with the default callback nothing below would change a thing - the host's time between the counts and the
+   * first launch that uses the maps is the device's idle time on a small alignment */
+  const int same = x->repeats_count[parent] == (enabled ? classes : 0) && r->pernode_ids[parent] == (enabled && classes < p->sites ? classes : 0) &&
+                   r->pernode_allocated_clvs[parent] == (enabled ? classes : p->sites);
+  x->repeats_stale[parent] = enabled ? 1 : 0;
+  if (same && r->reallocate_repeats == pll_default_reallocate_repeats)
+  {
+    if (op->parent_scaler_index != PLL_SCALE_BUFFER_NONE) r->perscale_ids[op->parent_scaler_index] = r->pernode_ids[parent];
+    return PLL_SUCCESS;
+  }
+  if (!same) *changed = 1;
+  adopt_classes(p, op, classes, enabled);
+  x->repeats_count[parent] = enabled ? classes : 0;
+  if (pllgpu_repeats_set_ids(x->ctx, parent, r->pernode_ids[parent]) != 0)
+  {
+    pll_set_gpu_error("pll_update_repeats");
+    return PLL_FAILURE;
+  }
+  return PLL_SUCCESS;
+}
+
 /* one piece of work for pllgpu_repeats_classes and what follows its counts */
 static int classes_call(pll_partition_t *p, pll_amd_ext_t *x, const pll_operation_t *ops, pllgpu_repop_t *rop,
                         const unsigned int *idx, unsigned int n, unsigned int *counts, int *changed)
 {
-  pll_repeats_t *r = p->repeats;
   unsigned int k;
   if (!n) return PLL_SUCCESS;
-  if (pllgpu_repeats_classes(x->ctx, rop, n, r->lookup_buffer_size, counts) != 0)
+  if (pllgpu_repeats_classes(x->ctx, rop, n, p->repeats->lookup_buffer_size, counts) != 0)
   {
     pll_set_gpu_error("pll_update_repeats");
     return PLL_FAILURE;
   }
   for (k = 0; k < n; ++k)
-  {
-    const pll_operation_t *op = &ops[idx[k]];
-    const unsigned int parent = op->parent_clv_index;
-    const int enabled = (counts[k] & PLLGPU_REPEATS_COMPRESSED) != 0;
-    const unsigned int classes = counts[k] & ~PLLGPU_REPEATS_COMPRESSED;
-    /* the same classes as before (a re-evaluation of the same tree): what pll_update_partials classified stays right,
-     * and with the default callback nothing below would change a thing - the host's time between the counts and the
-     * first launch that uses the maps is the device's idle time on a small alignment */
-    const int same = x->repeats_count[parent] == (enabled ? classes : 0) && r->pernode_ids[parent] == (enabled && classes < p->sites ? classes : 0) &&
-                     r->pernode_allocated_clvs[parent] == (enabled ? classes : p->sites);
-    x->repeats_stale[parent] = enabled ? 1 : 0;
-    if (same && r->reallocate_repeats == pll_default_reallocate_repeats)
-    {
-      if (op->parent_scaler_index != PLL_SCALE_BUFFER_NONE) r->perscale_ids[op->parent_scaler_index] = r->pernode_ids[parent];
-      continue;
-    }
-    if (!same) *changed = 1;
-    adopt_classes(p, op, classes, enabled);
-    x->repeats_count[parent] = enabled ? classes : 0;
-    if (pllgpu_repeats_set_ids(x->ctx, parent, r->pernode_ids[parent]) != 0)
-    {
-      pll_set_gpu_error("pll_update_repeats");
-      return PLL_FAILURE;
-    }
-  }
+    if (!follow_count(p, x, &ops[idx[k]], counts[k], changed)) return PLL_FAILURE;
   return PLL_SUCCESS;
 }
 
@@ -373,19 +377,34 @@ int pll_update_repeats_device(pll_partition_t *p, pll_amd_ext_t *x, const pll_op
       goto done;
     }
     const int stamps = x->map_stamps && r->reallocate_repeats == pll_default_reallocate_repeats;
+    /* ... and which of those cannot be compressed whatever the device finds: the rule (src/repeats.c:100-110) wants
+     * both children compressed, so a parent over a child that is not - known here for a child from outside the call, and
+     * from there up the list - stays uncompressed: no launch, the host's bookkeeping alone. In a tree search that is most of
+     * a partial traversal (the path from the moved edge to the evaluated one runs through large subtrees):
+     * keep = 1: to the device, 2: settled here. producer[]: -1 outside the call, -2 settled here, else the place in the call */
     unsigned int kept = 0;
+    for (i = 0; i < p->nodes; ++i) producer[i] = -1;
     for (i = 0; i < count; ++i)
     {
       keep[i] = !(stamps && stamp_holds(x, r, &ops[i]));
       if (!keep[i]) continue;
       stamp_set(x, r, &ops[i]);
+      const unsigned int left = ops[i].child1_clv_index, right = ops[i].child2_clv_index;
+      if (producer[left] == -2 || producer[right] == -2 || (producer[left] == -1 && !r->pernode_ids[left]) ||
+          (producer[right] == -1 && !r->pernode_ids[right]))
+      {
+        keep[i] = 2;
+        producer[ops[i].parent_clv_index] = -2;
+        continue;
+      }
+      producer[ops[i].parent_clv_index] = 0; /* (its place follows) */
       start[level[i] + 1]++;
       ++kept;
     }
     /* order by level (stable); a child's producer is the latest earlier op of the CALL that writes it */
     for (l = 0; l < nlevels; ++l) start[l + 1] += start[l];
     for (i = 0; i < count; ++i)
-      if (keep[i]) pos[i] = start[level[i]]++;
+      if (keep[i] == 1) pos[i] = start[level[i]]++;
     for (i = 0; i < p->nodes; ++i) producer[i] = -1;
     int failed = 0;
     for (i = 0; i < count && !failed; ++i)
@@ -393,8 +412,13 @@ int pll_update_repeats_device(pll_partition_t *p, pll_amd_ext_t *x, const pll_op
       if (!keep[i]) continue;
       const pll_operation_t *op = &ops[i];
       const unsigned int left = op->child1_clv_index, right = op->child2_clv_index, parent = op->parent_clv_index;
-      pllgpu_repop_t *o = &rop[pos[i]];
       x->repeats_dirty[parent] = 0;
+      if (keep[i] == 2)
+      {
+        producer[parent] = -1; /* (nothing of the call reads a settled parent's map: whoever does is settled too) */
+        continue;
+      }
+      pllgpu_repop_t *o = &rop[pos[i]];
       o->parent = parent;
       o->left = left;
       o->right = right;
@@ -413,6 +437,8 @@ int pll_update_repeats_device(pll_partition_t *p, pll_amd_ext_t *x, const pll_op
     free(start);
     free(pos);
     if (!failed) ok = classes_call(p, x, ops, rop, idx, kept, counts, &changed);
+    for (i = 0; i < count && ok; ++i)
+      if (keep[i] == 2) ok = follow_count(p, x, &ops[i], 0u, &changed);
     if (!ok) /* whatever the device left of these maps is not what their stamps say */
       for (i = 0; i < count; ++i)
         if (keep[i]) pll_maps_touched(x, p, (int)ops[i].parent_clv_index);

@@ -177,6 +177,7 @@ _GPU_PROTOS = {
     "pll_gpu_last_launch_count": (C.c_uint, [PartitionP]),
     "pll_gpu_last_update_replayed": (C.c_int, [PartitionP]),
     "pll_gpu_class_map_work": (C.c_ulonglong, [PartitionP, C.c_int]),
+    "pll_gpu_plan_replays": (C.c_ulonglong, [PartitionP]),
     "pll_core_seam_release": (None, []),
     "pll_gpu_group_join": (C.c_void_p, [C.c_char_p, C.c_uint, C.c_uint, C.c_int]),
     "pll_gpu_group_leave": (None, [C.c_void_p]),

@@ -33,10 +33,14 @@ def test_gpus_2_starts_two_ranks_and_runs_the_strong_scaling_flow(cut):
     assert out["value"] > 0 and out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
     assert "roofline" in out and out["t1_ms"] > 0
     # which call is timed, and the step as the reference's pll_update_partials defines it beside it
-    assert "update_repeats = 0" in out["config"]["step"] and "update_repeats = 1" in out["config"]["step_with_class_maps"]
+    # three timed figures (round 6): maps re-used, the default call on the unchanged tree, every map forced to be computed again
+    assert "update_repeats = 0" in out["config"]["step"] and "update_repeats = 1" in out["config"]["step_default_call"]
+    assert "PLL_GPU_FORGET_REPEATS" in out["config"]["step_with_class_maps"]
     assert out["ms_per_step_with_class_maps"] > out["ms_per_step"] and out["t1_ms_with_class_maps"] > out["t1_ms"]
-    assert out["speedup_with_class_maps"] > 0 and out["value_with_class_maps"] > 0
+    assert out["ms_per_step_with_class_maps"] > out["ms_per_step_default_call"] > 0 and out["t1_ms_with_class_maps"] > out["t1_ms_default_call"] > 0
+    assert out["speedup_with_class_maps"] > 0 and out["value_with_class_maps"] > 0 and out["speedup_default_call"] > 0
     assert abs(out["lnl_with_class_maps"] - out["lnl"]) <= 1e-12 * abs(out["lnl"])
+    assert abs(out["lnl_default_call"] - out["lnl"]) <= 1e-12 * abs(out["lnl"])
     assert out["exchange_timed"] == "peer" and len(out["cpu_affinity"]) == 2
 
 
@@ -74,10 +78,13 @@ def test_repeats_line_times_both_forms_of_the_step():
     """a SITE_REPEATS line says which call its `value` is timed with and carries the step with the class maps
     recomputed - pll_update_partials as the reference defines it - as a second timed figure"""
     out = run_bench("--config", "c4", "--sites", "100000", "--steps", "3", "--blocks", "2", "--warmup", "2", "--no-cpu")
-    assert "update_repeats = 0" in out["config"]["step"] and "update_repeats = 1" in out["config"]["step_with_class_maps"]
+    assert "update_repeats = 0" in out["config"]["step"] and "update_repeats = 1" in out["config"]["step_default_call"]
+    assert "PLL_GPU_FORGET_REPEATS" in out["config"]["step_with_class_maps"]
     assert out["ms_per_step_with_class_maps"] > out["ms_per_step"] > 0
-    assert 0 < out["value_with_class_maps"] < out["value"]
+    assert out["ms_per_step_with_class_maps"] > out["ms_per_step_default_call"] > 0   # an unchanged tree computes no maps
+    assert 0 < out["value_with_class_maps"] < out["value"] and out["value_default_call"] > out["value_with_class_maps"]
     assert abs(out["lnl_with_class_maps"] - out["lnl"]) <= 1e-12 * abs(out["lnl"])
+    assert abs(out["lnl_default_call"] - out["lnl"]) <= 1e-12 * abs(out["lnl"])
 
 
 def test_default_line_carries_the_contract_fields():

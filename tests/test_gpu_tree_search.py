@@ -264,8 +264,8 @@ def test_an_unchanged_tree_computes_no_class_maps_and_a_move_only_the_path_above
             x.update(ops)
         assert abs(d.lnl(tree.edge_args(rec)) - r.lnl(tree.edge_args(rec))) <= RTOL * abs(r.lnl(tree.edge_args(rec)))
         work = lambda: (amd_lib.pll_gpu_class_map_work(d.p, 0), amd_lib.pll_gpu_class_map_work(d.p, 1))
-        first = work()
-        assert first[0] == len(ops) and first[1] > 0
+        first = work()                                  # (parents that cannot be compressed - a child is not - never reach the device)
+        assert 0 < first[0] <= len(ops) and first[1] > 0
         d.update(ops)                                   # the same tree again, the reference's default call:
         assert work() == first                          # ... nothing to compute, nothing launched
         d.matrices([(m, 0.5 * x) for m, x in tree.branches()])
@@ -279,18 +279,22 @@ def test_an_unchanged_tree_computes_no_class_maps_and_a_move_only_the_path_above
         for x in (d, r):
             x.matrices(changed)
             x.update(ops2)
-        assert work()[0] == first[0] + len(ops2)
-        rec, ops = rec2, tree.ops_for(rec2)
-        assert not ops
+        after_nni = work()
+        assert after_nni[0] <= first[0] + len(ops2)
+        rec = rec2
+        assert not tree.ops_for(rec2)
         tree.forget()
         ops = tree.ops_for(rec)
         for x in (d, r):
             x.update(ops)                               # a full traversal of the moved tree: only what is NOT as the
         moved = work()                                  # partial traversals left it is computed (other orientations)
-        assert moved[0] < first[0] + len(ops2) + len(ops)
+        assert moved[0] - after_nni[0] < first[0]
         amd_lib.pll_gpu_invalidate(d.p, api.FORGET_REPEATS, -1)  # everything is computed again
         d.update(ops)
-        assert work()[0] == moved[0] + len(ops)
+        again = work()
+        assert again[0] - moved[0] > moved[0] - after_nni[0] and again[0] - moved[0] <= len(ops) and again[1] > moved[1]
+        d.update(ops)
+        assert work() == again
         for o in ops:
             a, b = d.maps(o[0]), r.maps(o[0])
             assert a[0] == b[0] and (a[0] == 0 or (np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])))

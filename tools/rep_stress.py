@@ -32,6 +32,7 @@ def main():
         rep = s.part.repeats.contents
         sample = [case.tips + i for i in (0, 1, 40, 70, 100, 111)]  # nodes of levels 0 .. 2 (and above: uncompressed)
         for it in range(iters):
+            lib.pll_gpu_invalidate(s.p, api.FORGET_REPEATS, -1)  # round 6: every map computed again (an unchanged tree computes none)
             lib.pll_update_partials(s.p, ops, n)
             lnl = s.edge_lnl(case.edges[0], persite=False)[0]
             h = hashlib.sha256()

@@ -40,6 +40,9 @@ for name, lib in libs:
                 sync()
                 t0 = time.perf_counter()
                 for _ in range(20):
+                    if upd and lib.is_amd:  # round 6: the path's maps forgotten first (an unchanged tree computes none)
+                        for o in path[-k:]:
+                            lib.pll_gpu_invalidate(s.p, api.FORGET_REPEATS, int(o[0]))
                     lib.pll_update_partials_rep(s.p, ops, k, upd)
                 sync()
                 row.append((time.perf_counter() - t0) / 20 * 1e6)
