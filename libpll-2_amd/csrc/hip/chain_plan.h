@@ -552,9 +552,10 @@ static int try_chain_plan(pllgpu_ctx *c, const pllgpu_op_t *ops, unsigned count,
     }
     // pageable sources are staged before hipMemcpyAsync returns; the stream orders the copies behind the
     // kernels of the previous plan that still read the old descriptors
-    hipError_t e = hipMemcpyAsync(c->chain_dev.p, pl->heads.data(), hb, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(c->chain_dev.p + hb, pl->loads.data(), lb, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(c->chain_dev.p + hb + lb, pl->sops.data(), ob, hipMemcpyHostToDevice, c->stream);
+    // (through the context's pinned block: a tree search plans a new list after every move)
+    hipError_t e = copy_up(c, c->chain_dev.p, pl->heads.data(), hb);
+    if (e == hipSuccess) e = copy_up(c, c->chain_dev.p + hb, pl->loads.data(), lb);
+    if (e == hipSuccess) e = copy_up(c, c->chain_dev.p + hb + lb, pl->sops.data(), ob);
     if (e != hipSuccess)
     {
       delete pl;

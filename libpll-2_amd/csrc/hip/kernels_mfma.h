@@ -174,7 +174,7 @@ template <int NG, bool LTIP, bool RTIP, bool GATHER>
 __global__ __launch_bounds__(256, NG > 8 ? 2 : 4) void k_partials_mfma(const OpPack pack, const GenGeo g,
                                                           const unsigned long long *__restrict__ tipmap,
                                                           unsigned items_per_wave, unsigned char *__restrict__ flagbuf,
-                                                          unsigned flag_stride /* bytes per (op, rate) */, unsigned xcd_nx, unsigned xcd_ny)
+                                                          unsigned flag_stride /* bytes per (op, rate) */)
 {
   extern __shared__ double lds[];
   typedef MfmaGeo<NG> MG;
@@ -183,17 +183,7 @@ __global__ __launch_bounds__(256, NG > 8 ? 2 : 4) void k_partials_mfma(const OpP
   double *PR = lds + MG::frag_array;
   double *RS = lds + MG::rowsum_off; // row sums of P_left [4 NG], P_right [4 NG]
 
-  // xcd_nx != 0: a 1-D grid in the XCD-aware order of the store-bound launches (kernels_common.h: xcd_linear) - every XCD
-  // a contiguous run of (op, rate, item blocks); else the (item blocks, ops, rates) grid as launched
-  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (xcd_nx)
-  {
-    const unsigned l = xcd_linear(xcd_nx * xcd_ny * g.R, 1u);
-    if (l == ~0u) return;
-    bx = l % xcd_nx;
-    bz = (l / xcd_nx) % g.R;
-    by = l / (xcd_nx * g.R);
-  }
+  const unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z; // (item blocks, ops, rates)
   const DevOp &op = pack.ops[by];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

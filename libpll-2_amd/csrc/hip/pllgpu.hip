@@ -215,9 +215,6 @@ struct pllgpu_ctx
   std::vector<RepOp> rep_ops_host;
   unsigned rep_wgs = 0;                  // PLL_AMD_REP_WGS: workgroups per op of k_rep_mark (0: by the launch's size)
   unsigned rep_max_ranges = 8;           // PLL_AMD_REP_RANGES: site ranges per part of a large table, at most (kernels_repeats.h)
-  unsigned rep_assign_iters = 0;         // PLL_AMD_REP_ASSIGN_ITERS: rounds per workgroup of k_rep_assign (0: by the launch's size)
-  unsigned rep_assign_lds = kRepAssignLds; // PLL_AMD_REP_ASSIGN_LDS: tables up to this many cells are looked up in LDS
-  bool mfma_tt_xcd = false;              // PLL_AMD_MFMA_TT_XCD=1: plain tip x tip launches of the matrix-pipe kernel in XCD-aware order (A/B)
   bool sub_pack_always = false;          // PLL_AMD_SUB_PACK_ALWAYS=1: k_sub_pack after every class-map call, whatever it reported (A/B)
   bool rep_bits = true;                  // PLL_AMD_REP_BITS=0: the bitmap of first sites by atomics + k_rep_scan for every table size (A/B)
   bool rep_hints = true;                 // PLL_AMD_REP_HINTS=0: every level of a class-map call is launched (A/B, tests)
@@ -603,12 +600,9 @@ extern "C" pllgpu_ctx_t *pllgpu_create(const pllgpu_geometry_t *geo, int device)
   (void)hipMemsetAsync(c->rep_sync.p, 0, c->rep_sync.cap * sizeof(unsigned), c->stream);
   (void)hipMemsetAsync(c->rep_changed.p, 0, sizeof(unsigned), c->stream);
   if (const char *v = getenv("PLL_AMD_REP_WGS")) c->rep_wgs = (unsigned)std::max(0, atoi(v));
-  if (const char *v = getenv("PLL_AMD_REP_ASSIGN_ITERS")) c->rep_assign_iters = (unsigned)std::max(0, atoi(v));
-  if (const char *v = getenv("PLL_AMD_REP_ASSIGN_LDS")) c->rep_assign_lds = (unsigned)std::min<int>(kRepAssignLds, std::max(0, atoi(v)));
   if (const char *v = getenv("PLL_AMD_REP_BITS")) c->rep_bits = !(*v == '0');
   if (const char *v = getenv("PLL_AMD_SUB_PACK_ALWAYS")) c->sub_pack_always = *v && *v != '0';
   if (const char *v = getenv("PLL_AMD_REP_FUSE")) c->rep_fuse = !(*v == '0');
-  if (const char *v = getenv("PLL_AMD_MFMA_TT_XCD")) c->mfma_tt_xcd = *v && *v != '0';
   if (const char *v = getenv("PLL_AMD_PINNED_STAGING")) c->ring_failed = *v == '0'; // 0: every transfer from / to pageable memory as the runtime does it (A/B)
   if (const char *v = getenv("PLL_AMD_REP_HINTS")) c->rep_hints = !(*v == '0');
   if (const char *v = getenv("PLL_AMD_REP_RANGES")) c->rep_max_ranges = (unsigned)std::max(1, atoi(v));
@@ -1325,9 +1319,8 @@ static int launch_mfma_t(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsig
   unsigned ipw = (unsigned)(((size_t)items * nops * R + want - 1) / want);
   ipw = std::max(1u, std::min(ipw, NG > 8 ? ~0u : 8u));
   dim3 grid((items + 4 * ipw - 1) / (4 * ipw), nops, R), block(256);
-  // plain tip x tip levels are store traffic and nothing else (C5's: 625 MB): PLL_AMD_MFMA_TT_XCD=1 runs them in the
-  // XCD-aware order of the other store-bound launches (A/B; profiles/README.md)
-  const bool xcd = c->mfma_tt_xcd && kind == 2 && !gather;
+  // (round 5 ran the plain tip x tip levels - store traffic and nothing else, C5's: 625 MB - in the XCD-aware order of the
+  // other store-bound launches as well: 119.7 -> 122.7 us, profiles/README.md; the switch and its code are gone)
   const size_t lds = MfmaGeo<NG>::lds_doubles * sizeof(double);
   const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
   bool scaling = false;
@@ -1340,7 +1333,7 @@ static int launch_mfma_t(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsig
   do                                                                                                            \
   {                                                                                                             \
     raise_lds_limit((const void *)k_partials_mfma<NG, LT, RT, GA>, c->device, lds);                             \
-    hipLaunchKernelGGL((k_partials_mfma<NG, LT, RT, GA>), xcd ? xcd_grid(grid.x, nops, R) : grid, block, lds, c->stream, pack, c->gg, tm, ipw, fb, fstride, xcd ? grid.x : 0u, nops); \
+    hipLaunchKernelGGL((k_partials_mfma<NG, LT, RT, GA>), grid, block, lds, c->stream, pack, c->gg, tm, ipw, fb, fstride); \
   } while (0)
   if (kind == 0)
   {
@@ -2966,8 +2959,10 @@ extern "C" int pllgpu_update_pmatrices(pllgpu_ctx_t *c, const unsigned *params_i
   if (int rc = c->mindex.ensure(count)) return rc;
   if (int rc = c->brlen.ensure(count)) return rc;
   for (unsigned i = 0; i < count; ++i) ++c->pm_version[matrix_indices[i]];
-  HIP_TRY(hipMemcpyAsync(c->mindex.p, matrix_indices, count * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->brlen.p, branch_lengths, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  // (through the context's pinned block: a copy from pageable memory is a blocking trip through the runtime's staging, and
+  // a tree search makes this call for one to three branches after every move)
+  HIP_TRY(copy_up(c, c->mindex.p, matrix_indices, count * sizeof(unsigned)));
+  HIP_TRY(copy_up(c, c->brlen.p, branch_lengths, count * sizeof(double)));
   d.pmat = c->pmat.p;
   d.evecs = c->evecs.p;
   d.ievecs = c->ievecs.p;
@@ -3238,7 +3233,7 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
       if (!(fuse[i] & kRepDeferred) && ub) L.assign = true;
       cells += slice;
       L.mark_lds = std::max<unsigned>(L.mark_lds, (unsigned)std::min<size_t>(ub, kRepLdsCells));
-      if (ub <= c->rep_assign_lds) L.assign_lds = std::max<unsigned>(L.assign_lds, (unsigned)((ub + 3u) & ~(size_t)3u));
+      if (ub <= kRepAssignLds) L.assign_lds = std::max<unsigned>(L.assign_lds, (unsigned)((ub + 3u) & ~(size_t)3u));
       ++L.n;
     }
     arena = std::max(arena, cells);
@@ -3270,8 +3265,8 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
   if (c->rep_ops_sent.size() != (size_t)ncut * sizeof(RepOp) || c->rep_ops_sent_at != c->rep_ops.p ||
       memcmp(c->rep_ops_sent.data(), rops.data(), c->rep_ops_sent.size()) != 0)
   {
-    // pageable source: staged before hipMemcpyAsync returns; ordered behind the previous call's kernels
-    HIP_TRY(hipMemcpyAsync(c->rep_ops.p, rops.data(), (size_t)ncut * sizeof(RepOp), hipMemcpyHostToDevice, c->stream));
+    // (staged in the context's pinned block; ordered behind the previous call's kernels)
+    HIP_TRY(copy_up(c, c->rep_ops.p, rops.data(), (size_t)ncut * sizeof(RepOp)));
     c->rep_ops_sent.assign(reinterpret_cast<const unsigned char *>(rops.data()), reinterpret_cast<const unsigned char *>(rops.data() + ncut));
     c->rep_ops_sent_at = c->rep_ops.p;
   }
@@ -3337,7 +3332,6 @@ extern "C" int pllgpu_repeats_classes(pllgpu_ctx_t *c, const pllgpu_repop_t *ops
     const size_t assign_bytes = (size_t)L.assign_lds * sizeof(unsigned short);
     const unsigned per_round = kRepAssignThreads * 16u, rounds = (sites + per_round - 1u) / per_round;
     pk.assign_iters = std::max(1u, std::min(4u, rounds * L.n / (assign_bytes > 32768 ? 256u : 512u)));
-    if (c->rep_assign_iters) pk.assign_iters = c->rep_assign_iters;
     pk.wgs = (rounds + pk.assign_iters - 1u) / pk.assign_iters;
     raise_lds_limit((const void *)k_rep_assign, c->device, assign_bytes);
     if (L.assign) hipLaunchKernelGGL(k_rep_assign, dim3(n8 * pk.wgs), dim3(kRepAssignThreads), assign_bytes, c->stream, pk);

@@ -132,7 +132,7 @@ static int upload_subtrees(pllgpu_ctx *c, const std::vector<SubItem> &items)
   if (c->sub_epoch == epoch && c->sub_cache.size() == items.size() && memcmp(c->sub_cache.data(), items.data(), nbytes) == 0) return 0;
   if (int rc = c->sub_dev.ensure(nbytes)) return rc;
   // pageable source: staged before hipMemcpyAsync returns; ordered behind the kernels that read the old array
-  HIP_TRY(hipMemcpyAsync(c->sub_dev.p, items.data(), nbytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(copy_up(c, c->sub_dev.p, items.data(), nbytes));
   c->sub_pack_valid = false; // other descriptors: their packed codes have to be formed
   c->sub_cache = items;
   c->sub_epoch = c->alloc_epoch;

@@ -242,7 +242,9 @@ def test_packed_subtree_lookups_follow_maps_and_tips(amd_lib, monkeypatch, alway
             assert np.array_equal(s.read_clv(case_a.edges[0][0]), fresh[tag][1]), tag
             s.update_partials(update_repeats=0)  # the cached plan and the packed words as they are
             assert s.edge_lnl(case_a.edges[0], persite=False)[0] == v
-            for _ in range(2):  # the maps again, as they were
+            for k in range(3):  # the maps again, as they were: recomputed (round 6: only when their inputs are forgotten) or recognised
+                if k < 2:
+                    amd_lib.pll_gpu_invalidate(s.p, api.FORGET_REPEATS, -1)
                 s.update_partials(update_repeats=1)
                 assert s.edge_lnl(case_a.edges[0], persite=False)[0] == v
                 assert np.array_equal(s.read_clv(case_a.edges[0][0]), fresh[tag][1]), tag
@@ -269,6 +271,8 @@ def test_class_maps_do_not_depend_on_how_the_launches_are_cut(amd_lib, ref_lib, 
     for lib in (amd_lib, ref_lib):
         with driver.Session(lib, case, api.ARCH_AVX2) as s:
             lib.pll_update_partials(s.p, ops, len(case.op_batches[0]))
+            if lib.is_amd:  # (round 6: an unchanged tree computes no maps - everything known about their inputs is dropped first)
+                lib.pll_gpu_invalidate(s.p, api.FORGET_REPEATS, -1)
             lib.pll_update_partials(s.p, ops, len(case.op_batches[0]))  # (the forecast of the first call, the cached launches)
             res[lib.is_amd] = (_maps(lib, s, case.sites, through_accessors=True), s.edge_lnl(case.edges[0], persite=False)[0])
     for node, (a, b) in enumerate(zip(res[True][0], res[False][0])):
@@ -355,7 +359,10 @@ def test_the_same_list_again_goes_straight_to_the_launches(amd_lib, attributes):
         s.update_partials()
         assert amd_lib.pll_gpu_last_update_replayed(s.p) == 0
         first = s.edge_lnl(case.edges[0], persite=False)[0]
-        for update_repeats in ((0, 1, 1, 0) if attributes & api.SITE_REPEATS else (1, 1)):
+        for update_repeats in ((0, 1, 2, 2, 0) if attributes & api.SITE_REPEATS else (1, 1)):
+            if update_repeats == 2:  # every class map computed again: they come out as they were, the short path stands
+                amd_lib.pll_gpu_invalidate(s.p, api.FORGET_REPEATS, -1)
+                update_repeats = 1
             s.update_partials(update_repeats=update_repeats)
             assert amd_lib.pll_gpu_last_update_replayed(s.p) == 1, update_repeats
             assert s.edge_lnl(case.edges[0], persite=False)[0] == first
