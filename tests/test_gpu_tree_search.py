@@ -105,7 +105,9 @@ def _alignment(states, tips, sites, seed, mutate_pct):
     if states == 4:
         return W.states_to_sequences(st, W.NT_CHARS), W.map_nt(), W.GTR_DNA["exch"], W.GTR_DNA["freqs"]
     ex, fr = W.synthetic_exch(states)
-    return W.states_to_sequences(st, W.AA_CHARS), W.map_aa(), ex, fr
+    if states == 20:
+        return W.states_to_sequences(st, W.AA_CHARS), W.map_aa(), ex, fr
+    return W.states_to_sequences(st, bytes(range(48, 48 + states))), W.map_generic(states), ex, fr
 
 
 def _search(libs, states, tips, sites, attrs, seed, moves, check=None, full_every=25, deriv_every=10, spr_radius=6, tip_every=23):
@@ -233,6 +235,16 @@ def test_a_tree_search_against_the_reference(amd_lib, ref_lib, attrs, states, sh
     moves = MOVES if tips <= 64 else max(40, MOVES // 2) if states == 20 else MOVES
     _search([amd_lib, ref_lib], states, tips, sites, ATTRS[attrs], seed=4100 + 7 * states + tips, moves=moves, check=check)
     print(f"tree search {attrs} {states} states {tips} taxa: {worst['n']} evaluations, worst lnL rel err {worst['lnl']:.2e}")
+
+
+@pytest.mark.parametrize("states,sites", [(7, 900), (61, 250)], ids=["7states", "61states"])
+@pytest.mark.parametrize("attrs", ["plain", "site_repeats"])
+def test_a_tree_search_in_other_state_counts(amd_lib, ref_lib, attrs, states, sites):
+    """odd state counts (padding) and the fp64 matrix pipe of 33...64 states (cherry tables per pair of tip matrices, the wide
+    inner x inner kernel, scaling epilogues) through the same search, 64 taxa"""
+    check, worst = _against_reference(sites)
+    _search([amd_lib, ref_lib], states, 64, sites, ATTRS[attrs], seed=5200 + states, moves=max(30, MOVES // 4), check=check)
+    print(f"tree search {attrs} {states} states 64 taxa: {worst['n']} evaluations, worst lnL rel err {worst['lnl']:.2e}")
 
 
 @pytest.mark.parametrize("switch", ["PLL_AMD_NO_PLAN_CACHE", "PLL_AMD_REP_STAMPS"])
