@@ -370,6 +370,155 @@ __global__ __launch_bounds__(256, NG > 8 ? 2 : 4) void k_partials_mfma(const OpP
   }
 }
 
+// Plain tip x tip levels of the large state spaces as what they are: a STORE STREAM (round 6). For a tip that is a single
+// state (or a full gap) P x is a column of P (its row sum), so a parent entry is a product of two column elements - no
+// contraction at all. k_partials_mfma<.., true, true> already takes the columns from LDS, but in the matrix pipe's lane
+// map: a store instruction covers 4 state rows x 16 sites, four 128-byte pieces 512 bytes apart, and a tile's row is
+// completed by four instructions of different items (C5: 119.6 us for 625 MB, 0.66 of the HBM peak). Here lane = site:
+// the wave that owns (tile, rate) writes its S rows of 64 sites one 512-byte instruction after the other - 31 KB of
+// consecutive addresses for 61 states - with two LDS reads and a multiplication per value. The matrices sit in LDS as
+// the host stores them (PT[j][i]: row j IS column j of P) at an ODD row stride, so that lanes with different codes
+// start in different banks, plus one row of row sums (ascending j, like the reference's set-bit walk,
+// src/core_partials.c:480-489 - the value k_partials_mfma uses). Codes with several but not all bits set walk their bits
+// in ascending order per lane (rare: not the matrix pipe's summation order - within 1e-15 of it, not the same bits).
+// Scaling decisions go to flagbuf for k_mfma_scale_epilogue exactly like k_partials_mfma's.
+// grid: 1-D, XCD-aware (kernels_common.h: xcd_linear), logical order rate category fastest - the four workgroups of a
+// tile block write one contiguous run; LDS 2 x (S + 1) x LD doubles.
+__device__ __forceinline__ unsigned tt_stream_ld(unsigned S) { return (S + 1u) | 1u; }
+
+constexpr unsigned kTtStreamThreads = 1024; // sixteen waves share one copy of the matrices: two workgroups per CU = eight waves per SIMD
+
+struct TtCodes
+{
+  unsigned long long ml, mr;
+};
+__device__ __forceinline__ TtCodes tt_stream_codes(const DevOp &op, const unsigned long long *__restrict__ tipmap, unsigned tile, unsigned lane)
+{
+  const unsigned n = tile * 64u + lane;
+  const unsigned nn = n < op.entries ? n : op.entries - 1u;
+  TtCodes c;
+  c.ml = tipmap ? tipmap[op.ltip[nn]] : (unsigned long long)op.ltip[nn];
+  c.mr = tipmap ? tipmap[op.rtip[nn]] : (unsigned long long)op.rtip[nn];
+  return c;
+}
+
+__global__ __launch_bounds__(kTtStreamThreads) void k_partials_tt_stream(const OpPack pack, const GenGeo g, const unsigned long long *__restrict__ tipmap,
+                                                                         unsigned tiles_per_wave, unsigned char *__restrict__ flagbuf, unsigned flag_stride,
+                                                                         unsigned nx, unsigned nops, unsigned xcd_order)
+{
+  extern __shared__ double lds[];
+  constexpr unsigned NW = kTtStreamThreads / 64u;
+  const unsigned S = g.S, LD = tt_stream_ld(S);
+  double *const ML = lds, *const MR = lds + (size_t)(S + 1u) * LD;
+  const unsigned l = xcd_linear(nx * nops * g.R, xcd_order);
+  if (l == ~0u) return;
+  const unsigned k = l % g.R, bx = (l / g.R) % nx, by = l / (g.R * nx);
+  const DevOp &op = pack.ops[by];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned ntiles = (op.entries + 63u) / 64u;
+  const unsigned tile0 = (bx * NW + wave) * tiles_per_wave;
+  // the first tile's codes are on their way while the matrices are staged
+  TtCodes cur = tt_stream_codes(op, tipmap, tile0 < ntiles ? tile0 : 0u, lane);
+  // ---- the two matrices of this rate category: every request before the first LDS write
+  {
+    constexpr unsigned PER = (64u * 64u + kTtStreamThreads - 1u) / kTtStreamThreads;
+    const double *__restrict__ sl = op.lmat + (size_t)k * S * g.SPT, *__restrict__ sr = op.rmat + (size_t)k * S * g.SPT;
+    double vl[PER], vr[PER];
+#pragma unroll
+    for (unsigned q = 0; q < PER; ++q)
+    {
+      const unsigned lin = threadIdx.x + kTtStreamThreads * q, j = lin / S, i = lin - j * S;
+      const bool in = lin < S * S;
+      const size_t off = in ? (size_t)j * g.SPT + i : 0;
+      vl[q] = sl[off];
+      vr[q] = sr[off];
+    }
+#pragma unroll
+    for (unsigned q = 0; q < PER; ++q)
+    {
+      const unsigned lin = threadIdx.x + kTtStreamThreads * q, j = lin / S, i = lin - j * S;
+      if (lin < S * S)
+      {
+        ML[j * LD + i] = vl[q];
+        MR[j * LD + i] = vr[q];
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 128u && lane < S)
+  {
+    // row sums in ascending j (wave 0: left, wave 1: right) into row S
+    double *M = wave == 0u ? ML : MR;
+    double sum = 0.0;
+    for (unsigned j = 0; j < S; ++j) sum += M[j * LD + lane];
+    M[S * LD + lane] = sum;
+  }
+  __syncthreads();
+
+  const int mode = op.pscaler ? g.scale_mode : 0;
+  const unsigned long long full = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
+  for (unsigned t = 0; t < tiles_per_wave; ++t)
+  {
+    const unsigned tile = tile0 + t;
+    if (tile >= ntiles) break; // wave-uniform; no barriers below
+    const unsigned n = tile * 64u + lane;
+    const bool valid = n < op.entries;
+    const unsigned long long ml = cur.ml, mr = cur.mr;
+    if (t + 1u < tiles_per_wave && tile + 1u < ntiles) cur = tt_stream_codes(op, tipmap, tile + 1u, lane); // the next tile's, ahead of this one's stores
+    const bool lsimple = __popcll(ml) == 1 || ml == full, rsimple = __popcll(mr) == 1 || mr == full;
+    const double *cl = ML + (ml == full ? S : (unsigned)__ffsll((long long)ml) - 1u) * LD;
+    const double *cr = MR + (mr == full ? S : (unsigned)__ffsll((long long)mr) - 1u) * LD;
+    double *__restrict__ out = op.parent + (size_t)tile * g.tile_sz + (size_t)k * S * 64 + lane;
+    bool small = true;
+    if (__all(lsimple && rsimple))
+    {
+      unsigned i = 0;
+      for (; i + 4u <= S; i += 4u)
+      {
+        double v[4];
+#pragma unroll
+        for (unsigned u = 0; u < 4u; ++u) v[u] = cl[i + u] * cr[i + u];
+#pragma unroll
+        for (unsigned u = 0; u < 4u; ++u)
+        {
+          small = small && (v[u] < PLLGPU_SCALE_THRESHOLD);
+          if (valid) out[(size_t)(i + u) * 64] = v[u];
+        }
+      }
+      for (; i < S; ++i)
+      {
+        const double v = cl[i] * cr[i];
+        small = small && (v < PLLGPU_SCALE_THRESHOLD);
+        if (valid) out[(size_t)i * 64] = v;
+      }
+    }
+    else
+    {
+      for (unsigned i = 0; i < S; ++i)
+      {
+        double a, b;
+        if (lsimple) a = cl[i];
+        else
+        {
+          a = 0.0;
+          for (unsigned long long m = ml & full; m; m &= m - 1ull) a += ML[((unsigned)__ffsll((long long)m) - 1u) * LD + i];
+        }
+        if (rsimple) b = cr[i];
+        else
+        {
+          b = 0.0;
+          for (unsigned long long m = mr & full; m; m &= m - 1ull) b += MR[((unsigned)__ffsll((long long)m) - 1u) * LD + i];
+        }
+        const double v = a * b;
+        small = small && (v < PLLGPU_SCALE_THRESHOLD);
+        if (valid) out[(size_t)i * 64] = v;
+      }
+    }
+    if (mode && valid) flagbuf[((size_t)by * g.R + k) * flag_stride + n] = small ? 1u : 0u;
+  }
+}
+
 // applies the scaling decisions k_partials_mfma left in flagbuf: one thread per parent entry
 template <bool GATHER>
 __global__ __launch_bounds__(256) void k_mfma_scale_epilogue(const OpPack pack, const GenGeo g,

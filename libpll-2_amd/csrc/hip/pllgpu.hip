@@ -240,6 +240,7 @@ struct pllgpu_ctx
   unsigned long long rep_ops_total = 0, rep_launches_total = 0; // class-map ops handed to the device / class kernels launched, ever
   double last_bytes = 0.0;       // algorithmic HBM bytes of the last update_partials call
   bool no_tip_columns = false;   // PLL_AMD_NO_TIP_COLUMNS=1: tips always through the FMA contraction
+  bool tt_stream = true;         // PLL_AMD_TT_STREAM=0: plain tip x tip levels of 33..64 states through k_partials_mfma's column route (round 5) - the control
   bool no_par_lds = false;       // PLL_AMD_NO_PARENT_LDS=1 (A/B): entry-contiguous parents stored 8 bytes per lane
   bool no_coop_fetch = false;    // PLL_AMD_NO_COOP_FETCH=1 (A/B): the FMA kernels' entry-contiguous children fetched per lane
   size_t stream_parent_bytes = (size_t)256 << 20; // parents of a grouped launch beyond this leave with streaming stores (the Infinity Cache)
@@ -427,6 +428,7 @@ static void derive_geometry(pllgpu_ctx *c)
   c->fuse = c->dna_fast;
   if (const char *v = getenv("PLL_AMD_NO_FUSE")) // experiment switch: one kernel per op group, no producer/consumer fusion
     if (*v && *v != '0') c->fuse = false;
+  if (const char *v = getenv("PLL_AMD_TT_STREAM")) c->tt_stream = !(*v == '0');
   if (const char *v = getenv("PLL_AMD_NO_TIP_COLUMNS"))
     if (*v && *v != '0') c->no_tip_columns = true;
   if (const char *v = getenv("PLL_AMD_NO_PARENT_LDS"))
@@ -1282,6 +1284,8 @@ static bool launch_wide(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsign
   return true;
 }
 
+static inline unsigned tt_stream_ld_host(unsigned S) { return (S + 1u) | 1u; } // (kernels_mfma.h: tt_stream_ld)
+
 template <int NG>
 static int launch_mfma_t(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsigned maxent, unsigned kind, bool gather)
 {
@@ -1310,6 +1314,34 @@ static int launch_mfma_t(pllgpu_ctx *c, const OpPack &pack, unsigned nops, unsig
       }
       return 0;
     }
+  }
+  if (kind == 2 && !gather && NG > 8 && c->tt_stream && !c->no_tip_columns)
+  {
+    // plain tip x tip level of a large state space: a store stream, lane = site (kernels_mfma.h: k_partials_tt_stream)
+    const unsigned tiles = (maxent + 63u) / 64u;
+    constexpr unsigned nw = kTtStreamThreads / 64u; // waves of a workgroup
+    // workgroups: each stages its rate category's two matrices (2 x 30 KB for 61 states) first, two fit a CU - one round of
+    // them (C5, same box: 1 / 2 / 3 / 5 tiles per wave = 1280 / 640 / 448 / 256 workgroups: 101.6 / 106.5 / 99.8 / 98.8 us)
+    const unsigned want = 512u;
+    unsigned tpw = (unsigned)(((size_t)((tiles + nw - 1u) / nw) * nops * R + want - 1u) / want);
+    tpw = std::max(1u, tpw);
+    const unsigned nx = (tiles + nw * tpw - 1u) / (nw * tpw);
+    const unsigned S = c->gg.S;
+    const size_t lds = 2u * (size_t)(S + 1u) * tt_stream_ld_host(S) * sizeof(double);
+    const unsigned long long *tm = c->tipmap_set ? c->tipmap.p : nullptr;
+    bool scaling = false;
+    for (unsigned i = 0; i < nops; ++i) scaling = scaling || pack.ops[i].pscaler != nullptr;
+    scaling = scaling && c->gg.scale_mode != 0;
+    const unsigned fstride = (maxent + 63u) & ~63u;
+    if (scaling && c->mfma_flags.ensure((size_t)kMaxOpsPerLaunch * R * fstride)) return PLLGPU_ENOMEM;
+    raise_lds_limit((const void *)k_partials_tt_stream, c->device, lds);
+    hipLaunchKernelGGL(k_partials_tt_stream, xcd_grid(nx, nops, R), dim3(kTtStreamThreads), lds, c->stream, pack, c->gg, tm, tpw, c->mfma_flags.p, fstride, nx, nops, c->xcd_order);
+    if (scaling)
+    {
+      dim3 eg((maxent + 255) / 256, nops);
+      hipLaunchKernelGGL((k_mfma_scale_epilogue<false>), eg, dim3(256), 0, c->stream, pack, c->gg, c->mfma_flags.p, fstride);
+    }
+    return 0;
   }
   // aim at two workgroups of four waves on every CU (2048 waves) - four where the small shapes leave room;
   // more work -> more items per wave. (Round 4, C5's tip x tip launch with 1024 / 2048 / 4096 / 8192 / 16384 / 40000

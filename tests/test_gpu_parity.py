@@ -872,6 +872,35 @@ def test_wide_matrix_pipe_kernel(amd_lib, kw, monkeypatch):
             assert np.array_equal(got[key]["clv"][c], ref["clv"][c]), (key, c)
 
 
+@pytest.mark.parametrize("kw", [dict(states=61, tips=16, sites=5001, seed=431),                                            # whole tiles + a ragged last one
+                                dict(states=61, tips=8, sites=70, seed=432, ambiguity_pct=20),                              # full gaps: the row sums
+                                dict(states=40, tips=16, sites=1300, seed=433, attributes=api.RATE_SCALERS),
+                                dict(states=64, tips=8, sites=4100, seed=434, ambiguity_pct=5),
+                                dict(states=33, tips=32, sites=900, seed=435, attributes=api.PATTERN_TIP)], ids=_id)
+def test_tip_tip_store_stream_is_bit_identical_to_the_matrix_pipes_column_route(amd_lib, kw, monkeypatch):
+    """round 6: plain tip x tip levels of 33..64 states as a store stream with lane = site (k_partials_tt_stream) against
+    k_partials_mfma's column route (PLL_AMD_TT_STREAM=0): single states and full gaps are products of the same two doubles -
+    the same bits in every CLV, scaler and log-likelihood; and both against the oracle"""
+    case = W.make_case("tts", **kw)
+    exp = O.run_case(case)
+    got = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("PLL_AMD_TT_STREAM", sw)
+        got[sw] = driver.run_case(amd_lib, case, api.ARCH_AVX2)
+        assert_results_match(got[sw], exp, what=f"{_id(kw)} stream={sw}")
+    assert got["1"]["lnl"] == got["0"]["lnl"]
+    for c in got["0"]["clv"]:
+        assert np.array_equal(got["1"]["clv"][c], got["0"]["clv"][c]), c
+    assert scalers_equal(got["1"], got["0"])
+
+
+def test_tip_tip_store_stream_with_partial_ambiguities(amd_lib):
+    """codes with several but not all bits set walk their bits in ascending order per lane (the reference's order,
+    src/core_partials.c:480-489): against the oracle"""
+    case = W.make_case("ttsp", states=61, tips=8, sites=700, seed=436, partial_pct=15, ambiguity_pct=5)
+    assert_results_match(driver.run_case(amd_lib, case, api.ARCH_AVX2), O.run_case(case), what="partial ambiguities")
+
+
 def test_partitions_in_concurrent_threads(amd_lib):
     """distinct partitions may be driven from distinct threads (no internal threads, no
     global state): four threads, each with its own partition, stream and shape, interleave freely"""
