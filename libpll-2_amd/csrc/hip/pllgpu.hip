@@ -62,12 +62,13 @@ static thread_local unsigned long long *t_epoch = &g_orphan_epoch;
 // hipMalloc per move, 330 us of a 450 us move; profiles/r6_tree_search.json). Everything a context does is ordered by its
 // one stream, so a block may serve its next owner at once: whatever was enqueued to read the old contents runs before
 // whatever is enqueued to write the new ones. Sizes are rounded up to four significant bits (at most 1/8 more), so that
-// blocks of nearly the same size are interchangeable; what is held idle is bounded (kPoolIdleMax, and a failed
-// hipMalloc gives everything back and tries again); pllgpu_destroy returns it all.
+// blocks of nearly the same size are interchangeable; what is held idle is bounded (a quarter of what the context's
+// buffers hold, and a failed hipMalloc gives everything back and tries again); pllgpu_destroy returns it all.
 struct BlockPool
 {
   std::multimap<size_t, void *> idle; // bytes -> block
   size_t idle_bytes = 0;
+  size_t live_bytes = 0;              // blocks the context's buffers hold
   void trim(size_t keep)
   {
     while (idle_bytes > keep && !idle.empty())
@@ -79,7 +80,9 @@ struct BlockPool
     }
   }
 };
-constexpr size_t kPoolIdleMax = (size_t)8 << 30;
+// idle blocks a context may hold: a quarter of what its buffers hold (at least 64 MB, at most 8 GB) - many partitions of a
+// multi-partition caller must not each sit on gigabytes they once needed
+constexpr size_t kPoolIdleMax = (size_t)8 << 30, kPoolIdleMin = (size_t)64 << 20;
 static thread_local BlockPool *t_pool = nullptr; // the running entry point's context (DeviceScope), like t_epoch
 
 static inline size_t block_bytes(size_t bytes)
@@ -99,6 +102,7 @@ static hipError_t block_take(size_t bytes, void **out)
     {
       *out = it->second;
       t_pool->idle_bytes -= it->first;
+      t_pool->live_bytes += bytes;
       t_pool->idle.erase(it);
       return hipSuccess;
     }
@@ -110,6 +114,7 @@ static hipError_t block_take(size_t bytes, void **out)
     t_pool->trim(0);
     e = hipMalloc(out, bytes);
   }
+  if (e == hipSuccess && t_pool) t_pool->live_bytes += bytes;
   return e;
 }
 
@@ -122,7 +127,9 @@ static void block_give(void *p, size_t bytes)
   }
   t_pool->idle.emplace(bytes, p);
   t_pool->idle_bytes += bytes;
-  if (t_pool->idle_bytes > kPoolIdleMax) t_pool->trim(kPoolIdleMax / 2);
+  t_pool->live_bytes -= std::min(bytes, t_pool->live_bytes);
+  const size_t cap = std::min(kPoolIdleMax, std::max(kPoolIdleMin, t_pool->live_bytes / 4u));
+  if (t_pool->idle_bytes > cap) t_pool->trim(cap / 2u);
 }
 
 template <typename T>
