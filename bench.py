@@ -877,6 +877,56 @@ def roofline_leg(args, cfg, lib, api, runner, reps=20):
     return roofline, codes
 
 
+def live_traffic(args, kernel):
+    """roofline.traffic measured IN THIS RUN: two child passes of this very command under rocprofv3 (--pmc FETCH_SIZE and --pmc
+    WRITE_SIZE cannot share a pass on gfx950; --kernel-trace only, as the guide prescribes), 3 steps each, the mean over the
+    dispatches of `kernel`; counters are KiB, FETCH_SIZE doubled (gfx950 counts 64 B per 128-B read request: tools/pmc_calib.hip),
+    WRITE_SIZE exact. Returns (bytes per launch, source dict) or (None, reason). Not under a profiler, not in a child of itself."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "running under a profiler"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "no rocprofv3 on this box"
+    want = kernel.replace(" ", "")
+    tmp = tempfile.mkdtemp(prefix="pll_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    sums = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--config", args.config, "--steps", "3", "--warmup", "1", "--blocks", "1", "--no-cpu", "--no-traffic"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=150)
+            except subprocess.TimeoutExpired:
+                return None, f"the {counter} pass did not finish within 150 s"
+            if r.returncode != 0:
+                return None, f"the {counter} pass failed (exit {r.returncode}): " + r.stderr.decode(errors="replace")[-200:]
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == counter and want in row["Kernel_Name"].replace(" ", ""):
+                            vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"no {counter} rows for {kernel}"
+            sums[counter] = (sum(vals) / len(vals), len(vals))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    per_launch = (2.0 * sums["FETCH_SIZE"][0] + sums["WRITE_SIZE"][0]) * 1024.0
+    return int(round(per_launch)), dict(
+        measured="in this run", kernel=kernel, dispatches=[sums["FETCH_SIZE"][1], sums["WRITE_SIZE"][1]],
+        fetch_KiB_mean=round(sums["FETCH_SIZE"][0], 2), write_KiB_mean=round(sums["WRITE_SIZE"][0], 2),
+        method="two child passes of this command under rocprofv3 (--pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, --kernel-trace only, "
+               "--steps 3 --warmup 1 --no-cpu); mean over the kernel's dispatches; counters are KiB; FETCH_SIZE doubled (gfx950 counts 64 B per "
+               "128-B read request, tools/pmc_calib.hip); WRITE_SIZE exact")
+
+
 def step_roofline(roofline, ms_per_step):
     """roofline.step: the WHOLE timed step - every update launch of the traversal as grouped plus the evaluation, whose
     operands the last launch leaves behind - against the HBM peak: as-launched bytes / ms_per_step"""
@@ -927,6 +977,17 @@ def main_single(args, h):
     value = total_sites * nops / (ms * 1e-3) / 1e6
     roofline, codes = roofline_leg(args, cfg, lib, api, runner)
     step_roofline(roofline, ms)
+    if roofline.get("bound") == "hbm" and roofline.get("traffic_source") and not args.no_cpu and not args.no_traffic and h.world == 1:
+        # the HBM bytes of the dominant kernel measured by THIS run (the committed summary stays as the fall-back, and says so)
+        kname = roofline["kernel"]
+        if " " not in kname and "+" not in kname:
+            got, src = live_traffic(args, kname.replace(",", ", "))
+            if got:
+                roofline["traffic"], roofline["traffic_source"] = got, src
+                roofline["frac_numerator"] = roofline["frac_numerator"].split(", checked against")[0] + ", checked against traffic = %.3f x" % (
+                    got / roofline["algorithmic_bytes_per_launch"])
+            else:
+                roofline["traffic_source"]["live_passes"] = "not taken: " + str(src)
     out = {
         "metric": "M site-CLV-updates/s", "value": round(value, 1), "unit": "M site-CLV-updates/s",
         "n_gpus": h.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
@@ -1133,7 +1194,8 @@ def main():
     ap.add_argument("--tree", default="balanced", choices=["balanced", "random", "caterpillar"],
                     help="topology (BASELINE's configs are balanced; the others show what irregular level structures cost)")
     ap.add_argument("--taxa", type=int, default=0, help="override the number of taxa")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and the live HBM-counter passes)")
+    ap.add_argument("--no-traffic", action="store_true", help="roofline.traffic from the committed summary instead of two rocprofv3 counter passes of this command")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the control plane (barriers, max over ranks) and of --reduce rccl; "
                          "gloo + PLL_BENCH_SAME_DEVICE=1 rehearses the N>1 flow on a one-GPU box")

@@ -94,6 +94,12 @@ def test_default_line_carries_the_contract_fields():
     rf, cb = out["roofline"], out["cpu_baseline"]
     assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and rf["achieved"] > 0
     assert (rf["traffic"] is None) == (rf["traffic_source"] is None)
+    # round 6: the HBM bytes of the dominant launch come from two rocprofv3 counter passes of THIS run (within 2 % of the
+    # algorithmic bytes: no wasted re-reads), the committed summary only where the passes could not be taken - and then it says why
+    src = rf["traffic_source"]
+    assert src.get("measured") == "in this run" or "live_passes" in src, src
+    if src.get("measured") == "in this run":
+        assert abs(rf["traffic"] / rf["algorithmic_bytes_per_launch"] - 1.0) < 0.02, (rf["traffic"], rf["algorithmic_bytes_per_launch"])
     assert 0 < rf["step"]["frac"] < 1 and abs(rf["step"]["ms"] - out["ms_per_step"]) < 1e-3 and "library" in rf["frac_numerator"]
     assert "NOT a roofline fraction" in rf["unfused_equivalent"]["label"]
     assert cb["kind"] == "reference" and len(cb["samples"]) == 3 and cb["one_core"]["cores"] == 1 and cb["pattern_tip"]["value"] > 0
