@@ -902,9 +902,9 @@ def live_traffic(args, kernel):
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
                    "--config", args.config, "--steps", "3", "--warmup", "1", "--blocks", "1", "--no-cpu", "--no-traffic"]
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=150)
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=60)
             except subprocess.TimeoutExpired:
-                return None, f"the {counter} pass did not finish within 150 s"
+                return None, f"the {counter} pass did not finish within 60 s"
             if r.returncode != 0:
                 return None, f"the {counter} pass failed (exit {r.returncode}): " + r.stderr.decode(errors="replace")[-200:]
             vals = []
