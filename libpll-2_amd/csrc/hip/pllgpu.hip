@@ -243,6 +243,7 @@ struct pllgpu_ctx
   double seq_override = 0.0;     // pllgpu_edge_t.sequence of the evaluation being issued (0: number it here)
   DevBuf<double> reduce;         // {lnL, sequence}: the operand of a caller's all-reduce (pllgpu_reduce_buffer)
   std::vector<double> stage;     // host staging for the P-matrix re-layout
+  std::vector<unsigned char> stage8; // ... and for a class map that goes up as bytes
   unsigned last_launches = 0;
   unsigned long long rep_ops_total = 0, rep_launches_total = 0; // class-map ops handed to the device / class kernels launched, ever
   double last_bytes = 0.0;       // algorithmic HBM bytes of the last update_partials call
@@ -1025,11 +1026,21 @@ extern "C" int pllgpu_repeats_upload(pllgpu_ctx_t *c, unsigned node, const unsig
   c->rep_left[node] = c->rep_right[node] = -1; // host-built maps: no entry-indexed child maps
   c->map_forms[node] = 0;
   if (!ids) return 0;
+  if (int rc = c->id_site[node].ensure(ids)) return rc;
+  if (id_site) HIP_TRY(copy_up(c, c->id_site[node].p, id_site, ids * sizeof(unsigned)));
+  if (ids <= kRepNarrow)
+  {
+    // at most 256 classes - every tip: the map goes up as BYTES (a quarter of the bus: 128 tips x 1M sites were 512 MB), the
+    // form the class kernels read; the 32-bit form the site-indexed gathers and the API want is made on the device on demand
+    if (int rc = c->site_id8[node].ensure(map_elems(c))) return rc;
+    c->stage8.resize(c->geo.sites_alloc);
+    for (unsigned s = 0; s < c->geo.sites_alloc; ++s) c->stage8[s] = (unsigned char)site_id[s];
+    HIP_TRY(hipMemcpyAsync(c->site_id8[node].p, c->stage8.data(), c->geo.sites_alloc, hipMemcpyHostToDevice, c->stream)); // (pageable: staged before it returns)
+    c->map_forms[node] = kMap8;
+    return 0;
+  }
   if (int rc = c->site_id[node].ensure(map_elems(c))) return rc;
-  if (int rc = c->id_site[node].ensure(c->geo.sites_alloc)) return rc;
   HIP_TRY(hipMemcpyAsync(c->site_id[node].p, site_id, c->geo.sites_alloc * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
-  if (id_site)
-    HIP_TRY(hipMemcpyAsync(c->id_site[node].p, id_site, ids * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
   c->map_forms[node] = kMap32;
   return 0;
 }
