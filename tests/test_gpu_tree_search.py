@@ -314,3 +314,27 @@ def test_an_unchanged_tree_computes_no_class_maps_and_a_move_only_the_path_above
     finally:
         d.close()
         r.close()
+
+
+def test_searches_in_concurrent_threads(amd_lib, ref_lib):
+    """partitions are independent: two threads drive a search each (a site-repeats and a plain partition per library) at the same
+    time - the device blocks a context recycles, the epoch of its plans and the stream they are ordered by belong to the context
+    whose entry point is running on the calling thread"""
+    import threading
+    errors = []
+
+    def run(attrs, states, sites, seed):
+        try:
+            check, worst = _against_reference(sites)
+            _search([amd_lib, ref_lib], states, 48, sites, ATTRS[attrs], seed=seed, moves=60, check=check)
+            assert worst["n"] > 100
+        except BaseException as e:  # noqa: BLE001 - reported by the main thread
+            errors.append((attrs, states, repr(e)))
+
+    threads = [threading.Thread(target=run, args=a) for a in (("site_repeats", 4, 2000, 7001), ("plain", 4, 3000, 7002),
+                                                              ("site_repeats_rate_scalers", 20, 300, 7003))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
