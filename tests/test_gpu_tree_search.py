@@ -307,6 +307,13 @@ def test_an_unchanged_tree_computes_no_class_maps_and_a_move_only_the_path_above
         assert again[0] - moved[0] > moved[0] - after_nni[0] and again[0] - moved[0] <= len(ops) and again[1] > moved[1]
         d.update(ops)
         assert work() == again
+        # a caller that wrote ONE tip's maps behind the library's back says so: that tip's ancestors are computed again, no more
+        v_before = d.lnl(tree.edge_args(rec))
+        amd_lib.pll_gpu_invalidate(d.p, api.DIRTY_REPEATS, 5)
+        d.update(ops)
+        one_tip = work()
+        assert 0 < one_tip[0] - again[0] < again[0] - moved[0]
+        assert d.lnl(tree.edge_args(rec)) == v_before
         for o in ops:
             a, b = d.maps(o[0]), r.maps(o[0])
             assert a[0] == b[0] and (a[0] == 0 or (np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])))
