@@ -361,15 +361,14 @@ struct DevPmat
   unsigned char fidx[kMaxRates];
 };
 
-__global__ __launch_bounds__(256) void k_pmatrix(const DevPmat d)
+__device__ __forceinline__ void pmatrix_body(const DevPmat &d, double t, unsigned mi)
 {
   extern __shared__ double sm[];
   const unsigned S = d.S, LD = S | 1u; // odd row stride: conflict-free column walks
   double *A = sm, *B = sm + (size_t)S * LD;
-  const unsigned b = blockIdx.x, n = blockIdx.y;
+  const unsigned n = blockIdx.y;
   const unsigned fi = d.fidx[n];
-  const double t = d.brlen[b];
-  double *out = d.pmat + (size_t)d.mindex[b] * d.pm_stride + (size_t)n * S * d.SPT;
+  double *out = d.pmat + (size_t)mi * d.pm_stride + (size_t)n * S * d.SPT;
   if (t > 0.0)
   {
     const double pinv = d.prop_invar[fi];
@@ -396,4 +395,23 @@ __global__ __launch_bounds__(256) void k_pmatrix(const DevPmat d)
     }
     out[idx] = acc;
   }
+}
+
+__global__ __launch_bounds__(256) void k_pmatrix(const DevPmat d)
+{
+  pmatrix_body(d, d.brlen[blockIdx.x], d.mindex[blockIdx.x]);
+}
+
+// a handful of branches (what a tree search changes per move): indices and lengths by value in the kernarg segment - no
+// staging copies ahead of the launch (two of them were half of the call's 12 us)
+constexpr unsigned kPmatInline = 16;
+struct DevPmatFew
+{
+  DevPmat d;
+  double t[kPmatInline];
+  unsigned mi[kPmatInline];
+};
+__global__ __launch_bounds__(256) void k_pmatrix_few(const DevPmatFew f)
+{
+  pmatrix_body(f.d, f.t[blockIdx.x], f.mi[blockIdx.x]);
 }

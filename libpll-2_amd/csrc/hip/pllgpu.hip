@@ -3004,15 +3004,16 @@ extern "C" int pllgpu_update_pmatrices(pllgpu_ctx_t *c, const unsigned *params_i
   for (unsigned i = 0; i < count; ++i)
     if (matrix_indices[i] >= g.prob_matrices || !(branch_lengths[i] >= 0))
       return fail(PLLGPU_EINVAL, "matrix index %u / branch length %g invalid", matrix_indices[i], branch_lengths[i]);
-  // earlier launches may still read the staging buffers: a grown buffer is a fresh allocation
-  // (ensure() frees synchronously), a reused one is overwritten in stream order
-  if (int rc = c->mindex.ensure(count)) return rc;
-  if (int rc = c->brlen.ensure(count)) return rc;
   for (unsigned i = 0; i < count; ++i) ++c->pm_version[matrix_indices[i]];
-  // (through the context's pinned block: a copy from pageable memory is a blocking trip through the runtime's staging, and
-  // a tree search makes this call for one to three branches after every move)
-  HIP_TRY(copy_up(c, c->mindex.p, matrix_indices, count * sizeof(unsigned)));
-  HIP_TRY(copy_up(c, c->brlen.p, branch_lengths, count * sizeof(double)));
+  const bool few = count <= kPmatInline;
+  if (!few)
+  {
+    // (a reused staging buffer is overwritten in stream order, behind the launches that still read it)
+    if (int rc = c->mindex.ensure(count)) return rc;
+    if (int rc = c->brlen.ensure(count)) return rc;
+    HIP_TRY(copy_up(c, c->mindex.p, matrix_indices, count * sizeof(unsigned)));
+    HIP_TRY(copy_up(c, c->brlen.p, branch_lengths, count * sizeof(double)));
+  }
   d.pmat = c->pmat.p;
   d.evecs = c->evecs.p;
   d.ievecs = c->ievecs.p;
@@ -3026,6 +3027,20 @@ extern "C" int pllgpu_update_pmatrices(pllgpu_ctx_t *c, const unsigned *params_i
   d.SP = g.states_padded;
   d.SPT = c->gg.SPT;
   const size_t lds = (size_t)2 * g.states * (g.states | 1u) * sizeof(double);
+  if (few)
+  {
+    DevPmatFew f;
+    f.d = d;
+    for (unsigned i = 0; i < count; ++i)
+    {
+      f.t[i] = branch_lengths[i];
+      f.mi[i] = matrix_indices[i];
+    }
+    raise_lds_limit((const void *)k_pmatrix_few, c->device, lds);
+    hipLaunchKernelGGL(k_pmatrix_few, dim3(count, g.rate_cats), dim3(256), lds, c->stream, f);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   raise_lds_limit((const void *)k_pmatrix, c->device, lds);
   for (unsigned first = 0; first < count; first += 65535u) // gridDim.x stays far below its limit; y = rate
   {
